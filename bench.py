@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the windowed-sinc hot path on MI355X, BASELINE.json's metric.
+
+One "step" = one pass of the hot path (ClownResampler_LowLevel_Resample's per-frame loop, reference
+clownresampler.h:1058-1092 / :986-1035, as the HIP kernel k_poly) over one batch of synthetic PCM, inputs and outputs
+resident in HBM.  At N=1 the batch is BASELINE configs[1]: stereo int16, 44.1 -> 48 kHz, 3-lobe Lanczos, 10 minutes
+(26,460,000 -> 28,800,096 frames).  With N ranks every rank owns one such 10-minute shard of an N x 10-minute stream
+(output-timeline sharding, input halo replicated, no collective in the data path): weak scaling.
+
+Prints ONE JSON line (rank 0).  `value` = output Msamples/s of the whole job, kernel time only (HIP events on the
+launch stream, barrier + synchronize on both sides, max over ranks).  `roofline` prices the same kernel against the
+8 TB/s HBM peak with ALGORITHMIC bytes (each input sample read once + each int32 output written once).
+`cpu_baseline` is the reference C path (oracle/_ref, the real header compiled in place, when that prebuilt checker is
+present; else the oracle restatement) timed on this box's host cores on the same workload - a baseline, not a target.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+WORKLOADS = {
+    # name: (radius, channels, (in, out, lowpass), input frames per GPU)
+    "cfg2": (3, 2, (44100, 48000, 44100), 26460000),   # BASELINE configs[1] - the headline
+    "cfg3": (8, 2, (8000, 96000, 8000), 4800000),      # configs[2] (10 min assumed)
+    "cfg4": (3, 8, (48000, 44100, 44100), 28800000),   # configs[3] (10 min assumed)
+    "cfg5": (3, 2, (44100, 48000, 44100), 158760000),  # configs[4] on ONE GPU (1 hour)
+}
+
+
+def device_noise(n_samples, first_index, device):
+    """Full-scale white int16 PCM as a pure function of the ABSOLUTE sample index (splitmix-style hash), generated on the
+    device: every rank can materialise any range of one and the same stream, halo included."""
+    import torch
+    out = torch.empty(n_samples, dtype=torch.int16, device=device)
+    step = 1 << 24
+    for s in range(0, n_samples, step):
+        n = min(step, n_samples - s)
+        x = torch.arange(first_index + s, first_index + s + n, dtype=torch.int64, device=device)
+        x = x * -7046029254386353131            # 0x9E3779B97F4A7C15 as int64
+        x = (x ^ (x >> 31)) * -4658895280553007687  # 0xBF58476D1CE4E5B9
+        x = x ^ (x >> 29)
+        out[s:s + n] = (x >> 40).to(torch.int16)
+    return out
+
+
+def cpu_baseline(radius, ch, rates, frames, max_seconds=30.0):
+    """Times the reference C path on the host: real reference (.so prebuilt from /root/reference) if present, else oracle."""
+    import numpy as np
+    import _checkers as ck
+    ref = ck.reference(radius)
+    eng, kind = (ref, "reference") if ref is not None else (ck.oracle(radius), "port")
+    ok, st = eng.low_init(ch, *rates)
+    R = int(st.cfg.radius_frames)
+    padded = ck.pad_frames(ck.noise_pcm(frames * ch), ch, R)
+    n_out = int(ck.count_output_frames(st, frames))
+    out = np.zeros((n_out + 1) * ch, dtype=np.int32)   # pre-faulted
+    t0 = time.perf_counter()
+    got, left, ran_out = eng.low_resample_i32(st, padded, frames, out=out)
+    dt = time.perf_counter() - t0
+    res = {"value": got.size / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": kind,
+           "sample": "full workload, %d -> %d frames x %d ch, callback API storing int32, gcc -O2, 1 thread, %.2f s" % (frames, n_out, ch, dt)}
+    # all host cores, independent states over contiguous input ranges (oracle driver)
+    cores = os.cpu_count() or 1
+    if cores > 1:
+        o = ck.oracle(radius)
+        ok, fresh = o.low_init(ch, *rates)
+        t0 = time.perf_counter()
+        got = o.low_resample_i32_mt(fresh, padded, frames, cores, out=out)
+        dt = time.perf_counter() - t0
+        res["all_cores"] = {"value": got.size / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port", "seconds": dt}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--sets", type=int, default=3, help="rotating buffer sets (defeats the 256 MiB Infinity Cache)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import clownresampler_amd as cr
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE %d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs the GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    radius, ch, rates, frames_per_gpu = WORKLOADS[args.workload]
+    api = cr.load(radius)
+    api.SetDevice(local_rank)
+    pre = api.precomputed()
+    whole = api.LowLevel_State()
+    assert api.LowLevel_Init(whole, ch, *rates)
+    R = whole.lowest_level.integer_stretched_kernel_radius
+    total_frames = frames_per_gpu * world
+    shard = api.PlanShard(whole, total_frames, rank, world)
+    plan = api.PlanCreate(whole, pre)
+    info = api.PlanGetInfo(plan)
+
+    # this rank's slice of the stream + halo; logical frame f of the stream is padded frame f + R; the zero padding of the
+    # stream's two ends is materialised only where a shard touches it
+    in_frames = shard.input_frames + 2 * R
+    first_logical = shard.first_input_frame - R
+    sets = []
+    for s in range(max(1, args.sets)):
+        pcm = device_noise(in_frames * ch, (first_logical * ch) + s * 7919, device)
+        lo_pad = max(0, -first_logical)
+        hi_pad = max(0, first_logical + in_frames - total_frames)
+        if lo_pad:
+            pcm[: lo_pad * ch] = 0
+        if hi_pad:
+            pcm[(in_frames - hi_pad) * ch:] = 0
+        out = torch.empty(shard.output_frames * ch, dtype=torch.int32, device=device)
+        sets.append((pcm, out))
+    stream = torch.cuda.current_stream(device)
+
+    def step(i):
+        pcm, out = sets[i % len(sets)]
+        st = cr.LowLevel_State.from_buffer_copy(shard.state)
+        n, left, ran_out = api.ResampleDevice(plan, st, pcm.data_ptr(), shard.input_frames, out.data_ptr(), shard.output_frames, stream.cuda_stream)
+        assert n == shard.output_frames
+        return n
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(args.steps):
+        step(i)
+    ev1.record(stream)
+    barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    ms_rank = max(dev_ms, 0.0)
+    if world > 1:
+        t = torch.tensor([ms_rank, wall * 1e3], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_rank, wall_ms = float(t[0]), float(t[1])
+    else:
+        wall_ms = wall * 1e3
+
+    out_frames_all = int(api.CountOutputFrames(whole, total_frames))
+    out_samples_all = out_frames_all * ch
+    ms_per_step = ms_rank / args.steps
+    value = out_samples_all / (ms_per_step * 1e-3) / 1e6
+
+    # the dominant (only) kernel: algorithmic bytes of THIS rank's launch / its average duration
+    launch_bytes = shard.input_frames * ch * 2 + shard.output_frames * ch * 4
+    achieved = launch_bytes / (dev_ms / args.steps * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "kernel": "k_poly<%d,%d>" % (ch, info.slots) if info.kernel else "k_generic",
+                "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_ms": dev_ms / args.steps,
+                "read_only_GBs": shard.input_frames * ch * 2 / (dev_ms / args.steps * 1e-3) / 1e9}
+
+    # correctness of what was just timed: spot-check a window of this rank's output against the oracle
+    check = None
+    if not args.no_check and rank == 0:
+        import _checkers as ck
+        o = ck.oracle(radius)
+        n_chk = min(200000, shard.output_frames)
+        pcm, out = sets[(args.steps - 1) % len(sets)]
+        ok, ost = o.low_init(ch, *rates)
+        ost.pos_int, ost.pos_frac = shard.state.position_integer, shard.state.position_fractional
+        need = min(in_frames, int(n_chk * whole.increment / 65536) + 4 * R + 8)
+        host_in = pcm[: need * ch].cpu().numpy()
+        want, _, _ = o.low_resample_i32(ost, host_in, need - 2 * R, capacity=n_chk)
+        got = out[: want.size].cpu().numpy()
+        check = bool(np.array_equal(got, want))
+        if not check:
+            raise SystemExit("bench: device output differs from the oracle - numbers void")
+
+    gather = None
+    if world > 1:
+        # the final concatenate (north_star): all ranks' int32 shards gathered over xGMI by RCCL; timed apart from the kernel
+        per = (out_frames_all + world - 1) // world * ch
+        send = torch.zeros(per, dtype=torch.int32, device=device)
+        send[: shard.output_frames * ch] = sets[0][1]
+        recv = torch.empty(per * world, dtype=torch.int32, device=device)
+        dist.all_gather_into_tensor(recv, send)
+        barrier()
+        g0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            dist.all_gather_into_tensor(recv, send)
+        barrier()
+        g_ms = (time.perf_counter() - g0) * 1e3 / reps
+        gather = {"collective": "all_gather_into_tensor (RCCL)", "ms": g_ms, "bytes_per_rank": per * 4,
+                  "value_with_gather": out_samples_all / ((ms_per_step + g_ms) * 1e-3) / 1e6}
+
+    if rank == 0:
+        line = {
+            "metric": "output Msamples/s at 44.1->48 kHz stereo" if args.workload in ("cfg2", "cfg5") else "output Msamples/s (%s)" % args.workload,
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "s16 in / int32 16.16 fixed-point arithmetic / int32 out", "data": "synthetic",
+            "config": {"workload": "%s: %d-ch int16 %d->%d Hz, %d-lobe Lanczos, %d input frames per GPU (%d -> %d frames in all), device-resident, %d rotating buffer sets"
+                                   % (args.workload, ch, rates[0], rates[1], radius, frames_per_gpu, total_frames, out_frames_all, len(sets)),
+                       "sharding": "output timeline split in %d contiguous blocks, input halo of %d frames replicated, no data-path collective" % (world, R),
+                       "plan": info.asdict()},
+            "roofline": roofline,
+            "wall_ms_per_step": wall_ms / args.steps,
+            "parity_spot_check": check,
+        }
+        if gather:
+            line["gather"] = gather
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(radius, ch, rates, frames_per_gpu)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

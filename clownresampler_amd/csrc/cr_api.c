@@ -1,0 +1,544 @@
+/*
+ * cr_api.c - one instance of the clownresampler API per kernel radius.
+ *
+ * Compiled once per supported CLOWNRESAMPLER_KERNEL_RADIUS (see Makefile); include/clownresampler.h redirects
+ * the function names to ..._R<radius> for radii other than the default 3, so all instances live in one library.
+ *
+ * Host C.  What stays on the host is what the reference runs once per stream or per call: the table
+ * (clownresampler.h:892-961), the ratio/configuration scalars (:913-984, :1044-1056), the high-level API's
+ * staging-buffer choreography (:1101-1250) and the bookkeeping of the output-timeline walk (:1058-1092).
+ * The per-frame arithmetic (:986-1035) is NOT implemented here: every frame comes from the HIP kernels behind
+ * cr_context.c, and when no device is usable these functions end in the error handler.
+ */
+#include "../../include/clownresampler_amd.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "cr_context.h"
+
+#define RADIUS CLOWNRESAMPLER_KERNEL_RADIUS
+#define TABLE_LEN ((size_t)RADIUS * 2u * CLOWNRESAMPLER_KERNEL_RESOLUTION)
+#define ONE 65536ul /* 16.16 */
+
+#if CLOWNRESAMPLER_KERNEL_RADIUS != 3
+ #define ClownResamplerAMD_BuildRows CLOWNRESAMPLER_AMD_SYM(ClownResamplerAMD_BuildRows)
+#endif
+
+/* ======================================================================================================= */
+/* Table                                                                                                   */
+/* ======================================================================================================= */
+
+void ClownResampler_Precompute(ClownResampler_Precomputed *precomputed)
+{
+	/* Lanczos-windowed sinc sampled at TABLE_LEN points over [-R, R), in 16.16, truncated toward zero.
+	   The order of the floating-point operations follows the reference (clownresampler.h:894-907, :960) because
+	   the integer table must come out identical: x*pi, (x*pi)/R, sin*sin/(a*b). */
+	const double radius = (double)RADIUS;
+	const double pi = 3.14159265358979323846264338327950288;
+	size_t i;
+
+	for (i = 0; i < TABLE_LEN; ++i)
+	{
+		const double x = ((double)i / (double)TABLE_LEN * 2.0 - 1.0) * radius;
+		double value = 1.0;
+
+		if (x != 0.0)
+		{
+			const double a = x * pi;
+			const double b = a / radius;
+			value = (sin(a) * sin(b)) / (a * b);
+		}
+
+		precomputed->lanczos_kernel_table[i] = (cc_s32l)(value * (double)ONE);
+	}
+}
+
+/* ======================================================================================================= */
+/* Ratio and configuration                                                                                 */
+/* ======================================================================================================= */
+
+/* floor(numerator * 65536 / denominator) in arithmetic that never needs more than the width of cc_u32f:
+   three base-65536 digits divided from the top, the remainder carried down (clownresampler.h:913-953).
+   0xFFFFFFFF marks a zero operand or a quotient of 2^32 or more; a zero quotient becomes 1. */
+static cc_u32f ratio_16_16(cc_u32f numerator, cc_u32f denominator)
+{
+	cc_u32f digit[3];
+	cc_u32f quotient;
+
+	if (numerator == 0 || denominator == 0)
+		return 0xFFFFFFFF;
+
+	digit[2] = numerator / ONE;
+	digit[1] = numerator % ONE;
+	digit[0] = 0;
+
+	digit[1] |= digit[2] % denominator * ONE;
+	digit[2] /= denominator;
+	digit[0] |= digit[1] % denominator * ONE;
+	digit[1] /= denominator;
+	digit[0] /= denominator;
+
+	if (digit[2] != 0 || digit[1] >= ONE)
+		return 0xFFFFFFFF;
+
+	quotient = digit[1] * ONE + digit[0];
+	return quotient != 0 ? quotient : 1;
+}
+
+cc_bool ClownResampler_LowestLevel_Configure(ClownResampler_LowestLevel_Configuration *configuration, cc_u32f input_sample_rate, cc_u32f output_sample_rate, cc_u32f low_pass_filter_sample_rate)
+{
+	/* the kernel is only ever stretched, to the lowest of the three rates (clownresampler.h:965-970) */
+	cc_u32f pass_rate = input_sample_rate;
+	cc_u32f stretch, squeeze;
+
+	if (output_sample_rate < pass_rate)
+		pass_rate = output_sample_rate;
+	if (low_pass_filter_sample_rate < pass_rate)
+		pass_rate = low_pass_filter_sample_rate;
+
+	stretch = ratio_16_16(input_sample_rate, pass_rate);
+	squeeze = ratio_16_16(pass_rate, input_sample_rate);
+
+	if (stretch >= 0x1000 * ONE) /* :974, leaves *configuration untouched */
+		return cc_false;
+
+	configuration->stretched_kernel_radius = RADIUS * stretch;                                                                    /* :977 */
+	configuration->integer_stretched_kernel_radius = (configuration->stretched_kernel_radius + (ONE - 1)) / ONE;                   /* :978 */
+	configuration->stretched_kernel_radius_delta = configuration->integer_stretched_kernel_radius * ONE - configuration->stretched_kernel_radius; /* :979 */
+	configuration->kernel_step_size = CLOWNRESAMPLER_KERNEL_RESOLUTION * squeeze / ONE;                                           /* :981 */
+
+	return cc_true;
+}
+
+cc_bool ClownResampler_LowLevel_Adjust(ClownResampler_LowLevel_State *resampler, cc_u32f input_sample_rate, cc_u32f output_sample_rate, cc_u32f low_pass_filter_sample_rate)
+{
+	/* increment first, validation second: a failed Adjust leaves the new increment behind (clownresampler.h:1054-1055) */
+	resampler->increment = ratio_16_16(input_sample_rate, output_sample_rate);
+	return ClownResampler_LowestLevel_Configure(&resampler->lowest_level, input_sample_rate, output_sample_rate, low_pass_filter_sample_rate);
+}
+
+cc_bool ClownResampler_LowLevel_Init(ClownResampler_LowLevel_State *resampler, cc_u8f channels, cc_u32f input_sample_rate, cc_u32f output_sample_rate, cc_u32f low_pass_filter_sample_rate)
+{
+	resampler->channels = channels; /* not range-checked, as in the reference (clownresampler.h:1046) */
+	resampler->position_integer = 0;
+	resampler->position_fractional = 0;
+	return ClownResampler_LowLevel_Adjust(resampler, input_sample_rate, output_sample_rate, low_pass_filter_sample_rate);
+}
+
+/* ======================================================================================================= */
+/* Plans                                                                                                   */
+/* ======================================================================================================= */
+
+static int fill_table_i32(const void *user, int32_t *dst, size_t count)
+{
+	const ClownResampler_Precomputed *precomputed = (const ClownResampler_Precomputed *)user;
+	size_t i;
+
+	for (i = 0; i < count; ++i)
+	{
+		const cc_s32l v = precomputed->lanczos_kernel_table[i];
+
+		if (v < -2147483647L - 1 || v > 2147483647L)
+			return -1;
+
+		dst[i] = (int32_t)v;
+	}
+
+	return 0;
+}
+
+static void config_of(const ClownResampler_LowestLevel_Configuration *configuration, cr_config *cfg)
+{
+	cfg->skr = configuration->stretched_kernel_radius;
+	cfg->radius_frames = configuration->integer_stretched_kernel_radius;
+	cfg->delta = configuration->stretched_kernel_radius_delta;
+	cfg->step = configuration->kernel_step_size;
+}
+
+static ClownResamplerAMD_Plan *plan_for(const ClownResampler_LowestLevel_Configuration *configuration, const ClownResampler_Precomputed *precomputed, cc_u8f channels, cc_u32f increment)
+{
+	cr_config cfg;
+
+	config_of(configuration, &cfg);
+	/* keyed by the CONTENTS of the caller's table (48 KB to hash): a caller may legitimately keep several
+	   tables, or const-initialise one from a dump (clownresampler.h:677-681) */
+	return cr_plan_get(cr_hash_bytes(precomputed->lanczos_kernel_table, sizeof(precomputed->lanczos_kernel_table), RADIUS),
+	                   TABLE_LEN, fill_table_i32, precomputed, RADIUS, &cfg, channels, increment);
+}
+
+ClownResamplerAMD_Plan *ClownResamplerAMD_PlanCreate(const ClownResampler_LowLevel_State *state, const ClownResampler_Precomputed *precomputed)
+{
+	return plan_for(&state->lowest_level, precomputed, state->channels, state->increment);
+}
+
+/* Host-only view of the polyphase rows a plan would use (no device needed): for tests and tools.
+   *rows_out is malloc'ed (info->rows * info->row_stride int32); free() it.  Returns 0, or non-zero with
+   *reason set when the configuration is unusable even for the reference. */
+int ClownResamplerAMD_BuildRows(const ClownResampler_LowestLevel_Configuration *configuration, const ClownResampler_Precomputed *precomputed,
+                                ClownResamplerAMD_PlanInfo *info, int32_t **rows_out, int *eligible, const char **reason, uint32_t *row_of_fraction)
+{
+	cr_config cfg;
+	cr_poly poly;
+	int32_t *table = (int32_t *)malloc(TABLE_LEN * sizeof(int32_t));
+	int r;
+	uint32_t frac;
+
+	config_of(configuration, &cfg);
+	memset(info, 0, sizeof(*info));
+	*rows_out = NULL;
+	*eligible = 0;
+	*reason = "";
+
+	if (table == NULL || fill_table_i32(precomputed, table, TABLE_LEN) != 0)
+	{
+		free(table);
+		*reason = "table entry does not fit 32 bits";
+		return -1;
+	}
+
+	r = cr_poly_build(table, TABLE_LEN, &cfg, &poly);
+	free(table);
+	*reason = poly.reason;
+	*eligible = poly.eligible;
+	info->slots = poly.slots;
+	info->first_slot = poly.first_slot;
+	info->rows = poly.rows;
+	info->row_stride = poly.row_stride;
+	info->row_mode = poly.row_mode;
+	*rows_out = poly.weights; /* ownership passes to the caller */
+
+	/* optional: the row every one of the 65536 fractional positions maps to (host mirror of the device formula) */
+	if (row_of_fraction != NULL && poly.weights != NULL)
+		for (frac = 0; frac < 65536u; ++frac)
+			row_of_fraction[frac] = cr_poly_row_of(&poly, frac);
+
+	return r;
+}
+
+/* ======================================================================================================= */
+/* The output-timeline walk (clownresampler.h:1058-1092), bulk form                                        */
+/* ======================================================================================================= */
+
+/* Leaves state and *total_input_frames as the reference does after `emitted` frames, the last of which made the
+   consumer say stop (clownresampler.h:1084-1088). */
+static void settle_stopped(ClownResampler_LowLevel_State *resampler, size_t *total_input_frames, uint64_t pos_int, uint64_t pos_frac, uint64_t emitted)
+{
+	size_t consumed;
+
+	cr_advance(&pos_int, &pos_frac, resampler->increment, emitted);
+	consumed = pos_int < *total_input_frames ? (size_t)pos_int : *total_input_frames;
+	*total_input_frames -= consumed;
+	resampler->position_integer = (size_t)pos_int - consumed;
+	resampler->position_fractional = (cc_u32f)pos_frac;
+}
+
+/* ... and after the input ran out (clownresampler.h:1065-1067). */
+static void settle_exhausted(ClownResampler_LowLevel_State *resampler, size_t *total_input_frames, uint64_t pos_int, uint64_t pos_frac, uint64_t emitted)
+{
+	cr_advance(&pos_int, &pos_frac, resampler->increment, emitted);
+	resampler->position_integer = (size_t)pos_int - *total_input_frames;
+	resampler->position_fractional = (cc_u32f)pos_frac;
+	*total_input_frames = 0;
+}
+
+size_t ClownResampler_LowLevel_ResampleBulk(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed, const cc_s16l *input_buffer, size_t *total_input_frames, int32_t *output, size_t output_capacity_frames, cc_bool *ran_out_of_input)
+{
+	const uint64_t pos_int = resampler->position_integer, pos_frac = resampler->position_fractional;
+	const uint64_t available = cr_count_output_frames(pos_int, pos_frac, resampler->increment, *total_input_frames);
+	const uint64_t emit = available < output_capacity_frames ? available : output_capacity_frames;
+	/* the consumer "returns 0" on the frame that fills it, even if that is also the last frame there is */
+	const int stopped = available >= output_capacity_frames && available != 0;
+
+	if (ran_out_of_input != NULL)
+		*ran_out_of_input = stopped ? cc_false : cc_true;
+
+	if (emit != 0)
+	{
+		const ClownResamplerAMD_Plan *plan = plan_for(&resampler->lowest_level, precomputed, resampler->channels, resampler->increment);
+
+		if (plan == NULL)
+			return 0;
+
+		if (cr_run_host(plan, input_buffer, (uint64_t)*total_input_frames + 2 * resampler->lowest_level.integer_stretched_kernel_radius,
+		                pos_int, pos_frac, emit, output) != 0)
+			return 0;
+	}
+	else if (stopped)
+	{
+		return 0; /* no room for even one frame: nothing happens, as if the call had not been made */
+	}
+
+	if (stopped)
+		settle_stopped(resampler, total_input_frames, pos_int, pos_frac, emit);
+	else
+		settle_exhausted(resampler, total_input_frames, pos_int, pos_frac, emit);
+
+	return (size_t)emit;
+}
+
+/* ======================================================================================================= */
+/* The callback form (the reference's own signature)                                                       */
+/* ======================================================================================================= */
+
+#ifndef CLOWNRESAMPLER_NO_LOW_LEVEL_API
+cc_bool ClownResampler_LowLevel_Resample(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed, const cc_s16l *input_buffer, size_t *total_input_frames, ClownResampler_OutputCallback output_callback, const void *user_data)
+{
+	const uint64_t start_int = resampler->position_integer, start_frac = resampler->position_fractional;
+	const uint64_t available = cr_count_output_frames(start_int, start_frac, resampler->increment, *total_input_frames);
+	const cc_u8f channels = resampler->channels;
+	const uint64_t padded_frames = (uint64_t)*total_input_frames + 2 * resampler->lowest_level.integer_stretched_kernel_radius;
+	const ClownResamplerAMD_Plan *plan;
+	int32_t *batch_out;
+	uint64_t done = 0;
+	/* A consumer may stop after a handful of frames (a sound-card callback asks for a few hundred,
+	   examples/low-level.c:84) or take the whole stream: frames are computed ahead speculatively in batches
+	   that start small and grow, so neither case wastes much. */
+	uint64_t batch = 1024;
+	const uint64_t batch_limit = 1u << 20;
+
+	if (available == 0)
+	{
+		settle_exhausted(resampler, total_input_frames, start_int, start_frac, 0);
+		return cc_true;
+	}
+
+	plan = plan_for(&resampler->lowest_level, precomputed, channels, resampler->increment);
+	if (plan == NULL)
+		return cc_true;
+
+	batch_out = (int32_t *)malloc((size_t)(available < batch_limit ? available : batch_limit) * channels * sizeof(int32_t));
+	if (batch_out == NULL)
+	{
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
+		return cc_true;
+	}
+
+	while (done < available)
+	{
+		const uint64_t n = available - done < batch ? available - done : batch;
+		uint64_t i;
+
+		{
+			uint64_t pi = start_int, pf = start_frac;
+			cr_advance(&pi, &pf, resampler->increment, done);
+			if (cr_run_host(plan, input_buffer, padded_frames, pi, pf, n, batch_out) != 0)
+				break;
+		}
+
+		for (i = 0; i < n; ++i)
+		{
+			cc_s32f frame[CLOWNRESAMPLER_MAXIMUM_CHANNELS];
+			cc_u8f c;
+
+			for (c = 0; c < channels; ++c)
+				frame[c] = batch_out[i * channels + c];
+
+			/* the position is moved on before the frame is handed out (clownresampler.h:1076-1081): a callback
+			   that looks at the state sees what it would see with the reference */
+			resampler->position_fractional += resampler->increment;
+			resampler->position_integer += resampler->position_fractional / ONE;
+			resampler->position_fractional %= ONE;
+
+			if (!output_callback((void *)user_data, frame, channels))
+			{
+				free(batch_out);
+				settle_stopped(resampler, total_input_frames, start_int, start_frac, done + i + 1);
+				return cc_false;
+			}
+		}
+
+		done += n;
+		if (batch < batch_limit)
+			batch *= 4;
+		if (batch > batch_limit)
+			batch = batch_limit;
+	}
+
+	free(batch_out);
+
+	if (done < available)
+	{
+		/* a device failure was reported through the error handler and the handler returned: stop where we are */
+		settle_stopped(resampler, total_input_frames, start_int, start_frac, done);
+		return cc_true;
+	}
+
+	settle_exhausted(resampler, total_input_frames, start_int, start_frac, available);
+	return cc_true;
+}
+#endif
+
+/* ======================================================================================================= */
+/* One frame (clownresampler.h:986-1035)                                                                   */
+/* ======================================================================================================= */
+
+void ClownResampler_LowestLevel_Resample(const ClownResampler_LowestLevel_Configuration *configuration, const ClownResampler_Precomputed *precomputed, cc_s32f *output_frame, cc_u8f channels, const cc_s16l *input_buffer, size_t position_integer, cc_u32f position_fractional)
+{
+	/* increment is irrelevant for a single frame; 65536 keeps the plan key well-formed */
+	const ClownResamplerAMD_Plan *plan = plan_for(configuration, precomputed, channels, ONE);
+	int64_t acc_in[CLOWNRESAMPLER_MAXIMUM_CHANNELS], acc_out[CLOWNRESAMPLER_MAXIMUM_CHANNELS];
+	cc_u8f c;
+
+	if (plan == NULL)
+		return;
+
+	for (c = 0; c < channels; ++c)
+		acc_in[c] = output_frame[c];
+
+	/* the frame reads padded-buffer frames [position_integer, position_integer + 2 * radius) at most (:995-996, :1003-1004) */
+	if (cr_run_single_frame(plan, input_buffer + position_integer * channels, 2 * (uint64_t)configuration->integer_stretched_kernel_radius,
+	                        position_fractional, acc_in, acc_out) != 0)
+		return;
+
+	for (c = 0; c < channels; ++c)
+		output_frame[c] = (cc_s32f)acc_out[c];
+}
+
+/* ======================================================================================================= */
+/* High-level API (clownresampler.h:1101-1250): host-side staging around the low-level call                */
+/* ======================================================================================================= */
+
+#ifndef CLOWNRESAMPLER_NO_HIGH_LEVEL_API
+
+#define STAGING_SAMPLES CLOWNRESAMPLER_COUNT_OF(((ClownResampler_HighLevel_State *)0)->input_buffer)
+
+cc_bool ClownResampler_HighLevel_Init(ClownResampler_HighLevel_State *resampler, cc_u8f channels, cc_u32f input_sample_rate, cc_u32f output_sample_rate, cc_u32f low_pass_filter_sample_rate)
+{
+	size_t halo_samples;
+
+	if (channels > CLOWNRESAMPLER_MAXIMUM_CHANNELS) /* :1103 */
+		return cc_false;
+
+	if (!ClownResampler_LowLevel_Init(&resampler->low_level, channels, input_sample_rate, output_sample_rate, low_pass_filter_sample_rate))
+		return cc_false;
+
+	/* the radius at Init is the largest this state will ever accept (:1109, :1195) */
+	resampler->maximum_integer_stretched_kernel_radius = resampler->low_level.lowest_level.integer_stretched_kernel_radius;
+	resampler->leading_padding_frames_needed = resampler->maximum_integer_stretched_kernel_radius;
+	resampler->trailing_padding_frames_remaining = resampler->maximum_integer_stretched_kernel_radius;
+
+	/* silence where the frames before the stream would be; empty window right behind it (:1112-1115) */
+	halo_samples = resampler->maximum_integer_stretched_kernel_radius * channels;
+	memset(resampler->input_buffer, 0, halo_samples * sizeof(resampler->input_buffer[0]));
+	resampler->input_buffer_start = resampler->input_buffer_end = resampler->input_buffer + halo_samples;
+
+	return cc_true;
+}
+
+cc_bool ClownResampler_HighLevel_Resample(ClownResampler_HighLevel_State *resampler, const ClownResampler_Precomputed *precomputed, ClownResampler_InputCallback input_callback, ClownResampler_OutputCallback output_callback, const void *user_data)
+{
+	const size_t channels = resampler->low_level.channels;
+	const size_t halo_samples = resampler->maximum_integer_stretched_kernel_radius * channels;
+	cc_bool consumer_stopped = cc_false;
+
+	/* Staging layout: [ left halo | window ... | look-ahead ] with the newest `halo` frames not yet consumed.
+	   First, collect the look-ahead: the first real frames go right-aligned into [halo, 2*halo) (:1127-1136). */
+	while (resampler->leading_padding_frames_needed != 0)
+	{
+		cc_s16l *where = resampler->input_buffer + 2 * halo_samples - resampler->leading_padding_frames_needed * channels;
+		const size_t got = input_callback((void *)user_data, where, resampler->leading_padding_frames_needed);
+
+		if (got == 0)
+			return cc_true;
+
+		resampler->leading_padding_frames_needed -= got;
+	}
+
+	while (!consumer_stopped)
+	{
+		if (resampler->input_buffer_start == resampler->input_buffer_end)
+		{
+			size_t got;
+
+			/* window used up: the last 2*halo samples (left halo + look-ahead of the next window) move to the
+			   front and new frames are pulled in behind them (:1143-1158) */
+			memmove(resampler->input_buffer, resampler->input_buffer_end - halo_samples, 2 * halo_samples * sizeof(resampler->input_buffer[0]));
+			resampler->input_buffer_start = resampler->input_buffer + halo_samples;
+			got = input_callback((void *)user_data, resampler->input_buffer + 2 * halo_samples, (STAGING_SAMPLES - 2 * halo_samples) / channels);
+			resampler->input_buffer_end = resampler->input_buffer_start + got * channels;
+
+			if (got == 0)
+				return cc_true;
+		}
+
+		{
+			/* the CURRENT radius flanks the window: it may be smaller than the one at Init after an Adjust (:1165) */
+			const size_t current_halo = resampler->low_level.lowest_level.integer_stretched_kernel_radius * channels;
+			size_t frames = (size_t)(resampler->input_buffer_end - resampler->input_buffer_start) / channels;
+
+			const unsigned long errors_before = cr_error_serial();
+
+			consumer_stopped = !ClownResampler_LowLevel_Resample(&resampler->low_level, precomputed, resampler->input_buffer_start - current_halo, &frames, output_callback, user_data);
+			resampler->input_buffer_start = resampler->input_buffer_end - frames * channels; /* :1171 */
+
+			/* a device failure was reported and the (non-default) error handler returned: the window was not
+			   consumed, so looping would never end - give control back to the caller */
+			if (cr_error_serial() != errors_before)
+				return cc_true;
+		}
+	}
+
+	return cc_false;
+}
+
+#ifndef CLOWNRESAMPLER_NO_HIGH_LEVEL_ADJUST
+cc_bool ClownResampler_HighLevel_Adjust(ClownResampler_HighLevel_State *resampler, cc_u32f input_sample_rate, cc_u32f output_sample_rate, cc_u32f low_pass_filter_sample_rate)
+{
+	const ClownResampler_LowLevel_State before = resampler->low_level;
+	const cc_bool accepted = ClownResampler_LowLevel_Adjust(&resampler->low_level, input_sample_rate, output_sample_rate, low_pass_filter_sample_rate)
+	    /* a wider kernel than at Init would outgrow the halos already in the staging buffer (:1195) */
+	    && resampler->low_level.lowest_level.integer_stretched_kernel_radius <= resampler->maximum_integer_stretched_kernel_radius
+	    /* and both halos must leave room in the staging buffer (:1202) */
+	    && resampler->low_level.lowest_level.integer_stretched_kernel_radius * 2 < STAGING_SAMPLES / resampler->low_level.channels;
+
+	if (!accepted)
+		resampler->low_level = before;
+
+	return accepted;
+}
+#endif
+
+#ifndef CLOWNRESAMPLER_NO_HIGH_LEVEL_RESAMPLE_END
+typedef struct drain_context
+{
+	ClownResampler_HighLevel_State *resampler;
+	ClownResampler_OutputCallback output_callback;
+	void *user_data;
+} drain_context;
+
+/* feeds what is left of the trailing silence (:1223-1233) */
+static size_t drain_input(void *user_data, cc_s16l *buffer, size_t total_frames)
+{
+	drain_context *context = (drain_context *)user_data;
+	size_t frames = context->resampler->trailing_padding_frames_remaining;
+
+	if (frames > total_frames)
+		frames = total_frames;
+
+	memset(buffer, 0, frames * context->resampler->low_level.channels * sizeof(*buffer));
+	context->resampler->trailing_padding_frames_remaining -= frames;
+	return frames;
+}
+
+static cc_bool drain_output(void *user_data, const cc_s32f *frame, cc_u8f total_samples)
+{
+	drain_context *context = (drain_context *)user_data;
+	return context->output_callback(context->user_data, frame, total_samples);
+}
+
+cc_bool ClownResampler_HighLevel_ResampleEnd(ClownResampler_HighLevel_State *resampler, const ClownResampler_Precomputed *precomputed, ClownResampler_OutputCallback output_callback, const void *user_data)
+{
+	/* flushes the look-ahead frames by pushing `radius` frames of silence through the same path (:1242-1250) */
+	drain_context context;
+
+	context.resampler = resampler;
+	context.output_callback = output_callback;
+	context.user_data = (void *)user_data;
+
+	return ClownResampler_HighLevel_Resample(resampler, precomputed, drain_input, drain_output, &context);
+}
+#endif
+
+#endif /* CLOWNRESAMPLER_NO_HIGH_LEVEL_API */

@@ -1,0 +1,689 @@
+/*
+ * cr_context.c - process-wide GPU context: error reporting, device selection, plan cache, staging workspace.
+ * Host C; reaches the GPU only through the crhip_* shim (crhip.h).  There is deliberately no CPU
+ * implementation of the resampling arithmetic anywhere in this library: without a usable device every resample
+ * entry point ends in cr_fail().
+ */
+#include "cr_context.h"
+
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/clownresampler_amd.h"
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* errors                                                                                                  */
+/* ------------------------------------------------------------------------------------------------------- */
+
+static ClownResamplerAMD_ErrorHandler g_handler = NULL;
+static void *g_handler_user = NULL;
+static __thread int t_last_code = 0;
+static __thread unsigned long t_error_serial = 0;
+static __thread char t_last_message[512];
+
+int cr_fail(int code, const char *format, ...)
+{
+	va_list ap;
+
+	va_start(ap, format);
+	vsnprintf(t_last_message, sizeof(t_last_message), format, ap);
+	va_end(ap);
+	t_last_code = code;
+	++t_error_serial;
+
+	if (g_handler != NULL)
+	{
+		g_handler(code, t_last_message, g_handler_user);
+	}
+	else
+	{
+		fprintf(stderr, "clownresampler_amd: %s\n", t_last_message);
+		fflush(stderr);
+		abort();
+	}
+
+	return code;
+}
+
+unsigned long cr_error_serial(void)
+{
+	return t_error_serial;
+}
+
+int cr_check_hip(int hip_code, const char *what)
+{
+	if (hip_code != 0)
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_HIP, "%s failed: %s (hipError %d)", what, crhip_error_string(hip_code), hip_code);
+	return hip_code;
+}
+
+void ClownResamplerAMD_SetErrorHandler(ClownResamplerAMD_ErrorHandler handler, void *user_data)
+{
+	g_handler = handler;
+	g_handler_user = user_data;
+}
+
+int ClownResamplerAMD_LastErrorCode(void)
+{
+	return t_last_code;
+}
+
+const char *ClownResamplerAMD_LastErrorMessage(void)
+{
+	return t_last_code != 0 ? t_last_message : "";
+}
+
+void ClownResamplerAMD_ClearError(void)
+{
+	t_last_code = 0;
+	t_last_message[0] = '\0';
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* device                                                                                                  */
+/* ------------------------------------------------------------------------------------------------------- */
+
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static int g_device = 0;
+static int g_device_ready = 0;
+static crhip_device_info g_info;
+static ClownResamplerAMD_Plan *g_plans = NULL;
+static cr_workspace g_workspace;
+static int g_workspace_busy = 0;
+static int g_force_generic = 0;
+static pthread_mutex_t g_workspace_lock = PTHREAD_MUTEX_INITIALIZER;
+
+int ClownResamplerAMD_DeviceCount(void)
+{
+	int count = 0;
+
+	if (crhip_device_count(&count) != 0)
+		return 0;
+
+	return count;
+}
+
+static int ensure_device_locked(void)
+{
+	int count = 0;
+	int e;
+
+	if (g_device_ready)
+		return cr_check_hip(crhip_set_device(g_device), "hipSetDevice"); /* the current device is per thread */
+
+	e = crhip_device_count(&count);
+
+	if (e != 0 || count <= 0)
+		return cr_fail(CLOWNRESAMPLER_AMD_ERROR_NO_DEVICE,
+		               "no usable HIP device (%s); this library has no CPU fallback for the resampling path",
+		               e != 0 ? crhip_error_string(e) : "device count is 0");
+
+	if (g_device >= count)
+		return cr_fail(CLOWNRESAMPLER_AMD_ERROR_NO_DEVICE, "device %d selected but only %d present", g_device, count);
+
+	if (cr_check_hip(crhip_set_device(g_device), "hipSetDevice") != 0)
+		return CLOWNRESAMPLER_AMD_ERROR_HIP;
+
+	if (cr_check_hip(crhip_get_device_info(g_device, &g_info), "hipGetDeviceProperties") != 0)
+		return CLOWNRESAMPLER_AMD_ERROR_HIP;
+
+	g_device_ready = 1;
+	return 0;
+}
+
+int cr_ensure_device(void)
+{
+	int r;
+
+	pthread_mutex_lock(&g_lock);
+	r = ensure_device_locked();
+	pthread_mutex_unlock(&g_lock);
+	return r;
+}
+
+const crhip_device_info *cr_device_info(void)
+{
+	return &g_info;
+}
+
+static void release_everything_locked(void)
+{
+	ClownResamplerAMD_Plan *p = g_plans;
+
+	while (p != NULL)
+	{
+		ClownResamplerAMD_Plan *next = p->next;
+
+		if (g_device_ready)
+		{
+			crhip_free(p->d_table);
+			crhip_free(p->d_rows);
+		}
+		cr_poly_free(&p->poly);
+		free(p);
+		p = next;
+	}
+	g_plans = NULL;
+
+	if (g_device_ready)
+	{
+		crhip_free(g_workspace.d_in);
+		crhip_free(g_workspace.d_out);
+		if (g_workspace.stream != NULL)
+			crhip_stream_destroy(g_workspace.stream);
+	}
+	memset(&g_workspace, 0, sizeof(g_workspace));
+}
+
+int ClownResamplerAMD_SetDevice(int ordinal)
+{
+	int r = 0;
+
+	pthread_mutex_lock(&g_lock);
+	if (ordinal != g_device || !g_device_ready)
+	{
+		if (g_device_ready)
+			crhip_set_device(g_device);
+		release_everything_locked(); /* plans and staging belong to the old device */
+		g_device = ordinal;
+		g_device_ready = 0;
+		r = ensure_device_locked();
+	}
+	pthread_mutex_unlock(&g_lock);
+	return r;
+}
+
+int ClownResamplerAMD_GetDevice(void)
+{
+	return g_device;
+}
+
+void ClownResamplerAMD_Shutdown(void)
+{
+	pthread_mutex_lock(&g_lock);
+	if (g_device_ready)
+		crhip_set_device(g_device);
+	release_everything_locked();
+	g_device_ready = 0;
+	pthread_mutex_unlock(&g_lock);
+}
+
+void *ClownResamplerAMD_DeviceAlloc(size_t bytes)
+{
+	void *p = NULL;
+
+	if (cr_ensure_device() != 0)
+		return NULL;
+	if (cr_check_hip(crhip_malloc(&p, bytes != 0 ? bytes : 16), "hipMalloc") != 0)
+		return NULL;
+	return p;
+}
+
+void ClownResamplerAMD_DeviceFree(void *device_pointer)
+{
+	if (device_pointer != NULL && cr_ensure_device() == 0)
+		cr_check_hip(crhip_free(device_pointer), "hipFree");
+}
+
+int ClownResamplerAMD_CopyToDevice(void *device_destination, const void *host_source, size_t bytes)
+{
+	if (cr_ensure_device() != 0)
+		return -1;
+	if (cr_check_hip(crhip_memcpy_h2d(device_destination, host_source, bytes, NULL), "hipMemcpyAsync(H2D)") != 0)
+		return -1;
+	return cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0 ? -1 : 0;
+}
+
+int ClownResamplerAMD_CopyFromDevice(void *host_destination, const void *device_source, size_t bytes)
+{
+	if (cr_ensure_device() != 0)
+		return -1;
+	if (cr_check_hip(crhip_memcpy_d2h(host_destination, device_source, bytes, NULL), "hipMemcpyAsync(D2H)") != 0)
+		return -1;
+	return cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0 ? -1 : 0;
+}
+
+int ClownResamplerAMD_StreamSynchronize(void *hip_stream)
+{
+	if (cr_ensure_device() != 0)
+		return -1;
+	return cr_check_hip(crhip_stream_sync(hip_stream), "hipStreamSynchronize") != 0 ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* plans                                                                                                   */
+/* ------------------------------------------------------------------------------------------------------- */
+
+static uint32_t supported_poly_channels(uint32_t channels)
+{
+	return channels >= 1 && channels <= 8;
+}
+
+/* Launch geometry of k_poly for this plan on the current device. */
+static void plan_geometry(ClownResamplerAMD_Plan *plan)
+{
+	const uint32_t frame_bytes = plan->channels * 2u;
+	const uint32_t rows_bytes = (plan->poly.rows * plan->poly.row_stride * 4u + 15u) & ~15u;
+	uint32_t tile_bytes, cap_frames, per_cu;
+	uint64_t tile;
+
+	crhip_poly_geometry(plan->channels, plan->poly.slots, &plan->threads, &plan->vecs);
+	tile_bytes = plan->vecs * 16u * plan->threads;
+	plan->lds_bytes = rows_bytes + 2u * tile_bytes;
+	plan->specialised = (uint32_t)crhip_poly_has_instance(plan->channels, plan->poly.slots, plan->poly.row_mode);
+
+	if (plan->lds_bytes > (uint32_t)g_info.max_lds_per_block)
+	{
+		plan->use_poly = 0;
+		plan->generic_reason = "polyphase rows + tiles exceed the LDS of one workgroup";
+		return;
+	}
+
+	/* frames the tile image can hold after the (< 16 byte) alignment shift */
+	cap_frames = (tile_bytes - 16u) / frame_bytes;
+
+	if (cap_frames <= plan->poly.slots)
+	{
+		plan->use_poly = 0;
+		plan->generic_reason = "tap window longer than an LDS tile";
+		return;
+	}
+
+	/* largest tile with ((65535 + (tile - 1) * increment) >> 16) + slots <= cap_frames */
+	tile = ((uint64_t)(cap_frames - plan->poly.slots) << 16) / plan->increment + 1u;
+
+	/* 32-bit relative positions and the 24-bit multiplier of the kernel */
+	if (tile > ((1ull << 32) - 65536u) / plan->increment)
+		tile = ((1ull << 32) - 65536u) / plan->increment;
+	if (tile > (1u << 24) - 1u)
+		tile = (1u << 24) - 1u;
+	if (tile >= plan->threads)
+		tile -= tile % plan->threads;
+
+	if (tile == 0)
+	{
+		plan->use_poly = 0;
+		plan->generic_reason = "increment too large for an LDS tile";
+		return;
+	}
+
+	plan->tile_frames = (uint32_t)tile;
+
+	/* persistent grid: as many workgroups as the LDS footprint lets the chip hold at once */
+	per_cu = (160u * 1024u) / plan->lds_bytes;
+	if (per_cu > 2048u / plan->threads)
+		per_cu = 2048u / plan->threads;
+	if (per_cu < 1u)
+		per_cu = 1u;
+	plan->max_blocks = per_cu * (uint32_t)(g_info.compute_units > 0 ? g_info.compute_units : 256);
+}
+
+ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_table_fill fill_table, const void *user,
+                                    unsigned radius, const cr_config *cfg, uint32_t channels, uint64_t increment)
+{
+	ClownResamplerAMD_Plan *plan;
+	int32_t *table = NULL;
+
+	pthread_mutex_lock(&g_lock);
+
+	if (ensure_device_locked() != 0)
+		goto fail;
+
+	for (plan = g_plans; plan != NULL; plan = plan->next)
+	{
+		if (plan->table_hash == table_hash && plan->radius == radius && plan->channels == channels && plan->increment == increment
+		 && plan->device == g_device && memcmp(&plan->cfg, cfg, sizeof(*cfg)) == 0)
+		{
+			pthread_mutex_unlock(&g_lock);
+			return plan;
+		}
+	}
+
+	if (channels == 0 || channels > CRHIP_MAX_CHANNELS)
+	{
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "channel count %u outside 1..%d (CLOWNRESAMPLER_MAXIMUM_CHANNELS)", channels, CRHIP_MAX_CHANNELS);
+		goto fail;
+	}
+
+	if (increment == 0 || increment >= 0xFFFFFFFFull)
+	{
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "increment %llu is not a valid 16.16 ratio (state not initialised?)", (unsigned long long)increment);
+		goto fail;
+	}
+
+	table = (int32_t *)malloc(table_len * sizeof(int32_t));
+	plan = (ClownResamplerAMD_Plan *)calloc(1, sizeof(*plan));
+
+	if (table == NULL || plan == NULL)
+	{
+		free(plan);
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
+		goto fail;
+	}
+
+	if (fill_table(user, table, table_len) != 0)
+	{
+		free(plan);
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "a Lanczos table entry does not fit 32 bits");
+		goto fail;
+	}
+
+	plan->table_hash = table_hash;
+	plan->radius = radius;
+	plan->cfg = *cfg;
+	plan->channels = channels;
+	plan->increment = increment;
+	plan->device = g_device;
+	plan->table_len = (uint32_t)table_len;
+
+	if (cr_poly_build(table, table_len, cfg, &plan->poly) != 0)
+	{
+		/* the reference itself would trap or read outside its table with this configuration */
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "unusable configuration: %s", plan->poly.reason);
+		free(plan);
+		goto fail;
+	}
+
+	plan->use_poly = plan->poly.eligible && plan->poly.weights != NULL;
+	plan->generic_reason = plan->poly.reason;
+
+	if (plan->use_poly && !supported_poly_channels(channels))
+	{
+		plan->use_poly = 0;
+		plan->generic_reason = "no polyphase kernel instance for this channel count";
+	}
+
+	if (plan->use_poly && increment >= (1u << 24))
+	{
+		plan->use_poly = 0;
+		plan->generic_reason = "increment does not fit the 24-bit multiplier";
+	}
+
+	if (plan->use_poly)
+		plan_geometry(plan);
+
+	if (cr_check_hip(crhip_malloc((void **)&plan->d_table, table_len * sizeof(int32_t)), "hipMalloc(table)") != 0
+	 || cr_check_hip(crhip_memcpy_h2d(plan->d_table, table, table_len * sizeof(int32_t), NULL), "hipMemcpy(table)") != 0)
+		goto fail_plan;
+
+	if (plan->use_poly)
+	{
+		const size_t bytes = ((size_t)plan->poly.rows * plan->poly.row_stride * 4u + 15u) & ~(size_t)15u;
+		/* the kernel stages whole 16-byte vectors: the device copy is padded to that */
+		if (cr_check_hip(crhip_malloc((void **)&plan->d_rows, bytes), "hipMalloc(rows)") != 0
+		 || cr_check_hip(crhip_memset(plan->d_rows, 0, bytes, NULL), "hipMemset(rows)") != 0
+		 || cr_check_hip(crhip_memcpy_h2d(plan->d_rows, plan->poly.weights, (size_t)plan->poly.rows * plan->poly.row_stride * 4u, NULL), "hipMemcpy(rows)") != 0)
+			goto fail_plan;
+	}
+
+	if (cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
+		goto fail_plan;
+
+	free(table);
+	plan->next = g_plans;
+	g_plans = plan;
+	pthread_mutex_unlock(&g_lock);
+	return plan;
+
+fail_plan:
+	crhip_free(plan->d_table);
+	crhip_free(plan->d_rows);
+	cr_poly_free(&plan->poly);
+	free(plan);
+fail:
+	free(table);
+	pthread_mutex_unlock(&g_lock);
+	return NULL;
+}
+
+int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_t in_valid_bytes, void *d_out,
+                   uint64_t pos_int, uint64_t pos_frac, uint64_t n_out, void *stream)
+{
+	if (n_out == 0)
+		return 0;
+
+	if (plan->use_poly && !g_force_generic && pos_int < (1ull << 47) && n_out < (1ull << 40))
+	{
+		crhip_poly_launch l;
+		uint64_t per_block, blocks;
+		const uint64_t min_per_block = 4u * plan->threads;
+
+		memset(&l, 0, sizeof(l));
+		l.d_in = d_in;
+		l.in_valid_bytes = in_valid_bytes;
+		l.d_out = d_out;
+		l.d_rows = plan->d_rows;
+		l.pos0 = (pos_int << 16) + pos_frac;
+		l.n_out = n_out;
+		l.increment = (uint32_t)plan->increment;
+		l.channels = plan->channels;
+		l.slots = plan->poly.slots;
+		l.first_slot = plan->poly.first_slot;
+		l.rows = plan->poly.rows;
+		l.row_stride = plan->poly.row_stride;
+		l.row_mode = plan->poly.row_mode;
+		l.norm_mode = plan->poly.norm_mode;
+		l.delta = plan->poly.delta;
+		l.skr = plan->poly.skr;
+		l.step = plan->poly.step;
+		l.aff_a = plan->poly.aff_a;
+		l.aff_b = plan->poly.aff_b;
+		l.aff_c = plan->poly.aff_c;
+		l.threads = plan->threads;
+		l.vecs = plan->vecs;
+		l.tile_frames = plan->tile_frames;
+		l.lds_bytes = plan->lds_bytes;
+		l.specialised = plan->specialised;
+
+		/* contiguous, equal blocks of output frames, multiples of 64 so that every workgroup's stores start on a
+		   line boundary; small launches use fewer workgroups rather than starving each of work */
+		per_block = (n_out + plan->max_blocks - 1) / plan->max_blocks;
+		if (per_block < min_per_block)
+			per_block = min_per_block;
+		per_block = (per_block + 63u) & ~(uint64_t)63u;
+		blocks = (n_out + per_block - 1) / per_block;
+		l.frames_per_block = per_block;
+		l.blocks = (uint32_t)blocks;
+
+		return cr_check_hip(crhip_launch_poly(&l, stream), "k_poly launch");
+	}
+	else
+	{
+		crhip_generic_launch g;
+
+		memset(&g, 0, sizeof(g));
+		g.d_in = d_in;
+		g.d_out = d_out;
+		g.d_table = plan->d_table;
+		g.d_acc_in = NULL;
+		g.pos_int = pos_int;
+		g.pos_frac = pos_frac;
+		g.increment = plan->increment;
+		g.n_out = n_out;
+		g.skr = plan->cfg.skr;
+		g.radius_frames = plan->cfg.radius_frames;
+		g.delta = plan->cfg.delta;
+		g.step = plan->cfg.step;
+		g.table_len = plan->table_len;
+		g.channels = plan->channels;
+		g.out64 = 0;
+
+		return cr_check_hip(crhip_launch_generic(&g, stream), "k_generic launch");
+	}
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* staging workspace + host-buffer runs                                                                    */
+/* ------------------------------------------------------------------------------------------------------- */
+
+static int grow(unsigned char **p, size_t *have, size_t want)
+{
+	if (*have >= want)
+		return 0;
+
+	/* grow-only, with headroom so a stream of slightly different call sizes does not reallocate every time */
+	want += want / 4 + 4096;
+
+	if (*p != NULL)
+		crhip_free(*p);
+	*p = NULL;
+	*have = 0;
+
+	if (cr_check_hip(crhip_malloc((void **)p, want), "hipMalloc(staging)") != 0)
+		return -1;
+
+	*have = want;
+	return 0;
+}
+
+cr_workspace *cr_workspace_acquire(size_t in_bytes, size_t out_bytes)
+{
+	if (cr_ensure_device() != 0)
+		return NULL;
+
+	pthread_mutex_lock(&g_workspace_lock);
+	g_workspace_busy = 1;
+
+	if (g_workspace.stream == NULL && cr_check_hip(crhip_stream_create(&g_workspace.stream), "hipStreamCreate") != 0)
+		goto fail;
+
+	if (grow(&g_workspace.d_in, &g_workspace.d_in_bytes, in_bytes + 64) != 0 || grow(&g_workspace.d_out, &g_workspace.d_out_bytes, out_bytes + 64) != 0)
+		goto fail;
+
+	return &g_workspace;
+
+fail:
+	g_workspace_busy = 0;
+	pthread_mutex_unlock(&g_workspace_lock);
+	return NULL;
+}
+
+void cr_workspace_release(cr_workspace *ws)
+{
+	(void)ws;
+	g_workspace_busy = 0;
+	pthread_mutex_unlock(&g_workspace_lock);
+}
+
+int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint64_t in_frames, uint64_t pos_int,
+                uint64_t pos_frac, uint64_t n_out, int32_t *host_out)
+{
+	/* bounded batches keep the staging buffers small whatever the stream length */
+	const uint64_t batch_frames = 4u << 20;
+	const size_t frame_in = (size_t)plan->channels * sizeof(int16_t);
+	const size_t frame_out = (size_t)plan->channels * sizeof(int32_t);
+	uint64_t done = 0;
+
+	while (done < n_out)
+	{
+		const uint64_t n = n_out - done < batch_frames ? n_out - done : batch_frames;
+		uint64_t pi = pos_int, pf = pos_frac, extent;
+		cr_workspace *ws;
+		int bad;
+
+		cr_advance(&pi, &pf, plan->increment, done);
+
+		/* padded-buffer frames [pi, pi + extent) cover everything this batch reads (clownresampler.h:995-996) */
+		extent = cr_input_extent(&plan->cfg, 0, pf, plan->increment, n);
+		if (pi >= in_frames)
+			extent = 0;
+		else if (extent > in_frames - pi)
+			extent = in_frames - pi;
+
+		ws = cr_workspace_acquire((size_t)extent * frame_in, (size_t)n * frame_out);
+		if (ws == NULL)
+			return -1;
+
+		bad = cr_check_hip(crhip_memcpy_h2d(ws->d_in, host_in + pi * plan->channels, (size_t)extent * frame_in, ws->stream), "hipMemcpyAsync(H2D)") != 0
+		   || cr_plan_launch(plan, ws->d_in, extent * frame_in, ws->d_out, 0, pf, n, ws->stream) != 0
+		   || cr_check_hip(crhip_memcpy_d2h(host_out + done * plan->channels, ws->d_out, (size_t)n * frame_out, ws->stream), "hipMemcpyAsync(D2H)") != 0
+		   || cr_check_hip(crhip_stream_sync(ws->stream), "hipStreamSynchronize") != 0;
+
+		cr_workspace_release(ws);
+
+		if (bad)
+			return -1;
+
+		done += n;
+	}
+
+	return 0;
+}
+
+int cr_run_single_frame(const ClownResamplerAMD_Plan *plan, const int16_t *host_window, uint64_t window_frames,
+                        uint64_t pos_frac, const int64_t *acc_in, int64_t *acc_out)
+{
+	const size_t in_bytes = (size_t)window_frames * plan->channels * sizeof(int16_t);
+	const size_t acc_bytes = (size_t)plan->channels * sizeof(int64_t);
+	cr_workspace *ws = cr_workspace_acquire(in_bytes, 2 * acc_bytes);
+	crhip_generic_launch g;
+	int bad;
+
+	if (ws == NULL)
+		return -1;
+
+	memset(&g, 0, sizeof(g));
+	g.d_in = ws->d_in;
+	g.d_out = ws->d_out;
+	g.d_table = plan->d_table;
+	g.d_acc_in = (const int64_t *)(ws->d_out + acc_bytes);
+	g.pos_int = 0;
+	g.pos_frac = pos_frac;
+	g.increment = plan->increment;
+	g.n_out = 1;
+	g.skr = plan->cfg.skr;
+	g.radius_frames = plan->cfg.radius_frames;
+	g.delta = plan->cfg.delta;
+	g.step = plan->cfg.step;
+	g.table_len = plan->table_len;
+	g.channels = plan->channels;
+	g.out64 = 1;
+
+	bad = cr_check_hip(crhip_memcpy_h2d(ws->d_in, host_window, in_bytes, ws->stream), "hipMemcpyAsync(H2D)") != 0
+	   || cr_check_hip(crhip_memcpy_h2d(ws->d_out + acc_bytes, acc_in, acc_bytes, ws->stream), "hipMemcpyAsync(H2D)") != 0
+	   || cr_check_hip(crhip_launch_generic(&g, ws->stream), "k_generic launch") != 0
+	   || cr_check_hip(crhip_memcpy_d2h(acc_out, ws->d_out, acc_bytes, ws->stream), "hipMemcpyAsync(D2H)") != 0
+	   || cr_check_hip(crhip_stream_sync(ws->stream), "hipStreamSynchronize") != 0;
+
+	cr_workspace_release(ws);
+	return bad ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* plan introspection and debug switches (public, radius-independent)                                                         */
+/* ------------------------------------------------------------------------------------------------------- */
+
+void ClownResamplerAMD_PlanGetInfo(const ClownResamplerAMD_Plan *plan, ClownResamplerAMD_PlanInfo *info)
+{
+	memset(info, 0, sizeof(*info));
+	info->kernel = plan->use_poly ? 1u : 0u;
+	info->channels = plan->channels;
+	info->slots = plan->poly.slots;
+	info->first_slot = plan->poly.first_slot;
+	info->rows = plan->poly.rows;
+	info->row_stride = plan->poly.row_stride;
+	info->row_mode = plan->poly.row_mode;
+	info->threads = plan->threads;
+	info->tile_frames = plan->tile_frames;
+	info->lds_bytes = plan->lds_bytes;
+	info->max_blocks = plan->max_blocks;
+	info->specialised = plan->specialised;
+}
+
+const int32_t *ClownResamplerAMD_PlanRows(const ClownResamplerAMD_Plan *plan)
+{
+	return plan->poly.weights;
+}
+
+uint32_t ClownResamplerAMD_PlanRowOf(const ClownResamplerAMD_Plan *plan, uint32_t position_fractional)
+{
+	return cr_poly_row_of(&plan->poly, position_fractional & 0xFFFFu);
+}
+
+void ClownResamplerAMD_DebugForceGenericKernel(int on)
+{
+	g_force_generic = on != 0;
+}

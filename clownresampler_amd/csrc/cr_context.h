@@ -1,0 +1,88 @@
+/*
+ * cr_context.h - process-wide GPU context of libclownresampler_amd.so: error reporting, device selection,
+ * the plan cache and the staging workspace used by the host-buffer entry points.  Radius-independent; the
+ * per-radius API instances (cr_api.c) sit on top.  Internal.
+ */
+#ifndef CR_CONTEXT_H
+#define CR_CONTEXT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "cr_plan.h"
+#include "crhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Reports through the installed error handler (default: print + abort).  Returns `code`. */
+int cr_fail(int code, const char *format, ...);
+/* Number of cr_fail calls made on this thread so far. */
+unsigned long cr_error_serial(void);
+/* cr_fail(CLOWNRESAMPLER_AMD_ERROR_HIP, ...) when hip_code != 0; returns hip_code. */
+int cr_check_hip(int hip_code, const char *what);
+
+/* Makes sure a device is selected and its properties are known.  0 on success. */
+int cr_ensure_device(void);
+const crhip_device_info *cr_device_info(void);
+
+/* The plan object behind the public opaque ClownResamplerAMD_Plan. */
+typedef struct ClownResamplerAMD_Plan
+{
+	struct ClownResamplerAMD_Plan *next;
+	/* key */
+	uint64_t table_hash;
+	unsigned radius;
+	cr_config cfg;
+	uint32_t channels;
+	uint64_t increment;
+	int device;
+	/* contents */
+	uint32_t table_len;
+	int32_t *d_table;       /* caller's table as int32 (generic kernel) */
+	cr_poly poly;           /* host copy of the rows + row-index form */
+	int use_poly;
+	const char *generic_reason;
+	int32_t *d_rows;
+	uint32_t threads, vecs, tile_frames, lds_bytes, max_blocks, specialised;
+} ClownResamplerAMD_Plan;
+
+/* Cache lookup by (hash of the caller's raw table bytes, radius, configuration, channels, increment); on a miss
+   `fill_table(user, dst)` is asked to write the table as int32 and the plan is built and uploaded.
+   NULL after cr_fail. */
+typedef int (*cr_table_fill)(const void *user, int32_t *dst, size_t count);
+ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_table_fill fill_table, const void *user,
+                                    unsigned radius, const cr_config *cfg, uint32_t channels, uint64_t increment);
+
+/* Enqueues the computation of output frames [0, n_out) starting at (pos_int, pos_frac) on `stream`. 0 on success. */
+int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_t in_valid_bytes, void *d_out,
+                   uint64_t pos_int, uint64_t pos_frac, uint64_t n_out, void *stream);
+
+/* Staging workspace for the host-buffer entry points: one per process, handed out under a lock. */
+typedef struct cr_workspace
+{
+	void *stream;
+	unsigned char *d_in;
+	size_t d_in_bytes;
+	unsigned char *d_out;
+	size_t d_out_bytes;
+} cr_workspace;
+
+cr_workspace *cr_workspace_acquire(size_t in_bytes, size_t out_bytes); /* NULL after cr_fail */
+void cr_workspace_release(cr_workspace *ws);
+
+/* Computes output frames [0, n_out) from HOST input into a HOST int32 buffer: uploads the input window, launches,
+   downloads, synchronises.  `host_in` points at padded-buffer frame 0 and in_frames frames are readable. 0 on success. */
+int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint64_t in_frames, uint64_t pos_int,
+                uint64_t pos_frac, uint64_t n_out, int32_t *host_out);
+
+/* One frame with incoming accumulators, 64-bit results (ClownResampler_LowestLevel_Resample). 0 on success. */
+int cr_run_single_frame(const ClownResamplerAMD_Plan *plan, const int16_t *host_window, uint64_t window_frames,
+                        uint64_t pos_frac, const int64_t *acc_in, int64_t *acc_out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CR_CONTEXT_H */

@@ -1,0 +1,444 @@
+/*
+ * cr_plan.c - host-side planning for the GPU hot path.  Pure C, no HIP.
+ *
+ * 1. Closed forms of the reference's output-timeline walk (clownresampler.h:1058-1092): how many frames a call
+ *    emits, where the position is after n frames, how much input n frames can touch.  The GPU computes frame j
+ *    directly at position P0 + j * increment, so the host needs these to size launches and to leave the caller's
+ *    state exactly as the reference's frame-by-frame loop would.
+ *
+ * 2. Polyphase rows.  For a fixed configuration the taps of an output frame depend only on its 16-bit fractional
+ *    position: the reference derives (min_relative, max_relative, kernel_start) from it (clownresampler.h:993-1001)
+ *    and then walks the Lanczos table with stride kernel_step_size (:1008).  cr_poly_build() performs that walk
+ *    once per distinct (min_relative, max_relative, kernel_start) on the host and stores, per such "phase row",
+ *    the weights laid out on a COMMON window of `slots` consecutive input frames starting `first_slot` frames
+ *    after position_integer (zero where the phase has no tap: a zero weight contributes exactly 0 to every
+ *    truncated product and to the weight sum), followed by the exact 17.15 reciprocal 0x80000000 / sum (:1025).
+ *    Window columns that are zero in every row are trimmed (e.g. for pure upsampling the reference's sixth tap
+ *    only exists at fraction 0 and lands on table[0] == 0, so 5 slots suffice).
+ *    The device then needs one row index per frame instead of a strided table walk and an integer divide.
+ *
+ *    Row index, two forms (the device mirrors are in cr_kernels.hip row_of<>):
+ *      UPSAMPLE  delta == 0 && step == 1024:  row = (65536 - frac) >> 6          (1025 rows)
+ *      AFFINE    otherwise:                    row = kernel_start + A*min_relative + B*max_relative + C
+ *                min_relative and max_relative each take at most two consecutive values and change at most once
+ *                as frac grows, so at most three (min,max) combinations occur and an affine function of the two
+ *                can give each combination its own contiguous block of rows.
+ *    Whatever the form, the builder walks ALL 65536 fractions and checks that every one maps to a row whose
+ *    contents equal what the reference's definition gives for that fraction.
+ *
+ *    The fast kernel is 32-bit; `eligible` records whether its preconditions hold for this table/configuration:
+ *    |weight| < 2^23, 0 < reciprocal < 2^23, |accumulator| < 2^23 and |accumulator * reciprocal| < 2^31 (signed
+ *    normalisation) or < 2^32 (magnitude normalisation, norm_mode), with |accumulator| bounded by
+ *    sum(|weight|)/2 + slots (|sample| <= 32768, each term truncated).
+ */
+#include "cr_plan.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "crhip.h"
+
+#define FRAC_ONE 65536u
+
+void cr_phase_of(const cr_config *cfg, uint32_t frac, cr_phase *out)
+{
+	/* reference clownresampler.h:993-994, :1001, :1008 (tap count = number of loop iterations) */
+	const uint64_t first_rel = ((uint64_t)frac + cfg->delta + (FRAC_ONE - 1)) / FRAC_ONE;
+	const uint64_t last_rel = ((uint64_t)frac + cfg->skr) / FRAC_ONE;
+
+	out->first_rel = (uint32_t)first_rel;
+	out->last_rel = (uint32_t)last_rel;
+	out->taps = (uint32_t)(cfg->radius_frames + last_rel - first_rel);
+	out->table_at = cfg->step * (first_rel * FRAC_ONE - frac) / FRAC_ONE;
+}
+
+uint32_t cr_poly_row_of(const cr_poly *poly, uint32_t frac)
+{
+	if (poly->row_mode == CRHIP_ROWMODE_UPSAMPLE)
+	{
+		return (FRAC_ONE - frac) >> 6;
+	}
+	else
+	{
+		/* must stay in step with row_of<CRHIP_ROWMODE_AFFINE> in cr_kernels.hip (32-bit arithmetic) */
+		const uint32_t mr = (frac + poly->delta + (FRAC_ONE - 1)) >> 16;
+		const uint32_t xr = (frac + poly->skr) >> 16;
+		const uint32_t kstart = (poly->step * ((mr << 16) - frac)) >> 16;
+		return (uint32_t)((int32_t)kstart + poly->aff_a * (int32_t)mr + poly->aff_b * (int32_t)xr + poly->aff_c);
+	}
+}
+
+void cr_poly_free(cr_poly *poly)
+{
+	free(poly->weights);
+	poly->weights = NULL;
+}
+
+static int fail(cr_poly *out, int fatal, const char *reason)
+{
+	out->eligible = 0;
+	out->fatal = fatal;
+	out->reason = reason;
+	return fatal;
+}
+
+typedef struct combo
+{
+	uint32_t mr, xr;
+	uint64_t klo, khi;
+	uint32_t base; /* first row of this combination's block */
+} combo;
+
+int cr_poly_build(const int32_t *table, size_t table_len, const cr_config *cfg, cr_poly *out)
+{
+	combo combos[4];
+	unsigned ncombos = 0;
+	uint32_t frac;
+	uint32_t nz_lo = 0xFFFFFFFFu, nz_hi = 0; /* frame-offset range [nz_lo, nz_hi) holding non-zero weights */
+	uint32_t off_lo = 0xFFFFFFFFu, off_hi = 0; /* frame-offset range holding taps at all */
+	int64_t max_abs_weight = 0;
+
+	memset(out, 0, sizeof(*out));
+	out->reason = "";
+
+	if (cfg->delta >= FRAC_ONE || cfg->skr >= ((uint64_t)1 << 40) || cfg->radius_frames >= ((uint64_t)1 << 24) || cfg->step > 0xFFFFFFFFu)
+		return fail(out, 1, "configuration scalars are not what ClownResampler_LowestLevel_Configure produces");
+
+	/* ---- pass 1: every fraction's tap window; table bounds; row blocks; non-zero window ----
+	   Neighbouring fractions mostly share (min_relative, max_relative, kernel_start); the table walk is only
+	   repeated when that key changes, so the cost is about rows * taps ~ the table size, whatever the stretch. */
+	{
+		cr_phase prev;
+		int have_prev = 0;
+
+		for (frac = 0; frac < FRAC_ONE; ++frac)
+		{
+			cr_phase ph;
+			uint32_t t;
+			unsigned c;
+			int64_t sum = 0;
+
+			cr_phase_of(cfg, frac, &ph);
+
+			if (have_prev && ph.first_rel == prev.first_rel && ph.last_rel == prev.last_rel && ph.table_at == prev.table_at)
+				continue;
+
+			prev = ph;
+			have_prev = 1;
+
+			if (ph.taps == 0 || ph.taps > 0x100000u)
+				return fail(out, 1, "configuration yields an empty tap window (the reference would divide by zero)");
+
+			if (ph.table_at + cfg->step * (uint64_t)(ph.taps - 1) >= table_len)
+				return fail(out, 1, "configuration indexes outside the Lanczos table (the reference asserts, clownresampler.h:1012)");
+
+			for (c = 0; c < ncombos; ++c)
+				if (combos[c].mr == ph.first_rel && combos[c].xr == ph.last_rel)
+					break;
+
+			if (c == ncombos)
+			{
+				if (ncombos == 4)
+					return fail(out, 1, "more than four (min_relative, max_relative) combinations");
+				combos[c].mr = ph.first_rel;
+				combos[c].xr = ph.last_rel;
+				combos[c].klo = combos[c].khi = ph.table_at;
+				++ncombos;
+			}
+			else
+			{
+				if (ph.table_at < combos[c].klo)
+					combos[c].klo = ph.table_at;
+				if (ph.table_at > combos[c].khi)
+					combos[c].khi = ph.table_at;
+			}
+
+			if (ph.first_rel < off_lo)
+				off_lo = ph.first_rel;
+			if (ph.first_rel + ph.taps > off_hi)
+				off_hi = ph.first_rel + ph.taps;
+
+			for (t = 0; t < ph.taps; ++t)
+			{
+				const int64_t w = table[ph.table_at + cfg->step * t];
+				const int64_t aw = w < 0 ? -w : w;
+
+				sum += w;
+
+				if (aw > max_abs_weight)
+					max_abs_weight = aw;
+
+				if (w != 0)
+				{
+					if (ph.first_rel + t < nz_lo)
+						nz_lo = ph.first_rel + t;
+					if (ph.first_rel + t + 1 > nz_hi)
+						nz_hi = ph.first_rel + t + 1;
+				}
+			}
+
+			if (sum == 0)
+				return fail(out, 1, "a phase has weight sum 0 (the reference divides by zero, clownresampler.h:1025)");
+		}
+	}
+
+	/* from here on a failure only means "use the generic kernel".  The device's 32-bit row-index arithmetic needs
+	   small scalars; the reference accepts stretches up to 4096 (clownresampler.h:974), far beyond any LDS window */
+	if (cfg->skr >= (1u << 28) || cfg->step > 1024u || cfg->radius_frames > 4096u)
+		return fail(out, 0, "configuration outside the fast kernel's 32-bit index range");
+
+	if (nz_lo >= nz_hi) /* cannot happen once every sum is non-zero, but keep the window sane */
+	{
+		nz_lo = off_lo;
+		nz_hi = off_hi;
+	}
+
+	out->first_slot = nz_lo;
+	out->slots = nz_hi - nz_lo;
+	out->row_stride = (out->slots + 1u + 3u) & ~3u;
+	out->delta = (uint32_t)cfg->delta;
+	out->skr = (uint32_t)cfg->skr;
+	out->step = (uint32_t)cfg->step;
+
+	/* ---- row-index form ---- */
+	if (cfg->delta == 0 && cfg->step == 1024u)
+	{
+		out->row_mode = CRHIP_ROWMODE_UPSAMPLE;
+		out->rows = (FRAC_ONE >> 6) + 1u;
+	}
+	else
+	{
+		/* combinations were met in order of increasing frac; each gets a contiguous block of rows */
+		unsigned c;
+		uint32_t next = 0;
+		int64_t off[4];
+		int64_t a = 0, b = 0, cc;
+
+		if (ncombos > 3)
+			return fail(out, 0, "four (min_relative, max_relative) combinations: not affine");
+
+		for (c = 0; c < ncombos; ++c)
+		{
+			combos[c].base = next;
+			next += (uint32_t)(combos[c].khi - combos[c].klo + 1);
+			off[c] = (int64_t)combos[c].base - (int64_t)combos[c].klo;
+		}
+
+		for (c = 1; c < ncombos; ++c)
+		{
+			const int dm = (int)combos[c].mr - (int)combos[c - 1].mr;
+			const int dx = (int)combos[c].xr - (int)combos[c - 1].xr;
+			const int64_t d = off[c] - off[c - 1];
+
+			if (dm == 1 && dx == 0)
+				a = d;
+			else if (dm == 0 && dx == 1)
+				b = d;
+			else if (dm == 1 && dx == 1)
+				a = d; /* both step together: either coefficient can carry the difference */
+			else
+				return fail(out, 0, "unexpected (min_relative, max_relative) sequence");
+		}
+
+		cc = off[0] - a * combos[0].mr - b * combos[0].xr;
+
+		if (a < -0x7FFFFFFF || a > 0x7FFFFFFF || b < -0x7FFFFFFF || b > 0x7FFFFFFF || cc < -0x7FFFFFFF || cc > 0x7FFFFFFF)
+			return fail(out, 0, "row-index coefficients out of range");
+
+		out->row_mode = CRHIP_ROWMODE_AFFINE;
+		out->aff_a = (int32_t)a;
+		out->aff_b = (int32_t)b;
+		out->aff_c = (int32_t)cc;
+		out->rows = next;
+	}
+
+	if ((uint64_t)out->rows * out->row_stride > (1u << 24))
+		return fail(out, 0, "polyphase table too large");
+
+	/* ---- pass 2: fill and cross-check the rows ---- */
+	{
+		const size_t row_ints = out->row_stride;
+		unsigned char *filled = (unsigned char *)calloc(out->rows, 1);
+		int32_t *scratch = (int32_t *)malloc(row_ints * sizeof(int32_t));
+		int ok = 1;
+		int eligible = 1;
+		const char *why = "";
+
+		out->weights = (int32_t *)calloc((size_t)out->rows * row_ints, sizeof(int32_t));
+
+		if (filled == NULL || scratch == NULL || out->weights == NULL)
+		{
+			free(filled);
+			free(scratch);
+			cr_poly_free(out);
+			return fail(out, 1, "out of host memory");
+		}
+
+		if (max_abs_weight >= (1 << 23))
+		{
+			eligible = 0;
+			why = "a table weight does not fit 24 bits";
+		}
+
+		{
+		cr_phase prev;
+		uint32_t prev_row = 0;
+		int have_prev = 0;
+
+		for (frac = 0; frac < FRAC_ONE && ok; ++frac)
+		{
+			cr_phase ph;
+			uint32_t t, row;
+			int64_t sum = 0, abs_sum = 0, recip, acc_bound;
+
+			cr_phase_of(cfg, frac, &ph);
+			row = cr_poly_row_of(out, frac);
+
+			if (row >= out->rows)
+			{
+				ok = 0;
+				break;
+			}
+
+			/* same taps as the previous fraction: it must land on the same row, whose contents were checked then */
+			if (have_prev && ph.first_rel == prev.first_rel && ph.last_rel == prev.last_rel && ph.table_at == prev.table_at)
+			{
+				if (row != prev_row)
+					ok = 0;
+				continue;
+			}
+
+			prev = ph;
+			prev_row = row;
+			have_prev = 1;
+
+			memset(scratch, 0, row_ints * sizeof(int32_t));
+
+			for (t = 0; t < ph.taps; ++t)
+			{
+				const int64_t w = table[ph.table_at + cfg->step * t];
+				const uint32_t offset = ph.first_rel + t;
+
+				sum += w;
+				abs_sum += w < 0 ? -w : w;
+
+				if (w != 0)
+				{
+					if (offset < out->first_slot || offset - out->first_slot >= out->slots)
+					{
+						ok = 0;
+						break;
+					}
+					scratch[offset - out->first_slot] = (int32_t)w;
+				}
+			}
+
+			if (!ok)
+				break;
+
+			/* (cc_s32f)0x80000000 / sum with the reference's LP64 types: signed 64-bit, truncating (:1025) */
+			recip = (int64_t)2147483648ll / sum;
+			acc_bound = abs_sum / 2 + out->slots;
+
+			if (recip <= 0 || recip >= (1 << 23))
+			{
+				eligible = 0;
+				why = "a reciprocal is not a positive 23-bit number";
+				recip = 0;
+			}
+			else if (acc_bound >= (1 << 23) || acc_bound * recip >= 4294967296ll)
+			{
+				eligible = 0;
+				why = "accumulator * reciprocal may exceed 32 bits";
+			}
+			else if (acc_bound * recip >= 2147483648ll)
+			{
+				out->norm_mode = CRHIP_NORM_U32; /* e.g. the 8-lobe table: sum|w| can exceed 2 * sum(w) in a row */
+			}
+
+			scratch[out->slots] = (int32_t)recip;
+
+			if (!filled[row])
+			{
+				memcpy(out->weights + (size_t)row * row_ints, scratch, row_ints * sizeof(int32_t));
+				filled[row] = 1;
+			}
+			else if (memcmp(out->weights + (size_t)row * row_ints, scratch, row_ints * sizeof(int32_t)) != 0)
+			{
+				ok = 0; /* two fractions with different taps share a row: the index form does not fit */
+			}
+		}
+		}
+
+		free(filled);
+		free(scratch);
+
+		if (!ok)
+		{
+			cr_poly_free(out);
+			return fail(out, 0, "row index form does not separate the phases");
+		}
+
+		out->eligible = eligible;
+		out->reason = why;
+	}
+
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+
+uint64_t cr_count_output_frames(uint64_t pos_int, uint64_t pos_frac, uint64_t increment, uint64_t total_input_frames)
+{
+	/* frames are emitted while position_integer < total (clownresampler.h:1063), i.e. while
+	   P0 + j * increment < total * 65536 with P0 = pos_int * 65536 + pos_frac */
+	const unsigned __int128 start = (unsigned __int128)pos_int * FRAC_ONE + pos_frac;
+	const unsigned __int128 limit = (unsigned __int128)total_input_frames * FRAC_ONE;
+
+	if (start >= limit || increment == 0)
+		return 0;
+
+	return (uint64_t)((limit - start + increment - 1) / increment);
+}
+
+void cr_advance(uint64_t *pos_int, uint64_t *pos_frac, uint64_t increment, uint64_t frames)
+{
+	/* clownresampler.h:1076-1078 applied `frames` times */
+	const unsigned __int128 fr = (unsigned __int128)*pos_frac + (unsigned __int128)increment * frames;
+
+	*pos_int += (uint64_t)(fr / FRAC_ONE);
+	*pos_frac = (uint64_t)(fr % FRAC_ONE);
+}
+
+uint64_t cr_input_extent(const cr_config *cfg, uint64_t pos_int, uint64_t pos_frac, uint64_t increment, uint64_t frames)
+{
+	/* the last frame's window ends at position_integer + radius_frames + max_relative (clownresampler.h:996),
+	   max_relative <= radius_frames (:1004) */
+	uint64_t pi = pos_int, pf = pos_frac;
+
+	if (frames == 0)
+		return 0;
+
+	cr_advance(&pi, &pf, increment, frames - 1);
+	return pi + 2 * cfg->radius_frames;
+}
+
+uint64_t cr_hash_bytes(const void *data, size_t bytes, uint64_t seed)
+{
+	/* FNV-1a over 8-byte words (tail bytewise); only used as a cache key */
+	const unsigned char *p = (const unsigned char *)data;
+	uint64_t h = seed ^ 1469598103934665603ull;
+	size_t i = 0;
+
+	for (; i + 8 <= bytes; i += 8)
+	{
+		uint64_t w;
+		memcpy(&w, p + i, 8);
+		h = (h ^ w) * 1099511628211ull;
+	}
+
+	for (; i < bytes; ++i)
+		h = (h ^ p[i]) * 1099511628211ull;
+
+	return h;
+}

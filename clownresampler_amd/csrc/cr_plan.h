@@ -1,0 +1,75 @@
+/*
+ * cr_plan.h - host-side planning for the GPU hot path (pure C, no HIP): closed forms of the output-timeline
+ * walk, and the re-indexing of the caller's Lanczos table into polyphase rows for k_poly (cr_kernels.hip).
+ * Internal to libclownresampler_amd.so.
+ */
+#ifndef CR_PLAN_H
+#define CR_PLAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The four scalars of ClownResampler_LowestLevel_Configuration (reference clownresampler.h:632-638) as fixed-width integers. */
+typedef struct cr_config
+{
+	uint64_t skr;           /* stretched_kernel_radius, 16.16 */
+	uint64_t radius_frames; /* integer_stretched_kernel_radius */
+	uint64_t delta;         /* stretched_kernel_radius_delta, 16.16 */
+	uint64_t step;          /* kernel_step_size */
+} cr_config;
+
+/* Tap window of one fractional position (reference clownresampler.h:993-1001). */
+typedef struct cr_phase
+{
+	uint32_t first_rel;     /* min_relative: first tap's frame offset from position_integer (padded-buffer frames) */
+	uint32_t last_rel;      /* max_relative */
+	uint32_t taps;          /* radius_frames + last_rel - first_rel */
+	uint64_t table_at;      /* kernel_start */
+} cr_phase;
+
+void cr_phase_of(const cr_config *cfg, uint32_t frac, cr_phase *out);
+
+typedef struct cr_poly
+{
+	int eligible;           /* 1: k_poly may be used */
+	const char *reason;     /* why not, when eligible == 0 (static string) */
+	int fatal;              /* 1: the reference itself would trap / read outside the table for some phase */
+
+	uint32_t slots;         /* taps evaluated per frame (common window, zero weights included) */
+	uint32_t first_slot;    /* frame offset of slot 0 from position_integer */
+	uint32_t rows;
+	uint32_t row_stride;    /* int32 per row: [slots weights][reciprocal][zero padding], multiple of 4 */
+	uint32_t row_mode;      /* CRHIP_ROWMODE_* */
+	int32_t aff_a, aff_b, aff_c;
+	uint32_t delta, skr, step;
+	uint32_t norm_mode;     /* CRHIP_NORM_*: how the kernel may multiply accumulator and reciprocal */
+	int32_t *weights;       /* rows * row_stride, malloc'ed */
+} cr_poly;
+
+/* Builds the polyphase rows for (table, cfg).  Walks all 65536 fractional positions, so every row is checked
+   against the definition for every position that maps to it.  Returns 0 on success (out->eligible says whether
+   the fast kernel's 32-bit preconditions hold), non-zero when out->fatal. */
+int cr_poly_build(const int32_t *table, size_t table_len, const cr_config *cfg, cr_poly *out);
+void cr_poly_free(cr_poly *poly);
+uint32_t cr_poly_row_of(const cr_poly *poly, uint32_t frac);
+
+/* ---- closed forms of the timeline walk (reference clownresampler.h:1058-1092) ---- */
+
+/* frames emitted while position_integer < total_input_frames */
+uint64_t cr_count_output_frames(uint64_t pos_int, uint64_t pos_frac, uint64_t increment, uint64_t total_input_frames);
+/* position after `frames` emitted frames */
+void cr_advance(uint64_t *pos_int, uint64_t *pos_frac, uint64_t increment, uint64_t frames);
+/* number of padded-buffer frames [0, n) that emitting output frames [0, frames) from (pos_int,pos_frac) can read */
+uint64_t cr_input_extent(const cr_config *cfg, uint64_t pos_int, uint64_t pos_frac, uint64_t increment, uint64_t frames);
+
+uint64_t cr_hash_bytes(const void *data, size_t bytes, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CR_PLAN_H */

@@ -1,0 +1,118 @@
+/*
+ * crhip.h - the thin C-ABI between the host code (C: cr_plan.c, cr_context.c, cr_api.c) and the HIP
+ * translation unit (cr_kernels.hip).  Plain pointers, sizes and fixed-width integers only.
+ * Internal to libclownresampler_amd.so; the public surface is include/clownresampler*.h.
+ */
+#ifndef CRHIP_H
+#define CRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRHIP_MAX_CHANNELS 16
+
+/* Row-index formulas (device and host mirror must agree; see cr_plan.c). */
+#define CRHIP_ROWMODE_AFFINE 0   /* row = ((step * ((mr << 16) - frac)) >> 16) + a*mr + b*xr + c */
+#define CRHIP_ROWMODE_UPSAMPLE 1 /* row = (65536 - frac) >> 6          (delta == 0, step == 1024) */
+
+/* Final normalisation accumulator * reciprocal / 32768 (reference clownresampler.h:1033), by proven product range. */
+#define CRHIP_NORM_S31 0         /* |acc * reciprocal| < 2^31: signed 24-bit multiply, signed truncating shift */
+#define CRHIP_NORM_U32 1         /* |acc| * reciprocal < 2^32: multiply magnitudes unsigned, shift, restore the sign */
+
+/* One launch of the polyphase/LDS kernel: output frames [0, n_out) of a timeline whose frame 0 sits at the
+   16.16 position pos0 relative to frame 0 of d_in (the start of the left padding). */
+typedef struct crhip_poly_launch
+{
+	const void *d_in;           /* interleaved int16 */
+	uint64_t in_valid_bytes;    /* bytes readable from d_in (loads beyond are suppressed by the buffer descriptor) */
+	void *d_out;                /* int32, n_out * channels */
+	const int32_t *d_rows;      /* rows * row_stride int32: [slots weights][17.15 reciprocal][padding] */
+	uint64_t pos0;              /* 16.16 */
+	uint64_t n_out;
+	uint64_t frames_per_block;  /* contiguous output frames owned by one workgroup */
+	uint32_t increment;         /* 16.16, < 2^24 */
+	uint32_t channels;
+	uint32_t slots;             /* taps evaluated per frame */
+	uint32_t first_slot;        /* frame offset of slot 0 relative to the integer position */
+	uint32_t rows;
+	uint32_t row_stride;        /* int32 per row, multiple of 4 */
+	uint32_t row_mode;
+	uint32_t norm_mode;
+	uint32_t delta;             /* stretched_kernel_radius_delta */
+	uint32_t skr;               /* stretched_kernel_radius */
+	uint32_t step;              /* kernel_step_size */
+	int32_t aff_a, aff_b, aff_c;
+	uint32_t threads;           /* workgroup size the instance was compiled for */
+	uint32_t vecs;              /* 16-byte input vectors per thread per tile (template NV) */
+	uint32_t tile_frames;       /* output frames per tile */
+	uint32_t lds_bytes;
+	uint32_t blocks;            /* grid size */
+	uint32_t specialised;       /* use the (channels, slots) template instance if there is one */
+	uint32_t variant;           /* tuning variant of the specialised kernels (0 = default) */
+} crhip_poly_launch;
+
+/* One launch of the generic kernel: the reference arithmetic restated with 64-bit integers, one thread per
+   output frame, weights read from the original table in global memory.  Handles every configuration the
+   reference accepts (any channel count up to 16, any ratio), plus the accumulate-into semantics of
+   ClownResampler_LowestLevel_Resample (reference clownresampler.h:1020,1033). */
+typedef struct crhip_generic_launch
+{
+	const void *d_in;
+	void *d_out;                /* int32 (out64 == 0) or int64 (out64 == 1), n_out * channels */
+	const int32_t *d_table;     /* the caller's Lanczos table repacked to int32 */
+	const int64_t *d_acc_in;    /* optional: channels initial accumulators added to frame 0 (n_out must be 1) */
+	uint64_t pos_int, pos_frac; /* of output frame 0 */
+	uint64_t increment;
+	uint64_t n_out;
+	uint64_t skr, radius_frames, delta, step;
+	uint32_t table_len;
+	uint32_t channels;
+	uint32_t out64;
+} crhip_generic_launch;
+
+typedef struct crhip_device_info
+{
+	int compute_units;
+	int max_lds_per_block;      /* bytes */
+	int wavefront;
+	int clock_khz;
+	size_t total_memory;
+	char name[128];
+	char arch[64];
+} crhip_device_info;
+
+/* Every function returns 0 on success or a hipError_t value; crhip_error_string translates it. */
+const char *crhip_error_string(int code);
+
+int crhip_device_count(int *count);
+int crhip_set_device(int ordinal);
+int crhip_get_device_info(int ordinal, crhip_device_info *info);
+
+int crhip_malloc(void **device_pointer, size_t bytes);
+int crhip_free(void *device_pointer);
+int crhip_host_alloc(void **host_pointer, size_t bytes);   /* pinned */
+int crhip_host_free(void *host_pointer);
+int crhip_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);   /* async on stream */
+int crhip_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);   /* async on stream */
+int crhip_memset(void *dst, int value, size_t bytes, void *stream);
+int crhip_stream_create(void **stream);
+int crhip_stream_destroy(void *stream);
+int crhip_stream_sync(void *stream);
+
+int crhip_launch_poly(const crhip_poly_launch *launch, void *stream);
+int crhip_launch_generic(const crhip_generic_launch *launch, void *stream);
+
+/* 1 when a (channels, slots) template instance exists for the polyphase kernel. */
+int crhip_poly_has_instance(uint32_t channels, uint32_t slots, uint32_t row_mode);
+/* Geometry the polyphase instances are compiled for. */
+void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t *threads, uint32_t *vecs);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CRHIP_H */

@@ -1,0 +1,209 @@
+/*
+ * clownresampler.h - drop-in interface header of clownresampler_amd.
+ *
+ * Same types, same ten functions and same call semantics as Clownacy/clownresampler's
+ * single header, but this file holds DECLARATIONS ONLY: the implementation is
+ * libclownresampler_amd.so, whose per-output-frame windowed-sinc arithmetic
+ * (reference clownresampler.h:986-1035 driven by :1058-1092) runs as hand-written
+ * HIP kernels on an AMD Instinct MI355X (gfx950).  There is no CPU fallback: if no
+ * usable GPU / HIP runtime is present the library reports through the error handler
+ * of clownresampler_amd.h, whose default prints the reason and aborts.
+ *
+ * How a client of the reference switches over (INTEGRATION.md has the details):
+ *   - keep its source unchanged; CLOWNRESAMPLER_IMPLEMENTATION / CLOWNRESAMPLER_STATIC
+ *     are accepted and ignored (the reference's tests and examples define both,
+ *     tests/test-low-level.c:25-28);
+ *   - put this directory first on the include path and link -lclownresampler_amd.
+ *
+ * ABI notes (reference clownresampler.h:480-611, :627-662):
+ *   - the integer typedefs below are the reference's DEFAULT (C89) choice; on LP64
+ *     that makes cc_s32f/cc_s32l 8 bytes, so the output callback receives 8-byte
+ *     samples and ClownResampler_Precomputed is 8 bytes per entry.  The library
+ *     binary is built with exactly these.  CC_USE_C99_INTEGERS changes widths and
+ *     struct layouts; it is honoured only if the library itself is rebuilt with it
+ *     (clownresampler_amd/csrc/Makefile, CRA_CFLAGS) - see the #error below.
+ *   - CLOWNRESAMPLER_KERNEL_RADIUS changes sizeof(ClownResampler_Precomputed) and the
+ *     arithmetic.  The library carries one instance of the API per supported radius;
+ *     for a radius other than the default 3 the function names below are redirected to
+ *     the instance's symbols (ClownResampler_Precompute -> ClownResampler_Precompute_R8 ...).
+ */
+#ifndef CLOWNRESAMPLER_AMD_DROPIN_H
+#define CLOWNRESAMPLER_AMD_DROPIN_H
+
+#include <stddef.h>
+
+/* ---- configuration (reference clownresampler.h:431-472) ---- */
+
+#ifndef CLOWNRESAMPLER_API
+ #define CLOWNRESAMPLER_API /* always external linkage here: the code lives in the shared library */
+#endif
+
+#ifndef CLOWNRESAMPLER_KERNEL_RADIUS
+ #define CLOWNRESAMPLER_KERNEL_RADIUS 3
+#endif
+
+#ifndef CLOWNRESAMPLER_KERNEL_RESOLUTION
+ #define CLOWNRESAMPLER_KERNEL_RESOLUTION 0x400
+#endif
+#if CLOWNRESAMPLER_KERNEL_RESOLUTION != 0x400
+ #error "libclownresampler_amd is built for CLOWNRESAMPLER_KERNEL_RESOLUTION 0x400 (the reference default)"
+#endif
+
+#ifndef CLOWNRESAMPLER_MAXIMUM_CHANNELS
+ #define CLOWNRESAMPLER_MAXIMUM_CHANNELS 16
+#endif
+#if CLOWNRESAMPLER_MAXIMUM_CHANNELS != 16
+ #error "libclownresampler_amd is built for CLOWNRESAMPLER_MAXIMUM_CHANNELS 16 (the reference default)"
+#endif
+
+/* ---- integer types (reference clownresampler.h:480-611) ---- */
+
+#ifndef CC_INTEGERS_DEFINED
+#define CC_INTEGERS_DEFINED
+
+#if defined(CC_USE_C99_INTEGERS) && !defined(CLOWNRESAMPLER_AMD_BUILT_WITH_C99_INTEGERS)
+ #error "CC_USE_C99_INTEGERS changes the ABI; rebuild libclownresampler_amd with CRA_CFLAGS='-DCC_USE_C99_INTEGERS -DCLOWNRESAMPLER_AMD_BUILT_WITH_C99_INTEGERS' and define both here"
+#endif
+
+#if defined(CC_USE_C99_INTEGERS)
+#include <inttypes.h>
+typedef int_least8_t cc_s8l;   typedef int_least16_t cc_s16l;   typedef int_least32_t cc_s32l;
+typedef uint_least8_t cc_u8l;  typedef uint_least16_t cc_u16l;  typedef uint_least32_t cc_u32l;
+typedef int_fast8_t cc_s8f;    typedef int_fast16_t cc_s16f;    typedef int_fast32_t cc_s32f;
+typedef uint_fast8_t cc_u8f;   typedef uint_fast16_t cc_u16f;   typedef uint_fast32_t cc_u32f;
+#define CC_PRIdLEAST32 PRIdLEAST32
+#define CC_PRIuLEAST32 PRIuLEAST32
+#define CC_PRIdFAST32 PRIdFAST32
+#define CC_PRIuFAST32 PRIuFAST32
+#define CC_PRIuFAST8 PRIuFAST8
+#else
+typedef signed char cc_s8l;    typedef signed short cc_s16l;    typedef signed long cc_s32l;
+typedef unsigned char cc_u8l;  typedef unsigned short cc_u16l;  typedef unsigned long cc_u32l;
+typedef signed int cc_s8f;     typedef signed int cc_s16f;      typedef signed long cc_s32f;
+typedef unsigned int cc_u8f;   typedef unsigned int cc_u16f;    typedef unsigned long cc_u32f;
+#define CC_PRIdLEAST32 "%ld"
+#define CC_PRIuLEAST32 "%lu"
+#define CC_PRIdFAST32 "%ld"
+#define CC_PRIuFAST32 "%lu"
+#define CC_PRIuFAST8 "%u"
+#endif
+
+typedef cc_u8l cc_bool;
+enum { cc_false = 0, cc_true = 1 };
+
+#endif /* CC_INTEGERS_DEFINED */
+
+/* ---- fixed-point helpers clients may use (reference clownresampler.h:615-625) ---- */
+
+#define CLOWNRESAMPLER_COUNT_OF(x) (sizeof(x) / sizeof(*(x)))
+#define CLOWNRESAMPLER_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define CLOWNRESAMPLER_MAX(a, b) ((a) > (b) ? (a) : (b))
+#define CLOWNRESAMPLER_CLAMP(min, max, x) (CLOWNRESAMPLER_MAX((min), CLOWNRESAMPLER_MIN((max), (x))))
+#define CLOWNRESAMPLER_FIXED_POINT_FRACTIONAL_SIZE (1L << 16)
+
+/* ---- caller-owned state (reference clownresampler.h:627-662; layouts must match field for field,
+        callers read e.g. lowest_level.integer_stretched_kernel_radius to size their padding) ---- */
+
+typedef struct ClownResampler_Precomputed
+{
+	cc_s32l lanczos_kernel_table[CLOWNRESAMPLER_KERNEL_RADIUS * 2 * CLOWNRESAMPLER_KERNEL_RESOLUTION];
+} ClownResampler_Precomputed;
+
+typedef struct ClownResampler_LowestLevel_Configuration
+{
+	size_t stretched_kernel_radius;         /* 16.16 */
+	size_t integer_stretched_kernel_radius; /* frames of padding needed each side of the input */
+	size_t stretched_kernel_radius_delta;   /* 16.16 */
+	size_t kernel_step_size;
+} ClownResampler_LowestLevel_Configuration;
+
+typedef struct ClownResampler_LowLevel_State
+{
+	ClownResampler_LowestLevel_Configuration lowest_level;
+	cc_u8f channels;
+	size_t position_integer;
+	cc_u32f position_fractional;            /* 16.16 */
+	cc_u32f increment;                      /* 16.16 */
+} ClownResampler_LowLevel_State;
+
+typedef struct ClownResampler_HighLevel_State
+{
+	ClownResampler_LowLevel_State low_level;
+	cc_s16l input_buffer[0x1000];
+	cc_s16l *input_buffer_start;
+	cc_s16l *input_buffer_end;
+	size_t maximum_integer_stretched_kernel_radius;
+	size_t leading_padding_frames_needed, trailing_padding_frames_remaining;
+} ClownResampler_HighLevel_State;
+
+typedef size_t (*ClownResampler_InputCallback)(void *user_data, cc_s16l *buffer, size_t total_frames);
+typedef cc_bool (*ClownResampler_OutputCallback)(void *user_data, const cc_s32f *frame, cc_u8f total_samples);
+
+/* ---- per-radius symbol redirection ---- */
+
+#define CLOWNRESAMPLER_AMD_CAT2(a, b) a##b
+#define CLOWNRESAMPLER_AMD_CAT(a, b) CLOWNRESAMPLER_AMD_CAT2(a, b)
+#define CLOWNRESAMPLER_AMD_SYM(name) CLOWNRESAMPLER_AMD_CAT(CLOWNRESAMPLER_AMD_CAT(name, _R), CLOWNRESAMPLER_KERNEL_RADIUS)
+
+#if CLOWNRESAMPLER_KERNEL_RADIUS != 3
+ #define ClownResampler_Precompute            CLOWNRESAMPLER_AMD_SYM(ClownResampler_Precompute)
+ #define ClownResampler_LowestLevel_Configure CLOWNRESAMPLER_AMD_SYM(ClownResampler_LowestLevel_Configure)
+ #define ClownResampler_LowestLevel_Resample  CLOWNRESAMPLER_AMD_SYM(ClownResampler_LowestLevel_Resample)
+ #define ClownResampler_LowLevel_Init         CLOWNRESAMPLER_AMD_SYM(ClownResampler_LowLevel_Init)
+ #define ClownResampler_LowLevel_Adjust       CLOWNRESAMPLER_AMD_SYM(ClownResampler_LowLevel_Adjust)
+ #define ClownResampler_LowLevel_Resample     CLOWNRESAMPLER_AMD_SYM(ClownResampler_LowLevel_Resample)
+ #define ClownResampler_HighLevel_Init        CLOWNRESAMPLER_AMD_SYM(ClownResampler_HighLevel_Init)
+ #define ClownResampler_HighLevel_Resample    CLOWNRESAMPLER_AMD_SYM(ClownResampler_HighLevel_Resample)
+ #define ClownResampler_HighLevel_Adjust      CLOWNRESAMPLER_AMD_SYM(ClownResampler_HighLevel_Adjust)
+ #define ClownResampler_HighLevel_ResampleEnd CLOWNRESAMPLER_AMD_SYM(ClownResampler_HighLevel_ResampleEnd)
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- common (reference clownresampler.h:682) ---- */
+
+/* Fills the Lanczos table; same values as the reference's (libm sin, truncation toward zero). Host-side. */
+CLOWNRESAMPLER_API void ClownResampler_Precompute(ClownResampler_Precomputed *precomputed);
+
+/* ---- lowest level (reference clownresampler.h:687-688) ---- */
+
+CLOWNRESAMPLER_API cc_bool ClownResampler_LowestLevel_Configure(ClownResampler_LowestLevel_Configuration *configuration, cc_u32f input_sample_rate, cc_u32f output_sample_rate, cc_u32f low_pass_filter_sample_rate);
+
+/* One output frame, ACCUMULATED INTO output_frame and then normalised as a whole, as in the reference.
+   Runs one (tiny) GPU launch: meant for compatibility, not speed. */
+CLOWNRESAMPLER_API void ClownResampler_LowestLevel_Resample(const ClownResampler_LowestLevel_Configuration *configuration, const ClownResampler_Precomputed *precomputed, cc_s32f *output_frame, cc_u8f channels, const cc_s16l *input_buffer, size_t position_integer, cc_u32f position_fractional);
+
+/* ---- low level (reference clownresampler.h:711, :719, :749) ---- */
+
+#ifndef CLOWNRESAMPLER_NO_LOW_LEVEL_API
+CLOWNRESAMPLER_API cc_bool ClownResampler_LowLevel_Init(ClownResampler_LowLevel_State *resampler, cc_u8f channels, cc_u32f input_sample_rate, cc_u32f output_sample_rate, cc_u32f low_pass_filter_sample_rate);
+CLOWNRESAMPLER_API cc_bool ClownResampler_LowLevel_Adjust(ClownResampler_LowLevel_State *resampler, cc_u32f input_sample_rate, cc_u32f output_sample_rate, cc_u32f low_pass_filter_sample_rate);
+
+/* input_buffer points at the START of the left padding (integer_stretched_kernel_radius frames each side, not
+   counted in *total_input_frames).  Returns cc_true when the input ran out, cc_false when output_callback
+   returned 0; *total_input_frames and the state are left exactly as the reference leaves them, so a caller can
+   resume.  The frames are computed on the GPU in growing batches and replayed through output_callback on the
+   calling thread, in order. */
+CLOWNRESAMPLER_API cc_bool ClownResampler_LowLevel_Resample(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed, const cc_s16l *input_buffer, size_t *total_input_frames, ClownResampler_OutputCallback output_callback, const void *user_data);
+#endif
+
+/* ---- high level (reference clownresampler.h:770, :825, :839, :847) ---- */
+
+#ifndef CLOWNRESAMPLER_NO_HIGH_LEVEL_API
+CLOWNRESAMPLER_API cc_bool ClownResampler_HighLevel_Init(ClownResampler_HighLevel_State *resampler, cc_u8f channels, cc_u32f input_sample_rate, cc_u32f output_sample_rate, cc_u32f low_pass_filter_sample_rate);
+CLOWNRESAMPLER_API cc_bool ClownResampler_HighLevel_Resample(ClownResampler_HighLevel_State *resampler, const ClownResampler_Precomputed *precomputed, ClownResampler_InputCallback input_callback, ClownResampler_OutputCallback output_callback, const void *user_data);
+#ifndef CLOWNRESAMPLER_NO_HIGH_LEVEL_ADJUST
+CLOWNRESAMPLER_API cc_bool ClownResampler_HighLevel_Adjust(ClownResampler_HighLevel_State *resampler, cc_u32f input_sample_rate, cc_u32f output_sample_rate, cc_u32f low_pass_filter_sample_rate);
+#endif
+#ifndef CLOWNRESAMPLER_NO_HIGH_LEVEL_RESAMPLE_END
+CLOWNRESAMPLER_API cc_bool ClownResampler_HighLevel_ResampleEnd(ClownResampler_HighLevel_State *resampler, const ClownResampler_Precomputed *precomputed, ClownResampler_OutputCallback output_callback, const void *user_data);
+#endif
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CLOWNRESAMPLER_AMD_DROPIN_H */

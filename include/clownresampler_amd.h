@@ -1,0 +1,153 @@
+/*
+ * clownresampler_amd.h - extension entry points of libclownresampler_amd.so (NOT in the reference).
+ *
+ * The reference's hot path delivers one frame per indirect call (clownresampler.h:662, :1081); that
+ * shape is kept for compatibility in include/clownresampler.h, but it can never run at memory speed.
+ * These are the callback-free forms of the SAME function: they produce exactly the frames
+ * ClownResampler_LowLevel_Resample (reference clownresampler.h:1058-1092) would hand to a callback that
+ * stores them and returns 0 once `output_capacity_frames` frames were stored, in the on-disk layout of the
+ * reference's harness (int32, frame-major, channel-minor: tests/test-low-level.c:43-49), and leave
+ * *total_input_frames and the state exactly as that call would.
+ *
+ * Everything here is a plain C ABI: pointers, sizes and the reference's own POD structs.  Device pointers
+ * and the HIP stream are passed as void*.
+ *
+ * Include after (or instead of) clownresampler.h; CLOWNRESAMPLER_KERNEL_RADIUS selects the instance as
+ * it does there.
+ */
+#ifndef CLOWNRESAMPLER_AMD_EXT_H
+#define CLOWNRESAMPLER_AMD_EXT_H
+
+#include <stdint.h>
+
+#include "clownresampler.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------
+ * Errors.  The reference's resample calls have no error channel (their cc_bool means "ran out of
+ * input" vs "callback stopped", clownresampler.h:746-748), and this library has no CPU fallback, so a
+ * runtime failure (no GPU, HIP error, out of device memory, unsupported argument) goes to a handler.
+ * The default handler prints "clownresampler_amd: <message>" to stderr and calls abort().
+ * A replacement handler may return; the failed call then produces no frames and leaves the state untouched.
+ * ------------------------------------------------------------------------------------------- */
+enum
+{
+	CLOWNRESAMPLER_AMD_OK = 0,
+	CLOWNRESAMPLER_AMD_ERROR_NO_DEVICE = 1,     /* no HIP device / runtime unusable */
+	CLOWNRESAMPLER_AMD_ERROR_HIP = 2,           /* a HIP call failed; message carries hipGetErrorString */
+	CLOWNRESAMPLER_AMD_ERROR_ARGUMENT = 3,      /* e.g. channels == 0, weight sum of 0 (the reference divides by zero there) */
+	CLOWNRESAMPLER_AMD_ERROR_PLAN_MISMATCH = 4  /* state does not match the plan it is used with */
+};
+
+typedef void (*ClownResamplerAMD_ErrorHandler)(int code, const char *message, void *user_data);
+
+void ClownResamplerAMD_SetErrorHandler(ClownResamplerAMD_ErrorHandler handler, void *user_data); /* NULL restores the default */
+int ClownResamplerAMD_LastErrorCode(void);              /* of the calling thread; reset by ClownResamplerAMD_ClearError */
+const char *ClownResamplerAMD_LastErrorMessage(void);
+void ClownResamplerAMD_ClearError(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Device selection and lifetime.  The reference API has no Deinit, so GPU resources live in a
+ * process-wide cache created on first use (per device: staging buffers, streams, uploaded tables and
+ * plans keyed by table contents + configuration) and released by Shutdown or at exit.
+ * ------------------------------------------------------------------------------------------- */
+int ClownResamplerAMD_DeviceCount(void);                /* 0 when there is none; never calls the error handler */
+int ClownResamplerAMD_SetDevice(int ordinal);           /* device used by subsequent calls of this process; returns 0 on success */
+int ClownResamplerAMD_GetDevice(void);
+void ClownResamplerAMD_Shutdown(void);
+
+/* Thin helpers so a C client needs no HIP headers. */
+void *ClownResamplerAMD_DeviceAlloc(size_t bytes);
+void ClownResamplerAMD_DeviceFree(void *device_pointer);
+int ClownResamplerAMD_CopyToDevice(void *device_destination, const void *host_source, size_t bytes);
+int ClownResamplerAMD_CopyFromDevice(void *host_destination, const void *device_source, size_t bytes);
+int ClownResamplerAMD_StreamSynchronize(void *hip_stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Closed forms of the output-timeline walk (reference clownresampler.h:1058-1092).  Host-only, no GPU.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Frames ClownResampler_LowLevel_Resample emits for `total_input_frames` from `state` if never stopped. */
+size_t ClownResamplerAMD_CountOutputFrames(const ClownResampler_LowLevel_State *state, size_t total_input_frames);
+
+/* Advances the position of `state` as if `frames` output frames had been emitted (clownresampler.h:1076-1078, n times). */
+void ClownResamplerAMD_AdvanceState(ClownResampler_LowLevel_State *state, size_t frames);
+
+/* One shard of an output timeline split into `shard_count` contiguous blocks of output frames (the last may be
+   shorter).  Filled from a state and the total number of input frames of the whole stream. */
+typedef struct ClownResamplerAMD_Shard
+{
+	size_t first_output_frame;      /* index in the whole stream's output */
+	size_t output_frames;           /* frames this shard produces */
+	size_t first_input_frame;       /* offset, in frames, to add to the whole stream's padded input pointer */
+	size_t input_frames;            /* value of *total_input_frames for the shard's call (excludes the halo); the call must
+	                                   also be given output_capacity_frames == output_frames, which is what ends it */
+	size_t halo_frames;             /* integer_stretched_kernel_radius: real neighbour frames needed each side */
+	ClownResampler_LowLevel_State state; /* state to run the shard with */
+} ClownResamplerAMD_Shard;
+
+int ClownResamplerAMD_PlanShard(const ClownResampler_LowLevel_State *state, size_t total_input_frames, unsigned shard, unsigned shard_count, ClownResamplerAMD_Shard *out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bulk resampling, host buffers (radius-specific: redirected like the reference functions).
+ * ------------------------------------------------------------------------------------------- */
+#if CLOWNRESAMPLER_KERNEL_RADIUS != 3
+ #define ClownResampler_LowLevel_ResampleBulk CLOWNRESAMPLER_AMD_SYM(ClownResampler_LowLevel_ResampleBulk)
+ #define ClownResamplerAMD_PlanCreate          CLOWNRESAMPLER_AMD_SYM(ClownResamplerAMD_PlanCreate)
+#endif
+
+/* Same arguments as ClownResampler_LowLevel_Resample with (output, output_capacity_frames) in place of the
+   callback.  Returns the number of frames written; *ran_out_of_input (may be NULL) receives what the reference
+   call would have returned.  Synchronous: input is uploaded, output downloaded. */
+size_t ClownResampler_LowLevel_ResampleBulk(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed, const cc_s16l *input_buffer, size_t *total_input_frames, int32_t *output, size_t output_capacity_frames, cc_bool *ran_out_of_input);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bulk resampling, device-resident buffers.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ClownResamplerAMD_Plan ClownResamplerAMD_Plan;
+
+typedef struct ClownResamplerAMD_PlanInfo
+{
+	uint32_t kernel;            /* 1 = polyphase rows staged in LDS (fast path), 0 = generic 64-bit kernel */
+	uint32_t channels;
+	uint32_t slots;             /* taps evaluated per output frame (zero-weight slots included) */
+	uint32_t first_slot;        /* frame offset of slot 0 relative to position_integer, in padded-buffer frames */
+	uint32_t rows;              /* polyphase rows */
+	uint32_t row_stride;        /* int32 per row: slots weights, then the 17.15 reciprocal, then padding */
+	uint32_t row_mode;          /* 0 = affine row index, 1 = pure-upsampling row index ((65536 - frac) >> 6) */
+	uint32_t threads;           /* workgroup size */
+	uint32_t tile_frames;       /* output frames per LDS tile */
+	uint32_t lds_bytes;         /* dynamic LDS per workgroup */
+	uint32_t max_blocks;        /* persistent grid size used for large launches */
+	uint32_t specialised;       /* 1 when a (channels, slots) template instance is used */
+} ClownResamplerAMD_PlanInfo;
+
+/* Builds (or fetches from the cache) the device-side plan for the configuration, channel count and increment
+   of `state` and the contents of `precomputed`: the polyphase weight rows with their reciprocals, uploaded to
+   the current device.  The plan stays valid until ClownResamplerAMD_Shutdown. */
+ClownResamplerAMD_Plan *ClownResamplerAMD_PlanCreate(const ClownResampler_LowLevel_State *state, const ClownResampler_Precomputed *precomputed);
+void ClownResamplerAMD_PlanGetInfo(const ClownResamplerAMD_Plan *plan, ClownResamplerAMD_PlanInfo *info);
+
+/* Debug/test access to the host copy of the polyphase rows (rows * row_stride int32). */
+const int32_t *ClownResamplerAMD_PlanRows(const ClownResamplerAMD_Plan *plan);
+/* Row index the kernels compute for a fractional position (host mirror of the device formula). */
+uint32_t ClownResamplerAMD_PlanRowOf(const ClownResamplerAMD_Plan *plan, uint32_t position_fractional);
+
+/* Test hook: route every launch through the generic 64-bit kernel (the independent second implementation). */
+void ClownResamplerAMD_DebugForceGenericKernel(int on);
+
+/* device_input: interleaved int16, pointing at the start of the left padding, as for the reference call;
+   at least *total_input_frames + 2 * integer_stretched_kernel_radius frames must be readable.
+   device_output: int32, room for output_capacity_frames frames.  The launch is enqueued on hip_stream
+   (NULL = the default stream) and NOT synchronised; the state and *total_input_frames are updated on the host
+   from the closed form before returning.  Returns the number of frames that will have been written. */
+size_t ClownResamplerAMD_ResampleDevice(ClownResamplerAMD_Plan *plan, ClownResampler_LowLevel_State *resampler, const void *device_input, size_t *total_input_frames, void *device_output, size_t output_capacity_frames, void *hip_stream, cc_bool *ran_out_of_input);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CLOWNRESAMPLER_AMD_EXT_H */

@@ -1,0 +1,184 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, against the committed known answers of the real reference
+(tests/golden/golden.json) and against the oracle run on the same inputs.  Bit-exact: this is integer work."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _cases
+import _checkers as ck
+import _product
+import clownresampler_amd as cr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def products():
+    assert cr.load(3).DeviceCount() > 0, "these tests need the GPU: the library has no other path"
+    return {3: _product.Product(3), 8: _product.Product(8)}
+
+
+@pytest.mark.parametrize("case", _cases.CASES, ids=[c["name"] for c in _cases.CASES])
+def test_case_bit_exact(golden, products, case):
+    """Every case of tests/_cases.py (reference fixture + ctest triples, BASELINE configs at 1 min, resume semantics,
+    1..16 channels, ratio sweep, 8-lobe build, adversarial amplitudes, ragged sizes): frame count, sha256, stream hash,
+    head, range and final state equal the real reference's; full arrays equal the oracle's."""
+    p = products[case["radius"]]
+    res = _cases.run_case(p, case, keep_output=True)
+    out = res.pop("_out")
+    want = _cases.run_case(ck.oracle(case["radius"]), case, keep_output=True)["_out"]
+    assert out.size == want.size
+    if not np.array_equal(out, want):
+        bad = np.nonzero(out != want)[0]
+        raise AssertionError("%d of %d samples differ, first at %d: got %d want %d" % (bad.size, out.size, bad[0], out[bad[0]], want[bad[0]]))
+    assert res == golden["cases"][case["name"]]
+
+
+@pytest.mark.parametrize("name", ["cfg2_1min", "cfg3_1min", "cfg4_1min", "flac_ctest3_low", "ch3_up", "ch16_down", "ratio_44100_1000_1000", "amp_square_r8", "tiny_65"])
+def test_generic_kernel_bit_exact(golden, products, name):
+    """The second, independent device implementation (k_generic: 64-bit, table walk + divide on the device)."""
+    case = _cases.CASE_BY_NAME[name]
+    p = products[case["radius"]]
+    p.api.DebugForceGenericKernel(True)
+    try:
+        res = _cases.run_case(p, case)
+    finally:
+        p.api.DebugForceGenericKernel(False)
+    assert res == golden["cases"][name]
+
+
+def test_fast_kernel_is_what_runs(products):
+    """The BASELINE configurations take the polyphase/LDS kernel, with the specialised instances."""
+    for radius, ch, rates, slots in [(3, 2, (44100, 48000, 44100), 5), (8, 2, (8000, 96000, 8000), 15), (3, 8, (48000, 44100, 44100), 7)]:
+        p = products[radius]
+        ok, st = p.low_init(ch, *rates)
+        info = p.api.PlanGetInfo(p.api.PlanCreate(st.raw, p.pre))
+        assert info.kernel == 1 and info.slots == slots and info.specialised == 1, info.asdict()
+        assert info.lds_bytes <= 160 * 1024 and info.tile_frames >= info.threads
+
+
+def test_single_frames(golden, products):
+    # ClownResampler_LowestLevel_Resample incl. "+=" into a non-zero accumulator (clownresampler.h:1020,1033)
+    for f in golden["single_frames"]:
+        p = products[f["radius"]]
+        ok, cfg = p.configure(*f["rates"])
+        pcm = ck.noise_pcm(f["pcm_frames"] * f["channels"], f["seed"])
+        out = p.frame(cfg, f["channels"], pcm, f["pos_int"], f["pos_frac"], f["acc_in"])
+        assert [int(v) for v in out] == f["acc_out"], f
+
+
+def test_callback_api_early_stop_and_resume(products):
+    """ClownResampler_LowLevel_Resample through the real callback ABI: stop every 100 frames, resume with the pointer advanced
+    by the consumed frames (examples/low-level.c:87-102); stream and states equal the oracle's at every stop."""
+    p, o = products[3], ck.oracle(3)
+    for rates, ch in [((44100, 48000, 44100), 2), ((48000, 11025, 11025), 3)]:
+        ok, a = p.low_init(ch, *rates)
+        ok, b = o.low_init(ch, *rates)
+        frames = 3000
+        padded = ck.pad_frames(ck.noise_pcm(frames * ch, 42), ch, int(b.cfg.radius_frames))
+        pos_a = pos_b = 0
+        left_a = left_b = frames
+        got_a, got_b = [], []
+        for _ in range(1000):
+            ca, cb = [], []
+            ra, la = p.low_resample_cb(a, padded[pos_a * ch:], left_a, lambda f: (ca.append(f), len(ca) < 100)[1])
+            rb, lb = o.low_resample_cb(b, padded[pos_b * ch:], left_b, lambda f: (cb.append(f), len(cb) < 100)[1])
+            assert (ra, la) == (rb, lb) and ca == cb and a.astuple() == b.astuple()
+            pos_a += left_a - la
+            pos_b += left_b - lb
+            left_a, left_b = la, lb
+            got_a += ca
+            if ra:
+                break
+        else:
+            raise AssertionError("did not finish")
+        assert len(got_a) == ck.count_output_frames(o.low_init(ch, *rates)[1], frames)
+
+
+def test_device_resident_api(products):
+    """ClownResamplerAMD_ResampleDevice on caller-owned device buffers, incl. capacity stop, resume and unaligned
+    (frame-aligned only) input pointers."""
+    p, o = products[3], ck.oracle(3)
+    api = p.api
+    ch, rates, frames = 2, (44100, 48000, 44100), 100000
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    R = int(ost.cfg.radius_frames)
+    padded = ck.pad_frames(ck.noise_pcm(frames * ch, 9), ch, R)
+    want, _, _ = o.low_resample_i32(ost, padded, frames)
+    total = want.size // ch
+    d_in = api.DeviceAlloc(padded.nbytes + 64)
+    d_out = api.DeviceAlloc(want.nbytes + 64)
+    try:
+        api.CopyToDevice(d_in, padded)
+        plan = api.PlanCreate(st.raw, p.pre)
+        got = np.empty_like(want)
+        # in three calls: 12345 frames, then 40001, then the rest; input pointer advanced by the consumed frames each time
+        pos, done, left = 0, 0, frames
+        for cap in (12345, 40001, total):
+            n, new_left, ran_out = api.ResampleDevice(plan, st.raw, d_in + pos * ch * 2, left, d_out + done * ch * 4, cap)
+            pos += left - new_left
+            left = new_left
+            done += n
+        api.StreamSynchronize()
+        assert done == total and ran_out == 1 and left == 0
+        api.CopyFromDevice(got, d_out)
+        assert np.array_equal(got, want)
+        # a plan does not fit a re-configured state
+        api.LowLevel_Adjust(st.raw, 48000, 44100, 44100)
+        with pytest.raises(cr.ClownResamplerError) as e:
+            api.ResampleDevice(plan, st.raw, d_in, 10, d_out, 10)
+        assert e.value.code == cr.ERROR_PLAN_MISMATCH
+    finally:
+        api.DeviceFree(d_in)
+        api.DeviceFree(d_out)
+
+
+@pytest.mark.parametrize("shards", [2, 8])
+def test_sharded_device_run_equals_one_shot(products, shards):
+    """Output-timeline sharding as the multi-GPU path does it (one shard per rank), here all on one GPU."""
+    p, o = products[3], ck.oracle(3)
+    api = p.api
+    ch, rates, frames = 2, (44100, 48000, 44100), 250001
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    R = int(ost.cfg.radius_frames)
+    padded = ck.pad_frames(ck.noise_pcm(frames * ch, 10), ch, R)
+    want, _, _ = o.low_resample_i32(ost, padded, frames)
+    d_in = api.DeviceAlloc(padded.nbytes)
+    d_out = api.DeviceAlloc(want.nbytes)
+    try:
+        api.CopyToDevice(d_in, padded)
+        plan = api.PlanCreate(st.raw, p.pre)
+        for s in range(shards):
+            sh = api.PlanShard(st.raw, frames, s, shards)
+            api.ResampleDevice(plan, sh.state, d_in + sh.first_input_frame * ch * 2, sh.input_frames,
+                               d_out + sh.first_output_frame * ch * 4, sh.output_frames)
+        api.StreamSynchronize()
+        got = np.empty_like(want)
+        api.CopyFromDevice(got, d_out)
+        assert np.array_equal(got, want)
+    finally:
+        api.DeviceFree(d_in)
+        api.DeviceFree(d_out)
+
+
+def test_cfg2_full_size_bit_exact(products):
+    """BASELINE configs[1] at its full size: 10 min stereo 44.1 -> 48 kHz, 26,460,000 -> 28,800,096 frames, against the
+    multi-threaded oracle (itself checked equal to the single-threaded one)."""
+    import os
+    p, o = products[3], ck.oracle(3)
+    ch, rates, frames = 2, (44100, 48000, 44100), 26460000
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    padded = ck.pad_frames(ck.noise_pcm(frames * ch), ch, 3)
+    want = o.low_resample_i32_mt(ost, padded, frames, threads=min(16, os.cpu_count() or 1))
+    got, left, ran_out = p.low_resample_i32(st, padded, frames)
+    assert got.size == want.size == 28800096 * 2 and ran_out == 1 and left == 0
+    assert np.array_equal(got, want)
+    # size-independent property: any split of the input with carried state gives the same stream
+    ok, st2 = p.low_init(ch, *rates)
+    a, l1, r1 = p.low_resample_i32(st2, padded, 10000001)
+    b, l2, r2 = p.low_resample_i32(st2, padded[10000001 * ch:], frames - 10000001)
+    assert np.array_equal(np.concatenate([a, b]), want)

@@ -1,0 +1,259 @@
+"""CPU: the host-side C of the product (no GPU needed): table, ratio/configuration scalars, closed forms, sharding,
+the polyphase re-indexing, the exported C ABI, and that the resample entry points fail loudly without a device."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import _cases
+import _checkers as ck
+import _product
+import clownresampler_amd as cr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported():
+    """include/*.h is the contract: every function it declares must be in the .so (all radius instances)."""
+    lib = C.CDLL(cr.LIB_PATH)
+    names = set()
+    for header in ("clownresampler.h", "clownresampler_amd.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names.update(re.findall(r"\b(ClownResampler(?:AMD)?_\w+)\s*\(", text))
+    names -= {"ClownResamplerAMD_ErrorHandler"}
+    assert len(names) >= 30
+    per_radius = {n for n in names if n.startswith("ClownResampler_")} | {"ClownResamplerAMD_PlanCreate"}
+    for n in sorted(names):
+        assert hasattr(lib, n), n
+        if n in per_radius:
+            assert hasattr(lib, n + "_R8"), n + "_R8"
+
+
+def test_no_internal_symbols_leak():
+    out = subprocess.run(["nm", "-D", "--defined-only", cr.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    assert syms and all(s.startswith("ClownResampler") for s in syms), [s for s in syms if not s.startswith("ClownResampler")]
+
+
+def test_struct_layouts_match_reference_lp64():
+    # Configuration 32, LowLevel_State 64, HighLevel_State 8296, Precomputed 49152 (R=3)
+    assert C.sizeof(cr.LowestLevel_Configuration) == 32
+    assert C.sizeof(cr.LowLevel_State) == 64
+    assert C.sizeof(cr.HighLevel_State) == 8296
+    assert C.sizeof(cr.load(3).Precomputed) == 49152
+    assert C.sizeof(cr.load(8).Precomputed) == 8 * 2 * 1024 * 8
+    # field-for-field with the oracle/reference layout used by the checkers
+    assert [getattr(cr.LowLevel_State, n).offset for n in ("lowest_level", "channels", "position_integer", "position_fractional", "increment")] == \
+           [getattr(ck.LowLevel, n).offset for n in ("cfg", "channels", "pos_int", "pos_frac", "increment")]
+
+
+def test_header_compiles_as_c89_and_cxx(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#define CLOWNRESAMPLER_IMPLEMENTATION\n#define CLOWNRESAMPLER_STATIC\n#include "clownresampler.h"\n'
+                   'int main(void){ClownResampler_Precomputed p; ClownResampler_LowLevel_State s; (void)p; (void)s; return (int)sizeof(ClownResampler_HighLevel_State) != 8296;}\n')
+    for cmd in (["gcc", "-std=c89", "-pedantic", "-Wall", "-Werror"], ["g++", "-x", "c++", "-Wall", "-Werror"]):
+        exe = tmp_path / "t"
+        subprocess.run(cmd + ["-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+        assert subprocess.run([str(exe)]).returncode == 0
+    src8 = tmp_path / "t8.c"
+    src8.write_text('#define CLOWNRESAMPLER_KERNEL_RADIUS 8\n#include "clownresampler_amd.h"\n'
+                    'int main(void){ClownResampler_Precomputed p; ClownResampler_Precompute(&p); return p.lanczos_kernel_table[8192] != 65536;}\n')
+    exe = tmp_path / "t8"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src8), "-o", str(exe), "-L", os.path.dirname(cr.LIB_PATH),
+                    "-lclownresampler_amd", "-Wl,-rpath," + os.path.dirname(cr.LIB_PATH)], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
+
+
+@pytest.mark.parametrize("radius", [3, 8])
+def test_table_is_the_references(golden, radius):
+    # host-side, reference clownresampler.h:955-961
+    import hashlib
+    t = _product.Product(radius).table()
+    assert hashlib.sha256(t.astype("<i4").tobytes()).hexdigest() == golden["table"][str(radius)]["sha256_i32le"]
+    assert np.array_equal(t, ck.oracle(radius).table())
+
+
+@pytest.mark.parametrize("radius", [3, 8])
+def test_config_scalars_are_the_references(golden, radius):
+    # host-side, reference clownresampler.h:913-984, :1044-1056; failure cases leave exactly what the reference leaves
+    p = _product.Product(radius)
+    for row in golden["config"][str(radius)]:
+        raw = p.api.LowLevel_State()
+        raw.position_integer = raw.position_fractional = raw.increment = 0x5A5A5A5A
+        ll = raw.lowest_level
+        ll.stretched_kernel_radius = ll.integer_stretched_kernel_radius = ll.stretched_kernel_radius_delta = ll.kernel_step_size = 0x5A5A5A5A
+        ok = p.api.LowLevel_Init(raw, 2, *row["rates"])
+        assert int(ok) == row["ok"], row
+        assert [int(v) for v in raw.astuple()] == row["state"], row
+
+
+def test_highlevel_init_adjust_rules():
+    # reference clownresampler.h:1103, :1109-1115, :1188-1206
+    p, o = _product.Product(3), ck.oracle(3)
+    assert not p.high_init(17, 44100, 48000, 44100)[0]
+    for first, then in [((48000, 8000, 8000), (48000, 44100, 44100)), ((44100, 48000, 44100), (48000, 8000, 8000)),
+                        ((48000, 24000, 24000), (0, 1, 1)), ((48000, 24000, 24000), (48000, 12000, 12000))]:
+        ok, a = p.high_init(2, *first)
+        ok2, b = o.high_init(2, *first)
+        assert ok == ok2 and (a.lead_needed, a.trail_left, a.max_radius_frames) == (b.lead_needed, b.trail_left, b.max_radius_frames)
+        assert p.high_adjust(a, *then) == o.high_adjust(b, *then)
+        assert a.low.astuple() == b.low.astuple()
+
+
+def test_closed_forms_against_oracle_walk():
+    import random
+    rng = random.Random(7)
+    p, o = _product.Product(3), ck.oracle(3)
+    for _ in range(300):
+        i, out = rng.randrange(1, 200000), rng.randrange(1, 200000)
+        ok, a = p.low_init(1, i, out, min(i, out))
+        ok2, b = o.low_init(1, i, out, min(i, out))
+        if not ok or b.cfg.table_step == 0 or b.cfg.radius_frames > 300:
+            continue
+        a.raw.position_integer = b.pos_int = rng.randrange(0, 50)
+        a.raw.position_fractional = b.pos_frac = rng.randrange(0, 65536)
+        frames = rng.randrange(0, 400)
+        n = p.api.CountOutputFrames(a.raw, frames)
+        assert n == ck.count_output_frames(b, frames)
+        padded = ck.pad_frames(ck.noise_pcm(frames), 1, int(b.cfg.radius_frames))
+        got, left, ran_out = o.low_resample_i32(b, padded, frames)
+        assert len(got) == n
+        # state after n frames + exhaustion bookkeeping == AdvanceState then subtract (clownresampler.h:1065-1067)
+        p.api.AdvanceState(a.raw, n)
+        assert (a.pos_int - frames, a.pos_frac) == (b.pos_int, b.pos_frac)
+
+
+def test_cfg_counts():
+    p = _product.Product(3)
+    ok, st = p.low_init(2, 44100, 48000, 44100)
+    assert p.api.CountOutputFrames(st.raw, 26460000) == 28800096
+    assert p.api.CountOutputFrames(st.raw, 158760000) == 172800574
+
+
+@pytest.mark.parametrize("shards", [1, 2, 3, 8])
+def test_shard_plan_reassembles_the_stream(shards):
+    """Sharding is host logic; here each shard is run by the ORACLE (test-only) to prove that the planned
+    (pointer offset, frame count, start state) triples concatenate to the one-shot stream bit for bit."""
+    o = ck.oracle(3)
+    p = _product.Product(3)
+    for rates, ch, frames in [((44100, 48000, 44100), 2, 30011), ((48000, 44100, 44100), 8, 9000), ((44100, 8000, 8000), 2, 20000), ((8000, 96000, 8000), 1, 700)]:
+        ok, whole = o.low_init(ch, *rates)
+        R = int(whole.cfg.radius_frames)
+        padded = ck.pad_frames(ck.noise_pcm(frames * ch, 5), ch, R)
+        want, _, _ = o.low_resample_i32(whole, padded, frames)
+        ok, st = p.low_init(ch, *rates)
+        parts, total = [], 0
+        for s in range(shards):
+            sh = p.api.PlanShard(st.raw, frames, s, shards)
+            assert sh.first_output_frame == total and sh.halo_frames == R
+            ok, ost = o.low_init(ch, *rates)
+            ost.pos_int, ost.pos_frac = sh.state.position_integer, sh.state.position_fractional
+            got, left, ran_out = o.low_resample_i32(ost, padded[sh.first_input_frame * ch:], sh.input_frames, capacity=sh.output_frames)
+            assert got.size == sh.output_frames * ch, (rates, s)
+            # the shard never looks beyond its halo
+            assert sh.first_input_frame + sh.input_frames <= frames
+            parts.append(got)
+            total += sh.output_frames
+        assert np.array_equal(np.concatenate(parts), want)
+
+
+POLY_CONFIGS = [(3, (44100, 48000, 44100)), (3, (48000, 44100, 44100)), (3, (44100, 8000, 8000)), (3, (8000, 44100, 8000)),
+                (8, (8000, 96000, 8000)), (8, (48000, 44100, 44100)), (3, (1, 1, 1)), (3, (44100, 48000, 20000)),
+                (3, (65537, 65536, 65536)), (3, (1000, 999, 999)), (3, (48000, 44100, 10000)), (3, (3, 7, 2)), (8, (48000, 8000, 8000)),
+                (3, (192000, 8000, 8000)), (3, (44100, 1000, 1000))]
+
+
+@pytest.mark.parametrize("radius,rates", POLY_CONFIGS)
+def test_polyphase_rows_equal_reference_taps(radius, rates):
+    """For EVERY fractional position: the row the device would pick, laid on the common window, holds exactly the taps
+    the reference's definition gives (clownresampler.h:993-1016) and the exact reciprocal (:1025)."""
+    p = _product.Product(radius)
+    ok, cfg = p.configure(*rates)
+    assert ok
+    row = np.zeros(65536, dtype=np.uint32)
+    info, rows, eligible, why = p.api.BuildRows(cfg, p.pre, row)
+    assert rows is not None, why
+    table = p.table()
+    skr, R, delta, step = cfg.stretched_kernel_radius, cfg.integer_stretched_kernel_radius, cfg.stretched_kernel_radius_delta, cfg.kernel_step_size
+    frac = np.arange(65536, dtype=np.int64)
+    mr = (frac + delta + 65535) >> 16
+    xr = (frac + skr) >> 16
+    ks = (step * ((mr << 16) - frac)) >> 16
+    taps = R + xr - mr
+    if info.row_mode == 1:
+        assert np.array_equal(row, (65536 - frac) >> 6)
+    assert row.max() == info.rows - 1 and len(np.unique(row)) == info.rows      # every row is used, none beyond
+    T, first = info.slots, info.first_slot
+    exp = np.zeros((65536, info.row_stride), dtype=np.int64)
+    for t in range(int(taps.max())):
+        active = t < taps
+        w = np.where(active, table[np.minimum(ks + step * t, len(table) - 1)], 0)
+        slot = mr + t - first
+        inside = active & (slot >= 0) & (slot < T)
+        assert np.all(w[active & ~inside] == 0)      # everything trimmed away is a zero weight
+        exp[frac[inside], slot[inside]] = w[inside]
+    sums = exp[:, :T].sum(axis=1)
+    exp[:, T] = (2 ** 31) // sums                    # 0x80000000 / sum, positive sums (clownresampler.h:1025)
+    assert np.all(sums > 0)
+    assert np.array_equal(rows[row], exp)
+    if eligible:
+        assert np.all(np.abs(rows[:, :T]) < 2 ** 23) and np.all(rows[:, T] > 0)
+
+
+def test_polyphase_shapes_of_baseline_configs():
+    p3, p8 = _product.Product(3), _product.Product(8)
+    info, rows, el, _ = p3.api.BuildRows(p3.configure(44100, 48000, 44100)[1], p3.pre)
+    assert (info.slots, info.first_slot, info.rows, info.row_stride, info.row_mode, el) == (5, 1, 1025, 8, 1, True)   # cfg 2 / 5
+    info, rows, el, _ = p8.api.BuildRows(p8.configure(8000, 96000, 8000)[1], p8.pre)
+    assert (info.slots, info.first_slot, info.rows, info.row_stride, info.row_mode, el) == (15, 1, 1025, 16, 1, True)  # cfg 3
+    info, rows, el, _ = p3.api.BuildRows(p3.configure(48000, 44100, 44100)[1], p3.pre)
+    assert (info.slots, info.row_stride, info.row_mode, el) == (7, 8, 0, True)                                       # cfg 4
+
+
+def test_rejects_what_the_reference_cannot_run():
+    p = _product.Product(3)
+    ok, cfg = p.configure(2048, 1, 1)      # step underflows to 0: every tap reads table[0] == 0 -> weight sum 0
+    assert ok and cfg.kernel_step_size == 0
+    info, rows, el, why = p.api.BuildRows(cfg, p.pre)
+    assert rows is None and "sum 0" in why
+
+
+@pytest.mark.skipif(cr.load(3).DeviceCount() > 0, reason="a GPU is present")
+def test_resample_fails_loudly_without_a_device():
+    """No CPU fallback: with no usable HIP device every resample entry point reports ERROR_NO_DEVICE."""
+    p = _product.Product(3)
+    ok, st = p.low_init(2, 44100, 48000, 44100)
+    padded = ck.pad_frames(ck.noise_pcm(200), 2, 3)
+    with pytest.raises(cr.ClownResamplerError) as e:
+        p.low_resample_i32(st, padded, 100)
+    assert e.value.code == cr.ERROR_NO_DEVICE and "no CPU fallback" in e.value.message
+    assert st.astuple() == p.low_init(2, 44100, 48000, 44100)[1].astuple()      # state untouched
+    with pytest.raises(cr.ClownResamplerError):
+        p.low_resample_cb(st, padded, 100, lambda f: True)
+    with pytest.raises(cr.ClownResamplerError):
+        p.frame(st.raw.lowest_level, 2, padded, 0, 0)
+    with pytest.raises(cr.ClownResamplerError):
+        p.api.PlanCreate(st.raw, p.pre)
+    ok, hs = p.high_init(2, 44100, 48000, 44100)
+    with pytest.raises(cr.ClownResamplerError):
+        p.high_run_i32(hs, ck.noise_pcm(200))
+
+
+def test_default_error_handler_aborts(tmp_path):
+    """The C default (no handler installed): message on stderr and abort()."""
+    src = tmp_path / "a.c"
+    src.write_text('#include "clownresampler_amd.h"\n#include <stdlib.h>\nstatic ClownResampler_Precomputed p; static ClownResampler_LowLevel_State s;\n'
+                   'int main(void){ short in[64] = {0}; int out[64]; size_t n = 4; if (ClownResamplerAMD_DeviceCount() > 0) return 77;\n'
+                   'ClownResampler_Precompute(&p); ClownResampler_LowLevel_Init(&s, 2, 44100, 48000, 44100);\n'
+                   'ClownResampler_LowLevel_ResampleBulk(&s, &p, in, &n, out, 8, NULL); return 0; }\n')
+    exe = tmp_path / "a"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", os.path.dirname(cr.LIB_PATH),
+                    "-lclownresampler_amd", "-Wl,-rpath," + os.path.dirname(cr.LIB_PATH)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    if r.returncode == 77:
+        pytest.skip("a GPU is present")
+    assert r.returncode < 0 and "clownresampler_amd: no usable HIP device" in r.stderr

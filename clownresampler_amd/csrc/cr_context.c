@@ -14,6 +14,9 @@
 
 #include "../../include/clownresampler_amd.h"
 
+/* tuning variant of the specialised k_poly instances used unless overridden: each instance's measured default */
+#define CR_DEFAULT_VARIANT ((int)CRHIP_VARIANT_DEFAULT)
+
 /* ------------------------------------------------------------------------------------------------------- */
 /* errors                                                                                                  */
 /* ------------------------------------------------------------------------------------------------------- */
@@ -94,6 +97,7 @@ static ClownResamplerAMD_Plan *g_plans = NULL;
 static cr_workspace g_workspace;
 static int g_workspace_busy = 0;
 static int g_force_generic = 0;
+static int g_variant = -1; /* -1: CLOWNRESAMPLER_AMD_VARIANT from the environment, else the default */
 static pthread_mutex_t g_workspace_lock = PTHREAD_MUTEX_INITIALIZER;
 
 int ClownResamplerAMD_DeviceCount(void)
@@ -257,6 +261,20 @@ int ClownResamplerAMD_StreamSynchronize(void *hip_stream)
 /* plans                                                                                                   */
 /* ------------------------------------------------------------------------------------------------------- */
 
+static void fill_poly_launch(const ClownResamplerAMD_Plan *plan, crhip_poly_launch *l);
+
+static uint32_t current_variant(void)
+{
+	if (g_variant < 0)
+	{
+		const char *e = getenv("CLOWNRESAMPLER_AMD_VARIANT");
+		g_variant = (e != NULL && *e != '\0') ? atoi(e) : CR_DEFAULT_VARIANT;
+		if (g_variant < 0 || (g_variant >= crhip_poly_variants() && !(g_variant >= 1000 && g_variant < 1010)))
+			g_variant = CR_DEFAULT_VARIANT;
+	}
+	return (uint32_t)g_variant;
+}
+
 static uint32_t supported_poly_channels(uint32_t channels)
 {
 	return channels >= 1 && channels <= 8;
@@ -266,14 +284,16 @@ static uint32_t supported_poly_channels(uint32_t channels)
 static void plan_geometry(ClownResamplerAMD_Plan *plan)
 {
 	const uint32_t frame_bytes = plan->channels * 2u;
-	const uint32_t rows_bytes = (plan->poly.rows * plan->poly.row_stride * 4u + 15u) & ~15u;
+	const uint32_t rows_bytes = cr_poly_plane_rows(&plan->poly) * plan->poly.row_stride * 4u;
 	uint32_t tile_bytes, cap_frames, per_cu;
 	uint64_t tile;
 
-	crhip_poly_geometry(plan->channels, plan->poly.slots, &plan->threads, &plan->vecs);
+	uint32_t frames_multiple = 0;
+
+	plan->specialised = (uint32_t)crhip_poly_has_instance(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
+	crhip_poly_geometry(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
 	tile_bytes = plan->vecs * 16u * plan->threads;
 	plan->lds_bytes = rows_bytes + 2u * tile_bytes;
-	plan->specialised = (uint32_t)crhip_poly_has_instance(plan->channels, plan->poly.slots, plan->poly.row_mode);
 
 	if (plan->lds_bytes > (uint32_t)g_info.max_lds_per_block)
 	{
@@ -300,8 +320,13 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 		tile = ((1ull << 32) - 65536u) / plan->increment;
 	if (tile > (1u << 24) - 1u)
 		tile = (1u << 24) - 1u;
-	if (tile >= plan->threads)
-		tile -= tile % plan->threads;
+	/* whole groups of threads * frames-in-flight; 4, 2 or 1 groups per tile run as straight-line code in the kernel */
+	if (tile >= 4u * frames_multiple)
+		tile = 4u * frames_multiple;
+	else if (tile >= 2u * frames_multiple)
+		tile = 2u * frames_multiple;
+	else if (tile >= frames_multiple)
+		tile = frames_multiple;
 
 	if (tile == 0)
 	{
@@ -335,7 +360,7 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 	for (plan = g_plans; plan != NULL; plan = plan->next)
 	{
 		if (plan->table_hash == table_hash && plan->radius == radius && plan->channels == channels && plan->increment == increment
-		 && plan->device == g_device && memcmp(&plan->cfg, cfg, sizeof(*cfg)) == 0)
+		 && plan->variant == current_variant() && plan->device == g_device && memcmp(&plan->cfg, cfg, sizeof(*cfg)) == 0)
 		{
 			pthread_mutex_unlock(&g_lock);
 			return plan;
@@ -377,6 +402,7 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 	plan->channels = channels;
 	plan->increment = increment;
 	plan->device = g_device;
+	plan->variant = current_variant();
 	plan->table_len = (uint32_t)table_len;
 
 	if (cr_poly_build(table, table_len, cfg, &plan->poly) != 0)
@@ -411,12 +437,39 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 
 	if (plan->use_poly)
 	{
-		const size_t bytes = ((size_t)plan->poly.rows * plan->poly.row_stride * 4u + 15u) & ~(size_t)15u;
-		/* the kernel stages whole 16-byte vectors: the device copy is padded to that */
-		if (cr_check_hip(crhip_malloc((void **)&plan->d_rows, bytes), "hipMalloc(rows)") != 0
-		 || cr_check_hip(crhip_memset(plan->d_rows, 0, bytes, NULL), "hipMemset(rows)") != 0
-		 || cr_check_hip(crhip_memcpy_h2d(plan->d_rows, plan->poly.weights, (size_t)plan->poly.rows * plan->poly.row_stride * 4u, NULL), "hipMemcpy(rows)") != 0)
+		int32_t *image;
+		size_t bytes;
+
+		plan->plane_rows = cr_poly_plane_rows(&plan->poly);
+		plan->swizzle = cr_poly_pick_swizzle(&plan->poly, increment, &plan->conflict_plain, &plan->conflict_best);
+		if (!crhip_poly_swizzled(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant))
+			plan->swizzle = 0; /* the selected instance reads the plain image */
+		bytes = (size_t)plan->plane_rows * plan->poly.row_stride * sizeof(int32_t);
+		image = cr_poly_device_image(&plan->poly, plan->swizzle);
+
+		if (image == NULL)
+		{
+			cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
 			goto fail_plan;
+		}
+
+		if (cr_check_hip(crhip_malloc((void **)&plan->d_rows, bytes), "hipMalloc(rows)") != 0
+		 || cr_check_hip(crhip_memcpy_h2d(plan->d_rows, image, bytes, NULL), "hipMemcpy(rows)") != 0
+		 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
+		{
+			free(image);
+			goto fail_plan;
+		}
+
+		free(image);
+
+		{
+			/* once per plan, never inside a caller's stream capture */
+			crhip_poly_launch l;
+			fill_poly_launch(plan, &l);
+			if (cr_check_hip(crhip_poly_prepare(&l), "hipFuncSetAttribute(dynamic LDS)") != 0)
+				goto fail_plan;
+		}
 	}
 
 	if (cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
@@ -439,6 +492,35 @@ fail:
 	return NULL;
 }
 
+/* the launch-independent part of a k_poly launch description */
+static void fill_poly_launch(const ClownResamplerAMD_Plan *plan, crhip_poly_launch *l)
+{
+	memset(l, 0, sizeof(*l));
+	l->d_rows = plan->d_rows;
+	l->increment = (uint32_t)plan->increment;
+	l->channels = plan->channels;
+	l->slots = plan->poly.slots;
+	l->first_slot = plan->poly.first_slot;
+	l->rows = plan->poly.rows;
+	l->row_stride = plan->poly.row_stride;
+	l->row_mode = plan->poly.row_mode;
+	l->norm_mode = plan->poly.norm_mode;
+	l->delta = plan->poly.delta;
+	l->skr = plan->poly.skr;
+	l->step = plan->poly.step;
+	l->aff_a = plan->poly.aff_a;
+	l->aff_b = plan->poly.aff_b;
+	l->aff_c = plan->poly.aff_c;
+	l->threads = plan->threads;
+	l->vecs = plan->vecs;
+	l->tile_frames = plan->tile_frames;
+	l->lds_bytes = plan->lds_bytes;
+	l->specialised = plan->specialised;
+	l->variant = plan->variant;
+	l->plane_rows = plan->plane_rows;
+	l->swizzle = plan->swizzle;
+}
+
 int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_t in_valid_bytes, void *d_out,
                    uint64_t pos_int, uint64_t pos_frac, uint64_t n_out, void *stream)
 {
@@ -448,44 +530,19 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 	if (plan->use_poly && !g_force_generic && pos_int < (1ull << 47) && n_out < (1ull << 40))
 	{
 		crhip_poly_launch l;
-		uint64_t per_block, blocks;
-		const uint64_t min_per_block = 4u * plan->threads;
+		uint64_t blocks;
 
-		memset(&l, 0, sizeof(l));
+		fill_poly_launch(plan, &l);
 		l.d_in = d_in;
 		l.in_valid_bytes = in_valid_bytes;
 		l.d_out = d_out;
-		l.d_rows = plan->d_rows;
 		l.pos0 = (pos_int << 16) + pos_frac;
 		l.n_out = n_out;
-		l.increment = (uint32_t)plan->increment;
-		l.channels = plan->channels;
-		l.slots = plan->poly.slots;
-		l.first_slot = plan->poly.first_slot;
-		l.rows = plan->poly.rows;
-		l.row_stride = plan->poly.row_stride;
-		l.row_mode = plan->poly.row_mode;
-		l.norm_mode = plan->poly.norm_mode;
-		l.delta = plan->poly.delta;
-		l.skr = plan->poly.skr;
-		l.step = plan->poly.step;
-		l.aff_a = plan->poly.aff_a;
-		l.aff_b = plan->poly.aff_b;
-		l.aff_c = plan->poly.aff_c;
-		l.threads = plan->threads;
-		l.vecs = plan->vecs;
-		l.tile_frames = plan->tile_frames;
-		l.lds_bytes = plan->lds_bytes;
-		l.specialised = plan->specialised;
 
-		/* contiguous, equal blocks of output frames, multiples of 64 so that every workgroup's stores start on a
-		   line boundary; small launches use fewer workgroups rather than starving each of work */
-		per_block = (n_out + plan->max_blocks - 1) / plan->max_blocks;
-		if (per_block < min_per_block)
-			per_block = min_per_block;
-		per_block = (per_block + 63u) & ~(uint64_t)63u;
-		blocks = (n_out + per_block - 1) / per_block;
-		l.frames_per_block = per_block;
+		/* tiles are dealt round-robin to a persistent grid (see k_poly) */
+		blocks = (n_out + plan->tile_frames - 1) / plan->tile_frames;
+		if (blocks > plan->max_blocks)
+			blocks = plan->max_blocks;
 		l.blocks = (uint32_t)blocks;
 
 		return cr_check_hip(crhip_launch_poly(&l, stream), "k_poly launch");
@@ -681,6 +738,11 @@ const int32_t *ClownResamplerAMD_PlanRows(const ClownResamplerAMD_Plan *plan)
 uint32_t ClownResamplerAMD_PlanRowOf(const ClownResamplerAMD_Plan *plan, uint32_t position_fractional)
 {
 	return cr_poly_row_of(&plan->poly, position_fractional & 0xFFFFu);
+}
+
+void ClownResamplerAMD_DebugSetVariant(int variant)
+{
+	g_variant = ((variant >= 0 && variant < crhip_poly_variants()) || (variant >= 1000 && variant < 1010)) ? variant : CR_DEFAULT_VARIANT;
 }
 
 void ClownResamplerAMD_DebugForceGenericKernel(int on)

@@ -45,7 +45,9 @@ typedef struct ClownResamplerAMD_Plan
 	int use_poly;
 	const char *generic_reason;
 	int32_t *d_rows;
-	uint32_t threads, vecs, tile_frames, lds_bytes, max_blocks, specialised;
+	uint32_t threads, vecs, tile_frames, lds_bytes, max_blocks, specialised, variant;
+	uint32_t plane_rows, swizzle;
+	double conflict_plain, conflict_best; /* modelled extra LDS cycles per row read without / with the swizzle */
 } ClownResamplerAMD_Plan;
 
 /* Cache lookup by (hash of the caller's raw table bytes, radius, configuration, channels, increment); on a miss

@@ -12,8 +12,9 @@
 //             (zero-padded to a common window) followed by the exact 17.15 reciprocal of their sum
 //             (clownresampler.h:1025), so the device does neither the strided table walk nor the integer divide.
 //             A persistent workgroup stages the rows in LDS once, then streams its contiguous block of output
-//             frames tile by tile: the input PCM window of a tile is fetched with 16-byte buffer loads into
-//             registers while the previous tile is being computed, parked in a double-buffered LDS tile, and each
+//             frames tile by tile: the input PCM window of the NEXT tile is fetched by LDS-DMA (16-byte
+//             `buffer_load ... lds`, bounds-checked by the buffer descriptor) into the other half of a double-buffered
+//             LDS tile while the current tile is being computed, and each
 //             lane produces whole output frames from LDS (weights: ds_read_b128 of its row; samples: one LDS read
 //             per tap covering all channels of the frame).  Per tap and channel the arithmetic is
 //             v_mul_i32_i24 + truncate-toward-zero /65536 + add, in that order: the reference truncates every
@@ -46,14 +47,9 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 // Fixed-point pieces
 // ---------------------------------------------------------------------------------------------------------
 
-// (sample * weight) / 65536 with C semantics (truncation toward zero), clownresampler.h:1020 via :625.
-// Both operands fit 24 bits (|sample| <= 2^15; |weight| < 2^23 checked by the host), the product fits int32
-// (-32768 * 65536 is exactly INT32_MIN), so the full-rate 24-bit multiplier is exact.
-__device__ __forceinline__ int tap_term(int sample, int weight)
-{
-	const int product = __mul24(sample, weight);
-	return (product + (int)((unsigned)(product >> 31) >> 16)) >> 16;
-}
+// The per-tap term is (sample * weight) / 65536 with C semantics (truncation toward zero), clownresampler.h:1020 via
+// :625.  Both operands fit 24 bits (|sample| <= 2^15; |weight| < 2^23 checked by the host) and the product fits int32
+// (-32768 * 65536 is exactly INT32_MIN), so the full-rate 24-bit multiplier is exact; see accumulate_product below.
 
 // (acc * reciprocal) / 32768 with C semantics, clownresampler.h:1033.  Host-proved: |acc| < 2^23,
 // 0 < reciprocal < 2^23 and either |acc * reciprocal| < 2^31 (NORM_S31) or < 2^32 (NORM_U32: the product of the
@@ -75,67 +71,135 @@ __device__ __forceinline__ int normalise(int acc, int reciprocal)
 	}
 }
 
-// One input frame (CH interleaved int16) from LDS -> CH ints.
-template <int CH>
-struct FrameLoad
+// ---------------------------------------------------------------------------------------------------------
+// Sub-dword (SDWA) forms of the tap arithmetic.  A stereo frame is one dword (left in the low word, right in the
+// high word); SDWA operand selects let the multiply read either word sign-extended, and let an add read the high
+// word of a register, which IS the shift by 16:
+//     x   = v_mul_i32_i24(sext(word k of frame), weight)            product, exact
+//     t   = x >> 31                                                  0 / -1
+//     x'  = x + (t >>> 16)                 add, src1 = WORD_1 of t   + 0xFFFF when negative (C truncation toward zero)
+//     acc = acc + (x' >> 16)               add, src1 = sext(WORD_1 of x')
+// 4 VALU per tap and channel instead of the 6-7 the compiler emits for the C expression (it unpacks the words
+// separately and redoes the multiply as a mad).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sdwa_mul_word0(int frame, int weight)
 {
-	static __device__ __forceinline__ void load(const unsigned char *p, int (&s)[CH])
+	int x;
+	asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(x) : "v"(frame), "v"(weight));
+	return x;
+}
+
+__device__ __forceinline__ int sdwa_mul_word1(int frame, int weight)
+{
+	int x;
+	asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(x) : "v"(frame), "v"(weight));
+	return x;
+}
+
+__device__ __forceinline__ int sdwa_add_word1_unsigned(int x, int t)
+{
+	int r;
+	asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(x), "v"(t));
+	return r;
+}
+
+__device__ __forceinline__ int sdwa_add_word1_signed(int acc, int x)
+{
+	int r;
+	asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(acc), "v"(x));
+	return r;
+}
+
+// acc += trunc(product / 65536)
+template <int ASM>
+__device__ __forceinline__ int accumulate_product(int acc, int product)
+{
+	if constexpr (ASM)
+		return sdwa_add_word1_signed(acc, sdwa_add_word1_unsigned(product, product >> 31));
+	else
+		return acc + ((product + (int)((unsigned)(product >> 31) >> 16)) >> 16);
+}
+
+// One input frame from LDS.  Even channel counts stay PACKED (two int16 per dword) and are multiplied straight out
+// of the dword; odd counts are read sample by sample.
+template <int CH>
+struct Frame
+{
+	static constexpr bool PACKED = (CH % 2) == 0;
+	static constexpr int WORDS = PACKED ? CH / 2 : CH;
+	int v[WORDS];
+
+	__device__ __forceinline__ void load(const unsigned char *p)
+	{
+		if constexpr (CH == 2)
+		{
+			v[0] = *reinterpret_cast<const int *>(p);
+		}
+		else if constexpr (CH == 4)
+		{
+			const i32x2 d = *reinterpret_cast<const i32x2 *>(p);
+			v[0] = d.x;
+			v[1] = d.y;
+		}
+		else if constexpr (CH == 8)
+		{
+			const i32x4 d = *reinterpret_cast<const i32x4 *>(p);
+			v[0] = d.x;
+			v[1] = d.y;
+			v[2] = d.z;
+			v[3] = d.w;
+		}
+		else if constexpr (PACKED)
+		{
+#pragma unroll
+			for (int k = 0; k < WORDS; ++k)
+				v[k] = reinterpret_cast<const int *>(p)[k];
+		}
+		else
+		{
+#pragma unroll
+			for (int c = 0; c < CH; ++c)
+				v[c] = reinterpret_cast<const short *>(p)[c];
+		}
+	}
+
+	template <int ASM>
+	__device__ __forceinline__ void mac(int (&acc)[CH], int weight) const
+	{
+		if constexpr (PACKED)
+		{
+#pragma unroll
+			for (int k = 0; k < WORDS; ++k)
+			{
+				if constexpr (ASM)
+				{
+					acc[2 * k] = accumulate_product<1>(acc[2 * k], sdwa_mul_word0(v[k], weight));
+					acc[2 * k + 1] = accumulate_product<1>(acc[2 * k + 1], sdwa_mul_word1(v[k], weight));
+				}
+				else
+				{
+					acc[2 * k] = accumulate_product<0>(acc[2 * k], __mul24((int)(short)v[k], weight));
+					acc[2 * k + 1] = accumulate_product<0>(acc[2 * k + 1], __mul24(v[k] >> 16, weight));
+				}
+			}
+		}
+		else
+		{
+#pragma unroll
+			for (int c = 0; c < CH; ++c)
+				acc[c] = accumulate_product<ASM>(acc[c], __mul24(v[c], weight));
+		}
+	}
+};
+
+// N consecutive output frames (N * CH int32) -> global memory, widest stores the size allows.
+template <int NINT>
+__device__ __forceinline__ void store_ints(int *dst, const int *v)
+{
+	if constexpr (NINT % 4 == 0)
 	{
 #pragma unroll
-		for (int c = 0; c < CH; ++c)
-			s[c] = reinterpret_cast<const short *>(p)[c];
-	}
-};
-
-template <>
-struct FrameLoad<2>
-{
-	static __device__ __forceinline__ void load(const unsigned char *p, int (&s)[2])
-	{
-		const int d = *reinterpret_cast<const int *>(p);
-		s[0] = (int)(short)d;
-		s[1] = d >> 16;
-	}
-};
-
-template <>
-struct FrameLoad<4>
-{
-	static __device__ __forceinline__ void load(const unsigned char *p, int (&s)[4])
-	{
-		const i32x2 d = *reinterpret_cast<const i32x2 *>(p);
-		s[0] = (int)(short)d.x;
-		s[1] = d.x >> 16;
-		s[2] = (int)(short)d.y;
-		s[3] = d.y >> 16;
-	}
-};
-
-template <>
-struct FrameLoad<8>
-{
-	static __device__ __forceinline__ void load(const unsigned char *p, int (&s)[8])
-	{
-		const i32x4 d = *reinterpret_cast<const i32x4 *>(p);
-		s[0] = (int)(short)d.x;
-		s[1] = d.x >> 16;
-		s[2] = (int)(short)d.y;
-		s[3] = d.y >> 16;
-		s[4] = (int)(short)d.z;
-		s[5] = d.z >> 16;
-		s[6] = (int)(short)d.w;
-		s[7] = d.w >> 16;
-	}
-};
-
-// One output frame (CH int32) -> global memory, widest stores the frame size allows.
-template <int CH>
-__device__ __forceinline__ void store_frame(int *dst, const int (&v)[CH])
-{
-	if constexpr (CH % 4 == 0)
-	{
-#pragma unroll
-		for (int c = 0; c < CH; c += 4)
+		for (int c = 0; c < NINT; c += 4)
 		{
 			i32x4 q;
 			q.x = v[c];
@@ -145,10 +209,10 @@ __device__ __forceinline__ void store_frame(int *dst, const int (&v)[CH])
 			*reinterpret_cast<i32x4 *>(dst + c) = q;
 		}
 	}
-	else if constexpr (CH % 2 == 0)
+	else if constexpr (NINT % 2 == 0)
 	{
 #pragma unroll
-		for (int c = 0; c < CH; c += 2)
+		for (int c = 0; c < NINT; c += 2)
 		{
 			i32x2 q;
 			q.x = v[c];
@@ -159,13 +223,13 @@ __device__ __forceinline__ void store_frame(int *dst, const int (&v)[CH])
 	else
 	{
 #pragma unroll
-		for (int c = 0; c < CH; ++c)
+		for (int c = 0; c < NINT; ++c)
 			dst[c] = v[c];
 	}
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Row index of a fractional position (host mirror: cr_plan.c cr_plan_row_of)
+// Row index of a fractional position (host mirror: cr_plan.c cr_poly_row_of)
 // ---------------------------------------------------------------------------------------------------------
 template <int MODE>
 __device__ __forceinline__ unsigned row_of(const crhip_poly_launch &a, unsigned frac)
@@ -184,6 +248,82 @@ __device__ __forceinline__ unsigned row_of(const crhip_poly_launch &a, unsigned 
 	}
 }
 
+// One output frame: CH normalised int32 into out[0..CH).
+//   rel   16.16 position relative to the tile's first integer position
+//   base  LDS address of the tile's first window frame (tile + shift)
+template <int CH, int TT, int MODE, int NORM, int ASM, int SWZ>
+__device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int *rows, const unsigned char *base, unsigned rel, int *out)
+{
+	constexpr unsigned FB = CH * 2;
+	constexpr int RS_CT = (TT + 1 + 3) & ~3;
+
+	const unsigned frac = rel & 0xFFFFu;
+	const unsigned row = row_of<MODE>(a, frac);
+	// LDS image of the rows: PLANAR (plane q holds int32 [4q, 4q+4) of every row, 16 bytes per row) and SWIZZLED
+	// within each block of 16 rows by a host-chosen multiple of the block number, so that the 16 lanes a
+	// ds_read_b128 services together fall on 16 different 16-byte bank slots instead of the 5-8 the plain layout
+	// gives for a fixed increment (cr_plan.c cr_poly_pick_swizzle).
+	const unsigned phys = SWZ ? ((row & ~15u) | ((__umul24(row >> 4, a.swizzle) + row) & 15u)) : row;
+	const unsigned char *src = base + (rel >> 16) * FB;
+	const i32x4 *plane0 = reinterpret_cast<const i32x4 *>(rows) + phys;
+
+	int acc[CH];
+#pragma unroll
+	for (int c = 0; c < CH; ++c)
+		acc[c] = 0;
+
+	int reciprocal = 0;
+
+	if constexpr (TT > 0)
+	{
+		int w[RS_CT];
+#pragma unroll
+		for (int q = 0; q < RS_CT / 4; ++q)
+		{
+			const i32x4 v = plane0[q * a.plane_rows];
+			w[4 * q] = v.x;
+			w[4 * q + 1] = v.y;
+			w[4 * q + 2] = v.z;
+			w[4 * q + 3] = v.w;
+		}
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+		{
+			Frame<CH> f;
+			f.load(src + s * FB);
+			f.template mac<ASM>(acc, w[s]);
+		}
+		reciprocal = w[TT];
+	}
+	else
+	{
+		const unsigned T = a.slots;
+		const unsigned planes = a.row_stride / 4u;
+		for (unsigned q = 0; q < planes; ++q)
+		{
+			const i32x4 v = plane0[q * a.plane_rows];
+			const int w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (int e = 0; e < 4; ++e)
+			{
+				const unsigned slot = 4u * q + e;
+				if (slot < T)
+				{
+					Frame<CH> f;
+					f.load(src + slot * FB);
+					f.template mac<ASM>(acc, w4[e]);
+				}
+				else if (slot == T)
+					reciprocal = w4[e];
+			}
+		}
+	}
+
+#pragma unroll
+	for (int c = 0; c < CH; ++c)
+		out[c] = normalise<NORM>(acc[c], reciprocal);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // k_poly
 // ---------------------------------------------------------------------------------------------------------
@@ -193,25 +333,32 @@ __device__ __forceinline__ unsigned row_of(const crhip_poly_launch &a, unsigned 
 // NORM      final normalisation form (CRHIP_NORM_*)
 // NTHREADS  workgroup size
 // NV        16-byte input vectors each thread moves per tile (LDS tile buffer = NV * 16 * NTHREADS bytes)
-template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV>
+// ASM       1 = SDWA tap arithmetic, 0 = what the compiler makes of the C expression
+// U         output frames a lane works on at once (independent instruction streams to cover LDS latency)
+// SWZ       1 = the LDS image of the rows is swizzled (a.swizzle), 0 = plain (a.swizzle must be 0)
+// ABL       0 in every shipped instance.  Timing-only ablations (WRONG results, reachable only through the debug
+//           launch flag of tools/): 1 = no output stores, 2 = no input DMA, 3 = neither, 4 = DMA + stores but no arithmetic
+template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 {
 	constexpr unsigned FB = CH * 2;                       // bytes per input frame
 	constexpr unsigned TILE_BYTES = NV * 16u * NTHREADS;
-	constexpr int RS_CT = (TT + 1 + 3) & ~3;              // row stride when TT is fixed
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 	const unsigned tid = threadIdx.x;
-	const unsigned rows_bytes = (a.rows * a.row_stride * 4u + 15u) & ~15u;
+	const unsigned rows_bytes = a.plane_rows * a.row_stride * 4u;   // planes of plane_rows x 16 bytes
 	const int *rows = reinterpret_cast<const int *>(smem);
 	unsigned char *tiles = smem + rows_bytes;
 
-	// contiguous block of output frames owned by this workgroup
-	const uint64_t j_begin = (uint64_t)blockIdx.x * a.frames_per_block;
-	if (j_begin >= a.n_out)
+	// Tiles of tile_frames output frames are dealt round-robin: workgroup b takes tiles b, b + gridDim.x, ...  At any
+	// moment the resident workgroups therefore stream ONE compact window of the input and of the output (like a flat
+	// grid would), instead of gridDim.x far-apart streams; on this chip that is worth ~10 % of HBM throughput for this
+	// read:write mix (tools/microbench/streambench.hip).
+	const uint64_t NT64 = a.tile_frames;
+	const uint64_t n_tiles = (a.n_out + NT64 - 1) / NT64;
+	if (blockIdx.x >= n_tiles)
 		return;
-	const uint64_t j_end = (j_begin + a.frames_per_block < a.n_out) ? j_begin + a.frames_per_block : a.n_out;
 
 	// stage the polyphase rows once per workgroup (L2-resident after the first workgroups)
 	{
@@ -225,12 +372,13 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 	const uint64_t in_base = reinterpret_cast<uint64_t>(a.d_in);
 	const uint64_t in_end = in_base + a.in_valid_bytes;
 	const unsigned T = TT > 0 ? (unsigned)TT : a.slots;
-	const unsigned RS = TT > 0 ? (unsigned)RS_CT : a.row_stride;
 
-	// Issues the global loads of the input window of the tile starting at output frame jt into registers.
-	// Returns the byte offset of the window's first frame inside the (16-byte aligned) tile image.
-	u32x4 pre[NV];
-	auto fetch = [&](uint64_t jt, unsigned n) -> unsigned {
+	// Starts the LDS-DMA of the input window of the tile that begins at output frame jt: 16-byte buffer loads that
+	// land directly in `tile` (no register staging, no ds_write), each wave filling a contiguous 1 KiB piece per
+	// instruction.  Returns the byte offset of the window's first frame inside the (16-byte aligned) tile image.
+	// The loads are NOT waited for here.
+	const unsigned wave_first = __builtin_amdgcn_readfirstlane(tid & ~63u);
+	auto fetch = [&](uint64_t jt, unsigned n, unsigned char *tile) -> unsigned {
 		const uint64_t pos = a.pos0 + jt * (uint64_t)a.increment;
 		const uint64_t first_byte = in_base + ((pos >> 16) + a.first_slot) * FB;
 		const uint64_t aligned = first_byte & ~(uint64_t)15;
@@ -241,7 +389,12 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 		uint64_t avail = in_end > aligned ? in_end - aligned : 0;
 		if (want > avail)
 			want = avail;
-		// wave-uniform descriptor: base = aligned window start, num_records = bytes we may touch
+		// The descriptor's range check works on whole dwords: a window that ends on a 2-byte boundary (odd channel
+		// counts, mono) would lose its last sample.  Rounding up stays inside the same aligned dword, hence inside the
+		// same page as the last valid sample; the extra half-dword only ever meets a zero weight.
+		want = (want + 3u) & ~(uint64_t)3u;
+		// wave-uniform descriptor: base = aligned window start, num_records = bytes we may touch (loads beyond it
+		// deliver zeros, which only ever meet zero weights)
 		const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)aligned);
 		const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(aligned >> 32));
 		const unsigned rec = __builtin_amdgcn_readfirstlane((unsigned)want);
@@ -249,103 +402,133 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 		    __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)rec, 0x00020000);
 #pragma unroll
 		for (int v = 0; v < NV; ++v)
-			pre[v] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((v * NTHREADS + tid) * 16u), 0, 0);
+			if (!(ABL == 2 || ABL == 3) || a.n_out == 1)
+			__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(tile + (v * NTHREADS + wave_first) * 16u), 16,
+			                                         (int)((v * NTHREADS + tid) * 16u), 0, 0, 0);
 		return shift;
 	};
-	auto park = [&](unsigned char *tile) {
-#pragma unroll
-		for (int v = 0; v < NV; ++v)
-			*reinterpret_cast<u32x4 *>(tile + (v * NTHREADS + tid) * 16u) = pre[v];
-	};
 
-	const unsigned NT = a.tile_frames;
-	uint64_t jt = j_begin;
-	unsigned n = (unsigned)((j_end - jt < NT) ? (j_end - jt) : NT);
-	unsigned shift = fetch(jt, n);
-	park(tiles);
-	__syncthreads();
+	// vmcnt counts loads, LDS-DMA and stores together, in issue order.  The DMA of the NEXT tile is issued before
+	// this tile's stores, so waiting until only this tile's stores are outstanding means the DMA has landed, while
+	// the stores stay in flight across the barrier.  The count must be a literal: full tiles of 4, 2 or 1 groups run
+	// as straight-line code for that reason; a ragged tile drains everything.
+	constexpr unsigned GROUP = NTHREADS * U;
+	constexpr int ADJ = 0;   // a lane's U frames are NTHREADS apart: every store instruction is coalesced across the wave
+	constexpr int STORES_PER_GROUP = U * (CH % 4 == 0 ? CH / 4 : (CH % 2 == 0 ? CH / 2 : CH));
+
+	uint64_t tile_index = blockIdx.x;
+	uint64_t jt = tile_index * NT64;
+	unsigned n = (unsigned)((a.n_out - jt < NT64) ? (a.n_out - jt) : NT64);
+	unsigned shift = fetch(jt, n, tiles);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();   // rows staged (plain stores to LDS) and first tile landed, for every wave
 
 	for (unsigned it = 0;; ++it)
 	{
 		const unsigned char *tile = tiles + (it & 1u) * TILE_BYTES;
-		const uint64_t jn = jt + n;
-		const bool more = jn < j_end;
+		const uint64_t next_index = tile_index + gridDim.x;
+		const bool more = next_index < n_tiles;
+		const uint64_t jn = next_index * NT64;
 		unsigned n_next = 0, shift_next = 0;
 
 		if (more)
 		{
-			n_next = (unsigned)((j_end - jn < NT) ? (j_end - jn) : NT);
-			shift_next = fetch(jn, n_next);   // in flight while this tile is computed
+			// the other buffer was last read in the previous iteration, which every wave has left (barrier below)
+			n_next = (unsigned)((a.n_out - jn < NT64) ? (a.n_out - jn) : NT64);
+			shift_next = fetch(jn, n_next, tiles + ((it + 1u) & 1u) * TILE_BYTES);
 		}
 
 		const uint64_t pos = a.pos0 + jt * (uint64_t)a.increment;
 		const unsigned frac0 = (unsigned)(pos & 0xFFFFu);
 		int *out_tile = reinterpret_cast<int *>(a.d_out) + jt * CH;
+		const unsigned char *base = tile + shift;
 
-		for (unsigned jl = tid; jl < n; jl += NTHREADS)
-		{
-			const unsigned rel = __umul24(jl, a.increment) + frac0;   // 16.16 relative to the tile's first integer position
-			const unsigned frac = rel & 0xFFFFu;
-			const unsigned row = row_of<MODE>(a, frac);
-			const unsigned char *src = tile + shift + (rel >> 16) * FB;
-			const int *wrow = rows + row * RS;
-
-			int acc[CH];
+		// One group = NTHREADS * U frames: U independent frames per lane, no bounds checks.
+		auto group = [&](unsigned g) {
+			int outv[U * CH];
 #pragma unroll
-			for (int c = 0; c < CH; ++c)
-				acc[c] = 0;
-
-			int reciprocal;
-
-			if constexpr (TT > 0)
+			for (int u = 0; u < U; ++u)
 			{
-				int w[RS_CT];
-#pragma unroll
-				for (int q = 0; q < RS_CT; q += 4)
+				const unsigned jl = ADJ ? g + tid * U + u : g + u * NTHREADS + tid;
+				if constexpr (ABL == 4)
 				{
-					const i32x4 v = *reinterpret_cast<const i32x4 *>(wrow + q);
-					w[q] = v.x;
-					w[q + 1] = v.y;
-					w[q + 2] = v.z;
-					w[q + 3] = v.w;
-				}
-#pragma unroll
-				for (int s = 0; s < TT; ++s)
-				{
-					int smp[CH];
-					FrameLoad<CH>::load(src + s * FB, smp);
 #pragma unroll
 					for (int c = 0; c < CH; ++c)
-						acc[c] += tap_term(smp[c], w[s]);
+						outv[u * CH + c] = (int)jl;
 				}
-				reciprocal = w[TT];
+				else
+					one_frame<CH, TT, MODE, NORM, ASM, SWZ>(a, rows, base, __umul24(jl, a.increment) + frac0, outv + u * CH);
+			}
+			if constexpr (ABL == 1 || ABL == 3)
+			{
+				// keep the arithmetic alive without the stores (cdna_hip_programming.md rule 17)
+#pragma unroll
+				for (int c = 0; c < U * CH; ++c)
+					asm volatile("" ::"v"(outv[c]));
+				return;
+			}
+			if constexpr (ADJ)
+			{
+				store_ints<U * CH>(out_tile + (size_t)(g + tid * U) * CH, outv);
 			}
 			else
 			{
-				for (unsigned s = 0; s < T; ++s)
-				{
-					const int weight = wrow[s];
-					int smp[CH];
-					FrameLoad<CH>::load(src + s * FB, smp);
 #pragma unroll
-					for (int c = 0; c < CH; ++c)
-						acc[c] += tap_term(smp[c], weight);
-				}
-				reciprocal = wrow[T];
+				for (int u = 0; u < U; ++u)
+					store_ints<CH>(out_tile + (size_t)(g + u * NTHREADS + tid) * CH, outv + u * CH);
 			}
+		};
 
-			int outv[CH];
-#pragma unroll
-			for (int c = 0; c < CH; ++c)
-				outv[c] = normalise<NORM>(acc[c], reciprocal);
-			store_frame<CH>(out_tile + (size_t)jl * CH, outv);
+		if (n == 4u * GROUP)
+		{
+			group(0);
+			group(GROUP);
+			group(2u * GROUP);
+			group(3u * GROUP);
+			if constexpr (4 * STORES_PER_GROUP <= 63)
+				asm volatile("s_waitcnt vmcnt(%0)" ::"i"(4 * STORES_PER_GROUP) : "memory");
+			else
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		else if (n == 2u * GROUP)
+		{
+			group(0);
+			group(GROUP);
+			if constexpr (2 * STORES_PER_GROUP <= 63)
+				asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * STORES_PER_GROUP) : "memory");
+			else
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		else if (n == GROUP)
+		{
+			group(0);
+			if constexpr (STORES_PER_GROUP <= 63)
+				asm volatile("s_waitcnt vmcnt(%0)" ::"i"(STORES_PER_GROUP) : "memory");
+			else
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		else
+		{
+			// ragged tile (only the stream's last tile can be one)
+			const unsigned n_full = n - n % GROUP;
+			unsigned g = 0;
+			for (; g < n_full; g += GROUP)
+				group(g);
+			for (unsigned jl = g + tid; jl < n; jl += NTHREADS)
+			{
+				int outv[CH];
+				one_frame<CH, TT, MODE, NORM, ASM, SWZ>(a, rows, base, __umul24(jl, a.increment) + frac0, outv);
+				store_ints<CH>(out_tile + (size_t)jl * CH, outv);
+			}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		}
 
 		if (!more)
 			break;
 
-		park(tiles + ((it + 1u) & 1u) * TILE_BYTES);
-		__syncthreads();
+		// every wave's share of the next tile has landed once every wave is past its wait
+		__builtin_amdgcn_s_barrier();
+		tile_index = next_index;
 		jt = jn;
 		n = n_next;
 		shift = shift_next;
@@ -412,60 +595,117 @@ __global__ __launch_bounds__(256) void k_generic(const crhip_generic_launch a)
 // ---------------------------------------------------------------------------------------------------------
 // Instance table of k_poly
 // ---------------------------------------------------------------------------------------------------------
-constexpr int POLY_THREADS = 256;
-constexpr int POLY_VECS = 2;
-
 typedef void (*poly_fn)(const crhip_poly_launch);
 
-template <int CH, int TT>
-poly_fn pick_mode(uint32_t mode, uint32_t norm)
+// Tuning variants of the specialised instances: geometry x frames in flight x row swizzle.
+//   variant = geo + 5 * ui + 10 * swz    geo: 0 (256 thr, 2 vec) 1 (512,1) 2 (512,2) 3 (1024,1) 4 (1024,2); ui: 0/1 -> U = 1/2
+// The specialised instances always use the SDWA arithmetic; the run-time-slot instances keep the compiler's, so the
+// test-suite exercises both forms against the oracle.
+struct geometry
 {
-	if (norm == CRHIP_NORM_S31)
-		return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<CH, TT, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, POLY_THREADS, POLY_VECS>
-		                                      : (poly_fn)k_poly<CH, TT, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, POLY_THREADS, POLY_VECS>;
-	return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<CH, TT, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, POLY_THREADS, POLY_VECS>
-	                                      : (poly_fn)k_poly<CH, TT, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, POLY_THREADS, POLY_VECS>;
+	int threads, vecs;
+};
+constexpr geometry GEOMETRY[5] = {{256, 2}, {512, 1}, {512, 2}, {1024, 1}, {1024, 2}};
+constexpr int VARIANTS = 20;
+
+template <int CH, int TT, int MODE, int NORM, int GEO, int ASM, int UI, int SWZ>
+constexpr poly_fn instance()
+{
+	return (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[GEO].threads, GEOMETRY[GEO].vecs, ASM, (1 << UI), SWZ>;
 }
 
-template <int CH>
-poly_fn pick_slots(uint32_t slots, uint32_t mode, uint32_t norm, bool specialised)
+template <int CH, int TT, int MODE, int NORM, int V>
+struct variant_table
 {
-	if (specialised)
+	static void fill(poly_fn *t)
 	{
-		switch (slots)
-		{
-			case 5: return pick_mode<CH, 5>(mode, norm);
-			case 6: return pick_mode<CH, 6>(mode, norm);
-			case 7: return pick_mode<CH, 7>(mode, norm);
-			case 15: return pick_mode<CH, 15>(mode, norm);
-			case 16: return pick_mode<CH, 16>(mode, norm);
-			default: break;
-		}
+		t[V] = instance<CH, TT, MODE, NORM, V % 5, 1, (V / 5) % 2, (V / 10) % 2>();
+		variant_table<CH, TT, MODE, NORM, V + 1>::fill(t);
 	}
-	return pick_mode<CH, 0>(mode, norm);
+};
+template <int CH, int TT, int MODE, int NORM>
+struct variant_table<CH, TT, MODE, NORM, VARIANTS>
+{
+	static void fill(poly_fn *) {}
+};
+
+// specialised (channels, slots, mode, norm) instances; the BASELINE.json configurations
+struct special
+{
+	uint32_t channels, slots, mode, norm;
+	uint32_t default_variant;   // from tools/sweep_variants.py on MI355X (profiles/)
+	poly_fn fn[VARIANTS];
+};
+
+template <int CH, int TT, int MODE, int NORM>
+special make_special(uint32_t default_variant)
+{
+	special s = {CH, TT, MODE, NORM, default_variant, {}};
+	variant_table<CH, TT, MODE, NORM, 0>::fill(s.fn);
+	return s;
 }
 
-poly_fn pick_poly(uint32_t channels, uint32_t slots, uint32_t mode, uint32_t norm, bool specialised)
+const special *specials(int *count)
 {
-	switch (channels)
+	static const special table[] = {
+	    make_special<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(8),   // cfg 2 / cfg 5: stereo 44.1 -> 48 kHz, 3 lobes
+	    make_special<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32>(9),  // cfg 3: stereo 8 -> 96 kHz, 8 lobes
+	    make_special<8, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(12),     // cfg 4: 8 channels 48 -> 44.1 kHz
+	    make_special<1, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(8),   // mono upsampling, 3 lobes
+	    make_special<2, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(8),     // stereo mild downsampling, 3 lobes
+	};
+	*count = (int)(sizeof(table) / sizeof(table[0]));
+	return table;
+}
+
+// timing-only ablations of the headline instance at the default geometry (see ABL above)
+poly_fn ablation_instance(int abl)
+{
+	switch (abl)
 	{
-		case 1: return pick_slots<1>(slots, mode, norm, specialised);
-		case 2: return pick_slots<2>(slots, mode, norm, specialised);
-		case 3: return pick_slots<3>(slots, mode, norm, false);
-		case 4: return pick_slots<4>(slots, mode, norm, specialised);
-		case 5: return pick_slots<5>(slots, mode, norm, false);
-		case 6: return pick_slots<6>(slots, mode, norm, false);
-		case 7: return pick_slots<7>(slots, mode, norm, false);
-		case 8: return pick_slots<8>(slots, mode, norm, specialised);
+		case 1: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 1>;
+		case 2: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 2>;
+		case 3: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 3>;
+		case 4: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 4>;
 		default: return nullptr;
 	}
 }
 
-bool slots_specialised(uint32_t channels, uint32_t slots)
+const special *find_special(uint32_t channels, uint32_t slots, uint32_t mode, uint32_t norm)
 {
-	const bool ch_ok = channels == 1 || channels == 2 || channels == 4 || channels == 8;
-	const bool slots_ok = slots == 5 || slots == 6 || slots == 7 || slots == 15 || slots == 16;
-	return ch_ok && slots_ok;
+	int n;
+	const special *t = specials(&n);
+	for (int i = 0; i < n; ++i)
+		if (t[i].channels == channels && t[i].slots == slots && t[i].mode == mode && t[i].norm == norm)
+			return &t[i];
+	return nullptr;
+}
+
+// run-time slot count: every channel count 1..8, both row modes, both normalisations, default geometry
+template <int CH>
+poly_fn pick_runtime(uint32_t mode, uint32_t norm)
+{
+	if (norm == CRHIP_NORM_S31)
+		return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 0, 0, 0, 0>()
+		                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 0, 0, 0, 0>();
+	return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 0, 0, 0, 0>()
+	                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, 0, 0, 0, 0>();
+}
+
+poly_fn pick_runtime_channels(uint32_t channels, uint32_t mode, uint32_t norm)
+{
+	switch (channels)
+	{
+		case 1: return pick_runtime<1>(mode, norm);
+		case 2: return pick_runtime<2>(mode, norm);
+		case 3: return pick_runtime<3>(mode, norm);
+		case 4: return pick_runtime<4>(mode, norm);
+		case 5: return pick_runtime<5>(mode, norm);
+		case 6: return pick_runtime<6>(mode, norm);
+		case 7: return pick_runtime<7>(mode, norm);
+		case 8: return pick_runtime<8>(mode, norm);
+		default: return nullptr;
+	}
 }
 
 } // namespace
@@ -562,36 +802,81 @@ int crhip_stream_sync(void *stream)
 	return (int)hipStreamSynchronize((hipStream_t)stream);
 }
 
-int crhip_poly_has_instance(uint32_t channels, uint32_t slots, uint32_t row_mode)
+int crhip_poly_has_instance(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
 {
-	(void)row_mode;
-	return slots_specialised(channels, slots) ? 1 : 0;
+	return find_special(channels, slots, row_mode, norm_mode) != nullptr ? 1 : 0;
 }
 
-void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t *threads, uint32_t *vecs)
+// variant actually used by a launch: an explicit one (< VARIANTS), an ablation (>= 1000: headline geometry), or the
+// instance's measured default (CRHIP_VARIANT_DEFAULT)
+static uint32_t resolve_variant(const special *sp, uint32_t variant)
 {
-	(void)channels;
-	(void)slots;
-	*threads = POLY_THREADS;
-	*vecs = POLY_VECS;
+	if (sp == nullptr)
+		return 0u;
+	if (variant < (uint32_t)VARIANTS)
+		return variant;
+	if (variant >= 1000u && variant < 1010u)
+		return 3u;
+	return sp->default_variant;
+}
+
+int crhip_poly_swizzled(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t variant)
+{
+	const special *sp = find_special(channels, slots, row_mode, norm_mode);
+	return (int)((resolve_variant(sp, variant) / 10) % 2);
+}
+
+int crhip_poly_variants(void)
+{
+	return VARIANTS;
+}
+
+void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t variant,
+                         uint32_t *threads, uint32_t *vecs, uint32_t *frames_multiple)
+{
+	const special *sp = find_special(channels, slots, row_mode, norm_mode);
+	const uint32_t v = resolve_variant(sp, variant);
+
+	*threads = (uint32_t)GEOMETRY[v % 5].threads;
+	*vecs = (uint32_t)GEOMETRY[v % 5].vecs;
+	*frames_multiple = *threads * (1u << ((v / 5) % 2));
+}
+
+static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
+{
+	const special *sp = launch->specialised ? find_special(launch->channels, launch->slots, launch->row_mode, launch->norm_mode) : nullptr;
+	const uint32_t v = resolve_variant(sp, launch->variant);
+	poly_fn fn = sp != nullptr ? sp->fn[v] : pick_runtime_channels(launch->channels, launch->row_mode, launch->norm_mode);
+
+	// debug: variant 1000 + k selects timing-only ablation k of the headline instance (results are wrong by design)
+	if (sp != nullptr && launch->variant >= 1000u && launch->variant < 1010u && launch->channels == 2 && launch->slots == 5)
+		fn = ablation_instance((int)(launch->variant - 1000u));
+
+	*geo = v % 5;
+	return fn;
+}
+
+// One-time per-instance setup (not legal inside a stream capture): allow more than 48 KiB of dynamic LDS.
+int crhip_poly_prepare(const crhip_poly_launch *launch)
+{
+	uint32_t geo;
+	const poly_fn fn = select_poly(launch, &geo);
+
+	if (fn == nullptr)
+		return (int)hipErrorInvalidValue;
+
+	return (int)hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)launch->lds_bytes);
 }
 
 int crhip_launch_poly(const crhip_poly_launch *launch, void *stream)
 {
-	const bool specialised = launch->specialised && slots_specialised(launch->channels, launch->slots);
-	const poly_fn fn = pick_poly(launch->channels, launch->slots, launch->row_mode, launch->norm_mode, specialised);
+	uint32_t geo;
+	const poly_fn fn = select_poly(launch, &geo);
 
-	if (fn == nullptr || launch->threads != POLY_THREADS || launch->vecs != POLY_VECS)
+	if (fn == nullptr || launch->threads != (uint32_t)GEOMETRY[geo].threads || launch->vecs != (uint32_t)GEOMETRY[geo].vecs)
 		return (int)hipErrorInvalidValue;
 	if (launch->n_out == 0)
 		return 0;
-
-	if (launch->lds_bytes > 48u * 1024u)
-	{
-		const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)launch->lds_bytes);
-		if (e != hipSuccess)
-			return (int)e;
-	}
 
 	hipLaunchKernelGGL(fn, dim3(launch->blocks), dim3(launch->threads), launch->lds_bytes, (hipStream_t)stream, *launch);
 	return (int)hipGetLastError();

@@ -387,6 +387,118 @@ int cr_poly_build(const int32_t *table, size_t table_len, const cr_config *cfg, 
 }
 
 /* ------------------------------------------------------------------------------------------------------- */
+/* LDS image of the rows                                                                                   */
+/* ------------------------------------------------------------------------------------------------------- */
+
+uint32_t cr_poly_plane_rows(const cr_poly *poly)
+{
+	return (poly->rows + 15u) & ~15u;
+}
+
+uint32_t cr_poly_phys_row(uint32_t row, uint32_t swizzle)
+{
+	return (row & ~15u) | ((row + swizzle * (row >> 4)) & 15u);
+}
+
+/* ds_read_b128 services a wave64 in four groups of 16 lanes; within a group, lanes whose 16-byte slots share a
+   bank slot (address / 16 mod 16) serialise, identical addresses broadcast (MI355X_MICROARCH.md, LDS). */
+static const unsigned char B128_GROUPS[4][16] = {
+	{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+	{4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+	{32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+	{36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63},
+};
+
+static double swizzle_cost(const cr_poly *poly, uint64_t increment, uint32_t swizzle)
+{
+	/* lanes of a wave hold consecutive output frames: fraction of lane l = frac0 + l * increment (mod 65536) */
+	double extra = 0.0;
+	unsigned trial;
+
+	for (trial = 0; trial < 128; ++trial)
+	{
+		const uint32_t frac0 = (trial * 40503u + 977u) & 0xFFFFu;
+		unsigned g;
+
+		for (g = 0; g < 4; ++g)
+		{
+			uint32_t phys[16];
+			unsigned count[16] = {0};
+			unsigned i, k, worst = 0;
+
+			for (i = 0; i < 16; ++i)
+			{
+				const uint32_t frac = (uint32_t)((frac0 + (uint64_t)B128_GROUPS[g][i] * increment) & 0xFFFFu);
+				phys[i] = cr_poly_phys_row(cr_poly_row_of(poly, frac), swizzle);
+			}
+
+			for (i = 0; i < 16; ++i)
+			{
+				int seen = 0;
+
+				for (k = 0; k < i; ++k)
+					if (phys[k] == phys[i])
+						seen = 1; /* same address: broadcast */
+
+				if (!seen && ++count[phys[i] & 15u] > worst)
+					worst = count[phys[i] & 15u];
+			}
+
+			extra += worst - 1;
+		}
+	}
+
+	return extra / 128.0;
+}
+
+uint32_t cr_poly_pick_swizzle(const cr_poly *poly, uint64_t increment, double *conflict_plain, double *conflict_best)
+{
+	uint32_t best = 0, k;
+	double best_cost = swizzle_cost(poly, increment, 0);
+
+	if (conflict_plain != NULL)
+		*conflict_plain = best_cost;
+
+	for (k = 1; k < 16; ++k)
+	{
+		const double cost = swizzle_cost(poly, increment, k);
+
+		if (cost < best_cost - 1e-9)
+		{
+			best_cost = cost;
+			best = k;
+		}
+	}
+
+	if (conflict_best != NULL)
+		*conflict_best = best_cost;
+
+	return best;
+}
+
+int32_t *cr_poly_device_image(const cr_poly *poly, uint32_t swizzle)
+{
+	const uint32_t plane_rows = cr_poly_plane_rows(poly);
+	const uint32_t planes = poly->row_stride / 4u;
+	int32_t *image = (int32_t *)calloc((size_t)plane_rows * poly->row_stride, sizeof(int32_t));
+	uint32_t row, q, e;
+
+	if (image == NULL)
+		return NULL;
+
+	for (row = 0; row < poly->rows; ++row)
+	{
+		const uint32_t phys = cr_poly_phys_row(row, swizzle);
+
+		for (q = 0; q < planes; ++q)
+			for (e = 0; e < 4; ++e)
+				image[((size_t)q * plane_rows + phys) * 4u + e] = poly->weights[(size_t)row * poly->row_stride + 4u * q + e];
+	}
+
+	return image;
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
 
 uint64_t cr_count_output_frames(uint64_t pos_int, uint64_t pos_frac, uint64_t increment, uint64_t total_input_frames)
 {

@@ -57,6 +57,16 @@ int cr_poly_build(const int32_t *table, size_t table_len, const cr_config *cfg, 
 void cr_poly_free(cr_poly *poly);
 uint32_t cr_poly_row_of(const cr_poly *poly, uint32_t frac);
 
+/* LDS/device image of the rows: row_stride/4 planes of plane_rows (= rows rounded up to 16) x 4 int32; within each block
+   of 16 rows, row r sits at (r & ~15) | ((r + swizzle * (r >> 4)) & 15). */
+uint32_t cr_poly_plane_rows(const cr_poly *poly);
+uint32_t cr_poly_phys_row(uint32_t row, uint32_t swizzle);
+/* Chooses the swizzle (0..15) that minimises ds_read_b128 bank conflicts for lanes that hold consecutive output frames
+   `increment` apart; *conflict_cycles_plain / _best receive the modelled extra LDS cycles per wave read. */
+uint32_t cr_poly_pick_swizzle(const cr_poly *poly, uint64_t increment, double *conflict_plain, double *conflict_best);
+/* malloc'ed image, cr_poly_plane_rows() * row_stride int32 */
+int32_t *cr_poly_device_image(const cr_poly *poly, uint32_t swizzle);
+
 /* ---- closed forms of the timeline walk (reference clownresampler.h:1058-1092) ---- */
 
 /* frames emitted while position_integer < total_input_frames */

@@ -30,16 +30,17 @@ typedef struct crhip_poly_launch
 	const void *d_in;           /* interleaved int16 */
 	uint64_t in_valid_bytes;    /* bytes readable from d_in (loads beyond are suppressed by the buffer descriptor) */
 	void *d_out;                /* int32, n_out * channels */
-	const int32_t *d_rows;      /* rows * row_stride int32: [slots weights][17.15 reciprocal][padding] */
+	const int32_t *d_rows;      /* device image of the rows: row_stride/4 planes of plane_rows x 4 int32, swizzled (cr_plan.c) */
 	uint64_t pos0;              /* 16.16 */
 	uint64_t n_out;
-	uint64_t frames_per_block;  /* contiguous output frames owned by one workgroup */
 	uint32_t increment;         /* 16.16, < 2^24 */
 	uint32_t channels;
 	uint32_t slots;             /* taps evaluated per frame */
 	uint32_t first_slot;        /* frame offset of slot 0 relative to the integer position */
 	uint32_t rows;
 	uint32_t row_stride;        /* int32 per row, multiple of 4 */
+	uint32_t plane_rows;        /* rows rounded up to a multiple of 16 */
+	uint32_t swizzle;           /* phys = (row & ~15) | ((row + swizzle * (row >> 4)) & 15) */
 	uint32_t row_mode;
 	uint32_t norm_mode;
 	uint32_t delta;             /* stretched_kernel_radius_delta */
@@ -103,13 +104,24 @@ int crhip_stream_create(void **stream);
 int crhip_stream_destroy(void *stream);
 int crhip_stream_sync(void *stream);
 
+/* variant value meaning: the instance's measured default */
+#define CRHIP_VARIANT_DEFAULT 0xFFFFu
+
+/* One-time setup of the instance a launch selects (raises its dynamic-LDS limit); call once per plan, outside any capture. */
+int crhip_poly_prepare(const crhip_poly_launch *launch);
 int crhip_launch_poly(const crhip_poly_launch *launch, void *stream);
 int crhip_launch_generic(const crhip_generic_launch *launch, void *stream);
 
-/* 1 when a (channels, slots) template instance exists for the polyphase kernel. */
-int crhip_poly_has_instance(uint32_t channels, uint32_t slots, uint32_t row_mode);
-/* Geometry the polyphase instances are compiled for. */
-void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t *threads, uint32_t *vecs);
+/* 1 when a specialised (channels, slots, row mode, norm mode) template instance exists for the polyphase kernel. */
+int crhip_poly_has_instance(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
+/* 1 when the instance a launch with these parameters selects applies the row swizzle. */
+int crhip_poly_swizzled(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t variant);
+/* Number of tuning variants of the specialised instances (crhip_poly_launch.variant). */
+int crhip_poly_variants(void);
+/* Geometry the instance that a launch with these parameters selects is compiled for: workgroup size, 16-byte input
+   vectors per thread per tile, and the multiple of output frames a tile should be (threads * frames in flight per lane). */
+void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t variant,
+                         uint32_t *threads, uint32_t *vecs, uint32_t *frames_multiple);
 
 #ifdef __cplusplus
 }

@@ -138,6 +138,9 @@ uint32_t ClownResamplerAMD_PlanRowOf(const ClownResamplerAMD_Plan *plan, uint32_
 
 /* Test hook: route every launch through the generic 64-bit kernel (the independent second implementation). */
 void ClownResamplerAMD_DebugForceGenericKernel(int on);
+/* Tuning hook: selects the variant (geometry / arithmetic form) of the specialised kernels for plans created afterwards;
+   the environment variable CLOWNRESAMPLER_AMD_VARIANT does the same at first use.  All variants give identical results. */
+void ClownResamplerAMD_DebugSetVariant(int variant);
 
 /* device_input: interleaved int16, pointing at the start of the left padding, as for the reference call;
    at least *total_input_frames + 2 * integer_stretched_kernel_radius frames must be readable.

@@ -1,0 +1,86 @@
+// valubench.hip - issue rate of the integer VALU instructions the tap arithmetic is made of, on MI355X.
+// Every wave runs ITER x 64 independent instructions of one kind (8 accumulators round-robin); 8 waves per SIMD.
+// Prints wave-instructions per cycle per SIMD (from the measured time and an assumed 2.4 GHz) and Tlane-ops/s.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define REP64(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X)
+
+template <int KIND>
+__global__ __launch_bounds__(512) void k(int *out, int iters, int seed)
+{
+	int a[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i)
+		a[i] = seed + threadIdx.x * (i + 1);
+	int w = seed * 3 + 1;
+	for (int it = 0; it < iters; ++it)
+	{
+#define ADD(i) asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(w));
+#define MUL(i) asm volatile("v_mul_i32_i24_e32 %0, %0, %1" : "+v"(a[i]) : "v"(w));
+#define ASHR(i) asm volatile("v_ashrrev_i32_e32 %0, 3, %0" : "+v"(a[i]));
+#define ADDSDWA(i) asm volatile("v_add_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(a[i]) : "v"(w));
+#define MULSDWA(i) asm volatile("v_mul_i32_i24_sdwa %0, sext(%0), %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(a[i]) : "v"(w));
+#define MAD(i) asm volatile("v_mad_i32_i24 %0, %0, %1, %1" : "+v"(a[i]) : "v"(w));
+#define FMA(i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(w));
+#define ADD3(i) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(w));
+#define MULLO(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(w));
+#define BFI(i) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(a[i]) : "v"(w));
+		if constexpr (KIND == 0) { REP64(ADD) }
+		if constexpr (KIND == 1) { REP64(MUL) }
+		if constexpr (KIND == 2) { REP64(ASHR) }
+		if constexpr (KIND == 3) { REP64(ADDSDWA) }
+		if constexpr (KIND == 4) { REP64(MULSDWA) }
+		if constexpr (KIND == 5) { REP64(MAD) }
+		if constexpr (KIND == 6) { REP64(FMA) }
+		if constexpr (KIND == 7) { REP64(ADD3) }
+		if constexpr (KIND == 8) { REP64(MULLO) }
+		if constexpr (KIND == 9) { REP64(BFI) }
+	}
+	int r = 0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i)
+		r ^= a[i];
+	if (r == 0x12345678)
+		out[threadIdx.x] = r;
+}
+
+template <int KIND>
+static void run(const char *name, int *d)
+{
+	const int iters = 2000, blocks = 256 * 4; // 4 blocks of 512 threads per CU = 32 waves/CU = 8 per SIMD
+	hipEvent_t e0, e1;
+	CHECK(hipEventCreate(&e0));
+	CHECK(hipEventCreate(&e1));
+	hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(512), 0, 0, d, iters, 7);
+	CHECK(hipDeviceSynchronize());
+	CHECK(hipEventRecord(e0));
+	hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(512), 0, 0, d, iters, 7);
+	CHECK(hipEventRecord(e1));
+	CHECK(hipEventSynchronize(e1));
+	float ms;
+	CHECK(hipEventElapsedTime(&ms, e0, e1));
+	const double wave_instr = (double)blocks * 8 * iters * 64;
+	const double per_simd_per_s = wave_instr / 1024.0 / (ms * 1e-3);
+	printf("%-22s %8.3f ms  %.3f wave-instr/cycle/SIMD @2.4GHz (%.2f cycles each)  %.1f Tlane-op/s\n", name, ms, per_simd_per_s / 2.4e9, 2.4e9 / per_simd_per_s, wave_instr * 64 / (ms * 1e-3) / 1e12);
+}
+
+int main()
+{
+	int *d;
+	CHECK(hipMalloc(&d, 4096));
+	run<0>("v_add_u32", d);
+	run<1>("v_mul_i32_i24", d);
+	run<2>("v_ashrrev_i32", d);
+	run<3>("v_add_u32_sdwa", d);
+	run<4>("v_mul_i32_i24_sdwa", d);
+	run<5>("v_mad_i32_i24", d);
+	run<6>("v_fma_f32", d);
+	run<7>("v_add3_u32", d);
+	run<8>("v_mul_lo_u32", d);
+	run<9>("v_bfi_b32", d);
+	return 0;
+}

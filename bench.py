@@ -95,6 +95,7 @@ def main():
     import numpy as np
     import torch
     import clownresampler_amd as cr
+    from clownresampler_amd import distributed as crd
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -118,7 +119,7 @@ def main():
     assert api.LowLevel_Init(whole, ch, *rates)
     R = whole.lowest_level.integer_stretched_kernel_radius
     total_frames = frames_per_gpu * world
-    shard = api.PlanShard(whole, total_frames, rank, world)
+    shard = crd.shard_of(api, whole, total_frames, rank, world)
     plan = api.PlanCreate(whole, pre)
     info = api.PlanGetInfo(plan)
 
@@ -141,10 +142,7 @@ def main():
 
     def step(i):
         pcm, out = sets[i % len(sets)]
-        st = cr.LowLevel_State.from_buffer_copy(shard.state)
-        n, left, ran_out = api.ResampleDevice(plan, st, pcm.data_ptr(), shard.input_frames, out.data_ptr(), shard.output_frames, stream.cuda_stream)
-        assert n == shard.output_frames
-        return n
+        return crd.resample_shard_device(api, plan, shard, pcm.data_ptr(), out.data_ptr(), stream.cuda_stream)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -225,8 +223,20 @@ def main():
     # the dominant (only) kernel: algorithmic bytes of THIS rank's launch / its average duration
     launch_bytes = shard.input_frames * ch * 2 + shard.output_frames * ch * 4
     achieved = launch_bytes / (dev_ms / args.steps * 1e-3) / 1e9
+    traffic, traffic_note = None, "no PMC summary for this workload under profiles/"
+    pmc_file = os.path.join(ROOT, "profiles", "r01_%s_pmc_summary.txt" % args.workload)
+    if world == 1 and os.path.exists(pmc_file):
+        vals = {}
+        for ln in open(pmc_file):
+            f = ln.split()
+            if len(f) > 3 and f[1] == "per-dispatch":
+                vals[f[0]] = float(f[3])
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            # KiB units; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads: x2 (MI355X_MICROARCH.md, HBM)
+            traffic = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+            traffic_note = "bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes: profiles/" + os.path.basename(pmc_file)
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "k_poly<%d,%d>" % (ch, info.slots) if info.kernel else "k_generic",
+                "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_poly<%d,%d>" % (ch, info.slots) if info.kernel else "k_generic",
                 "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_ms": dev_ms / args.steps,
                 "read_only_GBs": shard.input_frames * ch * 2 / (dev_ms / args.steps * 1e-3) / 1e9}
 

@@ -182,3 +182,21 @@ def test_cfg2_full_size_bit_exact(products):
     a, l1, r1 = p.low_resample_i32(st2, padded, 10000001)
     b, l2, r2 = p.low_resample_i32(st2, padded[10000001 * ch:], frames - 10000001)
     assert np.array_equal(np.concatenate([a, b]), want)
+
+
+def test_c_harness_reproduces_reference_harness_outputs(golden, tmp_path):
+    """tools/cr_resample.c - a plain C client of include/clownresampler.h, shaped like tests/test-low-level.c and
+    tests/test-high-level.c - on the reference's own fixture and ctest triples: byte-identical files (sha256 of the real
+    reference harnesses' outputs, tests/golden/golden.json)."""
+    import hashlib
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "bin", "cr_resample")
+    assert os.path.exists(exe), "build() makes tools/bin/cr_resample"
+    for name, rates in [("cfg1", (44100, 48000, 44100)), ("ctest1", (8000, 44100, 44100)), ("ctest3", (44100, 8000, 44100)), ("ctest4", (44100, 8000, 8000))]:
+        for mode in ("low", "high", "bulk"):
+            outp = str(tmp_path / "o.bin")
+            subprocess.run([exe, mode, _cases.FLAC_PCM, outp, "2"] + [str(r) for r in rates], check=True, timeout=300)
+            got = hashlib.sha256(open(outp, "rb").read()).hexdigest()
+            assert got == golden["harness"][name + "_low"]["sha256"], (name, mode)

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""End-to-end (PCIe-inclusive) rates of the host-buffer entry points on cfg 2: the boundary hands over HOST buffers, so
+these include H2D of the int16 input, the kernel, and D2H of the int32 output (and, for the callback form, one indirect
+call per frame).  Never the bench `value`; quoted in DESIGN.md."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ctypes as C  # noqa: E402
+import numpy as np  # noqa: E402
+import _checkers as ck  # noqa: E402
+import _product  # noqa: E402
+import clownresampler_amd as cr  # noqa: E402
+
+p = _product.Product(3)
+ch, rates, frames = 2, (44100, 48000, 44100), 26460000
+padded = ck.pad_frames(ck.noise_pcm(frames * ch), ch, 3)
+for rep in range(3):
+    ok, st = p.low_init(ch, *rates)
+    out = np.zeros((28800096 + 1) * ch, dtype=np.int32)
+    t0 = time.perf_counter()
+    got, left, ran_out = p.api.LowLevel_ResampleBulk(st.raw, p.pre, padded, frames, None, out)
+    dt = time.perf_counter() - t0
+    print("ResampleBulk (host buffers, pageable): %.1f ms  %.0f Msamples/s" % (dt * 1e3, got.size / dt / 1e6))
+
+# callback form with a C callback (storing int32), as a C client would use it
+src = r'''
+#include <stddef.h>
+typedef struct { int *out; size_t n; } sink;
+unsigned char store(void *u, const long *frame, unsigned int samples) { sink *s = (sink *)u; unsigned int c; for (c = 0; c < samples; ++c) s->out[s->n++] = (int)frame[c]; return 1; }
+'''
+import subprocess, tempfile
+d = tempfile.mkdtemp()
+open(d + "/cb.c", "w").write(src)
+subprocess.run(["gcc", "-O2", "-shared", "-fPIC", d + "/cb.c", "-o", d + "/cb.so"], check=True)
+cb = C.CDLL(d + "/cb.so")
+
+
+class Sink(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("n", C.c_size_t)]
+
+
+for rep in range(2):
+    ok, st = p.low_init(ch, *rates)
+    out = np.zeros((28800096 + 1) * ch, dtype=np.int32)
+    sink = Sink(out.ctypes.data, 0)
+    left = C.c_size_t(frames)
+    fn = p.api.lib.ClownResampler_LowLevel_Resample
+    fn.restype = C.c_ubyte
+    fn.argtypes = [C.c_void_p] * 6
+    t0 = time.perf_counter()
+    fn(C.addressof(st.raw), C.addressof(p.pre), padded.ctypes.data, C.addressof(left), C.cast(cb.store, C.c_void_p), C.addressof(sink))
+    dt = time.perf_counter() - t0
+    print("LowLevel_Resample (reference signature, C callback per frame): %.1f ms  %.0f Msamples/s" % (dt * 1e3, sink.n / dt / 1e6))

@@ -162,6 +162,7 @@ class Api:
         self._HighAdjust = fn("ClownResampler_HighLevel_Adjust", cc_bool, [P(HighLevel_State), cc_u32f, cc_u32f, cc_u32f])
         self._HighEnd = fn("ClownResampler_HighLevel_ResampleEnd", cc_bool, [P(HighLevel_State), P(Precomputed), OutputCallback, C.c_void_p])
         self._Bulk = fn("ClownResampler_LowLevel_ResampleBulk", C.c_size_t, [P(LowLevel_State), P(Precomputed), P(cc_s16l), P(C.c_size_t), P(C.c_int32), C.c_size_t, P(cc_bool)])
+        self._BulkS16 = fn("ClownResampler_LowLevel_ResampleBulkS16", C.c_size_t, [P(LowLevel_State), P(Precomputed), P(cc_s16l), P(C.c_size_t), P(C.c_int16), C.c_size_t, P(cc_bool)])
         self._PlanCreate = fn("ClownResamplerAMD_PlanCreate", C.c_void_p, [P(LowLevel_State), P(Precomputed)])
         self._BuildRows = fn("ClownResamplerAMD_BuildRows", C.c_int, [P(LowestLevel_Configuration), P(Precomputed), P(PlanInfo), P(P(C.c_int32)), P(C.c_int), P(C.c_char_p), P(C.c_uint32)])
         # radius-independent
@@ -169,6 +170,7 @@ class Api:
         self._PlanRows = fn("ClownResamplerAMD_PlanRows", P(C.c_int32), [C.c_void_p], False)
         self._PlanRowOf = fn("ClownResamplerAMD_PlanRowOf", C.c_uint32, [C.c_void_p, C.c_uint32], False)
         self._ResampleDevice = fn("ClownResamplerAMD_ResampleDevice", C.c_size_t, [C.c_void_p, P(LowLevel_State), C.c_void_p, P(C.c_size_t), C.c_void_p, C.c_size_t, C.c_void_p, P(cc_bool)], False)
+        self._ResampleDeviceS16 = fn("ClownResamplerAMD_ResampleDeviceS16", C.c_size_t, [C.c_void_p, P(LowLevel_State), C.c_void_p, P(C.c_size_t), C.c_void_p, C.c_size_t, C.c_void_p, P(cc_bool)], False)
         self._Count = fn("ClownResamplerAMD_CountOutputFrames", C.c_size_t, [P(LowLevel_State), C.c_size_t], False)
         self._Advance = fn("ClownResamplerAMD_AdvanceState", None, [P(LowLevel_State), C.c_size_t], False)
         self._PlanShard = fn("ClownResamplerAMD_PlanShard", C.c_int, [P(LowLevel_State), C.c_size_t, C.c_uint, C.c_uint, P(Shard)], False)
@@ -269,6 +271,20 @@ class Api:
         _raise_if_failed(self.lib)
         return output[: n * ch], left.value, int(ran_out.value)
 
+    def LowLevel_ResampleBulkS16(self, resampler, precomputed, input_buffer, total_input_frames, output_capacity_frames=None):
+        """Clamped int16 output (examples/low-level.c:69-80 fused in).  Returns (int16 array, frames_not_processed, ran_out_of_input)."""
+        keep, ptr = _as_i16(input_buffer)
+        ch = resampler.channels
+        if output_capacity_frames is None:
+            output_capacity_frames = self.CountOutputFrames(resampler, total_input_frames) + 1
+        output = np.empty(max(output_capacity_frames, 1) * ch, dtype=np.int16)
+        left = C.c_size_t(total_input_frames)
+        ran_out = cc_bool(0)
+        n = self._BulkS16(C.byref(resampler), C.byref(precomputed), ptr, C.byref(left), output.ctypes.data_as(C.POINTER(C.c_int16)),
+                          output_capacity_frames, C.byref(ran_out))
+        _raise_if_failed(self.lib)
+        return output[: n * ch], left.value, int(ran_out.value)
+
     def CountOutputFrames(self, state, total_input_frames):
         return self._Count(C.byref(state), total_input_frames)
 
@@ -315,12 +331,12 @@ class Api:
     def PlanRowOf(self, plan, position_fractional):
         return self._PlanRowOf(plan, position_fractional)
 
-    def ResampleDevice(self, plan, resampler, device_input, total_input_frames, device_output, output_capacity_frames, hip_stream=None):
+    def ResampleDevice(self, plan, resampler, device_input, total_input_frames, device_output, output_capacity_frames, hip_stream=None, s16=False):
         """device_input / device_output: integer device addresses (e.g. torch_tensor.data_ptr()).  Enqueues on hip_stream and
         returns (frames, frames_not_processed, ran_out_of_input) without synchronising."""
         left = C.c_size_t(total_input_frames)
         ran_out = cc_bool(0)
-        n = self._ResampleDevice(plan, C.byref(resampler), C.c_void_p(device_input), C.byref(left), C.c_void_p(device_output),
+        n = (self._ResampleDeviceS16 if s16 else self._ResampleDevice)(plan, C.byref(resampler), C.c_void_p(device_input), C.byref(left), C.c_void_p(device_output),
                                  output_capacity_frames, C.c_void_p(hip_stream or 0), C.byref(ran_out))
         _raise_if_failed(self.lib)
         return n, left.value, int(ran_out.value)

@@ -243,7 +243,7 @@ static void settle_exhausted(ClownResampler_LowLevel_State *resampler, size_t *t
 	*total_input_frames = 0;
 }
 
-size_t ClownResampler_LowLevel_ResampleBulk(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed, const cc_s16l *input_buffer, size_t *total_input_frames, int32_t *output, size_t output_capacity_frames, cc_bool *ran_out_of_input)
+static size_t resample_bulk(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed, const cc_s16l *input_buffer, size_t *total_input_frames, void *output, size_t output_capacity_frames, cc_bool *ran_out_of_input, int out_s16)
 {
 	const uint64_t pos_int = resampler->position_integer, pos_frac = resampler->position_fractional;
 	const uint64_t available = cr_count_output_frames(pos_int, pos_frac, resampler->increment, *total_input_frames);
@@ -262,7 +262,7 @@ size_t ClownResampler_LowLevel_ResampleBulk(ClownResampler_LowLevel_State *resam
 			return 0;
 
 		if (cr_run_host(plan, input_buffer, (uint64_t)*total_input_frames + 2 * resampler->lowest_level.integer_stretched_kernel_radius,
-		                pos_int, pos_frac, emit, output) != 0)
+		                pos_int, pos_frac, emit, output, out_s16) != 0)
 			return 0;
 	}
 	else if (stopped)
@@ -276,6 +276,16 @@ size_t ClownResampler_LowLevel_ResampleBulk(ClownResampler_LowLevel_State *resam
 		settle_exhausted(resampler, total_input_frames, pos_int, pos_frac, emit);
 
 	return (size_t)emit;
+}
+
+size_t ClownResampler_LowLevel_ResampleBulk(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed, const cc_s16l *input_buffer, size_t *total_input_frames, int32_t *output, size_t output_capacity_frames, cc_bool *ran_out_of_input)
+{
+	return resample_bulk(resampler, precomputed, input_buffer, total_input_frames, output, output_capacity_frames, ran_out_of_input, 0);
+}
+
+size_t ClownResampler_LowLevel_ResampleBulkS16(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed, const cc_s16l *input_buffer, size_t *total_input_frames, int16_t *output, size_t output_capacity_frames, cc_bool *ran_out_of_input)
+{
+	return resample_bulk(resampler, precomputed, input_buffer, total_input_frames, output, output_capacity_frames, ran_out_of_input, 1);
 }
 
 /* ======================================================================================================= */
@@ -323,7 +333,7 @@ cc_bool ClownResampler_LowLevel_Resample(ClownResampler_LowLevel_State *resample
 		{
 			uint64_t pi = start_int, pf = start_frac;
 			cr_advance(&pi, &pf, resampler->increment, done);
-			if (cr_run_host(plan, input_buffer, padded_frames, pi, pf, n, batch_out) != 0)
+			if (cr_run_host(plan, input_buffer, padded_frames, pi, pf, n, batch_out, 0) != 0)
 				break;
 		}
 

@@ -469,6 +469,9 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 			fill_poly_launch(plan, &l);
 			if (cr_check_hip(crhip_poly_prepare(&l), "hipFuncSetAttribute(dynamic LDS)") != 0)
 				goto fail_plan;
+			l.out_s16 = 1; /* the int16-output instance is a different function */
+			if (cr_check_hip(crhip_poly_prepare(&l), "hipFuncSetAttribute(dynamic LDS, int16 form)") != 0)
+				goto fail_plan;
 		}
 	}
 
@@ -522,7 +525,7 @@ static void fill_poly_launch(const ClownResamplerAMD_Plan *plan, crhip_poly_laun
 }
 
 int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_t in_valid_bytes, void *d_out,
-                   uint64_t pos_int, uint64_t pos_frac, uint64_t n_out, void *stream)
+                   uint64_t pos_int, uint64_t pos_frac, uint64_t n_out, void *stream, int out_s16)
 {
 	if (n_out == 0)
 		return 0;
@@ -538,6 +541,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		l.d_out = d_out;
 		l.pos0 = (pos_int << 16) + pos_frac;
 		l.n_out = n_out;
+		l.out_s16 = out_s16 ? 1u : 0u;
 
 		/* tiles are dealt round-robin to a persistent grid (see k_poly) */
 		blocks = (n_out + plan->tile_frames - 1) / plan->tile_frames;
@@ -566,7 +570,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		g.step = plan->cfg.step;
 		g.table_len = plan->table_len;
 		g.channels = plan->channels;
-		g.out64 = 0;
+		g.out64 = out_s16 ? 2u : 0u;
 
 		return cr_check_hip(crhip_launch_generic(&g, stream), "k_generic launch");
 	}
@@ -626,12 +630,12 @@ void cr_workspace_release(cr_workspace *ws)
 }
 
 int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint64_t in_frames, uint64_t pos_int,
-                uint64_t pos_frac, uint64_t n_out, int32_t *host_out)
+                uint64_t pos_frac, uint64_t n_out, void *host_out, int out_s16)
 {
 	/* bounded batches keep the staging buffers small whatever the stream length */
 	const uint64_t batch_frames = 4u << 20;
 	const size_t frame_in = (size_t)plan->channels * sizeof(int16_t);
-	const size_t frame_out = (size_t)plan->channels * sizeof(int32_t);
+	const size_t frame_out = (size_t)plan->channels * (out_s16 ? sizeof(int16_t) : sizeof(int32_t));
 	uint64_t done = 0;
 
 	while (done < n_out)
@@ -655,8 +659,8 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 			return -1;
 
 		bad = cr_check_hip(crhip_memcpy_h2d(ws->d_in, host_in + pi * plan->channels, (size_t)extent * frame_in, ws->stream), "hipMemcpyAsync(H2D)") != 0
-		   || cr_plan_launch(plan, ws->d_in, extent * frame_in, ws->d_out, 0, pf, n, ws->stream) != 0
-		   || cr_check_hip(crhip_memcpy_d2h(host_out + done * plan->channels, ws->d_out, (size_t)n * frame_out, ws->stream), "hipMemcpyAsync(D2H)") != 0
+		   || cr_plan_launch(plan, ws->d_in, extent * frame_in, ws->d_out, 0, pf, n, ws->stream, out_s16) != 0
+		   || cr_check_hip(crhip_memcpy_d2h((unsigned char *)host_out + done * frame_out, ws->d_out, (size_t)n * frame_out, ws->stream), "hipMemcpyAsync(D2H)") != 0
 		   || cr_check_hip(crhip_stream_sync(ws->stream), "hipStreamSynchronize") != 0;
 
 		cr_workspace_release(ws);

@@ -59,7 +59,7 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 
 /* Enqueues the computation of output frames [0, n_out) starting at (pos_int, pos_frac) on `stream`. 0 on success. */
 int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_t in_valid_bytes, void *d_out,
-                   uint64_t pos_int, uint64_t pos_frac, uint64_t n_out, void *stream);
+                   uint64_t pos_int, uint64_t pos_frac, uint64_t n_out, void *stream, int out_s16);
 
 /* Staging workspace for the host-buffer entry points: one per process, handed out under a lock. */
 typedef struct cr_workspace
@@ -77,7 +77,7 @@ void cr_workspace_release(cr_workspace *ws);
 /* Computes output frames [0, n_out) from HOST input into a HOST int32 buffer: uploads the input window, launches,
    downloads, synchronises.  `host_in` points at padded-buffer frame 0 and in_frames frames are readable. 0 on success. */
 int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint64_t in_frames, uint64_t pos_int,
-                uint64_t pos_frac, uint64_t n_out, int32_t *host_out);
+                uint64_t pos_frac, uint64_t n_out, void *host_out, int out_s16);
 
 /* One frame with incoming accumulators, 64-bit results (ClownResampler_LowestLevel_Resample). 0 on success. */
 int cr_run_single_frame(const ClownResamplerAMD_Plan *plan, const int16_t *host_window, uint64_t window_frames,

@@ -70,7 +70,7 @@ int ClownResamplerAMD_PlanShard(const ClownResampler_LowLevel_State *state, size
 	return 0;
 }
 
-size_t ClownResamplerAMD_ResampleDevice(ClownResamplerAMD_Plan *plan, ClownResampler_LowLevel_State *resampler, const void *device_input, size_t *total_input_frames, void *device_output, size_t output_capacity_frames, void *hip_stream, cc_bool *ran_out_of_input)
+static size_t resample_device(ClownResamplerAMD_Plan *plan, ClownResampler_LowLevel_State *resampler, const void *device_input, size_t *total_input_frames, void *device_output, size_t output_capacity_frames, void *hip_stream, cc_bool *ran_out_of_input, int out_s16)
 {
 	const uint64_t pos_int = resampler->position_integer, pos_frac = resampler->position_fractional;
 	cr_config cfg;
@@ -105,7 +105,7 @@ size_t ClownResamplerAMD_ResampleDevice(ClownResamplerAMD_Plan *plan, ClownResam
 		if (cr_ensure_device() != 0)
 			return 0;
 
-		if (cr_plan_launch(plan, device_input, valid_bytes, device_output, pos_int, pos_frac, emit, hip_stream) != 0)
+		if (cr_plan_launch(plan, device_input, valid_bytes, device_output, pos_int, pos_frac, emit, hip_stream, out_s16) != 0)
 			return 0;
 	}
 
@@ -130,4 +130,14 @@ size_t ClownResamplerAMD_ResampleDevice(ClownResamplerAMD_Plan *plan, ClownResam
 	}
 
 	return (size_t)emit;
+}
+
+size_t ClownResamplerAMD_ResampleDevice(ClownResamplerAMD_Plan *plan, ClownResampler_LowLevel_State *resampler, const void *device_input, size_t *total_input_frames, void *device_output, size_t output_capacity_frames, void *hip_stream, cc_bool *ran_out_of_input)
+{
+	return resample_device(plan, resampler, device_input, total_input_frames, device_output, output_capacity_frames, hip_stream, ran_out_of_input, 0);
+}
+
+size_t ClownResamplerAMD_ResampleDeviceS16(ClownResamplerAMD_Plan *plan, ClownResampler_LowLevel_State *resampler, const void *device_input, size_t *total_input_frames, void *device_output, size_t output_capacity_frames, void *hip_stream, cc_bool *ran_out_of_input)
+{
+	return resample_device(plan, resampler, device_input, total_input_frames, device_output, output_capacity_frames, hip_stream, ran_out_of_input, 1);
 }

@@ -110,6 +110,64 @@ __device__ __forceinline__ int sdwa_add_word1_signed(int acc, int x)
 	return r;
 }
 
+// One tap of a packed pair of channels as ONE statement (8 instructions): hipcc pads every asm statement whose outputs
+// the next instruction reads with an s_nop, so the four-statement form above costs three pads per tap and channel; here
+// the only values that leave the statement are the two accumulators.
+__device__ __forceinline__ void sdwa_tap_pair(int &acc_lo, int &acc_hi, int frame, int weight)
+{
+	int x0, x1, t0, t1;
+	asm("v_mul_i32_i24_sdwa %2, sext(%6), %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
+	    "v_mul_i32_i24_sdwa %3, sext(%6), %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+	    "v_ashrrev_i32_e32 %4, 31, %2\n\t"
+	    "v_ashrrev_i32_e32 %5, 31, %3\n\t"
+	    "v_add_u32_sdwa %2, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_add_u32_sdwa %3, %3, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_add_u32_sdwa %0, %0, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_add_u32_sdwa %1, %1, sext(%3) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+	    : "+v"(acc_lo), "+v"(acc_hi), "=&v"(x0), "=&v"(x1), "=&v"(t0), "=&v"(t1)
+	    : "v"(frame), "v"(weight));
+}
+
+// The same for the FIRST tap of an accumulator pair: the truncated terms are written, not added (no zeroing moves, and
+// the final shift is a plain v_ashrrev, which issues at twice the rate of an SDWA add on gfx950).
+__device__ __forceinline__ void sdwa_tap_pair_first(int &acc_lo, int &acc_hi, int frame, int weight)
+{
+	int t0, t1;
+	asm("v_mul_i32_i24_sdwa %0, sext(%4), %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
+	    "v_mul_i32_i24_sdwa %1, sext(%4), %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+	    "v_ashrrev_i32_e32 %2, 31, %0\n\t"
+	    "v_ashrrev_i32_e32 %3, 31, %1\n\t"
+	    "v_add_u32_sdwa %0, %0, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_add_u32_sdwa %1, %1, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_ashrrev_i32_e32 %0, 16, %0\n\t"
+	    "v_ashrrev_i32_e32 %1, 16, %1"
+	    : "=&v"(acc_lo), "=&v"(acc_hi), "=&v"(t0), "=&v"(t1)
+	    : "v"(frame), "v"(weight));
+}
+
+__device__ __forceinline__ void sdwa_tap_single_first(int &acc, int sample, int weight)
+{
+	int t;
+	asm("v_mul_i32_i24_e32 %0, %2, %3\n\t"
+	    "v_ashrrev_i32_e32 %1, 31, %0\n\t"
+	    "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_ashrrev_i32_e32 %0, 16, %0"
+	    : "=&v"(acc), "=&v"(t)
+	    : "v"(sample), "v"(weight));
+}
+
+// One tap of one (already sign-extended) sample as one statement (4 instructions).
+__device__ __forceinline__ void sdwa_tap_single(int &acc, int sample, int weight)
+{
+	int x, t;
+	asm("v_mul_i32_i24_e32 %1, %3, %4\n\t"
+	    "v_ashrrev_i32_e32 %2, 31, %1\n\t"
+	    "v_add_u32_sdwa %1, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_add_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+	    : "+v"(acc), "=&v"(x), "=&v"(t)
+	    : "v"(sample), "v"(weight));
+}
+
 // acc += trunc(product / 65536)
 template <int ASM>
 __device__ __forceinline__ int accumulate_product(int acc, int product)
@@ -163,6 +221,31 @@ struct Frame
 		}
 	}
 
+	// acc = first tap's terms (no previous contents)
+	template <int ASM>
+	__device__ __forceinline__ void mac_first(int (&acc)[CH], int weight) const
+	{
+		if constexpr (!ASM)
+		{
+#pragma unroll
+			for (int c = 0; c < CH; ++c)
+				acc[c] = 0;
+			mac<0>(acc, weight);
+		}
+		else if constexpr (PACKED)
+		{
+#pragma unroll
+			for (int k = 0; k < WORDS; ++k)
+				sdwa_tap_pair_first(acc[2 * k], acc[2 * k + 1], v[k], weight);
+		}
+		else
+		{
+#pragma unroll
+			for (int c = 0; c < CH; ++c)
+				sdwa_tap_single_first(acc[c], v[c], weight);
+		}
+	}
+
 	template <int ASM>
 	__device__ __forceinline__ void mac(int (&acc)[CH], int weight) const
 	{
@@ -173,8 +256,7 @@ struct Frame
 			{
 				if constexpr (ASM)
 				{
-					acc[2 * k] = accumulate_product<1>(acc[2 * k], sdwa_mul_word0(v[k], weight));
-					acc[2 * k + 1] = accumulate_product<1>(acc[2 * k + 1], sdwa_mul_word1(v[k], weight));
+					sdwa_tap_pair(acc[2 * k], acc[2 * k + 1], v[k], weight);
 				}
 				else
 				{
@@ -187,7 +269,12 @@ struct Frame
 		{
 #pragma unroll
 			for (int c = 0; c < CH; ++c)
-				acc[c] = accumulate_product<ASM>(acc[c], __mul24(v[c], weight));
+			{
+				if constexpr (ASM)
+					sdwa_tap_single(acc[c], v[c], weight);
+				else
+					acc[c] = accumulate_product<0>(acc[c], __mul24(v[c], weight));
+			}
 		}
 	}
 };
@@ -226,6 +313,38 @@ __device__ __forceinline__ void store_ints(int *dst, const int *v)
 		for (int c = 0; c < NINT; ++c)
 			dst[c] = v[c];
 	}
+}
+
+// The consumers of the reference clamp every sample to 16 bits in their output callback, to +-0x7FFF (note: -0x7FFF, not
+// -0x8000; examples/low-level.c:69-80, examples/high-level.c:74-85).  Opt-in fused form of that callback: clamp and
+// store int16, which also halves the write traffic.
+__device__ __forceinline__ int clamp_s16(int v)
+{
+	return v > 0x7FFF ? 0x7FFF : (v < -0x7FFF ? -0x7FFF : v);
+}
+
+template <int NSHORT>
+__device__ __forceinline__ void store_shorts(short *dst, const int *v)
+{
+	if constexpr (NSHORT % 2 == 0)
+	{
+		int packed[NSHORT / 2];
+#pragma unroll
+		for (int k = 0; k < NSHORT / 2; ++k)
+			packed[k] = (clamp_s16(v[2 * k]) & 0xFFFF) | (clamp_s16(v[2 * k + 1]) << 16);
+		store_ints<NSHORT / 2>(reinterpret_cast<int *>(dst), packed);
+	}
+	else
+	{
+#pragma unroll
+		for (int c = 0; c < NSHORT; ++c)
+			dst[c] = (short)clamp_s16(v[c]);
+	}
+}
+
+constexpr int stores_of_ints(int n)
+{
+	return n % 4 == 0 ? n / 4 : (n % 2 == 0 ? n / 2 : n);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -286,12 +405,28 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 			w[4 * q + 2] = v.z;
 			w[4 * q + 3] = v.w;
 		}
+		// two accumulator sets, taps alternating between them: consecutive tap statements are then independent (no asm
+		// boundary pad, more overlap); integer addition is associative, so the sum is the same
+		int acc2[CH];
 #pragma unroll
 		for (int s = 0; s < TT; ++s)
 		{
 			Frame<CH> f;
 			f.load(src + s * FB);
-			f.template mac<ASM>(acc, w[s]);
+			if (s == 0)
+				f.template mac_first<ASM>(acc, w[s]);
+			else if (s == 1)
+				f.template mac_first<ASM>(acc2, w[s]);
+			else if (s & 1)
+				f.template mac<ASM>(acc2, w[s]);
+			else
+				f.template mac<ASM>(acc, w[s]);
+		}
+		if constexpr (TT > 1)
+		{
+#pragma unroll
+			for (int c = 0; c < CH; ++c)
+				acc[c] += acc2[c];
 		}
 		reciprocal = w[TT];
 	}
@@ -338,7 +473,8 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 // SWZ       1 = the LDS image of the rows is swizzled (a.swizzle), 0 = plain (a.swizzle must be 0)
 // ABL       0 in every shipped instance.  Timing-only ablations (WRONG results, reachable only through the debug
 //           launch flag of tools/): 1 = no output stores, 2 = no input DMA, 3 = neither, 4 = DMA + stores but no arithmetic
-template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0>
+// OUT16     1 = clamp to +-0x7FFF and store int16 (opt-in extension), 0 = the reference's unclamped int32
+template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0, int OUT16 = 0>
 __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 {
 	constexpr unsigned FB = CH * 2;                       // bytes per input frame
@@ -414,7 +550,7 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 	// as straight-line code for that reason; a ragged tile drains everything.
 	constexpr unsigned GROUP = NTHREADS * U;
 	constexpr int ADJ = 0;   // a lane's U frames are NTHREADS apart: every store instruction is coalesced across the wave
-	constexpr int STORES_PER_GROUP = U * (CH % 4 == 0 ? CH / 4 : (CH % 2 == 0 ? CH / 2 : CH));
+	constexpr int STORES_PER_GROUP = U * (OUT16 ? (CH % 2 == 0 ? stores_of_ints(CH / 2) : CH) : stores_of_ints(CH));
 
 	uint64_t tile_index = blockIdx.x;
 	uint64_t jt = tile_index * NT64;
@@ -440,24 +576,28 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 
 		const uint64_t pos = a.pos0 + jt * (uint64_t)a.increment;
 		const unsigned frac0 = (unsigned)(pos & 0xFFFFu);
-		int *out_tile = reinterpret_cast<int *>(a.d_out) + jt * CH;
+		int *out_tile = reinterpret_cast<int *>(a.d_out) + jt * CH;             // OUT16 == 0
+		short *out_tile16 = reinterpret_cast<short *>(a.d_out) + jt * CH;       // OUT16 == 1
 		const unsigned char *base = tile + shift;
 
 		// One group = NTHREADS * U frames: U independent frames per lane, no bounds checks.
+		// Positions are formed as (lane part, once per tile) + (group part, wave-uniform, scalar unit): one VALU add per
+		// frame instead of a 24-bit multiply-add; same for the output address, which goes out as SGPR base + lane offset.
+		const unsigned lane_rel = __umul24(tid, a.increment) + frac0;
 		auto group = [&](unsigned g) {
 			int outv[U * CH];
 #pragma unroll
 			for (int u = 0; u < U; ++u)
 			{
-				const unsigned jl = ADJ ? g + tid * U + u : g + u * NTHREADS + tid;
+				const unsigned first = g + u * NTHREADS;   // wave-uniform: frame of lane 0 of the workgroup
 				if constexpr (ABL == 4)
 				{
 #pragma unroll
 					for (int c = 0; c < CH; ++c)
-						outv[u * CH + c] = (int)jl;
+						outv[u * CH + c] = (int)(first + tid);
 				}
 				else
-					one_frame<CH, TT, MODE, NORM, ASM, SWZ>(a, rows, base, __umul24(jl, a.increment) + frac0, outv + u * CH);
+					one_frame<CH, TT, MODE, NORM, ASM, SWZ>(a, rows, base, lane_rel + first * a.increment, outv + u * CH);
 			}
 			if constexpr (ABL == 1 || ABL == 3)
 			{
@@ -467,15 +607,19 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 					asm volatile("" ::"v"(outv[c]));
 				return;
 			}
-			if constexpr (ADJ)
-			{
-				store_ints<U * CH>(out_tile + (size_t)(g + tid * U) * CH, outv);
-			}
-			else
-			{
 #pragma unroll
-				for (int u = 0; u < U; ++u)
-					store_ints<CH>(out_tile + (size_t)(g + u * NTHREADS + tid) * CH, outv + u * CH);
+			for (int u = 0; u < U; ++u)
+			{
+				if constexpr (OUT16)
+				{
+					short *group_out = out_tile16 + (size_t)(g + u * NTHREADS) * CH;   // uniform
+					store_shorts<CH>(group_out + tid * CH, outv + u * CH);
+				}
+				else
+				{
+					int *group_out = out_tile + (size_t)(g + u * NTHREADS) * CH;   // uniform
+					store_ints<CH>(group_out + tid * CH, outv + u * CH);
+				}
 			}
 		};
 
@@ -518,7 +662,10 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 			{
 				int outv[CH];
 				one_frame<CH, TT, MODE, NORM, ASM, SWZ>(a, rows, base, __umul24(jl, a.increment) + frac0, outv);
-				store_ints<CH>(out_tile + (size_t)jl * CH, outv);
+				if constexpr (OUT16)
+					store_shorts<CH>(out_tile16 + (size_t)jl * CH, outv);
+				else
+					store_ints<CH>(out_tile + (size_t)jl * CH, outv);
 			}
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		}
@@ -584,7 +731,9 @@ __global__ __launch_bounds__(256) void k_generic(const crhip_generic_launch a)
 		if (c < (int)ch)
 		{
 			const long long v = acc[c] * reciprocal / 32768;                           // :1033
-			if (a.out64)
+			if (a.out64 == 2)
+				reinterpret_cast<short *>(a.d_out)[j * ch + c] = (short)(v > 0x7FFF ? 0x7FFF : (v < -0x7FFF ? -0x7FFF : v));
+			else if (a.out64)
 				reinterpret_cast<long long *>(a.d_out)[j * ch + c] = v;
 			else
 				reinterpret_cast<int *>(a.d_out)[j * ch + c] = (int)v;
@@ -608,10 +757,10 @@ struct geometry
 constexpr geometry GEOMETRY[5] = {{256, 2}, {512, 1}, {512, 2}, {1024, 1}, {1024, 2}};
 constexpr int VARIANTS = 20;
 
-template <int CH, int TT, int MODE, int NORM, int GEO, int ASM, int UI, int SWZ>
+template <int CH, int TT, int MODE, int NORM, int GEO, int ASM, int UI, int SWZ, int OUT16 = 0>
 constexpr poly_fn instance()
 {
-	return (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[GEO].threads, GEOMETRY[GEO].vecs, ASM, (1 << UI), SWZ>;
+	return (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[GEO].threads, GEOMETRY[GEO].vecs, ASM, (1 << UI), SWZ, 0, OUT16>;
 }
 
 template <int CH, int TT, int MODE, int NORM, int V>
@@ -635,24 +784,26 @@ struct special
 	uint32_t channels, slots, mode, norm;
 	uint32_t default_variant;   // from tools/sweep_variants.py on MI355X (profiles/)
 	poly_fn fn[VARIANTS];
+	poly_fn fn16;               // int16-output form, default variant only
 };
 
-template <int CH, int TT, int MODE, int NORM>
-special make_special(uint32_t default_variant)
+template <int CH, int TT, int MODE, int NORM, int DV>
+special make_special()
 {
-	special s = {CH, TT, MODE, NORM, default_variant, {}};
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr};
 	variant_table<CH, TT, MODE, NORM, 0>::fill(s.fn);
+	s.fn16 = instance<CH, TT, MODE, NORM, DV % 5, 1, (DV / 5) % 2, (DV / 10) % 2, 1>();
 	return s;
 }
 
 const special *specials(int *count)
 {
 	static const special table[] = {
-	    make_special<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(8),   // cfg 2 / cfg 5: stereo 44.1 -> 48 kHz, 3 lobes
-	    make_special<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32>(9),  // cfg 3: stereo 8 -> 96 kHz, 8 lobes
-	    make_special<8, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(12),     // cfg 4: 8 channels 48 -> 44.1 kHz
-	    make_special<1, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(8),   // mono upsampling, 3 lobes
-	    make_special<2, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(8),     // stereo mild downsampling, 3 lobes
+	    make_special<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 8>(),   // cfg 2 / cfg 5: stereo 44.1 -> 48 kHz, 3 lobes
+	    make_special<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 9>(),  // cfg 3: stereo 8 -> 96 kHz, 8 lobes
+	    make_special<8, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 2>(),     // cfg 4: 8 channels 48 -> 44.1 kHz
+	    make_special<1, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 8>(),   // mono upsampling, 3 lobes
+	    make_special<2, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 8>(),     // stereo mild downsampling, 3 lobes
 	};
 	*count = (int)(sizeof(table) / sizeof(table[0]));
 	return table;
@@ -681,29 +832,30 @@ const special *find_special(uint32_t channels, uint32_t slots, uint32_t mode, ui
 	return nullptr;
 }
 
-// run-time slot count: every channel count 1..8, both row modes, both normalisations, default geometry
-template <int CH>
+// run-time slot count: every channel count 1..8, both row modes, both normalisations, both output forms, default geometry
+template <int CH, int OUT16>
 poly_fn pick_runtime(uint32_t mode, uint32_t norm)
 {
 	if (norm == CRHIP_NORM_S31)
-		return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 0, 0, 0, 0>()
-		                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 0, 0, 0, 0>();
-	return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 0, 0, 0, 0>()
-	                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, 0, 0, 0, 0>();
+		return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 0, 0, 0, 0, OUT16>()
+		                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 0, 0, 0, 0, OUT16>();
+	return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 0, 0, 0, 0, OUT16>()
+	                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, 0, 0, 0, 0, OUT16>();
 }
 
+template <int OUT16>
 poly_fn pick_runtime_channels(uint32_t channels, uint32_t mode, uint32_t norm)
 {
 	switch (channels)
 	{
-		case 1: return pick_runtime<1>(mode, norm);
-		case 2: return pick_runtime<2>(mode, norm);
-		case 3: return pick_runtime<3>(mode, norm);
-		case 4: return pick_runtime<4>(mode, norm);
-		case 5: return pick_runtime<5>(mode, norm);
-		case 6: return pick_runtime<6>(mode, norm);
-		case 7: return pick_runtime<7>(mode, norm);
-		case 8: return pick_runtime<8>(mode, norm);
+		case 1: return pick_runtime<1, OUT16>(mode, norm);
+		case 2: return pick_runtime<2, OUT16>(mode, norm);
+		case 3: return pick_runtime<3, OUT16>(mode, norm);
+		case 4: return pick_runtime<4, OUT16>(mode, norm);
+		case 5: return pick_runtime<5, OUT16>(mode, norm);
+		case 6: return pick_runtime<6, OUT16>(mode, norm);
+		case 7: return pick_runtime<7, OUT16>(mode, norm);
+		case 8: return pick_runtime<8, OUT16>(mode, norm);
 		default: return nullptr;
 	}
 }
@@ -809,10 +961,12 @@ int crhip_poly_has_instance(uint32_t channels, uint32_t slots, uint32_t row_mode
 
 // variant actually used by a launch: an explicit one (< VARIANTS), an ablation (>= 1000: headline geometry), or the
 // instance's measured default (CRHIP_VARIANT_DEFAULT)
-static uint32_t resolve_variant(const special *sp, uint32_t variant)
+static uint32_t resolve_variant(const special *sp, uint32_t variant, uint32_t out_s16 = 0)
 {
 	if (sp == nullptr)
 		return 0u;
+	if (out_s16)
+		return sp->default_variant;   // the int16 form exists for the default variant only
 	if (variant < (uint32_t)VARIANTS)
 		return variant;
 	if (variant >= 1000u && variant < 1010u)
@@ -845,8 +999,13 @@ void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, u
 static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 {
 	const special *sp = launch->specialised ? find_special(launch->channels, launch->slots, launch->row_mode, launch->norm_mode) : nullptr;
-	const uint32_t v = resolve_variant(sp, launch->variant);
-	poly_fn fn = sp != nullptr ? sp->fn[v] : pick_runtime_channels(launch->channels, launch->row_mode, launch->norm_mode);
+	const uint32_t v = resolve_variant(sp, launch->variant, launch->out_s16);
+	poly_fn fn;
+
+	if (launch->out_s16)
+		fn = sp != nullptr ? sp->fn16 : pick_runtime_channels<1>(launch->channels, launch->row_mode, launch->norm_mode);
+	else
+		fn = sp != nullptr ? sp->fn[v] : pick_runtime_channels<0>(launch->channels, launch->row_mode, launch->norm_mode);
 
 	// debug: variant 1000 + k selects timing-only ablation k of the headline instance (results are wrong by design)
 	if (sp != nullptr && launch->variant >= 1000u && launch->variant < 1010u && launch->channels == 2 && launch->slots == 5)

@@ -53,7 +53,8 @@ typedef struct crhip_poly_launch
 	uint32_t lds_bytes;
 	uint32_t blocks;            /* grid size */
 	uint32_t specialised;       /* use the (channels, slots) template instance if there is one */
-	uint32_t variant;           /* tuning variant of the specialised kernels (0 = default) */
+	uint32_t variant;           /* tuning variant of the specialised kernels (CRHIP_VARIANT_DEFAULT = the measured default) */
+	uint32_t out_s16;           /* 1: d_out is int16, samples clamped to +-0x7FFF (extension); 0: int32 unclamped (reference) */
 } crhip_poly_launch;
 
 /* One launch of the generic kernel: the reference arithmetic restated with 64-bit integers, one thread per
@@ -63,7 +64,7 @@ typedef struct crhip_poly_launch
 typedef struct crhip_generic_launch
 {
 	const void *d_in;
-	void *d_out;                /* int32 (out64 == 0) or int64 (out64 == 1), n_out * channels */
+	void *d_out;                /* int32 (out64 == 0), int64 (out64 == 1) or clamped int16 (out64 == 2), n_out * channels */
 	const int32_t *d_table;     /* the caller's Lanczos table repacked to int32 */
 	const int64_t *d_acc_in;    /* optional: channels initial accumulators added to frame 0 (n_out must be 1) */
 	uint64_t pos_int, pos_frac; /* of output frame 0 */

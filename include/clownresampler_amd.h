@@ -96,6 +96,7 @@ int ClownResamplerAMD_PlanShard(const ClownResampler_LowLevel_State *state, size
  * ------------------------------------------------------------------------------------------- */
 #if CLOWNRESAMPLER_KERNEL_RADIUS != 3
  #define ClownResampler_LowLevel_ResampleBulk CLOWNRESAMPLER_AMD_SYM(ClownResampler_LowLevel_ResampleBulk)
+ #define ClownResampler_LowLevel_ResampleBulkS16 CLOWNRESAMPLER_AMD_SYM(ClownResampler_LowLevel_ResampleBulkS16)
  #define ClownResamplerAMD_PlanCreate          CLOWNRESAMPLER_AMD_SYM(ClownResamplerAMD_PlanCreate)
 #endif
 
@@ -103,6 +104,11 @@ int ClownResamplerAMD_PlanShard(const ClownResampler_LowLevel_State *state, size
    callback.  Returns the number of frames written; *ran_out_of_input (may be NULL) receives what the reference
    call would have returned.  Synchronous: input is uploaded, output downloaded. */
 size_t ClownResampler_LowLevel_ResampleBulk(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed, const cc_s16l *input_buffer, size_t *total_input_frames, int32_t *output, size_t output_capacity_frames, cc_bool *ran_out_of_input);
+
+/* The same with the 16-bit clamp every consumer of the reference applies in its output callback fused in: each sample is
+   clamped to [-0x7FFF, 0x7FFF] (sic: examples/low-level.c:69-80, examples/high-level.c:74-85) and stored as int16.
+   Opt-in: the reference's own output is the unclamped int32 of ClownResampler_LowLevel_ResampleBulk. */
+size_t ClownResampler_LowLevel_ResampleBulkS16(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed, const cc_s16l *input_buffer, size_t *total_input_frames, int16_t *output, size_t output_capacity_frames, cc_bool *ran_out_of_input);
 
 /* ---------------------------------------------------------------------------------------------
  * Bulk resampling, device-resident buffers.
@@ -148,6 +154,10 @@ void ClownResamplerAMD_DebugSetVariant(int variant);
    (NULL = the default stream) and NOT synchronised; the state and *total_input_frames are updated on the host
    from the closed form before returning.  Returns the number of frames that will have been written. */
 size_t ClownResamplerAMD_ResampleDevice(ClownResamplerAMD_Plan *plan, ClownResampler_LowLevel_State *resampler, const void *device_input, size_t *total_input_frames, void *device_output, size_t output_capacity_frames, void *hip_stream, cc_bool *ran_out_of_input);
+
+/* As ClownResamplerAMD_ResampleDevice, with device_output an int16 buffer and the clamp of
+   ClownResampler_LowLevel_ResampleBulkS16 (4 bytes less write traffic per output sample). */
+size_t ClownResamplerAMD_ResampleDeviceS16(ClownResamplerAMD_Plan *plan, ClownResampler_LowLevel_State *resampler, const void *device_input, size_t *total_input_frames, void *device_output, size_t output_capacity_frames, void *hip_stream, cc_bool *ran_out_of_input);
 
 #ifdef __cplusplus
 }

@@ -200,3 +200,45 @@ def test_c_harness_reproduces_reference_harness_outputs(golden, tmp_path):
             subprocess.run([exe, mode, _cases.FLAC_PCM, outp, "2"] + [str(r) for r in rates], check=True, timeout=300)
             got = hashlib.sha256(open(outp, "rb").read()).hexdigest()
             assert got == golden["harness"][name + "_low"]["sha256"], (name, mode)
+
+
+@pytest.mark.parametrize("name", ["cfg2_1min", "cfg4_1min", "cfg3_1min", "ch1_up", "ch3_down", "ch5_up", "ch12_down", "amp_square_up", "amp_min_down", "amp_max_r8", "tiny_65", "ratio_44100_1000_1000"])
+def test_clamped_int16_output(products, name):
+    """Opt-in extension: the 16-bit clamp of the reference's consumers (examples/low-level.c:69-80: to +-0x7FFF) fused into
+    the kernel.  Must equal clamp(oracle int32) exactly, through the specialised, run-time-slot and generic kernels."""
+    case = _cases.CASE_BY_NAME[name]
+    p, o = products[case["radius"]], ck.oracle(case["radius"])
+    ch, rates = case["channels"], case["rates"]
+    pcm = _cases.make_input(case)
+    frames = len(pcm) // ch
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    padded = ck.pad_frames(pcm, ch, int(ost.cfg.radius_frames))
+    want32, _, _ = o.low_resample_i32(ost, padded, frames)
+    want = np.clip(want32, -0x7FFF, 0x7FFF).astype(np.int16)
+    got, left, ran_out = p.api.LowLevel_ResampleBulkS16(st.raw, p.pre, padded, frames)
+    assert ran_out == 1 and left == 0 and np.array_equal(got, want)
+    assert st.astuple() == ost.astuple()
+    if name in ("amp_square_up", "cfg2_1min"):
+        assert np.abs(want32).max() > 0x7FFF      # the clamp is actually exercised
+
+
+def test_adjust_between_calls(products):
+    """Mid-stream re-configuration (clownresampler.h:1052-1056): piecewise segments, each its own launch, position carried."""
+    p, o = products[3], ck.oracle(3)
+    ch, frames = 2, 60000
+    ok, a = p.low_init(ch, 44100, 48000, 44100)
+    ok, b = o.low_init(ch, 44100, 48000, 44100)
+    padded = ck.pad_frames(ck.noise_pcm(frames * ch, 3), ch, 8)      # roomy halo: radius changes along the way
+    pos, left = 0, frames
+    got, want = [], []
+    for rates, n in [((44100, 48000, 44100), 20000), ((48000, 44100, 44100), 15000), ((44100, 44100, 22050), 9000), ((44100, 88200, 44100), 16000)]:
+        assert p.low_adjust(a, *rates) == o.low_adjust(b, *rates)
+        R = int(b.cfg.radius_frames)
+        base = (pos + 8 - R) * ch                                       # pointer at the start of THIS configuration's padding
+        xa, la, ra = p.low_resample_i32(a, padded[base:], n)
+        xb, lb, rb = o.low_resample_i32(b, padded[base:], n)
+        assert (la, ra) == (lb, rb) and a.astuple() == b.astuple()
+        got.append(xa); want.append(xb)
+        pos += n - la
+    assert np.array_equal(np.concatenate(got), np.concatenate(want))

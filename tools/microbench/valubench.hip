@@ -10,8 +10,9 @@
 #define REP64(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X)
 
 template <int KIND>
-__global__ __launch_bounds__(512) void k(int *out, int iters, int seed)
+__global__ __launch_bounds__(512) void k(int *out, int iters, int seed, unsigned long long *stamps)
 {
+	const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 	int a[8];
 #pragma unroll
 	for (int i = 0; i < 8; ++i)
@@ -29,6 +30,15 @@ __global__ __launch_bounds__(512) void k(int *out, int iters, int seed)
 #define ADD3(i) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(w));
 #define MULLO(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(w));
 #define BFI(i) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(a[i]) : "v"(w));
+#define AND(i) asm volatile("v_and_b32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(w));
+#define LSHR(i) asm volatile("v_lshrrev_b32_e32 %0, 1, %0" : "+v"(a[i]));
+#define PKADD(i) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(w));
+#define PKMUL(i) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(a[i]) : "v"(w));
+#define PERM(i) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(w));
+#define MULU(i) asm volatile("v_mul_u32_u24_e32 %0, %0, %1" : "+v"(a[i]) : "v"(w));
+#define CNDM(i) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(w));
+#define MADU16(i) asm volatile("v_mad_u32_u16 %0, %0, %1, %1" : "+v"(a[i]) : "v"(w));
+#define ADDC(i) asm volatile("v_add_co_u32_e32 %0, vcc, %0, %1" : "+v"(a[i]) : "v"(w) : "vcc");
 		if constexpr (KIND == 0) { REP64(ADD) }
 		if constexpr (KIND == 1) { REP64(MUL) }
 		if constexpr (KIND == 2) { REP64(ASHR) }
@@ -39,6 +49,20 @@ __global__ __launch_bounds__(512) void k(int *out, int iters, int seed)
 		if constexpr (KIND == 7) { REP64(ADD3) }
 		if constexpr (KIND == 8) { REP64(MULLO) }
 		if constexpr (KIND == 9) { REP64(BFI) }
+		if constexpr (KIND == 10) { REP64(AND) }
+		if constexpr (KIND == 11) { REP64(LSHR) }
+		if constexpr (KIND == 12) { REP64(PKADD) }
+		if constexpr (KIND == 13) { REP64(PKMUL) }
+		if constexpr (KIND == 14) { REP64(PERM) }
+		if constexpr (KIND == 15) { REP64(MULU) }
+		if constexpr (KIND == 16) { REP64(CNDM) }
+		if constexpr (KIND == 17) { REP64(MADU16) }
+		if constexpr (KIND == 18) { REP64(ADDC) }
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		stamps[0] = __builtin_amdgcn_s_memtime() - c0;
+		stamps[1] = __builtin_amdgcn_s_memrealtime() - r0;
 	}
 	int r = 0;
 #pragma unroll
@@ -55,17 +79,23 @@ static void run(const char *name, int *d)
 	hipEvent_t e0, e1;
 	CHECK(hipEventCreate(&e0));
 	CHECK(hipEventCreate(&e1));
-	hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(512), 0, 0, d, iters, 7);
+	unsigned long long *stamps;
+	CHECK(hipMalloc(&stamps, 16));
+	for (int w = 0; w < 50; ++w)
+		hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(512), 0, 0, d, iters, 7, stamps);
 	CHECK(hipDeviceSynchronize());
 	CHECK(hipEventRecord(e0));
-	hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(512), 0, 0, d, iters, 7);
+	hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(512), 0, 0, d, iters, 7, stamps);
 	CHECK(hipEventRecord(e1));
 	CHECK(hipEventSynchronize(e1));
 	float ms;
 	CHECK(hipEventElapsedTime(&ms, e0, e1));
+	unsigned long long h[2];
+	CHECK(hipMemcpy(h, stamps, 16, hipMemcpyDeviceToHost));
+	const double ghz = (double)h[0] / ((double)h[1] / 100e6) / 1e9;
 	const double wave_instr = (double)blocks * 8 * iters * 64;
 	const double per_simd_per_s = wave_instr / 1024.0 / (ms * 1e-3);
-	printf("%-22s %8.3f ms  %.3f wave-instr/cycle/SIMD @2.4GHz (%.2f cycles each)  %.1f Tlane-op/s\n", name, ms, per_simd_per_s / 2.4e9, 2.4e9 / per_simd_per_s, wave_instr * 64 / (ms * 1e-3) / 1e12);
+	printf("%-22s %8.3f ms  in-kernel clock %.2f GHz  %.2f cycles per wave-instr per SIMD at that clock  %.1f Tlane-op/s\n", name, ms, ghz, ghz * 1e9 / per_simd_per_s, wave_instr * 64 / (ms * 1e-3) / 1e12);
 }
 
 int main()
@@ -82,5 +112,14 @@ int main()
 	run<7>("v_add3_u32", d);
 	run<8>("v_mul_lo_u32", d);
 	run<9>("v_bfi_b32", d);
+	run<10>("v_and_b32", d);
+	run<11>("v_lshrrev_b32", d);
+	run<12>("v_pk_add_u16", d);
+	run<13>("v_pk_mul_lo_u16", d);
+	run<14>("v_perm_b32", d);
+	run<15>("v_mul_u32_u24", d);
+	run<16>("v_cndmask_b32", d);
+	run<17>("v_mad_u32_u16", d);
+	run<18>("v_add_co_u32", d);
 	return 0;
 }

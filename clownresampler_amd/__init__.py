@@ -184,6 +184,7 @@ class Api:
         self._StreamSync = fn("ClownResamplerAMD_StreamSynchronize", C.c_int, [C.c_void_p], False)
         self._ForceGeneric = fn("ClownResamplerAMD_DebugForceGenericKernel", None, [C.c_int], False)
         self._SetVariant = fn("ClownResamplerAMD_DebugSetVariant", None, [C.c_int], False)
+        self._SetStreamingWindow = fn("ClownResamplerAMD_SetStreamingWindow", None, [C.c_size_t], False)
         self._libc_free = C.CDLL(None).free
         self._libc_free.argtypes = [C.c_void_p]
 
@@ -340,6 +341,9 @@ class Api:
                                  output_capacity_frames, C.c_void_p(hip_stream or 0), C.byref(ran_out))
         _raise_if_failed(self.lib)
         return n, left.value, int(ran_out.value)
+
+    def SetStreamingWindow(self, frames):
+        self._SetStreamingWindow(frames)
 
     def DebugSetVariant(self, variant):
         self._SetVariant(variant)

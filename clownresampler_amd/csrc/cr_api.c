@@ -414,8 +414,37 @@ void ClownResampler_LowestLevel_Resample(const ClownResampler_LowestLevel_Config
 
 #define STAGING_SAMPLES CLOWNRESAMPLER_COUNT_OF(((ClownResampler_HighLevel_State *)0)->input_buffer)
 
+/* The state's own 0x1000-sample buffer (clownresampler.h:654) is not used for audio here: the staging lives in a side
+   window that can grow (cr_stream, cr_context.c).  The buffer's first bytes carry the key of that window, so the state
+   stays a plain struct the caller owns (a byte copy of the state shares the window with the original). */
+#define STREAM_MAGIC 0x314C48444D415243ull /* "CRAMDHL1" */
+
+static void stream_key_store(ClownResampler_HighLevel_State *resampler, uint64_t id)
+{
+	const uint64_t magic = STREAM_MAGIC;
+
+	memcpy((unsigned char *)resampler->input_buffer, &magic, sizeof(magic));
+	memcpy((unsigned char *)resampler->input_buffer + sizeof(magic), &id, sizeof(id));
+}
+
+static cr_stream *stream_of(ClownResampler_HighLevel_State *resampler)
+{
+	uint64_t magic, id;
+
+	memcpy(&magic, (unsigned char *)resampler->input_buffer, sizeof(magic));
+	memcpy(&id, (unsigned char *)resampler->input_buffer + sizeof(magic), sizeof(id));
+	return magic == STREAM_MAGIC ? cr_stream_lookup(id) : NULL;
+}
+
+/* frames the reference asks its input callback for per refill (clownresampler.h:1154) */
+static size_t reference_pull_frames(const ClownResampler_HighLevel_State *resampler)
+{
+	return (STAGING_SAMPLES - 2 * resampler->maximum_integer_stretched_kernel_radius * resampler->low_level.channels) / resampler->low_level.channels;
+}
+
 cc_bool ClownResampler_HighLevel_Init(ClownResampler_HighLevel_State *resampler, cc_u8f channels, cc_u32f input_sample_rate, cc_u32f output_sample_rate, cc_u32f low_pass_filter_sample_rate)
 {
+	cr_stream *stream;
 	size_t halo_samples;
 
 	if (channels > CLOWNRESAMPLER_MAXIMUM_CHANNELS) /* :1103 */
@@ -431,8 +460,20 @@ cc_bool ClownResampler_HighLevel_Init(ClownResampler_HighLevel_State *resampler,
 
 	/* silence where the frames before the stream would be; empty window right behind it (:1112-1115) */
 	halo_samples = resampler->maximum_integer_stretched_kernel_radius * channels;
-	memset(resampler->input_buffer, 0, halo_samples * sizeof(resampler->input_buffer[0]));
-	resampler->input_buffer_start = resampler->input_buffer_end = resampler->input_buffer + halo_samples;
+	memset(resampler->input_buffer, 0, sizeof(resampler->input_buffer));
+	stream = cr_stream_create();
+
+	if (stream == NULL || channels == 0 || cr_stream_reserve(stream, 2 * halo_samples + reference_pull_frames(resampler) * channels) != 0)
+	{
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, channels == 0 ? "channel count 0" : "out of host memory");
+		return cc_false;
+	}
+
+	memset(stream->window, 0, halo_samples * sizeof(stream->window[0]));
+	stream->start = stream->end = halo_samples;
+	stream->target_frames = reference_pull_frames(resampler);
+	stream_key_store(resampler, stream->id);
+	resampler->input_buffer_start = resampler->input_buffer_end = NULL; /* the window may move; see cr_stream */
 
 	return cc_true;
 }
@@ -441,13 +482,22 @@ cc_bool ClownResampler_HighLevel_Resample(ClownResampler_HighLevel_State *resamp
 {
 	const size_t channels = resampler->low_level.channels;
 	const size_t halo_samples = resampler->maximum_integer_stretched_kernel_radius * channels;
+	const size_t one_pull = reference_pull_frames(resampler);
+	cr_stream *stream = stream_of(resampler);
 	cc_bool consumer_stopped = cc_false;
 
-	/* Staging layout: [ left halo | window ... | look-ahead ] with the newest `halo` frames not yet consumed.
-	   First, collect the look-ahead: the first real frames go right-aligned into [halo, 2*halo) (:1127-1136). */
+	if (stream == NULL)
+	{
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "ClownResampler_HighLevel_Resample on a state that ClownResampler_HighLevel_Init of this library did not set up");
+		return cc_true;
+	}
+
+	/* Window layout, as the reference's staging buffer: [ left halo | frames ... | look-ahead ], the newest `halo` frames
+	   not yet consumed.  First, collect the look-ahead: the first real frames go right-aligned into [halo, 2*halo)
+	   (:1127-1136). */
 	while (resampler->leading_padding_frames_needed != 0)
 	{
-		cc_s16l *where = resampler->input_buffer + 2 * halo_samples - resampler->leading_padding_frames_needed * channels;
+		cc_s16l *where = stream->window + 2 * halo_samples - resampler->leading_padding_frames_needed * channels;
 		const size_t got = input_callback((void *)user_data, where, resampler->leading_padding_frames_needed);
 
 		if (got == 0)
@@ -458,35 +508,65 @@ cc_bool ClownResampler_HighLevel_Resample(ClownResampler_HighLevel_State *resamp
 
 	while (!consumer_stopped)
 	{
-		if (resampler->input_buffer_start == resampler->input_buffer_end)
+		if (stream->start == stream->end)
 		{
-			size_t got;
+			/* window used up: the last 2*halo samples (left halo + look-ahead of the next window) move to the front and
+			   new frames are pulled in behind them (:1143-1158).  The reference pulls ONCE per refill, into what is
+			   left of its 0x1000 samples; here the same-sized pulls are repeated until the window's target is reached
+			   or the source runs dry, so that one GPU call covers them all. */
+			size_t limit = stream->target_frames;
+			size_t have = 0;
 
-			/* window used up: the last 2*halo samples (left halo + look-ahead of the next window) move to the
-			   front and new frames are pulled in behind them (:1143-1158) */
-			memmove(resampler->input_buffer, resampler->input_buffer_end - halo_samples, 2 * halo_samples * sizeof(resampler->input_buffer[0]));
-			resampler->input_buffer_start = resampler->input_buffer + halo_samples;
-			got = input_callback((void *)user_data, resampler->input_buffer + 2 * halo_samples, (STAGING_SAMPLES - 2 * halo_samples) / channels);
-			resampler->input_buffer_end = resampler->input_buffer_start + got * channels;
+			if (limit > cr_stream_max_frames())
+				limit = cr_stream_max_frames();
+			if (limit < one_pull)
+				limit = one_pull;
 
-			if (got == 0)
+			memmove(stream->window, stream->window + stream->end - halo_samples, 2 * halo_samples * sizeof(stream->window[0]));
+
+			if (cr_stream_reserve(stream, 2 * halo_samples + limit * channels) != 0)
+			{
+				cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
+				return cc_true;
+			}
+
+			stream->start = halo_samples;
+
+			while (have + one_pull <= limit || have == 0)
+			{
+				const size_t got = input_callback((void *)user_data, stream->window + 2 * halo_samples + have * channels, one_pull);
+
+				have += got;
+
+				if (got == 0)
+					break;
+			}
+
+			stream->end = stream->start + have * channels;
+
+			if (have == 0)
 				return cc_true;
 		}
 
 		{
 			/* the CURRENT radius flanks the window: it may be smaller than the one at Init after an Adjust (:1165) */
 			const size_t current_halo = resampler->low_level.lowest_level.integer_stretched_kernel_radius * channels;
-			size_t frames = (size_t)(resampler->input_buffer_end - resampler->input_buffer_start) / channels;
-
+			size_t frames = (stream->end - stream->start) / channels;
 			const unsigned long errors_before = cr_error_serial();
 
-			consumer_stopped = !ClownResampler_LowLevel_Resample(&resampler->low_level, precomputed, resampler->input_buffer_start - current_halo, &frames, output_callback, user_data);
-			resampler->input_buffer_start = resampler->input_buffer_end - frames * channels; /* :1171 */
+			consumer_stopped = !ClownResampler_LowLevel_Resample(&resampler->low_level, precomputed, stream->window + stream->start - current_halo, &frames, output_callback, user_data);
+			stream->start = stream->end - frames * channels; /* :1171 */
 
 			/* a device failure was reported and the (non-default) error handler returned: the window was not
 			   consumed, so looping would never end - give control back to the caller */
 			if (cr_error_serial() != errors_before)
 				return cc_true;
+
+			/* read further ahead only for consumers that take everything they are given */
+			if (consumer_stopped)
+				stream->target_frames = one_pull;
+			else if (stream->target_frames < cr_stream_max_frames())
+				stream->target_frames *= 4;
 		}
 	}
 

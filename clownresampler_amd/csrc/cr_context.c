@@ -153,8 +153,13 @@ const crhip_device_info *cr_device_info(void)
 	return &g_info;
 }
 
+static cr_stream *g_streams = NULL;
+static uint64_t g_stream_serial = 0;
+static size_t g_stream_max_frames = (size_t)1 << 18;
+
 static void release_everything_locked(void)
 {
+	/* streaming side windows are host memory: they stay valid across device changes and are only dropped by Shutdown */
 	ClownResamplerAMD_Plan *p = g_plans;
 
 	while (p != NULL)
@@ -208,6 +213,13 @@ int ClownResamplerAMD_GetDevice(void)
 void ClownResamplerAMD_Shutdown(void)
 {
 	pthread_mutex_lock(&g_lock);
+	while (g_streams != NULL)
+	{
+		cr_stream *next = g_streams->next;
+		free(g_streams->window);
+		free(g_streams);
+		g_streams = next;
+	}
 	if (g_device_ready)
 		crhip_set_device(g_device);
 	release_everything_locked();
@@ -752,4 +764,62 @@ void ClownResamplerAMD_DebugSetVariant(int variant)
 void ClownResamplerAMD_DebugForceGenericKernel(int on)
 {
 	g_force_generic = on != 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* streaming side windows                                                                                  */
+/* ------------------------------------------------------------------------------------------------------- */
+
+cr_stream *cr_stream_create(void)
+{
+	cr_stream *stream = (cr_stream *)calloc(1, sizeof(*stream));
+
+	if (stream == NULL)
+		return NULL;
+
+	pthread_mutex_lock(&g_lock);
+	stream->id = ++g_stream_serial ^ 0x434C4F574E5253ull; /* never 0 */
+	stream->next = g_streams;
+	g_streams = stream;
+	pthread_mutex_unlock(&g_lock);
+	return stream;
+}
+
+cr_stream *cr_stream_lookup(uint64_t id)
+{
+	cr_stream *stream;
+
+	pthread_mutex_lock(&g_lock);
+	for (stream = g_streams; stream != NULL; stream = stream->next)
+		if (stream->id == id)
+			break;
+	pthread_mutex_unlock(&g_lock);
+	return stream;
+}
+
+int cr_stream_reserve(cr_stream *stream, size_t samples)
+{
+	int16_t *grown;
+
+	if (stream->window_samples >= samples)
+		return 0;
+
+	grown = (int16_t *)realloc(stream->window, samples * sizeof(int16_t));
+	if (grown == NULL)
+		return -1;
+
+	memset(grown + stream->window_samples, 0, (samples - stream->window_samples) * sizeof(int16_t));
+	stream->window = grown;
+	stream->window_samples = samples;
+	return 0;
+}
+
+size_t cr_stream_max_frames(void)
+{
+	return g_stream_max_frames;
+}
+
+void ClownResamplerAMD_SetStreamingWindow(size_t frames)
+{
+	g_stream_max_frames = frames;
 }

@@ -83,6 +83,23 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 int cr_run_single_frame(const ClownResamplerAMD_Plan *plan, const int16_t *host_window, uint64_t window_frames,
                         uint64_t pos_frac, const int64_t *acc_in, int64_t *acc_out);
 
+/* Side window of one high-level (streaming) state: the reference's fixed 0x1000-sample staging buffer
+   (clownresampler.h:654, with the TODO there) made large, so that a whole batch of input pulls becomes one GPU call. */
+typedef struct cr_stream
+{
+	uint64_t id;
+	struct cr_stream *next;
+	int16_t *window;        /* [left halo | unconsumed frames ... | look-ahead], same layout as the reference's buffer */
+	size_t window_samples;  /* allocated */
+	size_t start, end;      /* sample indices into window: the frames not yet resampled (input_buffer_start / _end) */
+	size_t target_frames;   /* payload frames to collect per refill; grows while the consumer keeps draining whole windows */
+} cr_stream;
+
+cr_stream *cr_stream_create(void);             /* new id, registered for Shutdown */
+cr_stream *cr_stream_lookup(uint64_t id);
+int cr_stream_reserve(cr_stream *stream, size_t samples);   /* grows window keeping its contents; 0 on success */
+size_t cr_stream_max_frames(void);             /* ClownResamplerAMD_SetStreamingWindow */
+
 #ifdef __cplusplus
 }
 #endif

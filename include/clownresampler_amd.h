@@ -59,6 +59,14 @@ int ClownResamplerAMD_SetDevice(int ordinal);           /* device used by subseq
 int ClownResamplerAMD_GetDevice(void);
 void ClownResamplerAMD_Shutdown(void);
 
+/* High-level (streaming) API: how many input frames ClownResampler_HighLevel_Resample may collect from the input callback
+   before it resamples them in one GPU call (default 262144).  The reference's 0x1000-sample staging buffer
+   (clownresampler.h:654) corresponds to 0: one input pull per GPU call - exact call-for-call behaviour, but every call
+   then pays a launch and two PCIe copies for ~2000 frames.  The output is identical for every setting; what changes is
+   how far ahead of the output the input callback is asked for data (the window grows 4x per refill only while the
+   consumer keeps draining whole windows, and falls back to one pull as soon as the output callback stops a call). */
+void ClownResamplerAMD_SetStreamingWindow(size_t frames);
+
 /* Thin helpers so a C client needs no HIP headers. */
 void *ClownResamplerAMD_DeviceAlloc(size_t bytes);
 void ClownResamplerAMD_DeviceFree(void *device_pointer);

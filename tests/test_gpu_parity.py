@@ -242,3 +242,56 @@ def test_adjust_between_calls(products):
         got.append(xa); want.append(xb)
         pos += n - la
     assert np.array_equal(np.concatenate(got), np.concatenate(want))
+
+
+@pytest.mark.parametrize("window", [0, 5000, 1 << 18])
+def test_highlevel_stop_and_resume_any_window(products, window):
+    """ClownResampler_HighLevel_Resample with the output callback stopping every 1,000 frames, then ResampleEnd; the input is
+    pulled 333 frames at a time.  Whatever the streaming window (0 = the reference's one pull per GPU call), the frames and the
+    return values equal the oracle's; with window 0 the input callback is also called exactly as often as the reference calls it."""
+    p, o = products[3], ck.oracle(3)
+    p.api.SetStreamingWindow(window)
+    try:
+        for ch, rates, frames in [(2, (44100, 48000, 44100), 30000), (3, (48000, 11025, 11025), 20000)]:
+            pcm = ck.noise_pcm(frames * ch, 21)
+            results = []
+            for eng in (p, o):
+                ok, st = eng.high_init(ch, *rates)
+                pos, pulls, out, rets = [0], [0], [], []
+
+                def pull(n, pos=pos, pulls=pulls):
+                    k = min(n, 333, frames - pos[0])
+                    pulls[0] += 1
+                    a = pcm[pos[0] * ch:(pos[0] + k) * ch]
+                    pos[0] += k
+                    return a
+
+                budget = [0]
+
+                def emit(f, out=out, budget=budget):
+                    out.extend(f)
+                    budget[0] -= 1
+                    return budget[0] > 0
+
+                for _ in range(100000):
+                    budget[0] = 1000
+                    if eng is p:
+                        r = eng.api.HighLevel_Resample(st.raw, eng.pre, pull, emit)
+                    else:
+                        r = eng.high_resample_cb(st, lambda n: list(pull(n)), emit)
+                    rets.append(int(bool(r)))
+                    if r:
+                        break
+                for _ in range(100000):
+                    budget[0] = 1000
+                    r = eng.api.HighLevel_ResampleEnd(st.raw, eng.pre, emit) if eng is p else eng.high_end_cb(st, emit)
+                    rets.append(int(bool(r)))
+                    if r:
+                        break
+                results.append((out, rets, pulls[0]))
+            assert results[0][0] == results[1][0]
+            assert results[0][1] == results[1][1]
+            if window == 0:
+                assert results[0][2] == results[1][2]
+    finally:
+        p.api.SetStreamingWindow(1 << 18)

@@ -55,3 +55,37 @@ for rep in range(2):
     fn(C.addressof(st.raw), C.addressof(p.pre), padded.ctypes.data, C.addressof(left), C.cast(cb.store, C.c_void_p), C.addressof(sink))
     dt = time.perf_counter() - t0
     print("LowLevel_Resample (reference signature, C callback per frame): %.1f ms  %.0f Msamples/s" % (dt * 1e3, sink.n / dt / 1e6))
+
+# high-level streaming API with C callbacks (pull from memory, push storing int32)
+src2 = r'''
+#include <stddef.h>
+#include <string.h>
+typedef struct { const short *in; size_t left; unsigned ch; int *out; size_t n; size_t pulls; } io;
+size_t pull(void *u, short *buf, size_t frames) { io *s = (io *)u; size_t k = frames < s->left ? frames : s->left; memcpy(buf, s->in, k * s->ch * 2); s->in += k * s->ch; s->left -= k; s->pulls++; return k; }
+unsigned char push(void *u, const long *frame, unsigned int samples) { io *s = (io *)u; unsigned int c; for (c = 0; c < samples; ++c) s->out[s->n++] = (int)frame[c]; return 1; }
+'''
+open(d + "/hl.c", "w").write(src2)
+subprocess.run(["gcc", "-O2", "-shared", "-fPIC", d + "/hl.c", "-o", d + "/hl.so"], check=True)
+hl = C.CDLL(d + "/hl.so")
+
+
+class IO(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("left", C.c_size_t), ("ch", C.c_uint), ("out", C.c_void_p), ("n", C.c_size_t), ("pulls", C.c_size_t)]
+
+
+pcm = padded[3 * ch: 3 * ch + 2646000 * ch].copy()   # 1 minute
+for rep in range(2):
+    hs = p.api.HighLevel_State()
+    p.api.HighLevel_Init(hs, ch, *rates)
+    out = np.zeros((2880010 + 8) * ch, dtype=np.int32)
+    io = IO(pcm.ctypes.data, 2646000, ch, out.ctypes.data, 0, 0)
+    f1 = p.api.lib.ClownResampler_HighLevel_Resample
+    f2 = p.api.lib.ClownResampler_HighLevel_ResampleEnd
+    f1.restype = f2.restype = C.c_ubyte
+    f1.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    f2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    t0 = time.perf_counter()
+    f1(C.addressof(hs), C.addressof(p.pre), C.cast(hl.pull, C.c_void_p), C.cast(hl.push, C.c_void_p), C.addressof(io))
+    f2(C.addressof(hs), C.addressof(p.pre), C.cast(hl.push, C.c_void_p), C.addressof(io))
+    dt = time.perf_counter() - t0
+    print("HighLevel_Resample + ResampleEnd (1 min stereo, C callbacks, %d input pulls): %.1f ms  %.0f Msamples/s" % (io.pulls, dt * 1e3, io.n / dt / 1e6))

@@ -34,6 +34,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "crhip.h"
 
 namespace
@@ -279,8 +281,10 @@ struct Frame
 	}
 };
 
-// N consecutive output frames (N * CH int32) -> global memory, widest stores the size allows.
-template <int NINT>
+// NINT consecutive int32 -> global memory, widest stores the size allows.  NT = 1 marks them non-temporal: the output
+// is written once and never read by the kernel; on MI355X that is worth ~7 % of HBM throughput for the stereo stream
+// (8-byte stores) and costs a few % with 16-byte stores, so it is part of the per-instance tuning.
+template <int NINT, int NT>
 __device__ __forceinline__ void store_ints(int *dst, const int *v)
 {
 	if constexpr (NINT % 4 == 0)
@@ -293,7 +297,10 @@ __device__ __forceinline__ void store_ints(int *dst, const int *v)
 			q.y = v[c + 1];
 			q.z = v[c + 2];
 			q.w = v[c + 3];
-			*reinterpret_cast<i32x4 *>(dst + c) = q;
+			if constexpr (NT)
+				__builtin_nontemporal_store(q, reinterpret_cast<i32x4 *>(dst + c));
+			else
+				*reinterpret_cast<i32x4 *>(dst + c) = q;
 		}
 	}
 	else if constexpr (NINT % 2 == 0)
@@ -304,14 +311,22 @@ __device__ __forceinline__ void store_ints(int *dst, const int *v)
 			i32x2 q;
 			q.x = v[c];
 			q.y = v[c + 1];
-			*reinterpret_cast<i32x2 *>(dst + c) = q;
+			if constexpr (NT)
+				__builtin_nontemporal_store(q, reinterpret_cast<i32x2 *>(dst + c));
+			else
+				*reinterpret_cast<i32x2 *>(dst + c) = q;
 		}
 	}
 	else
 	{
 #pragma unroll
 		for (int c = 0; c < NINT; ++c)
-			dst[c] = v[c];
+		{
+			if constexpr (NT)
+				__builtin_nontemporal_store(v[c], dst + c);
+			else
+				dst[c] = v[c];
+		}
 	}
 }
 
@@ -323,7 +338,7 @@ __device__ __forceinline__ int clamp_s16(int v)
 	return v > 0x7FFF ? 0x7FFF : (v < -0x7FFF ? -0x7FFF : v);
 }
 
-template <int NSHORT>
+template <int NSHORT, int NT>
 __device__ __forceinline__ void store_shorts(short *dst, const int *v)
 {
 	if constexpr (NSHORT % 2 == 0)
@@ -332,7 +347,7 @@ __device__ __forceinline__ void store_shorts(short *dst, const int *v)
 #pragma unroll
 		for (int k = 0; k < NSHORT / 2; ++k)
 			packed[k] = (clamp_s16(v[2 * k]) & 0xFFFF) | (clamp_s16(v[2 * k + 1]) << 16);
-		store_ints<NSHORT / 2>(reinterpret_cast<int *>(dst), packed);
+		store_ints<NSHORT / 2, NT>(reinterpret_cast<int *>(dst), packed);
 	}
 	else
 	{
@@ -365,6 +380,71 @@ __device__ __forceinline__ unsigned row_of(const crhip_poly_launch &a, unsigned 
 		const unsigned kstart = __umul24(a.step, (mr << 16) - frac) >> 16;
 		return (unsigned)((int)kstart + a.aff_a * (int)mr + a.aff_b * (int)xr + a.aff_c);
 	}
+}
+
+// Everything one output frame reads from LDS, held in registers: its row (weights + reciprocal) and its window of
+// input frames.  Splitting the frame into fetch_frame (LDS reads only) and compute_frame (VALU only) lets the kernel
+// issue the reads of frame i+1 before the arithmetic of frame i: hipcc does not software-pipeline across the asm tap
+// statements on its own, and with every wave of a workgroup released by the same barrier the waves otherwise alternate
+// in lockstep between an LDS phase and a VALU phase.
+template <int CH, int TT>
+struct FrameData
+{
+	static constexpr int RS = (TT + 1 + 3) & ~3;
+	int w[RS];
+	Frame<CH> f[TT];
+};
+
+template <int CH, int TT, int MODE, int SWZ>
+__device__ __forceinline__ void fetch_frame(const crhip_poly_launch &a, const int *rows, const unsigned char *base, unsigned rel, FrameData<CH, TT> &d)
+{
+	constexpr unsigned FB = CH * 2;
+	const unsigned row = row_of<MODE>(a, rel & 0xFFFFu);
+	const unsigned phys = SWZ ? ((row & ~15u) | ((__umul24(row >> 4, a.swizzle) + row) & 15u)) : row;
+	const unsigned char *src = base + (rel >> 16) * FB;
+	const i32x4 *plane0 = reinterpret_cast<const i32x4 *>(rows) + phys;
+
+#pragma unroll
+	for (int q = 0; q < FrameData<CH, TT>::RS / 4; ++q)
+	{
+		const i32x4 v = plane0[q * a.plane_rows];
+		d.w[4 * q] = v.x;
+		d.w[4 * q + 1] = v.y;
+		d.w[4 * q + 2] = v.z;
+		d.w[4 * q + 3] = v.w;
+	}
+#pragma unroll
+	for (int s = 0; s < TT; ++s)
+		d.f[s].load(src + s * FB);
+}
+
+template <int CH, int TT, int NORM, int ASM>
+__device__ __forceinline__ void compute_frame(const FrameData<CH, TT> &d, int *out)
+{
+	// two accumulator sets, taps alternating between them: consecutive tap statements are independent (no asm boundary
+	// pad, more overlap); integer addition is associative, so the sum is the same
+	int acc[CH], acc2[CH];
+#pragma unroll
+	for (int s = 0; s < TT; ++s)
+	{
+		if (s == 0)
+			d.f[s].template mac_first<ASM>(acc, d.w[s]);
+		else if (s == 1)
+			d.f[s].template mac_first<ASM>(acc2, d.w[s]);
+		else if (s & 1)
+			d.f[s].template mac<ASM>(acc2, d.w[s]);
+		else
+			d.f[s].template mac<ASM>(acc, d.w[s]);
+	}
+	if constexpr (TT > 1)
+	{
+#pragma unroll
+		for (int c = 0; c < CH; ++c)
+			acc[c] += acc2[c];
+	}
+#pragma unroll
+	for (int c = 0; c < CH; ++c)
+		out[c] = normalise<NORM>(acc[c], d.w[TT]);
 }
 
 // One output frame: CH normalised int32 into out[0..CH).
@@ -474,7 +554,8 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 // ABL       0 in every shipped instance.  Timing-only ablations (WRONG results, reachable only through the debug
 //           launch flag of tools/): 1 = no output stores, 2 = no input DMA, 3 = neither, 4 = DMA + stores but no arithmetic
 // OUT16     1 = clamp to +-0x7FFF and store int16 (opt-in extension), 0 = the reference's unclamped int32
-template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0, int OUT16 = 0>
+// NT        1 = non-temporal output stores
+template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0, int OUT16 = 0, int NT = 0>
 __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 {
 	constexpr unsigned FB = CH * 2;                       // bytes per input frame
@@ -613,44 +694,67 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 				if constexpr (OUT16)
 				{
 					short *group_out = out_tile16 + (size_t)(g + u * NTHREADS) * CH;   // uniform
-					store_shorts<CH>(group_out + tid * CH, outv + u * CH);
+					store_shorts<CH, NT>(group_out + tid * CH, outv + u * CH);
 				}
 				else
 				{
 					int *group_out = out_tile + (size_t)(g + u * NTHREADS) * CH;   // uniform
-					store_ints<CH>(group_out + tid * CH, outv + u * CH);
+					store_ints<CH, NT>(group_out + tid * CH, outv + u * CH);
 				}
 			}
 		};
 
+		// Full tiles of 4, 2 or 1 groups as straight-line code (see the vmcnt note above).  Specialised instances
+		// (TT > 0) run the frames of a tile as a software pipeline: the LDS reads of frame i+1 are issued before the
+		// arithmetic of frame i.
+		auto run_groups = [&](auto groups_tag) {
+			constexpr int G = decltype(groups_tag)::value;
+			constexpr int N = G * U;   // frames per lane in this tile
+
+			if constexpr (TT > 0 && ABL == 0)
+			{
+				FrameData<CH, TT> d[2];
+				fetch_frame<CH, TT, MODE, SWZ>(a, rows, base, lane_rel, d[0]);
+#pragma unroll
+				for (int i = 0; i < N; ++i)
+				{
+					const unsigned first = (unsigned)(i / U) * GROUP + (unsigned)(i % U) * NTHREADS;   // uniform
+					int outv[CH];
+
+					if (i + 1 < N)
+					{
+						const unsigned next_first = (unsigned)((i + 1) / U) * GROUP + (unsigned)((i + 1) % U) * NTHREADS;
+						fetch_frame<CH, TT, MODE, SWZ>(a, rows, base, lane_rel + next_first * a.increment, d[(i + 1) & 1]);
+					}
+					__builtin_amdgcn_sched_barrier(0);   // keep the reads above the arithmetic below
+					compute_frame<CH, TT, NORM, ASM>(d[i & 1], outv);
+
+					if constexpr (OUT16)
+						store_shorts<CH, NT>(out_tile16 + (size_t)first * CH + tid * CH, outv);
+					else
+						store_ints<CH, NT>(out_tile + (size_t)first * CH + tid * CH, outv);
+					__builtin_amdgcn_sched_barrier(0);
+				}
+			}
+			else
+			{
+#pragma unroll
+				for (int gi = 0; gi < G; ++gi)
+					group((unsigned)gi * GROUP);
+			}
+
+			if constexpr (G * STORES_PER_GROUP <= 63)
+				asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G * STORES_PER_GROUP) : "memory");
+			else
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		};
+
 		if (n == 4u * GROUP)
-		{
-			group(0);
-			group(GROUP);
-			group(2u * GROUP);
-			group(3u * GROUP);
-			if constexpr (4 * STORES_PER_GROUP <= 63)
-				asm volatile("s_waitcnt vmcnt(%0)" ::"i"(4 * STORES_PER_GROUP) : "memory");
-			else
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		}
+			run_groups(std::integral_constant<int, 4>());
 		else if (n == 2u * GROUP)
-		{
-			group(0);
-			group(GROUP);
-			if constexpr (2 * STORES_PER_GROUP <= 63)
-				asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * STORES_PER_GROUP) : "memory");
-			else
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		}
+			run_groups(std::integral_constant<int, 2>());
 		else if (n == GROUP)
-		{
-			group(0);
-			if constexpr (STORES_PER_GROUP <= 63)
-				asm volatile("s_waitcnt vmcnt(%0)" ::"i"(STORES_PER_GROUP) : "memory");
-			else
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		}
+			run_groups(std::integral_constant<int, 1>());
 		else
 		{
 			// ragged tile (only the stream's last tile can be one)
@@ -663,9 +767,9 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 				int outv[CH];
 				one_frame<CH, TT, MODE, NORM, ASM, SWZ>(a, rows, base, __umul24(jl, a.increment) + frac0, outv);
 				if constexpr (OUT16)
-					store_shorts<CH>(out_tile16 + (size_t)jl * CH, outv);
+					store_shorts<CH, NT>(out_tile16 + (size_t)jl * CH, outv);
 				else
-					store_ints<CH>(out_tile + (size_t)jl * CH, outv);
+					store_ints<CH, NT>(out_tile + (size_t)jl * CH, outv);
 			}
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		}
@@ -746,8 +850,9 @@ __global__ __launch_bounds__(256) void k_generic(const crhip_generic_launch a)
 // ---------------------------------------------------------------------------------------------------------
 typedef void (*poly_fn)(const crhip_poly_launch);
 
-// Tuning variants of the specialised instances: geometry x frames in flight x row swizzle.
-//   variant = geo + 5 * ui + 10 * swz    geo: 0 (256 thr, 2 vec) 1 (512,1) 2 (512,2) 3 (1024,1) 4 (1024,2); ui: 0/1 -> U = 1/2
+// Tuning variants of the specialised instances: geometry x frames in flight x non-temporal stores.
+// (A swizzled LDS row image, SWZ = 1, measured no better than the plain one and is not instantiated.)
+//   variant = geo + 5 * ui + 10 * nt     geo: 0 (256 thr, 2 vec) 1 (512,1) 2 (512,2) 3 (1024,1) 4 (1024,2); ui: 0/1 -> U = 1/2
 // The specialised instances always use the SDWA arithmetic; the run-time-slot instances keep the compiler's, so the
 // test-suite exercises both forms against the oracle.
 struct geometry
@@ -757,10 +862,10 @@ struct geometry
 constexpr geometry GEOMETRY[5] = {{256, 2}, {512, 1}, {512, 2}, {1024, 1}, {1024, 2}};
 constexpr int VARIANTS = 20;
 
-template <int CH, int TT, int MODE, int NORM, int GEO, int ASM, int UI, int SWZ, int OUT16 = 0>
+template <int CH, int TT, int MODE, int NORM, int GEO, int ASM, int UI, int NT, int OUT16 = 0>
 constexpr poly_fn instance()
 {
-	return (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[GEO].threads, GEOMETRY[GEO].vecs, ASM, (1 << UI), SWZ, 0, OUT16>;
+	return (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[GEO].threads, GEOMETRY[GEO].vecs, ASM, (1 << UI), 0, 0, OUT16, NT>;
 }
 
 template <int CH, int TT, int MODE, int NORM, int V>
@@ -799,11 +904,11 @@ special make_special()
 const special *specials(int *count)
 {
 	static const special table[] = {
-	    make_special<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 8>(),   // cfg 2 / cfg 5: stereo 44.1 -> 48 kHz, 3 lobes
-	    make_special<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 9>(),  // cfg 3: stereo 8 -> 96 kHz, 8 lobes
-	    make_special<8, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 2>(),     // cfg 4: 8 channels 48 -> 44.1 kHz
-	    make_special<1, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 8>(),   // mono upsampling, 3 lobes
-	    make_special<2, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 8>(),     // stereo mild downsampling, 3 lobes
+	    make_special<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 18>(),   // cfg 2 / cfg 5: stereo 44.1 -> 48 kHz, 3 lobes
+	    make_special<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 19>(),  // cfg 3: stereo 8 -> 96 kHz, 8 lobes
+	    make_special<8, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 14>(),     // cfg 4: 8 channels 48 -> 44.1 kHz
+	    make_special<1, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 18>(),   // mono upsampling, 3 lobes
+	    make_special<2, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 18>(),     // stereo mild downsampling, 3 lobes
 	};
 	*count = (int)(sizeof(table) / sizeof(table[0]));
 	return table;
@@ -818,6 +923,7 @@ poly_fn ablation_instance(int abl)
 		case 2: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 2>;
 		case 3: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 3>;
 		case 4: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 4>;
+		case 5: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 4, 0, 1>;   // as 4, non-temporal stores
 		default: return nullptr;
 	}
 }
@@ -977,7 +1083,9 @@ static uint32_t resolve_variant(const special *sp, uint32_t variant, uint32_t ou
 int crhip_poly_swizzled(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t variant)
 {
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
-	return (int)((resolve_variant(sp, variant) / 10) % 2);
+	(void)sp;
+	(void)variant;
+	return 0;   // no swizzled instance is built
 }
 
 int crhip_poly_variants(void)

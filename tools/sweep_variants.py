@@ -74,7 +74,7 @@ def main():
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) / args.steps * 1e3)
     nbytes = frames * ch * 2 + n_out * ch * 4
-    print("variant geo(thr,vec) asm U swz tile lds blocks | us median  min | GB/s(median)  frac of 8 TB/s")
+    print("variant geo(thr,vec) asm U nt  tile lds blocks | us median  min | GB/s(median)  frac of 8 TB/s")
     geos = [(256, 2), (512, 1), (512, 2), (1024, 1), (1024, 2)]
     for v in sorted(variants, key=lambda v: sorted(times[v])[len(times[v]) // 2]):
         t = sorted(times[v])

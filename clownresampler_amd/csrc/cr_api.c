@@ -460,8 +460,11 @@ cc_bool ClownResampler_HighLevel_Init(ClownResampler_HighLevel_State *resampler,
 
 	/* silence where the frames before the stream would be; empty window right behind it (:1112-1115) */
 	halo_samples = resampler->maximum_integer_stretched_kernel_radius * channels;
+	/* re-initialising a state that already owns a side window reuses it (there is no Deinit to free it) */
+	stream = stream_of(resampler);
 	memset(resampler->input_buffer, 0, sizeof(resampler->input_buffer));
-	stream = cr_stream_create();
+	if (stream == NULL)
+		stream = cr_stream_create();
 
 	if (stream == NULL || channels == 0 || cr_stream_reserve(stream, 2 * halo_samples + reference_pull_frames(resampler) * channels) != 0)
 	{

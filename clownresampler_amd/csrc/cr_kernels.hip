@@ -853,8 +853,8 @@ typedef void (*poly_fn)(const crhip_poly_launch);
 // Tuning variants of the specialised instances: geometry x frames in flight x non-temporal stores.
 // (A swizzled LDS row image, SWZ = 1, measured no better than the plain one and is not instantiated.)
 //   variant = geo + 5 * ui + 10 * nt     geo: 0 (256 thr, 2 vec) 1 (512,1) 2 (512,2) 3 (1024,1) 4 (1024,2); ui: 0/1 -> U = 1/2
-// The specialised instances always use the SDWA arithmetic; the run-time-slot instances keep the compiler's, so the
-// test-suite exercises both forms against the oracle.
+// All k_poly instances use the SDWA arithmetic (ASM = 1); the plain-C form (ASM = 0) is kept in the source as its
+// readable definition, and k_generic is the independent 64-bit implementation the tests compare against the oracle too.
 struct geometry
 {
 	int threads, vecs;
@@ -938,15 +938,23 @@ const special *find_special(uint32_t channels, uint32_t slots, uint32_t mode, ui
 	return nullptr;
 }
 
-// run-time slot count: every channel count 1..8, both row modes, both normalisations, both output forms, default geometry
+// run-time slot count: every channel count 1..8, both row modes, both normalisations, both output forms.  One geometry
+// per channel count - 1024 threads; 16 KiB tiles for up to 4 channels, 32 KiB above (an 8-channel frame is 16 bytes) -
+// SDWA arithmetic, one frame in flight, non-temporal stores.
+constexpr int runtime_geo(int channels)
+{
+	return channels <= 4 ? 3 : 4;
+}
+
 template <int CH, int OUT16>
 poly_fn pick_runtime(uint32_t mode, uint32_t norm)
 {
+	constexpr int GEO = runtime_geo(CH);
 	if (norm == CRHIP_NORM_S31)
-		return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 0, 0, 0, 0, OUT16>()
-		                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 0, 0, 0, 0, OUT16>();
-	return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 0, 0, 0, 0, OUT16>()
-	                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, 0, 0, 0, 0, OUT16>();
+		return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, GEO, 1, 0, 1, OUT16>()
+		                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, GEO, 1, 0, 1, OUT16>();
+	return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, GEO, 1, 0, 1, OUT16>()
+	                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, GEO, 1, 0, 1, OUT16>();
 }
 
 template <int OUT16>
@@ -1097,7 +1105,7 @@ void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, u
                          uint32_t *threads, uint32_t *vecs, uint32_t *frames_multiple)
 {
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
-	const uint32_t v = resolve_variant(sp, variant);
+	const uint32_t v = sp != nullptr ? resolve_variant(sp, variant) : (uint32_t)runtime_geo((int)channels);
 
 	*threads = (uint32_t)GEOMETRY[v % 5].threads;
 	*vecs = (uint32_t)GEOMETRY[v % 5].vecs;
@@ -1119,7 +1127,7 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 	if (sp != nullptr && launch->variant >= 1000u && launch->variant < 1010u && launch->channels == 2 && launch->slots == 5)
 		fn = ablation_instance((int)(launch->variant - 1000u));
 
-	*geo = v % 5;
+	*geo = sp != nullptr ? v % 5 : (uint32_t)runtime_geo((int)launch->channels);
 	return fn;
 }
 

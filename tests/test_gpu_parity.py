@@ -295,3 +295,45 @@ def test_highlevel_stop_and_resume_any_window(products, window):
                 assert results[0][2] == results[1][2]
     finally:
         p.api.SetStreamingWindow(1 << 18)
+
+
+def test_concurrent_callers(products):
+    """Distinct states used from different threads, sharing one Precomputed (the reference's threading contract)."""
+    import threading
+    p, o = products[3], ck.oracle(3)
+    jobs = [(2, (44100, 48000, 44100), 120000, 1), (1, (48000, 44100, 44100), 90000, 2), (8, (48000, 44100, 44100), 30000, 3), (2, (44100, 8000, 8000), 100000, 4)]
+    want, got, errs = {}, {}, []
+    for ch, rates, frames, seed in jobs:
+        ok, st = o.low_init(ch, *rates)
+        want[seed] = o.low_resample_i32(st, ck.pad_frames(ck.noise_pcm(frames * ch, seed), ch, int(st.cfg.radius_frames)), frames)[0]
+
+    def work(ch, rates, frames, seed):
+        try:
+            for _ in range(3):
+                ok, st = p.low_init(ch, *rates)
+                padded = ck.pad_frames(ck.noise_pcm(frames * ch, seed), ch, int(st.cfg.radius_frames))
+                got[seed] = p.low_resample_i32(st, padded, frames)[0]
+                assert np.array_equal(got[seed], want[seed])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    assert len(got) == len(jobs)
+
+
+def test_highlevel_reinit_reuses_window(products):
+    p = products[3]
+    hs = p.api.HighLevel_State()
+    import ctypes as C
+    keys = set()
+    for _ in range(5):
+        assert p.api.HighLevel_Init(hs, 2, 44100, 48000, 44100)
+        keys.add(bytes(C.string_at(C.addressof(hs.input_buffer), 16)))
+        out = p.high_run_i32(_product.HighView(hs), ck.noise_pcm(2 * 5000, 8))
+        assert out.size == 2 * 5443
+    assert len(keys) == 1

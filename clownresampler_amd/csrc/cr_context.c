@@ -97,6 +97,13 @@ static ClownResamplerAMD_Plan *g_plans = NULL;
 static cr_workspace g_workspace;
 static int g_workspace_busy = 0;
 static int g_force_generic = 0;
+/* ticket slots for k_poly's dynamic tile scheduling: a ring of counter blocks (crhip.h CRHIP_TICKET_WORDS), zeroed
+   once; every launch takes the next block (launches that overlap in time - different streams - must not share one) and
+   leaves it zeroed */
+#define CR_TICKET_SLOTS 512u
+static uint32_t *g_tickets = NULL;
+static unsigned g_ticket_serial = 0;
+static unsigned long long *g_debug_stamps = NULL;
 static int g_variant = -1; /* -1: CLOWNRESAMPLER_AMD_VARIANT from the environment, else the default */
 static pthread_mutex_t g_workspace_lock = PTHREAD_MUTEX_INITIALIZER;
 
@@ -133,6 +140,14 @@ static int ensure_device_locked(void)
 
 	if (cr_check_hip(crhip_get_device_info(g_device, &g_info), "hipGetDeviceProperties") != 0)
 		return CLOWNRESAMPLER_AMD_ERROR_HIP;
+
+	if (g_tickets == NULL)
+	{
+		if (cr_check_hip(crhip_malloc((void **)&g_tickets, CR_TICKET_SLOTS * CRHIP_TICKET_WORDS * sizeof(uint32_t)), "hipMalloc(tickets)") != 0
+		 || cr_check_hip(crhip_memset(g_tickets, 0, CR_TICKET_SLOTS * CRHIP_TICKET_WORDS * sizeof(uint32_t), NULL), "hipMemset(tickets)") != 0
+		 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
+			return CLOWNRESAMPLER_AMD_ERROR_HIP;
+	}
 
 	g_device_ready = 1;
 	return 0;
@@ -179,6 +194,8 @@ static void release_everything_locked(void)
 
 	if (g_device_ready)
 	{
+		crhip_free(g_tickets);
+		g_tickets = NULL;
 		crhip_free(g_workspace.d_in);
 		crhip_free(g_workspace.d_out);
 		if (g_workspace.stream != NULL)
@@ -305,7 +322,7 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	plan->specialised = (uint32_t)crhip_poly_has_instance(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
 	crhip_poly_geometry(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
 	tile_bytes = plan->vecs * 16u * plan->threads;
-	plan->lds_bytes = rows_bytes + 2u * tile_bytes;
+	plan->lds_bytes = rows_bytes + 2u * tile_bytes + 16u; /* + the ticket mailbox */
 
 	if (plan->lds_bytes > (uint32_t)g_info.max_lds_per_block)
 	{
@@ -333,6 +350,12 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	if (tile > (1u << 24) - 1u)
 		tile = (1u << 24) - 1u;
 	/* whole groups of threads * frames-in-flight; 4, 2 or 1 groups per tile run as straight-line code in the kernel */
+	{
+		const char *e = getenv("CLOWNRESAMPLER_AMD_TILE_GROUPS"); /* tuning hook: cap the groups per tile */
+		const uint64_t cap = (e != NULL && atoi(e) > 0) ? (uint64_t)atoi(e) * frames_multiple : 0;
+		if (cap != 0 && tile > cap)
+			tile = cap;
+	}
 	if (tile >= 4u * frames_multiple)
 		tile = 4u * frames_multiple;
 	else if (tile >= 2u * frames_multiple)
@@ -534,6 +557,7 @@ static void fill_poly_launch(const ClownResamplerAMD_Plan *plan, crhip_poly_laun
 	l->variant = plan->variant;
 	l->plane_rows = plan->plane_rows;
 	l->swizzle = plan->swizzle;
+	l->debug_stamps = g_debug_stamps;
 }
 
 int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_t in_valid_bytes, void *d_out,
@@ -560,6 +584,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		if (blocks > plan->max_blocks)
 			blocks = plan->max_blocks;
 		l.blocks = (uint32_t)blocks;
+		l.d_tickets = g_tickets + CRHIP_TICKET_WORDS * (__atomic_fetch_add(&g_ticket_serial, 1u, __ATOMIC_RELAXED) % CR_TICKET_SLOTS);
 
 		return cr_check_hip(crhip_launch_poly(&l, stream), "k_poly launch");
 	}
@@ -822,4 +847,9 @@ size_t cr_stream_max_frames(void)
 void ClownResamplerAMD_SetStreamingWindow(size_t frames)
 {
 	g_stream_max_frames = frames;
+}
+
+void ClownResamplerAMD_DebugSetStampBuffer(void *device_buffer)
+{
+	g_debug_stamps = (unsigned long long *)device_buffer;
 }

@@ -564,18 +564,31 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 	const unsigned tid = threadIdx.x;
+	unsigned long long stamp_cycles = 0, stamp_ticks = 0;
+	if constexpr (ABL == 6)
+	{
+		// diagnostic build only: in-kernel clock = cycles / (ticks / 100 MHz)  (MI355X_MICROARCH.md, DVFS give-back item 6)
+		stamp_cycles = __builtin_amdgcn_s_memtime();
+		stamp_ticks = __builtin_amdgcn_s_memrealtime();
+	}
 	const unsigned rows_bytes = a.plane_rows * a.row_stride * 4u;   // planes of plane_rows x 16 bytes
 	const int *rows = reinterpret_cast<const int *>(smem);
 	unsigned char *tiles = smem + rows_bytes;
 
-	// Tiles of tile_frames output frames are dealt round-robin: workgroup b takes tiles b, b + gridDim.x, ...  At any
-	// moment the resident workgroups therefore stream ONE compact window of the input and of the output (like a flat
-	// grid would), instead of gridDim.x far-apart streams; on this chip that is worth ~10 % of HBM throughput for this
-	// read:write mix (tools/microbench/streambench.hip).
+	// Tiles of tile_frames output frames are handed out in order: the first gridDim.x tiles by workgroup number, every
+	// further one by an atomic ticket (a.d_tickets[0]).  (1) At any moment the resident workgroups stream ONE compact
+	// window of the input and of the output, like a flat grid would, instead of gridDim.x far-apart streams: worth ~10 %
+	// of HBM throughput for this read:write mix (tools/microbench/streambench.hip).  (2) Workgroups do not run at the
+	// same speed - with equal shares the median workgroup finished at 49 us of a 64 us kernel - so whoever is free takes
+	// the next tile.  The ticket of the tile AFTER the next one is drawn while the current tile is computed and handed to
+	// the other waves through an LDS mailbox, so neither the atomic's latency nor the DMA of the next tile is exposed.
+	// The last workgroup to finish zeroes the two counters again: the slot is clean for the next launch (also for a
+	// hipGraph replay of this one).
 	const uint64_t NT64 = a.tile_frames;
 	const uint64_t n_tiles = (a.n_out + NT64 - 1) / NT64;
 	if (blockIdx.x >= n_tiles)
 		return;
+	volatile unsigned *mailbox = reinterpret_cast<volatile unsigned *>(smem + rows_bytes + 2u * TILE_BYTES);
 
 	// stage the polyphase rows once per workgroup (L2-resident after the first workgroups)
 	{
@@ -633,26 +646,64 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 	constexpr int ADJ = 0;   // a lane's U frames are NTHREADS apart: every store instruction is coalesced across the wave
 	constexpr int STORES_PER_GROUP = U * (OUT16 ? (CH % 2 == 0 ? stores_of_ints(CH / 2) : CH) : stores_of_ints(CH));
 
+	// Tickets.  One global counter would serialise: a single word sustains ~88 atomic draws per microsecond on this
+	// chip (MI355X_MICROARCH.md, "dequeue") and a 10-minute stereo launch draws 7,000 of them - measured 92 us instead
+	// of 64.  So there are LANES counters (each on its own 128-byte line); the tiles are dealt round-robin to LANES
+	// sequences, workgroup b belongs to sequence b % LANES (workgroups b and b + 8 are observed to share an XCD, so with
+	// 8 lanes a sequence is mostly one XCD's - a speed matter only), starts with the tile of its own number and then
+	// draws from its sequence's counter.  Every sequence has at least one workgroup (LANES <= gridDim.x), so every tile
+	// is computed wherever the workgroups land.  Only thread 0 of the workgroup draws.
+	const unsigned LANES = gridDim.x < 8u ? gridDim.x : 8u;
+	const unsigned lane_id = blockIdx.x % LANES;
+	const uint64_t lane_tiles = (n_tiles - lane_id + LANES - 1u) / LANES;            // tiles of this sequence
+	const unsigned lane_groups = (gridDim.x - lane_id + LANES - 1u) / LANES;          // its workgroups = its pre-assigned tiles
+	unsigned *lane_counter = a.d_tickets + lane_id * 32u;
+	// (Helping other sequences out once the own one is exhausted was tried: deciding where to draw needs the counter's
+	// value NOW, and a dependent load at the top of every tile stalls wave 0 - and with it the workgroup - for a memory
+	// round trip per tile: 148 us instead of 64.  The draw below has no consumer until the end of the tile.)
+	auto draw = [&]() -> unsigned {
+		const uint64_t k = (uint64_t)lane_groups + __hip_atomic_fetch_add(lane_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return k < lane_tiles ? (unsigned)(lane_id + LANES * k) : 0xFFFFFFFFu;
+	};
+	// a workgroup that has drawn a ticket beyond its sequence is done drawing; the last such workgroup zeroes the slot
+	auto retire = [&]() {
+		if (tid == 0)
+		{
+			unsigned *finished = a.d_tickets + 8u * 32u;
+			if (__hip_atomic_fetch_add(finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u)
+			{
+				for (unsigned c = 0; c < 8u; ++c)
+					__hip_atomic_store(a.d_tickets + c * 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	};
+
 	uint64_t tile_index = blockIdx.x;
 	uint64_t jt = tile_index * NT64;
 	unsigned n = (unsigned)((a.n_out - jt < NT64) ? (a.n_out - jt) : NT64);
 	unsigned shift = fetch(jt, n, tiles);
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	__syncthreads();   // rows staged (plain stores to LDS) and first tile landed, for every wave
+	if (tid == 0)
+		mailbox[0] = draw();
+	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+	__syncthreads();   // rows staged (plain stores to LDS), first tile landed and first ticket posted, for every wave
+	uint64_t next_index = __builtin_amdgcn_readfirstlane(mailbox[0]);   // wave-uniform: keeps the tile bookkeeping on the scalar unit
 
 	for (unsigned it = 0;; ++it)
 	{
 		const unsigned char *tile = tiles + (it & 1u) * TILE_BYTES;
-		const uint64_t next_index = tile_index + gridDim.x;
 		const bool more = next_index < n_tiles;
 		const uint64_t jn = next_index * NT64;
 		unsigned n_next = 0, shift_next = 0;
+		unsigned ticket = 0;
 
 		if (more)
 		{
 			// the other buffer was last read in the previous iteration, which every wave has left (barrier below)
 			n_next = (unsigned)((a.n_out - jn < NT64) ? (a.n_out - jn) : NT64);
 			shift_next = fetch(jn, n_next, tiles + ((it + 1u) & 1u) * TILE_BYTES);
+			if (tid == 0)
+				ticket = draw();   // for the tile after the next one; posted below, just before the barrier
 		}
 
 		const uint64_t pos = a.pos0 + jt * (uint64_t)a.increment;
@@ -711,7 +762,7 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 			constexpr int G = decltype(groups_tag)::value;
 			constexpr int N = G * U;   // frames per lane in this tile
 
-			if constexpr (TT > 0 && ABL == 0)
+			if constexpr (TT > 0 && (ABL == 0 || ABL == 6))
 			{
 				FrameData<CH, TT> d[2];
 				fetch_frame<CH, TT, MODE, SWZ>(a, rows, base, lane_rel, d[0]);
@@ -775,14 +826,33 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 		}
 
 		if (!more)
+		{
+			if constexpr (ABL == 6)
+			{
+				if (tid == 0 && a.debug_stamps != nullptr)
+				{
+					// per workgroup: {shader cycles of its lifetime, start tick, end tick, XCC id}
+					a.debug_stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - stamp_cycles;
+					a.debug_stamps[4 * blockIdx.x + 1] = stamp_ticks;
+					a.debug_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+					a.debug_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(63508 /* HW_REG_XCC_ID, bits 0..3 */) & 0xF;
+				}
+			}
+			retire();
 			break;
+		}
 
-		// every wave's share of the next tile has landed once every wave is past its wait
+		// every wave's share of the next tile has landed once every wave is past its wait; the mailbox has two slots,
+		// used alternately, so that a slot is never rewritten before every wave has read it
+		if (tid == 0)
+			mailbox[(it + 1u) & 1u] = ticket;
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		__builtin_amdgcn_s_barrier();
 		tile_index = next_index;
 		jt = jn;
 		n = n_next;
 		shift = shift_next;
+		next_index = __builtin_amdgcn_readfirstlane(mailbox[(it + 1u) & 1u]);
 	}
 }
 
@@ -924,6 +994,7 @@ poly_fn ablation_instance(int abl)
 		case 3: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 3>;
 		case 4: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 4>;
 		case 5: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 4, 0, 1>;   // as 4, non-temporal stores
+		case 6: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 6, 0, 1>;   // the real kernel (variant 13) + clock stamps
 		default: return nullptr;
 	}
 }

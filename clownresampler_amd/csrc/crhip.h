@@ -50,10 +50,14 @@ typedef struct crhip_poly_launch
 	uint32_t threads;           /* workgroup size the instance was compiled for */
 	uint32_t vecs;              /* 16-byte input vectors per thread per tile (template NV) */
 	uint32_t tile_frames;       /* output frames per tile */
-	uint32_t lds_bytes;
+	uint32_t lds_bytes;         /* polyphase rows + two tiles + 16 bytes of mailbox */
 	uint32_t blocks;            /* grid size */
 	uint32_t specialised;       /* use the (channels, slots) template instance if there is one */
 	uint32_t variant;           /* tuning variant of the specialised kernels (CRHIP_VARIANT_DEFAULT = the measured default) */
+	uint32_t *d_tickets;        /* CRHIP_TICKET_WORDS zeroed uint32 in device memory: 8 tile-ticket counters and a
+	                               finished-workgroup counter, each on its own 128-byte line; the kernel leaves them
+	                               zeroed.  Launches that may overlap in time need different blocks */
+	unsigned long long *debug_stamps; /* diagnostic instances only: receives {shader cycles, 100 MHz ticks} of workgroup 0 */
 	uint32_t out_s16;           /* 1: d_out is int16, samples clamped to +-0x7FFF (extension); 0: int32 unclamped (reference) */
 } crhip_poly_launch;
 
@@ -104,6 +108,8 @@ int crhip_memset(void *dst, int value, size_t bytes, void *stream);
 int crhip_stream_create(void **stream);
 int crhip_stream_destroy(void *stream);
 int crhip_stream_sync(void *stream);
+
+#define CRHIP_TICKET_WORDS (9u * 32u)
 
 /* variant value meaning: the instance's measured default */
 #define CRHIP_VARIANT_DEFAULT 0xFFFFu

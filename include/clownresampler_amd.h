@@ -155,6 +155,9 @@ void ClownResamplerAMD_DebugForceGenericKernel(int on);
 /* Tuning hook: selects the variant (geometry / arithmetic form) of the specialised kernels for plans created afterwards;
    the environment variable CLOWNRESAMPLER_AMD_VARIANT does the same at first use.  All variants give identical results. */
 void ClownResamplerAMD_DebugSetVariant(int variant);
+/* Diagnostic: device memory (32 bytes per workgroup) that the clock-stamp instance (variant 1006) fills with
+   {shader cycles, start tick, end tick, XCC id} per workgroup (ticks of 10 ns). */
+void ClownResamplerAMD_DebugSetStampBuffer(void *device_buffer);
 
 /* device_input: interleaved int16, pointing at the start of the left padding, as for the reference call;
    at least *total_input_frames + 2 * integer_stretched_kernel_radius frames must be readable.

@@ -45,6 +45,10 @@ def main():
         plans[v] = api.PlanCreate(st0, pre)
         infos[v] = api.PlanGetInfo(plans[v])
 
+    stamp = torch.zeros(4 * 4096, dtype=torch.int64, device=dev)
+    api.lib.ClownResamplerAMD_DebugSetStampBuffer.argtypes = [__import__('ctypes').c_void_p]
+    api.lib.ClownResamplerAMD_DebugSetStampBuffer(stamp.data_ptr())
+
     def run(v, i):
         pcm, out = sets[i % len(sets)]
         st = cr.LowLevel_State.from_buffer_copy(st0)
@@ -81,7 +85,22 @@ def main():
         med, mn = t[len(t) // 2], t[0]
         i = infos[v]
         if v >= 1000:
-            print("ablation %d (timing only, results wrong by design): %7.1f us median %7.1f min" % (v - 1000, med, mn))
+            extra = ""
+            if v == 1006:
+                import numpy as _np
+                st = stamp.cpu().numpy().reshape(-1, 4)
+                st = st[st[:, 2] != 0]
+                t0 = st[:, 1].min()
+                life = (st[:, 2] - st[:, 1]) / 100.0
+                endt = (st[:, 2] - t0) / 100.0
+                clk = st[:, 0] / _np.maximum(st[:, 2] - st[:, 1], 1) / 10.0
+                extra = "\n   %d workgroups: clock %.2f-%.2f GHz; start spread %.1f us; lifetime us min/median/max %.1f/%.1f/%.1f; end time us min/median/max %.1f/%.1f/%.1f" % (
+                    len(st), clk.min(), clk.max(), (st[:, 1].max() - t0) / 100.0, life.min(), _np.median(life), life.max(), endt.min(), _np.median(endt), endt.max())
+                for x in range(8):
+                    m = st[:, 3] == x
+                    if m.any():
+                        extra += "\n   XCC %d: %3d workgroups, end time median %.1f max %.1f us" % (x, m.sum(), _np.median(endt[m]), endt[m].max())
+            print("ablation %d (timing only%s): %7.1f us median %7.1f min%s" % (v - 1000, "" if v == 1006 else ", results wrong by design", med, mn, extra))
             continue
         print("%3d  %-10s %d  %d  %d  %5d %6d %4d | %7.1f %7.1f | %7.0f  %.3f %s" % (v, geos[v % 5], 1, 1 << ((v // 5) % 2), (v // 10) % 2,
               i.tile_frames, i.lds_bytes, i.max_blocks, med, mn, nbytes / med / 1e3, nbytes / med / 1e3 / 8000, "MISMATCH" if v in bad else ""))

@@ -76,7 +76,7 @@ class Shard(C.Structure):  # ClownResamplerAMD_Shard
 
 class PlanInfo(C.Structure):  # ClownResamplerAMD_PlanInfo
     _fields_ = [(n, C.c_uint32) for n in ("kernel", "channels", "slots", "first_slot", "rows", "row_stride", "row_mode", "threads",
-                                          "tile_frames", "lds_bytes", "max_blocks", "specialised")]
+                                          "tile_frames", "lds_bytes", "max_blocks", "specialised", "variant")]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

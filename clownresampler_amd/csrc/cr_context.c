@@ -321,6 +321,34 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 
 	plan->specialised = (uint32_t)crhip_poly_has_instance(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
 	crhip_poly_geometry(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
+	if (plan->vecs >= 100u)
+	{
+		/* k_wave: every wave streams wave-tiles of 64 * 4 frames through a private, double-buffered (vecs - 100) KiB
+		   slice of LDS; work is handed out in chunks of 4 wave-tiles (frames_multiple) */
+		const uint32_t piece_bytes = (plan->vecs - 100u) * 1024u;
+		const uint32_t wave_tile = frames_multiple / 4u;
+		const uint64_t last_rel = (65535u + (uint64_t)(wave_tile - 1u) * plan->increment) >> 16;
+		const uint64_t window = 12u + (last_rel + plan->poly.slots) * frame_bytes;
+
+		if (window <= piece_bytes && (uint64_t)wave_tile * plan->increment < (1ull << 32) - 65536u)
+		{
+			plan->lds_bytes = rows_bytes + (plan->threads / 64u) * 2u * piece_bytes + 16u; /* + the retired-waves counter */
+			plan->tile_frames = frames_multiple;
+			per_cu = (160u * 1024u) / plan->lds_bytes;
+			if (per_cu > 2048u / plan->threads)
+				per_cu = 2048u / plan->threads;
+			if (per_cu >= 1u && plan->lds_bytes <= (uint32_t)g_info.max_lds_per_block)
+			{
+				plan->max_blocks = per_cu * (uint32_t)(g_info.compute_units > 0 ? g_info.compute_units : 256);
+				return;
+			}
+		}
+
+		/* the window of this configuration does not fit a wave's slice: use a k_poly variant instead */
+		plan->variant = crhip_poly_fallback_variant();
+		crhip_poly_geometry(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
+	}
+
 	tile_bytes = plan->vecs * 16u * plan->threads;
 	plan->lds_bytes = rows_bytes + 2u * tile_bytes + 16u; /* + the ticket mailbox */
 
@@ -581,9 +609,18 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 
 		/* tiles are dealt round-robin to a persistent grid (see k_poly) */
 		blocks = (n_out + plan->tile_frames - 1) / plan->tile_frames;
+		if (plan->vecs >= 100u)
+			blocks = (blocks + plan->threads / 64u - 1) / (plan->threads / 64u); /* k_wave hands chunks to WAVES */
 		if (blocks > plan->max_blocks)
 			blocks = plan->max_blocks;
 		l.blocks = (uint32_t)blocks;
+		{
+			/* tickets pay off where workgroups drift apart over many medium-sized tiles; measured on MI355X (profiles/):
+			   stereo 3-lobe upsampling gains ~4 %, 8-channel and 8-lobe instances lose 1-8 %: a per-instance default */
+			const char *e = getenv("CLOWNRESAMPLER_AMD_DYNAMIC_TILES");
+			l.dynamic_tiles = e != NULL ? (uint32_t)(atoi(e) != 0)
+			                            : (uint32_t)crhip_poly_dynamic_default(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
+		}
 		l.d_tickets = g_tickets + CRHIP_TICKET_WORDS * (__atomic_fetch_add(&g_ticket_serial, 1u, __ATOMIC_RELAXED) % CR_TICKET_SLOTS);
 
 		return cr_check_hip(crhip_launch_poly(&l, stream), "k_poly launch");
@@ -757,7 +794,8 @@ int cr_run_single_frame(const ClownResamplerAMD_Plan *plan, const int16_t *host_
 void ClownResamplerAMD_PlanGetInfo(const ClownResamplerAMD_Plan *plan, ClownResamplerAMD_PlanInfo *info)
 {
 	memset(info, 0, sizeof(*info));
-	info->kernel = plan->use_poly ? 1u : 0u;
+	info->kernel = plan->use_poly ? (plan->vecs >= 100u ? 2u : 1u) : 0u;
+	info->variant = plan->variant;
 	info->channels = plan->channels;
 	info->slots = plan->poly.slots;
 	info->first_slot = plan->poly.first_slot;

@@ -683,11 +683,14 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 	uint64_t jt = tile_index * NT64;
 	unsigned n = (unsigned)((a.n_out - jt < NT64) ? (a.n_out - jt) : NT64);
 	unsigned shift = fetch(jt, n, tiles);
-	if (tid == 0)
+	// a.dynamic_tiles == 0: plain round-robin (tile + gridDim.x), no tickets - for configurations whose tiles are so
+	// small that a ticket and a mailbox hand-over per tile cost more than the imbalance they remove (8-channel frames)
+	const bool dynamic = a.dynamic_tiles != 0;
+	if (dynamic && tid == 0)
 		mailbox[0] = draw();
 	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 	__syncthreads();   // rows staged (plain stores to LDS), first tile landed and first ticket posted, for every wave
-	uint64_t next_index = __builtin_amdgcn_readfirstlane(mailbox[0]);   // wave-uniform: keeps the tile bookkeeping on the scalar unit
+	uint64_t next_index = dynamic ? __builtin_amdgcn_readfirstlane(mailbox[0]) : tile_index + gridDim.x;   // wave-uniform
 
 	for (unsigned it = 0;; ++it)
 	{
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 			// the other buffer was last read in the previous iteration, which every wave has left (barrier below)
 			n_next = (unsigned)((a.n_out - jn < NT64) ? (a.n_out - jn) : NT64);
 			shift_next = fetch(jn, n_next, tiles + ((it + 1u) & 1u) * TILE_BYTES);
-			if (tid == 0)
+			if (dynamic && tid == 0)
 				ticket = draw();   // for the tile after the next one; posted below, just before the barrier
 		}
 
@@ -838,13 +841,14 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 					a.debug_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(63508 /* HW_REG_XCC_ID, bits 0..3 */) & 0xF;
 				}
 			}
-			retire();
+			if (dynamic)
+				retire();
 			break;
 		}
 
 		// every wave's share of the next tile has landed once every wave is past its wait; the mailbox has two slots,
 		// used alternately, so that a slot is never rewritten before every wave has read it
-		if (tid == 0)
+		if (dynamic && tid == 0)
 			mailbox[(it + 1u) & 1u] = ticket;
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		__builtin_amdgcn_s_barrier();
@@ -852,8 +856,270 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 		jt = jn;
 		n = n_next;
 		shift = shift_next;
-		next_index = __builtin_amdgcn_readfirstlane(mailbox[(it + 1u) & 1u]);
+		next_index = dynamic ? __builtin_amdgcn_readfirstlane(mailbox[(it + 1u) & 1u]) : tile_index + gridDim.x;
 	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_wave - the same arithmetic with WAVE-AUTONOMOUS streaming: no workgroup barrier after the rows are staged
+// ---------------------------------------------------------------------------------------------------------
+// k_poly pays about a microsecond per tile in its barrier (every wave waits for the slowest, then all start their LDS
+// reads at once): ~12 us of a 64 us launch.  Here every wave owns a private, double-buffered 1 KiB (x NVW) slice of LDS,
+// fills it with its own LDS-DMA and only ever waits for itself (s_waitcnt vmcnt): the rows are the one thing the waves
+// of a workgroup share, read-only.  Work is handed out per WAVE in chunks of 4 wave-tiles (4 x 64 x ITER output
+// frames): the first chunk by global wave number, the rest by atomic tickets over 32 counter lanes (see k_poly), drawn
+// one chunk ahead.
+//   WAVES  waves per workgroup          NVW  1 KiB DMA pieces per wave-tile          ITER  frames per lane per wave-tile
+template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, int OUT16, int NT, int ABL = 0>
+__global__ __launch_bounds__(WAVES * 64) void k_wave(const crhip_poly_launch a)
+{
+	static_assert(TT > 0, "k_wave exists for specialised slot counts only");
+	constexpr unsigned FB = CH * 2;
+	constexpr unsigned NTHREADS = WAVES * 64;
+	constexpr unsigned WT = 64u * ITER;            // frames per wave-tile
+	constexpr unsigned CW = 4;                     // wave-tiles per chunk (ticket)
+	constexpr unsigned CHUNK = WT * CW;
+	constexpr unsigned BUF = NVW * 1024u;          // bytes per wave-tile buffer
+	constexpr int STORES_PER_FRAME = OUT16 ? (CH % 2 == 0 ? stores_of_ints(CH / 2) : CH) : stores_of_ints(CH);
+
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+	const unsigned tid = threadIdx.x;
+	const unsigned lane = tid & 63u;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	unsigned long long stamp_cycles = 0, stamp_ticks = 0;
+	if constexpr (ABL == 6)
+	{
+		stamp_cycles = __builtin_amdgcn_s_memtime();
+		stamp_ticks = __builtin_amdgcn_s_memrealtime();
+	}
+
+	const unsigned rows_bytes = a.plane_rows * a.row_stride * 4u;
+	const int *rows = reinterpret_cast<const int *>(smem);
+	unsigned char *my_buf = smem + rows_bytes + wave * (2u * BUF);
+
+	unsigned *waves_done = reinterpret_cast<unsigned *>(smem + rows_bytes + WAVES * (2u * BUF));
+	if (tid == 0)
+		*waves_done = 0;
+
+	// stage the polyphase rows once per workgroup: the only barrier of the kernel
+	{
+		const unsigned nvec = rows_bytes / 16u;
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.d_rows);
+		u32x4 *dst = reinterpret_cast<u32x4 *>(smem);
+		for (unsigned i = tid; i < nvec; i += NTHREADS)
+			dst[i] = src[i];
+	}
+	__syncthreads();
+
+	const uint64_t n_chunks = (a.n_out + CHUNK - 1) / CHUNK;
+	const uint64_t global_wave = (uint64_t)blockIdx.x * WAVES + wave;
+	const uint64_t global_waves = (uint64_t)gridDim.x * WAVES;
+
+	// tickets: as in k_poly, per wave, 32 counter lanes
+	const unsigned LANES = global_waves < 32u ? (unsigned)global_waves : 32u;
+	const unsigned lane_id = (unsigned)(global_wave % LANES);
+	const uint64_t lane_chunks = n_chunks > lane_id ? (n_chunks - lane_id + LANES - 1u) / LANES : 0;
+	const unsigned lane_waves = (unsigned)((global_waves - lane_id + LANES - 1u) / LANES);
+	unsigned *lane_counter = a.d_tickets + lane_id * 32u;
+	// the draw is split: the atomic is issued at the start of a chunk, its result is first looked at when the last
+	// wave-tile of the chunk needs it - by then the per-wave-tile vmcnt waits have long covered it
+	auto draw_issue = [&]() -> unsigned {
+		unsigned got = 0;
+		if (lane == 0)
+			got = __hip_atomic_fetch_add(lane_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return got;
+	};
+	auto draw_resolve = [&](unsigned got) -> uint64_t {
+		const uint64_t k = (uint64_t)lane_waves + __builtin_amdgcn_readfirstlane(got);
+		return k < lane_chunks ? lane_id + (uint64_t)LANES * k : ~0ull;
+	};
+	// a wave that has run out of tickets retires; the waves of a workgroup count down in LDS and only the last of them
+	// touches the global finished counter (8,192 waves on one word would serialise for ~100 us: one word takes ~88
+	// atomics per microsecond), and the last workgroup zeroes the ticket block for the next launch
+	auto retire = [&]() {
+		if (lane == 0 && __hip_atomic_fetch_add(waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == WAVES - 1u)
+		{
+			unsigned *finished = a.d_tickets + 32u * 32u;
+			if (__hip_atomic_fetch_add(finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u)
+			{
+				for (unsigned c = 0; c < 32u; ++c)
+					__hip_atomic_store(a.d_tickets + c * 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+		if constexpr (ABL == 6)
+		{
+			if (lane == 0 && wave == 0 && a.debug_stamps != nullptr)
+			{
+				a.debug_stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - stamp_cycles;
+				a.debug_stamps[4 * blockIdx.x + 1] = stamp_ticks;
+				a.debug_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+				a.debug_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(63508) & 0xF;
+			}
+		}
+	};
+
+	const uint64_t in_base = reinterpret_cast<uint64_t>(a.d_in);
+	const uint64_t in_end = in_base + a.in_valid_bytes;
+
+	// LDS-DMA of the input window of the wave-tile of `n` frames starting at output frame `first` into `buf`; returns the
+	// byte offset of the window's first frame inside the buffer.  Not waited for.
+	auto fetch = [&](uint64_t first, unsigned n, unsigned char *buf) -> unsigned {
+		const uint64_t pos = a.pos0 + first * (uint64_t)a.increment;
+		const uint64_t first_byte = in_base + ((pos >> 16) + a.first_slot) * FB;
+		const uint64_t aligned = first_byte & ~(uint64_t)15;
+		const unsigned shift = (unsigned)(first_byte - aligned);
+		const unsigned last_rel = (unsigned)(((pos & 0xFFFFu) + (uint64_t)(n - 1) * a.increment) >> 16);
+		uint64_t want = (uint64_t)shift + (uint64_t)(last_rel + TT) * FB;
+		uint64_t avail = in_end > aligned ? in_end - aligned : 0;
+		if (want > avail)
+			want = avail;
+		want = (want + 3u) & ~(uint64_t)3u;   // whole dwords: see k_poly
+		const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)aligned);
+		const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(aligned >> 32));
+		const unsigned rec = __builtin_amdgcn_readfirstlane((unsigned)want);
+		const __amdgpu_buffer_rsrc_t rsrc =
+		    __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)rec, 0x00020000);
+#pragma unroll
+		for (int v = 0; v < NVW; ++v)
+			__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + v * 1024u), 16,
+			                                         (int)(v * 1024u + lane * 16u), 0, 0, 0);
+		return shift;
+	};
+
+	// one full wave-tile (WT frames, ITER per lane) from `buf`, software-pipelined; leaves its stores in flight
+	auto wave_tile = [&](uint64_t first, const unsigned char *base) {
+		const uint64_t pos = a.pos0 + first * (uint64_t)a.increment;
+		const unsigned lane_rel = __umul24(lane, a.increment) + (unsigned)(pos & 0xFFFFu);
+		int *out32 = reinterpret_cast<int *>(a.d_out) + first * CH;
+		short *out16 = reinterpret_cast<short *>(a.d_out) + first * CH;
+
+		FrameData<CH, TT> d[2];
+		fetch_frame<CH, TT, MODE, 0>(a, rows, base, lane_rel, d[0]);
+#pragma unroll
+		for (int i = 0; i < ITER; ++i)
+		{
+			int outv[CH];
+			if (i + 1 < ITER)
+				fetch_frame<CH, TT, MODE, 0>(a, rows, base, lane_rel + (unsigned)(i + 1) * 64u * a.increment, d[(i + 1) & 1]);
+			__builtin_amdgcn_sched_barrier(0);
+			compute_frame<CH, TT, NORM, 1>(d[i & 1], outv);
+			if constexpr (OUT16)
+				store_shorts<CH, NT>(out16 + (size_t)(i * 64u) * CH + lane * CH, outv);
+			else
+				store_ints<CH, NT>(out32 + (size_t)(i * 64u) * CH + lane * CH, outv);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	};
+
+	if (global_wave >= n_chunks)
+	{
+		retire();
+		return;
+	}
+
+	uint64_t chunk = global_wave;
+	unsigned parity = 0;
+	// first wave-tile of the first chunk
+	{
+		const uint64_t first = chunk * CHUNK;
+		const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
+		const unsigned shift0 = fetch(first, n, my_buf);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		// `shift` of the buffered wave-tile travels in a scalar
+		parity = shift0 << 1;   // bit 0: buffer index, bits 1..: shift
+	}
+
+	for (;;)
+	{
+		const unsigned ticket = draw_issue();          // one chunk ahead; resolved at the end of this chunk
+		uint64_t next_chunk = ~0ull;
+		const uint64_t chunk_first = chunk * CHUNK;
+		const bool full = chunk_first + CHUNK <= a.n_out;
+
+		if (full)
+		{
+#pragma unroll
+			for (unsigned j = 0; j < CW; ++j)
+			{
+				const uint64_t first = chunk_first + j * WT;
+				const unsigned cur = parity & 1u;
+				const unsigned shift = parity >> 1;
+				unsigned shift_next = 0;
+				bool have_next = true;
+
+				// start the DMA of the wave-tile after this one (the other buffer was consumed one step ago)
+				if (j + 1 == CW)
+					next_chunk = draw_resolve(ticket);
+
+				if (j + 1 < CW)
+					shift_next = fetch(first + WT, WT, my_buf + (cur ^ 1u) * BUF);
+				else if (next_chunk != ~0ull)
+				{
+					const uint64_t nf = next_chunk * CHUNK;
+					const unsigned n = (unsigned)((a.n_out - nf < WT) ? (a.n_out - nf) : WT);
+					shift_next = fetch(nf, n, my_buf + (cur ^ 1u) * BUF);
+				}
+				else
+					have_next = false;
+
+				wave_tile(first, my_buf + cur * BUF + shift);
+
+				// own DMA landed once only this wave-tile's stores are outstanding (vmcnt is in order); no barrier:
+				// nobody else reads this wave's buffers
+				if constexpr (ITER * STORES_PER_FRAME <= 63)
+					asm volatile("s_waitcnt vmcnt(%0)" ::"i"(ITER * STORES_PER_FRAME) : "memory");
+				else
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				(void)have_next;
+				parity = (shift_next << 1) | (cur ^ 1u);
+			}
+		}
+		else
+		{
+			// the stream's ragged last chunk: frame by frame with bounds checks, wave-tile by wave-tile
+			for (uint64_t first = chunk_first; first < a.n_out; first += WT)
+			{
+				const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
+				const unsigned cur = parity & 1u;
+				const unsigned shift = parity >> 1;
+				const uint64_t pos = a.pos0 + first * (uint64_t)a.increment;
+				const unsigned frac0 = (unsigned)(pos & 0xFFFFu);
+				const unsigned char *base = my_buf + cur * BUF + shift;
+
+				for (unsigned jl = lane; jl < n; jl += 64u)
+				{
+					int outv[CH];
+					one_frame<CH, TT, MODE, NORM, 1, 0>(a, rows, base, __umul24(jl, a.increment) + frac0, outv);
+					if constexpr (OUT16)
+						store_shorts<CH, NT>(reinterpret_cast<short *>(a.d_out) + (first + jl) * CH, outv);
+					else
+						store_ints<CH, NT>(reinterpret_cast<int *>(a.d_out) + (first + jl) * CH, outv);
+				}
+
+				if (first + WT < a.n_out)
+				{
+					const uint64_t nf = first + WT;
+					const unsigned nn = (unsigned)((a.n_out - nf < WT) ? (a.n_out - nf) : WT);
+					const unsigned shift_next = fetch(nf, nn, my_buf + (cur ^ 1u) * BUF);
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					parity = (shift_next << 1) | (cur ^ 1u);
+				}
+			}
+		}
+
+		if (!full)
+		{
+			(void)draw_resolve(ticket);   // the last chunk of the stream is the last of its sequence: nothing follows
+			break;
+		}
+		if (next_chunk == ~0ull)
+			break;
+		chunk = next_chunk;
+	}
+
+	retire();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -960,25 +1226,38 @@ struct special
 	uint32_t default_variant;   // from tools/sweep_variants.py on MI355X (profiles/)
 	poly_fn fn[VARIANTS];
 	poly_fn fn16;               // int16-output form, default variant only
+	poly_fn wave[2];            // k_wave (variants WAVE_VARIANT + {0: non-temporal stores, 1: plain}); nullptr if none
+	poly_fn wave16;             // k_wave, int16 output
+	bool dynamic_tiles;         // k_poly: draw tiles as tickets (measured per instance; see crhip_poly_launch.dynamic_tiles)
 };
 
-template <int CH, int TT, int MODE, int NORM, int DV>
+constexpr uint32_t WAVE_VARIANT = 20;   // variant ids 20, 21 select k_wave where the instance has one
+constexpr int WAVE_WAVES = 16, WAVE_NVW = 1, WAVE_ITER = 4;
+
+template <int CH, int TT, int MODE, int NORM, int DV, bool WAVE = false, bool DYNAMIC = false>
 special make_special()
 {
-	special s = {CH, TT, MODE, NORM, DV, {}, nullptr};
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC};
 	variant_table<CH, TT, MODE, NORM, 0>::fill(s.fn);
-	s.fn16 = instance<CH, TT, MODE, NORM, DV % 5, 1, (DV / 5) % 2, (DV / 10) % 2, 1>();
+	constexpr int KV = DV < 20 ? DV : 13;   // the k_poly variant behind a k_wave default (its fallback and int16 geometry)
+	s.fn16 = instance<CH, TT, MODE, NORM, KV % 5, 1, (KV / 5) % 2, (KV / 10) % 2, 1>();
+	if constexpr (WAVE)
+	{
+		s.wave[0] = (poly_fn)k_wave<CH, TT, MODE, NORM, WAVE_WAVES, WAVE_NVW, WAVE_ITER, 0, 1>;
+		s.wave[1] = (poly_fn)k_wave<CH, TT, MODE, NORM, WAVE_WAVES, WAVE_NVW, WAVE_ITER, 0, 0>;
+		s.wave16 = (poly_fn)k_wave<CH, TT, MODE, NORM, WAVE_WAVES, WAVE_NVW, WAVE_ITER, 1, 1>;
+	}
 	return s;
 }
 
 const special *specials(int *count)
 {
 	static const special table[] = {
-	    make_special<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 18>(),   // cfg 2 / cfg 5: stereo 44.1 -> 48 kHz, 3 lobes
-	    make_special<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 19>(),  // cfg 3: stereo 8 -> 96 kHz, 8 lobes
+	    make_special<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 13, true, true>(),   // cfg 2 / cfg 5: stereo 44.1 -> 48 kHz, 3 lobes
+	    make_special<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 20, true>(),  // cfg 3: stereo 8 -> 96 kHz, 8 lobes
 	    make_special<8, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 14>(),     // cfg 4: 8 channels 48 -> 44.1 kHz
-	    make_special<1, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 18>(),   // mono upsampling, 3 lobes
-	    make_special<2, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 18>(),     // stereo mild downsampling, 3 lobes
+	    make_special<1, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 13, true, true>(),   // mono upsampling, 3 lobes
+	    make_special<2, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>(),     // stereo mild downsampling, 3 lobes
 	};
 	*count = (int)(sizeof(table) / sizeof(table[0]));
 	return table;
@@ -995,6 +1274,7 @@ poly_fn ablation_instance(int abl)
 		case 4: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 4>;
 		case 5: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 4, 0, 1>;   // as 4, non-temporal stores
 		case 6: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 6, 0, 1>;   // the real kernel (variant 13) + clock stamps
+		case 7: return (poly_fn)k_wave<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, WAVE_WAVES, WAVE_NVW, WAVE_ITER, 0, 1, 6>;   // k_wave + stamps
 		default: return nullptr;
 	}
 }
@@ -1150,13 +1430,17 @@ static uint32_t resolve_variant(const special *sp, uint32_t variant, uint32_t ou
 {
 	if (sp == nullptr)
 		return 0u;
-	if (out_s16)
-		return sp->default_variant;   // the int16 form exists for the default variant only
-	if (variant < (uint32_t)VARIANTS)
-		return variant;
+	if (variant == 1007u && sp->wave[0] != nullptr)
+		return WAVE_VARIANT;                                  // diagnostic k_wave instance: k_wave geometry
 	if (variant >= 1000u && variant < 1010u)
-		return 3u;
-	return sp->default_variant;
+		return 3u;                                            // diagnostic k_poly instances: headline geometry
+	if (variant >= (uint32_t)VARIANTS + 2u)
+		variant = sp->default_variant;
+	if (variant >= WAVE_VARIANT && sp->wave[0] == nullptr)
+		variant = 13u;
+	if (out_s16 && variant < WAVE_VARIANT)
+		return sp->default_variant < WAVE_VARIANT ? sp->default_variant : 13u;   // the k_poly int16 form exists for one variant
+	return variant;
 }
 
 int crhip_poly_swizzled(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t variant)
@@ -1169,7 +1453,18 @@ int crhip_poly_swizzled(uint32_t channels, uint32_t slots, uint32_t row_mode, ui
 
 int crhip_poly_variants(void)
 {
-	return VARIANTS;
+	return VARIANTS + 2;   // + the two k_wave variants
+}
+
+int crhip_poly_dynamic_default(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
+{
+	const special *sp = find_special(channels, slots, row_mode, norm_mode);
+	return sp != nullptr && sp->dynamic_tiles ? 1 : 0;
+}
+
+uint32_t crhip_poly_fallback_variant(void)
+{
+	return 13u;   // a k_poly variant every specialised instance has
 }
 
 void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t variant,
@@ -1178,16 +1473,35 @@ void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, u
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
 	const uint32_t v = sp != nullptr ? resolve_variant(sp, variant) : (uint32_t)runtime_geo((int)channels);
 
+	if (sp != nullptr && v >= WAVE_VARIANT)
+	{
+		// k_wave: vecs = 100 + (1 KiB DMA pieces per wave-tile); frames_multiple = frames per ticket
+		*threads = WAVE_WAVES * 64u;
+		*vecs = 100u + WAVE_NVW;
+		*frames_multiple = 64u * WAVE_ITER * 4u;
+		return;
+	}
+
 	*threads = (uint32_t)GEOMETRY[v % 5].threads;
 	*vecs = (uint32_t)GEOMETRY[v % 5].vecs;
 	*frames_multiple = *threads * (1u << ((v / 5) % 2));
 }
 
+// geo: index into GEOMETRY, or 100 for k_wave
 static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 {
 	const special *sp = launch->specialised ? find_special(launch->channels, launch->slots, launch->row_mode, launch->norm_mode) : nullptr;
 	const uint32_t v = resolve_variant(sp, launch->variant, launch->out_s16);
 	poly_fn fn;
+
+	if (sp != nullptr && v >= WAVE_VARIANT)
+	{
+		fn = launch->out_s16 ? sp->wave16 : sp->wave[v - WAVE_VARIANT];
+		if (launch->variant == 1007u)
+			fn = ablation_instance(7);
+		*geo = 100u;
+		return fn;
+	}
 
 	if (launch->out_s16)
 		fn = sp != nullptr ? sp->fn16 : pick_runtime_channels<1>(launch->channels, launch->row_mode, launch->norm_mode);
@@ -1219,7 +1533,10 @@ int crhip_launch_poly(const crhip_poly_launch *launch, void *stream)
 	uint32_t geo;
 	const poly_fn fn = select_poly(launch, &geo);
 
-	if (fn == nullptr || launch->threads != (uint32_t)GEOMETRY[geo].threads || launch->vecs != (uint32_t)GEOMETRY[geo].vecs)
+	if (fn == nullptr)
+		return (int)hipErrorInvalidValue;
+	if (geo == 100u ? (launch->threads != WAVE_WAVES * 64u || launch->vecs != 100u + WAVE_NVW)
+	                : (launch->threads != (uint32_t)GEOMETRY[geo].threads || launch->vecs != (uint32_t)GEOMETRY[geo].vecs))
 		return (int)hipErrorInvalidValue;
 	if (launch->n_out == 0)
 		return 0;

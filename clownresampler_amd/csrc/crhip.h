@@ -48,7 +48,7 @@ typedef struct crhip_poly_launch
 	uint32_t step;              /* kernel_step_size */
 	int32_t aff_a, aff_b, aff_c;
 	uint32_t threads;           /* workgroup size the instance was compiled for */
-	uint32_t vecs;              /* 16-byte input vectors per thread per tile (template NV) */
+	uint32_t vecs;              /* k_poly: 16-byte input vectors per thread per tile (template NV); k_wave: 100 + NVW */
 	uint32_t tile_frames;       /* output frames per tile */
 	uint32_t lds_bytes;         /* polyphase rows + two tiles + 16 bytes of mailbox */
 	uint32_t blocks;            /* grid size */
@@ -58,6 +58,7 @@ typedef struct crhip_poly_launch
 	                               finished-workgroup counter, each on its own 128-byte line; the kernel leaves them
 	                               zeroed.  Launches that may overlap in time need different blocks */
 	unsigned long long *debug_stamps; /* diagnostic instances only: receives {shader cycles, 100 MHz ticks} of workgroup 0 */
+	uint32_t dynamic_tiles;     /* k_poly: 1 = tiles beyond the first gridDim.x are drawn as tickets, 0 = plain round-robin */
 	uint32_t out_s16;           /* 1: d_out is int16, samples clamped to +-0x7FFF (extension); 0: int32 unclamped (reference) */
 } crhip_poly_launch;
 
@@ -109,7 +110,7 @@ int crhip_stream_create(void **stream);
 int crhip_stream_destroy(void *stream);
 int crhip_stream_sync(void *stream);
 
-#define CRHIP_TICKET_WORDS (9u * 32u)
+#define CRHIP_TICKET_WORDS (33u * 32u)   /* up to 32 ticket counters + the finished counter, 128 bytes apart */
 
 /* variant value meaning: the instance's measured default */
 #define CRHIP_VARIANT_DEFAULT 0xFFFFu
@@ -123,6 +124,10 @@ int crhip_launch_generic(const crhip_generic_launch *launch, void *stream);
 int crhip_poly_has_instance(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
 /* 1 when the instance a launch with these parameters selects applies the row swizzle. */
 int crhip_poly_swizzled(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t variant);
+/* measured default of crhip_poly_launch.dynamic_tiles for the instance a launch with these parameters selects */
+int crhip_poly_dynamic_default(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
+/* a k_poly variant to fall back on when the k_wave geometry does not fit a configuration */
+uint32_t crhip_poly_fallback_variant(void);
 /* Number of tuning variants of the specialised instances (crhip_poly_launch.variant). */
 int crhip_poly_variants(void);
 /* Geometry the instance that a launch with these parameters selects is compiled for: workgroup size, 16-byte input

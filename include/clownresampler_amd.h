@@ -125,7 +125,7 @@ typedef struct ClownResamplerAMD_Plan ClownResamplerAMD_Plan;
 
 typedef struct ClownResamplerAMD_PlanInfo
 {
-	uint32_t kernel;            /* 1 = polyphase rows staged in LDS (fast path), 0 = generic 64-bit kernel */
+	uint32_t kernel;            /* 1 = k_poly (polyphase rows in LDS, workgroup tiles), 2 = k_wave (same, wave-autonomous), 0 = generic 64-bit kernel */
 	uint32_t channels;
 	uint32_t slots;             /* taps evaluated per output frame (zero-weight slots included) */
 	uint32_t first_slot;        /* frame offset of slot 0 relative to position_integer, in padded-buffer frames */
@@ -137,6 +137,7 @@ typedef struct ClownResamplerAMD_PlanInfo
 	uint32_t lds_bytes;         /* dynamic LDS per workgroup */
 	uint32_t max_blocks;        /* persistent grid size used for large launches */
 	uint32_t specialised;       /* 1 when a (channels, slots) template instance is used */
+	uint32_t variant;           /* tuning variant the plan was built for (0xFFFF: the instance's measured default) */
 } ClownResamplerAMD_PlanInfo;
 
 /* Builds (or fetches from the cache) the device-side plan for the configuration, channel count and increment

@@ -38,7 +38,7 @@ def main():
         sets.append((pcm, torch.empty(n_out * ch, dtype=torch.int32, device=dev)))
     stream = torch.cuda.current_stream(dev)
     nvar = api.lib.crhip_poly_variants() if hasattr(api.lib, "crhip_poly_variants") else 48
-    variants = [int(v) for v in args.variants.split(",")] if args.variants else list(range(20))
+    variants = [int(v) for v in args.variants.split(",")] if args.variants else list(range(22))
     plans, infos = {}, {}
     for v in variants:
         api.DebugSetVariant(v)
@@ -86,7 +86,7 @@ def main():
         i = infos[v]
         if v >= 1000:
             extra = ""
-            if v == 1006:
+            if v in (1006, 1007):
                 import numpy as _np
                 st = stamp.cpu().numpy().reshape(-1, 4)
                 st = st[st[:, 2] != 0]
@@ -100,7 +100,10 @@ def main():
                     m = st[:, 3] == x
                     if m.any():
                         extra += "\n   XCC %d: %3d workgroups, end time median %.1f max %.1f us" % (x, m.sum(), _np.median(endt[m]), endt[m].max())
-            print("ablation %d (timing only%s): %7.1f us median %7.1f min%s" % (v - 1000, "" if v == 1006 else ", results wrong by design", med, mn, extra))
+            print("ablation %d (timing only%s): %7.1f us median %7.1f min%s" % (v - 1000, "" if v in (1006, 1007) else ", results wrong by design", med, mn, extra))
+            continue
+        if v in (20, 21):
+            print("%3d  k_wave     nt=%d          %5d %6d %4d | %7.1f %7.1f | %7.0f  %.3f %s" % (v, 21 - v, i.tile_frames, i.lds_bytes, i.max_blocks, med, mn, nbytes / med / 1e3, nbytes / med / 1e3 / 8000, "MISMATCH" if v in bad else ""))
             continue
         print("%3d  %-10s %d  %d  %d  %5d %6d %4d | %7.1f %7.1f | %7.0f  %.3f %s" % (v, geos[v % 5], 1, 1 << ((v // 5) % 2), (v // 10) % 2,
               i.tile_frames, i.lds_bytes, i.max_blocks, med, mn, nbytes / med / 1e3, nbytes / med / 1e3 / 8000, "MISMATCH" if v in bad else ""))

@@ -5,22 +5,27 @@
 // ClownResampler_LowLevel_Resample (clownresampler.h:1058-1092) would walk to.  Output frames are independent:
 // frame j sits at the 16.16 position pos0 + j * increment (closed form of clownresampler.h:1076-1078).
 //
-// Two kernels:
+// Three kernels:
 //
 //  k_poly     The fast path.  The host (cr_plan.c) re-indexes the caller's Lanczos table into POLYPHASE ROWS:
 //             every fractional position maps to one row holding the `slots` weights that position uses
 //             (zero-padded to a common window) followed by the exact 17.15 reciprocal of their sum
 //             (clownresampler.h:1025), so the device does neither the strided table walk nor the integer divide.
-//             A persistent workgroup stages the rows in LDS once, then streams its contiguous block of output
-//             frames tile by tile: the input PCM window of the NEXT tile is fetched by LDS-DMA (16-byte
-//             `buffer_load ... lds`, bounds-checked by the buffer descriptor) into the other half of a double-buffered
-//             LDS tile while the current tile is being computed, and each
-//             lane produces whole output frames from LDS (weights: ds_read_b128 of its row; samples: one LDS read
-//             per tap covering all channels of the frame).  Per tap and channel the arithmetic is
-//             v_mul_i32_i24 + truncate-toward-zero /65536 + add, in that order: the reference truncates every
-//             product BEFORE accumulating (clownresampler.h:1020), which is what rules out dot-product
-//             instructions and MFMA.  All of it is 32-bit: the host only selects this kernel when it has proved
-//             the bounds (|weight| < 2^23, |acc| < 2^23, |acc * reciprocal| < 2^31).
+//             A persistent workgroup stages the rows in LDS once, then takes tiles of output frames in stream order
+//             (the first by its own number, the rest as atomic tickets - or plain round-robin where that measured
+//             better): the input PCM window of the NEXT tile is fetched by LDS-DMA (16-byte `buffer_load ... lds`,
+//             bounds-checked by a per-tile buffer descriptor) into the other half of a double-buffered LDS tile while
+//             the current tile is computed; each lane produces whole output frames from LDS (weights: ds_read_b128
+//             of its row; samples: one LDS read per tap covering all channels of the frame; the reads of frame i+1
+//             are issued before the arithmetic of frame i) and stores them non-temporally.  Per tap and channel the
+//             arithmetic is v_mul_i32_i24 + truncate-toward-zero /65536 + add, in that order: the reference
+//             truncates every product BEFORE accumulating (clownresampler.h:1020), which is what rules out
+//             dot-product instructions and MFMA.  All of it is 32-bit: the host only selects this kernel when it has
+//             proved the bounds (|weight| < 2^23, |acc| < 2^23, |acc * reciprocal| < 2^31 or 2^32).
+//
+//  k_wave     The same rows and arithmetic without any workgroup barrier after the staging: every wave streams
+//             wave-tiles of 256 frames through its own double-buffered 1 KiB of LDS and draws its own tickets.
+//             Faster than k_poly where the arithmetic dominates (8-lobe stereo), slower where memory does.
 //
 //  k_generic  The reference arithmetic restated with 64-bit integers, one lane per output frame, weights read
 //             from the original table in global memory.  It takes every configuration the reference accepts and
@@ -84,20 +89,6 @@ __device__ __forceinline__ int normalise(int acc, int reciprocal)
 // 4 VALU per tap and channel instead of the 6-7 the compiler emits for the C expression (it unpacks the words
 // separately and redoes the multiply as a mad).
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int sdwa_mul_word0(int frame, int weight)
-{
-	int x;
-	asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(x) : "v"(frame), "v"(weight));
-	return x;
-}
-
-__device__ __forceinline__ int sdwa_mul_word1(int frame, int weight)
-{
-	int x;
-	asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(x) : "v"(frame), "v"(weight));
-	return x;
-}
-
 __device__ __forceinline__ int sdwa_add_word1_unsigned(int x, int t)
 {
 	int r;

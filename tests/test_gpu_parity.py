@@ -351,3 +351,43 @@ def test_kernel_variants_bit_exact(golden, products, name, variant):
     finally:
         p.api.DebugSetVariant(0xFFFF)
     assert res == golden["cases"][name]
+
+
+def test_random_configurations_bit_exact(products):
+    """300 random (radius, channels, rates, low-pass, length) draws, incl. carried state across two calls and capacity stops:
+    whatever kernel the plan picks (specialised, run-time-slot, wave-autonomous, generic), the stream equals the oracle's."""
+    import random
+    rng = random.Random(20261002)
+    kernels = {0: 0, 1: 0, 2: 0}
+    done = 0
+    while done < 300:
+        radius = rng.choice([3, 3, 8])
+        ch = rng.choice([1, 2, 2, 2, 3, 4, 5, 6, 7, 8, 8, 11, 16])
+        i, o = rng.randrange(1, 200000), rng.randrange(1, 200000)
+        if rng.random() < 0.5:
+            o = max(1, int(i * rng.choice([0.03, 0.25, 0.5, 0.9, 0.999, 1.0, 1.001, 1.0884, 1.1, 2, 3, 12, 40])))
+        lp = rng.choice([min(i, o), i, o, max(1, min(i, o) // rng.randrange(1, 4)), rng.randrange(1, 200000)])
+        frames = rng.choice([rng.randrange(1, 300), rng.randrange(300, 20000), rng.randrange(20000, 120000)])
+        p, orc = products[radius], ck.oracle(radius)
+        ok_a, a = p.low_init(ch, i, o, lp)
+        ok_b, b = orc.low_init(ch, i, o, lp)
+        assert ok_a == ok_b and a.astuple() == b.astuple()
+        if not ok_a or b.cfg.table_step == 0 or b.cfg.radius_frames > 600:
+            continue
+        if ck.count_output_frames(b, frames) * ch > 6_000_000:
+            continue
+        R = int(b.cfg.radius_frames)
+        padded = ck.pad_frames(ck.noise_pcm(frames * ch, 5000 + done), ch, R)
+        split = rng.randrange(0, frames + 1)
+        cap = rng.choice([None, None, rng.randrange(0, 50)])
+        got, want = [], []
+        xa, la, ra = p.low_resample_i32(a, padded, split)
+        xb, lb, rb = orc.low_resample_i32(b, padded, split)
+        assert (la, ra) == (lb, rb) and np.array_equal(xa, xb) and a.astuple() == b.astuple(), (radius, ch, i, o, lp, frames, split)
+        xa, la, ra = p.low_resample_i32(a, padded[split * ch:], frames - split, capacity=cap)
+        xb, lb, rb = orc.low_resample_i32(b, padded[split * ch:], frames - split, capacity=cap)
+        assert (la, ra) == (lb, rb) and np.array_equal(xa, xb) and a.astuple() == b.astuple(), (radius, ch, i, o, lp, frames, split, cap)
+        ok, st = p.low_init(ch, i, o, lp)
+        kernels[p.api.PlanGetInfo(p.api.PlanCreate(st.raw, p.pre)).kernel] += 1
+        done += 1
+    assert kernels[0] > 0 and kernels[1] > 0, kernels      # both the generic and the polyphase kernels were exercised

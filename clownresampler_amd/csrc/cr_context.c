@@ -309,18 +309,29 @@ static uint32_t supported_poly_channels(uint32_t channels)
 	return channels >= 1 && channels <= 8;
 }
 
+static uint32_t plan_image_stride(const ClownResamplerAMD_Plan *plan)
+{
+	const int special = crhip_poly_has_instance(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode)
+	                    && getenv("CLOWNRESAMPLER_AMD_NO_SPECIAL") == NULL;
+	return special ? plan->poly.row_stride : 4u * ((plan->poly.slots + 3u) / 4u + 1u);
+}
+
 /* Launch geometry of k_poly for this plan on the current device. */
 static void plan_geometry(ClownResamplerAMD_Plan *plan)
 {
 	const uint32_t frame_bytes = plan->channels * 2u;
-	const uint32_t rows_bytes = cr_poly_plane_rows(&plan->poly) * plan->poly.row_stride * 4u;
+	/* int32 per row of the device image: see cr_poly_device_image */
+	const uint32_t image_stride = plan_image_stride(plan);
+	const uint32_t rows_bytes = cr_poly_plane_rows(&plan->poly) * image_stride * 4u;
 	uint32_t tile_bytes, cap_frames, per_cu;
 	uint64_t tile;
 
 	uint32_t frames_multiple = 0;
 
 	plan->specialised = (uint32_t)crhip_poly_has_instance(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
-	crhip_poly_geometry(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
+	if (getenv("CLOWNRESAMPLER_AMD_NO_SPECIAL") != NULL) /* tuning hook: time the run-time-slot instance instead */
+		plan->specialised = 0;
+	crhip_poly_geometry(plan->channels, plan->specialised ? plan->poly.slots : 0xFFFFu, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
 	if (plan->vecs >= 100u)
 	{
 		/* k_wave: every wave streams wave-tiles of 64 * 4 frames through a private, double-buffered (vecs - 100) KiB
@@ -507,8 +518,8 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 		plan->swizzle = cr_poly_pick_swizzle(&plan->poly, increment, &plan->conflict_plain, &plan->conflict_best);
 		if (!crhip_poly_swizzled(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant))
 			plan->swizzle = 0; /* the selected instance reads the plain image */
-		bytes = (size_t)plan->plane_rows * plan->poly.row_stride * sizeof(int32_t);
-		image = cr_poly_device_image(&plan->poly, plan->swizzle);
+		image = cr_poly_device_image(&plan->poly, plan->swizzle, plan->specialised ? CR_IMAGE_COMPACT : CR_IMAGE_SPLIT, &plan->device_row_stride);
+		bytes = (size_t)plan->plane_rows * plan->device_row_stride * sizeof(int32_t);
 
 		if (image == NULL)
 		{
@@ -568,7 +579,7 @@ static void fill_poly_launch(const ClownResamplerAMD_Plan *plan, crhip_poly_laun
 	l->slots = plan->poly.slots;
 	l->first_slot = plan->poly.first_slot;
 	l->rows = plan->poly.rows;
-	l->row_stride = plan->poly.row_stride;
+	l->row_stride = plan->device_row_stride;
 	l->row_mode = plan->poly.row_mode;
 	l->norm_mode = plan->poly.norm_mode;
 	l->delta = plan->poly.delta;

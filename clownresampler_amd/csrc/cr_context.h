@@ -47,6 +47,7 @@ typedef struct ClownResamplerAMD_Plan
 	int32_t *d_rows;
 	uint32_t threads, vecs, tile_frames, lds_bytes, max_blocks, specialised, variant;
 	uint32_t plane_rows, swizzle;
+	uint32_t device_row_stride; /* int32 per row of the device image (COMPACT for specialised instances, SPLIT otherwise) */
 	double conflict_plain, conflict_best; /* modelled extra LDS cycles per row read without / with the swizzle */
 } ClownResamplerAMD_Plan;
 

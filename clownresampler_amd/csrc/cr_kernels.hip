@@ -503,26 +503,25 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 	}
 	else
 	{
-		const unsigned T = a.slots;
-		const unsigned planes = a.row_stride / 4u;
-		for (unsigned q = 0; q < planes; ++q)
+		// Run-time slot count.  The device image of the rows is laid out for this loop (cr_plan.c, SPLIT layout):
+		// ceil(slots / 4) planes of weights, zero-padded, then one plane that holds only the reciprocal.  Four taps
+		// per trip - one ds_read_b128 of weights, four frame reads, four independent multiply-accumulates - and no
+		// per-slot bounds test: a padded slot has weight 0 and contributes exactly 0 whatever the LDS read returns.
+		const unsigned weight_planes = a.row_stride / 4u - 1u;
+		for (unsigned q = 0; q < weight_planes; ++q)
 		{
 			const i32x4 v = plane0[q * a.plane_rows];
-			const int w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-			for (int e = 0; e < 4; ++e)
-			{
-				const unsigned slot = 4u * q + e;
-				if (slot < T)
-				{
-					Frame<CH> f;
-					f.load(src + slot * FB);
-					f.template mac<ASM>(acc, w4[e]);
-				}
-				else if (slot == T)
-					reciprocal = w4[e];
-			}
+			Frame<CH> f0, f1, f2, f3;
+			f0.load(src + (4u * q + 0u) * FB);
+			f1.load(src + (4u * q + 1u) * FB);
+			f2.load(src + (4u * q + 2u) * FB);
+			f3.load(src + (4u * q + 3u) * FB);
+			f0.template mac<ASM>(acc, v.x);
+			f1.template mac<ASM>(acc, v.y);
+			f2.template mac<ASM>(acc, v.z);
+			f3.template mac<ASM>(acc, v.w);
 		}
+		reciprocal = reinterpret_cast<const int *>(plane0 + weight_planes * a.plane_rows)[0];
 	}
 
 #pragma unroll

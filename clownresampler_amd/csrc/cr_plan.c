@@ -476,12 +476,16 @@ uint32_t cr_poly_pick_swizzle(const cr_poly *poly, uint64_t increment, double *c
 	return best;
 }
 
-int32_t *cr_poly_device_image(const cr_poly *poly, uint32_t swizzle)
+int32_t *cr_poly_device_image(const cr_poly *poly, uint32_t swizzle, int layout, uint32_t *device_row_stride)
 {
 	const uint32_t plane_rows = cr_poly_plane_rows(poly);
-	const uint32_t planes = poly->row_stride / 4u;
-	int32_t *image = (int32_t *)calloc((size_t)plane_rows * poly->row_stride, sizeof(int32_t));
+	const uint32_t weight_planes = (poly->slots + 3u) / 4u;
+	const uint32_t stride = layout == CR_IMAGE_SPLIT ? 4u * (weight_planes + 1u) : poly->row_stride;
+	const uint32_t planes = stride / 4u;
+	int32_t *image = (int32_t *)calloc((size_t)plane_rows * stride, sizeof(int32_t));
 	uint32_t row, q, e;
+
+	*device_row_stride = stride;
 
 	if (image == NULL)
 		return NULL;
@@ -489,10 +493,23 @@ int32_t *cr_poly_device_image(const cr_poly *poly, uint32_t swizzle)
 	for (row = 0; row < poly->rows; ++row)
 	{
 		const uint32_t phys = cr_poly_phys_row(row, swizzle);
+		const int32_t *src = poly->weights + (size_t)row * poly->row_stride;
 
 		for (q = 0; q < planes; ++q)
+		{
 			for (e = 0; e < 4; ++e)
-				image[((size_t)q * plane_rows + phys) * 4u + e] = poly->weights[(size_t)row * poly->row_stride + 4u * q + e];
+			{
+				const uint32_t index = 4u * q + e;
+				int32_t value;
+
+				if (layout == CR_IMAGE_SPLIT)
+					value = q < weight_planes ? (index < poly->slots ? src[index] : 0) : (e == 0 ? src[poly->slots] : 0);
+				else
+					value = src[index];
+
+				image[((size_t)q * plane_rows + phys) * 4u + e] = value;
+			}
+		}
 	}
 
 	return image;

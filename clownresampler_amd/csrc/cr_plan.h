@@ -64,8 +64,12 @@ uint32_t cr_poly_phys_row(uint32_t row, uint32_t swizzle);
 /* Chooses the swizzle (0..15) that minimises ds_read_b128 bank conflicts for lanes that hold consecutive output frames
    `increment` apart; *conflict_cycles_plain / _best receive the modelled extra LDS cycles per wave read. */
 uint32_t cr_poly_pick_swizzle(const cr_poly *poly, uint64_t increment, double *conflict_plain, double *conflict_best);
-/* malloc'ed image, cr_poly_plane_rows() * row_stride int32 */
-int32_t *cr_poly_device_image(const cr_poly *poly, uint32_t swizzle);
+/* Device/LDS image of the rows, malloc'ed.  COMPACT (specialised kernels): row_stride/4 planes, a row's int32 [4q,4q+4) in
+   plane q, the reciprocal right behind the last weight.  SPLIT (run-time-slot kernels): ceil(slots/4) planes of weights
+   (zero-padded) plus one plane holding only the reciprocal.  *device_row_stride receives the int32 per row of the image. */
+#define CR_IMAGE_COMPACT 0
+#define CR_IMAGE_SPLIT 1
+int32_t *cr_poly_device_image(const cr_poly *poly, uint32_t swizzle, int layout, uint32_t *device_row_stride);
 
 /* ---- closed forms of the timeline walk (reference clownresampler.h:1058-1092) ---- */
 

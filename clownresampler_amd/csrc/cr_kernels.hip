@@ -1245,7 +1245,7 @@ const special *specials(int *count)
 	static const special table[] = {
 	    make_special<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 13, true, true>(),   // cfg 2 / cfg 5: stereo 44.1 -> 48 kHz, 3 lobes
 	    make_special<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 20, true>(),  // cfg 3: stereo 8 -> 96 kHz, 8 lobes
-	    make_special<8, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 14>(),     // cfg 4: 8 channels 48 -> 44.1 kHz
+	    make_special<8, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 2>(),     // cfg 4: 8 channels 48 -> 44.1 kHz
 	    make_special<1, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 13, true, true>(),   // mono upsampling, 3 lobes
 	    make_special<2, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>(),     // stereo mild downsampling, 3 lobes
 	};

@@ -36,6 +36,34 @@ __global__ __launch_bounds__(256) void k_flat(const u32x4 *in, size_t in_vecs, u
 	}
 }
 
+// A2: flat grid, every thread writes one 32-byte output record as two 16-byte stores (lane stride 32 B: the shape of an
+// 8-channel int32 frame per lane) or, INTERLEAVED = 1, two fully coalesced 16-byte stores; reads 16 bytes
+template <int INTERLEAVED, int NT>
+__global__ __launch_bounds__(256) void k_rec32(const u32x4 *in, size_t in_vecs, u32x4 *out, size_t out_recs)
+{
+	const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+	u32x4 acc = {0, 0, 0, 0};
+	if (t < in_vecs)
+		acc = in[t];
+	if (t < out_recs)
+	{
+		const size_t wave_base = (t & ~(size_t)63) * 2;   // first 16-byte vector of this wave's 2 KiB
+		const size_t lane = t & 63;
+		u32x4 *p0 = INTERLEAVED ? out + wave_base + lane : out + t * 2;
+		u32x4 *p1 = INTERLEAVED ? out + wave_base + 64 + lane : out + t * 2 + 1;
+		if (NT)
+		{
+			__builtin_nontemporal_store(acc, p0);
+			__builtin_nontemporal_store(acc + 1u, p1);
+		}
+		else
+		{
+			*p0 = acc;
+			*p1 = acc + 1u;
+		}
+	}
+}
+
 // B: persistent workgroups, contiguous block of the streams per workgroup, tile loop (reads via LDS-free registers)
 template <int THREADS, int STORE_BYTES>
 __global__ __launch_bounds__(THREADS) void k_persist(const u32x4 *in, size_t in_vecs, unsigned *out, size_t out_bytes, unsigned tile_out_bytes)
@@ -117,6 +145,20 @@ int main()
 		report("flat, write only (2 vecs per thread)", time_us([&](int i) { hipLaunchKernelGGL((k_flat<0, 2>), dim3(grid), dim3(256), 0, 0, in[i % SETS], in_vecs, out[i % SETS], out_vecs); }));
 		const unsigned gridr = (unsigned)((in_vecs + 255) / 256);
 		report("flat, read only (1 vec per thread; bytes counted as all)", time_us([&](int i) { hipLaunchKernelGGL((k_flat<1, 0>), dim3(gridr), dim3(256), 0, 0, in[i % SETS], in_vecs, out[i % SETS], (size_t)0); }));
+	}
+	{
+		// 8-channel shape (cfg 4): 28.8 M frames of 16 B in, 26.46 M frames of 32 B out
+		const size_t in8 = 28800000ull, out8 = 26460260ull;
+		u32x4 *i8, *o8;
+		CHECK(hipMalloc(&i8, in8 * 16 + 4096));
+		CHECK(hipMalloc(&o8, out8 * 32 + 4096));
+		const double tot8 = in8 * 16.0 + out8 * 32.0;
+		const unsigned g8 = (unsigned)((in8 + 255) / 256);
+		auto rep8 = [&](const char *name, double us) { printf("%-58s %8.1f us  %7.0f GB/s  (%.3f of 8 TB/s)\n", name, us, tot8 / us / 1e3, tot8 / us / 1e3 / 8000); };
+		rep8("8-ch shape: 2 x 16 B stores per lane, lane stride 32 B", time_us([&](int) { hipLaunchKernelGGL((k_rec32<0, 0>), dim3(g8), dim3(256), 0, 0, i8, in8, o8, out8); }));
+		rep8("8-ch shape: same, non-temporal", time_us([&](int) { hipLaunchKernelGGL((k_rec32<0, 1>), dim3(g8), dim3(256), 0, 0, i8, in8, o8, out8); }));
+		rep8("8-ch shape: 2 fully coalesced 16 B stores per lane", time_us([&](int) { hipLaunchKernelGGL((k_rec32<1, 0>), dim3(g8), dim3(256), 0, 0, i8, in8, o8, out8); }));
+		rep8("8-ch shape: same, non-temporal", time_us([&](int) { hipLaunchKernelGGL((k_rec32<1, 1>), dim3(g8), dim3(256), 0, 0, i8, in8, o8, out8); }));
 	}
 	for (unsigned blocks : {512u, 1024u, 2048u})
 		for (unsigned tile : {32768u, 65536u, 131072u})

@@ -386,10 +386,12 @@ struct FrameData
 	Frame<CH> f[TT];
 };
 
-template <int CH, int TT, int MODE, int SWZ>
+// SPLIT > 1: a frame of CH * SPLIT channels is shared by SPLIT neighbouring lanes, each taking CH of them (`base` then
+// already points at the lane's share of the first frame); FS is the distance between consecutive frames.
+template <int CH, int TT, int MODE, int SWZ, int SPLIT = 1>
 __device__ __forceinline__ void fetch_frame(const crhip_poly_launch &a, const int *rows, const unsigned char *base, unsigned rel, FrameData<CH, TT> &d)
 {
-	constexpr unsigned FB = CH * 2;
+	constexpr unsigned FB = CH * 2 * SPLIT;
 	const unsigned row = row_of<MODE>(a, rel & 0xFFFFu);
 	const unsigned phys = SWZ ? ((row & ~15u) | ((__umul24(row >> 4, a.swizzle) + row) & 15u)) : row;
 	const unsigned char *src = base + (rel >> 16) * FB;
@@ -441,10 +443,10 @@ __device__ __forceinline__ void compute_frame(const FrameData<CH, TT> &d, int *o
 // One output frame: CH normalised int32 into out[0..CH).
 //   rel   16.16 position relative to the tile's first integer position
 //   base  LDS address of the tile's first window frame (tile + shift)
-template <int CH, int TT, int MODE, int NORM, int ASM, int SWZ>
+template <int CH, int TT, int MODE, int NORM, int ASM, int SWZ, int SPLIT = 1>
 __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int *rows, const unsigned char *base, unsigned rel, int *out)
 {
-	constexpr unsigned FB = CH * 2;
+	constexpr unsigned FB = CH * 2 * SPLIT;
 	constexpr int RS_CT = (TT + 1 + 3) & ~3;
 
 	const unsigned frac = rel & 0xFFFFu;
@@ -545,10 +547,13 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 //           launch flag of tools/): 1 = no output stores, 2 = no input DMA, 3 = neither, 4 = DMA + stores but no arithmetic
 // OUT16     1 = clamp to +-0x7FFF and store int16 (opt-in extension), 0 = the reference's unclamped int32
 // NT        1 = non-temporal output stores
-template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0, int OUT16 = 0, int NT = 0>
+// SPLIT     lanes per frame: CH is then the channels of ONE lane and a frame has CH * SPLIT channels (8-channel
+//           frames as two lanes of 4: every store instruction of a wave is one contiguous 1 KiB)
+template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0, int OUT16 = 0, int NT = 0, int SPLIT = 1>
 __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 {
-	constexpr unsigned FB = CH * 2;                       // bytes per input frame
+	constexpr unsigned FB = CH * 2 * SPLIT;               // bytes per input frame (all channels)
+	constexpr unsigned FBL = CH * 2;                      // bytes of one lane's share of a frame
 	constexpr unsigned TILE_BYTES = NV * 16u * NTHREADS;
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -682,6 +687,25 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 	__syncthreads();   // rows staged (plain stores to LDS), first tile landed and first ticket posted, for every wave
 	uint64_t next_index = dynamic ? __builtin_amdgcn_readfirstlane(mailbox[0]) : tile_index + gridDim.x;   // wave-uniform
 
+	// diagnostic instance (ABL == 6) only: where a tile's cycles go, summed over the tiles of this workgroup as seen by
+	// wave 0 - [0] issuing the next tile's DMA + ticket, [1] arithmetic + stores, [2] waiting for the DMA (vmcnt),
+	// [3] waiting at the barrier (+ mailbox)
+	unsigned long long phase[4] = {0, 0, 0, 0};
+	unsigned long long t_mark = 0;
+	auto mark = [&](int which) {
+		if constexpr (ABL == 6)
+		{
+			__builtin_amdgcn_sched_barrier(0);
+			const unsigned long long now = __builtin_amdgcn_s_memtime();
+			__builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): s_memtime returns through the scalar data path
+			if (which >= 0)
+				phase[which] += now - t_mark;
+			t_mark = now;
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	};
+	mark(-1);
+
 	for (unsigned it = 0;; ++it)
 	{
 		const unsigned char *tile = tiles + (it & 1u) * TILE_BYTES;
@@ -698,17 +722,20 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 			if (dynamic && tid == 0)
 				ticket = draw();   // for the tile after the next one; posted below, just before the barrier
 		}
+		mark(0);
 
 		const uint64_t pos = a.pos0 + jt * (uint64_t)a.increment;
 		const unsigned frac0 = (unsigned)(pos & 0xFFFFu);
-		int *out_tile = reinterpret_cast<int *>(a.d_out) + jt * CH;             // OUT16 == 0
-		short *out_tile16 = reinterpret_cast<short *>(a.d_out) + jt * CH;       // OUT16 == 1
-		const unsigned char *base = tile + shift;
+		// lane-frames: a frame shared by SPLIT lanes counts SPLIT times; lane-frame L is lane share L % SPLIT of frame L / SPLIT
+		const unsigned nl = n * SPLIT;
+		int *out_tile = reinterpret_cast<int *>(a.d_out) + jt * (CH * SPLIT);             // OUT16 == 0
+		short *out_tile16 = reinterpret_cast<short *>(a.d_out) + jt * (CH * SPLIT);       // OUT16 == 1
+		const unsigned char *base = tile + shift + (tid % SPLIT) * FBL;
 
 		// One group = NTHREADS * U frames: U independent frames per lane, no bounds checks.
 		// Positions are formed as (lane part, once per tile) + (group part, wave-uniform, scalar unit): one VALU add per
 		// frame instead of a 24-bit multiply-add; same for the output address, which goes out as SGPR base + lane offset.
-		const unsigned lane_rel = __umul24(tid, a.increment) + frac0;
+		const unsigned lane_rel = __umul24(tid / SPLIT, a.increment) + frac0;
 		auto group = [&](unsigned g) {
 			int outv[U * CH];
 #pragma unroll
@@ -722,7 +749,7 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 						outv[u * CH + c] = (int)(first + tid);
 				}
 				else
-					one_frame<CH, TT, MODE, NORM, ASM, SWZ>(a, rows, base, lane_rel + first * a.increment, outv + u * CH);
+					one_frame<CH, TT, MODE, NORM, ASM, SWZ, SPLIT>(a, rows, base, lane_rel + (first / SPLIT) * a.increment, outv + u * CH);
 			}
 			if constexpr (ABL == 1 || ABL == 3)
 			{
@@ -758,7 +785,7 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 			if constexpr (TT > 0 && (ABL == 0 || ABL == 6))
 			{
 				FrameData<CH, TT> d[2];
-				fetch_frame<CH, TT, MODE, SWZ>(a, rows, base, lane_rel, d[0]);
+				fetch_frame<CH, TT, MODE, SWZ, SPLIT>(a, rows, base, lane_rel, d[0]);
 #pragma unroll
 				for (int i = 0; i < N; ++i)
 				{
@@ -768,7 +795,7 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 					if (i + 1 < N)
 					{
 						const unsigned next_first = (unsigned)((i + 1) / U) * GROUP + (unsigned)((i + 1) % U) * NTHREADS;
-						fetch_frame<CH, TT, MODE, SWZ>(a, rows, base, lane_rel + next_first * a.increment, d[(i + 1) & 1]);
+						fetch_frame<CH, TT, MODE, SWZ, SPLIT>(a, rows, base, lane_rel + (next_first / SPLIT) * a.increment, d[(i + 1) & 1]);
 					}
 					__builtin_amdgcn_sched_barrier(0);   // keep the reads above the arithmetic below
 					compute_frame<CH, TT, NORM, ASM>(d[i & 1], outv);
@@ -787,29 +814,31 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 					group((unsigned)gi * GROUP);
 			}
 
+			mark(1);
 			if constexpr (G * STORES_PER_GROUP <= 63)
 				asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G * STORES_PER_GROUP) : "memory");
 			else
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			mark(2);
 		};
 
-		if (n == 4u * GROUP)
+		if (nl == 4u * GROUP)
 			run_groups(std::integral_constant<int, 4>());
-		else if (n == 2u * GROUP)
+		else if (nl == 2u * GROUP)
 			run_groups(std::integral_constant<int, 2>());
-		else if (n == GROUP)
+		else if (nl == GROUP)
 			run_groups(std::integral_constant<int, 1>());
 		else
 		{
 			// ragged tile (only the stream's last tile can be one)
-			const unsigned n_full = n - n % GROUP;
+			const unsigned n_full = nl - nl % GROUP;
 			unsigned g = 0;
 			for (; g < n_full; g += GROUP)
 				group(g);
-			for (unsigned jl = g + tid; jl < n; jl += NTHREADS)
+			for (unsigned jl = g + tid; jl < nl; jl += NTHREADS)
 			{
 				int outv[CH];
-				one_frame<CH, TT, MODE, NORM, ASM, SWZ>(a, rows, base, __umul24(jl, a.increment) + frac0, outv);
+				one_frame<CH, TT, MODE, NORM, ASM, SWZ, SPLIT>(a, rows, base, __umul24(jl / SPLIT, a.increment) + frac0, outv);
 				if constexpr (OUT16)
 					store_shorts<CH, NT>(out_tile16 + (size_t)jl * CH, outv);
 				else
@@ -829,6 +858,9 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 					a.debug_stamps[4 * blockIdx.x + 1] = stamp_ticks;
 					a.debug_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
 					a.debug_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(63508 /* HW_REG_XCC_ID, bits 0..3 */) & 0xF;
+					if (blockIdx.x < 64u)
+						for (int k = 0; k < 4; ++k)
+							a.debug_stamps[4 * 4096 + 4 * blockIdx.x + k] = phase[k];
 				}
 			}
 			if (dynamic)
@@ -842,6 +874,7 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 			mailbox[(it + 1u) & 1u] = ticket;
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		__builtin_amdgcn_s_barrier();
+		mark(3);
 		tile_index = next_index;
 		jt = jn;
 		n = n_next;
@@ -1219,7 +1252,12 @@ struct special
 	poly_fn wave[2];            // k_wave (variants WAVE_VARIANT + {0: non-temporal stores, 1: plain}); nullptr if none
 	poly_fn wave16;             // k_wave, int16 output
 	bool dynamic_tiles;         // k_poly: draw tiles as tickets (measured per instance; see crhip_poly_launch.dynamic_tiles)
+	poly_fn split[4];           // k_poly with two lanes per frame (variants SPLIT_VARIANT + i: geometry {4, 2} x nt {1, 0}); nullptr if none
 };
+
+constexpr uint32_t SPLIT_VARIANT = 22;   // variant ids 22..25
+constexpr int SPLIT_GEO[4] = {4, 2, 4, 2};
+constexpr int SPLIT_NT[4] = {1, 1, 0, 0};
 
 constexpr uint32_t WAVE_VARIANT = 20;   // variant ids 20, 21 select k_wave where the instance has one
 constexpr int WAVE_WAVES = 16, WAVE_NVW = 1, WAVE_ITER = 4;
@@ -1227,10 +1265,18 @@ constexpr int WAVE_WAVES = 16, WAVE_NVW = 1, WAVE_ITER = 4;
 template <int CH, int TT, int MODE, int NORM, int DV, bool WAVE = false, bool DYNAMIC = false>
 special make_special()
 {
-	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC};
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}};
 	variant_table<CH, TT, MODE, NORM, 0>::fill(s.fn);
 	constexpr int KV = DV < 20 ? DV : 13;   // the k_poly variant behind a k_wave default (its fallback and int16 geometry)
 	s.fn16 = instance<CH, TT, MODE, NORM, KV % 5, 1, (KV / 5) % 2, (KV / 10) % 2, 1>();
+	if constexpr (CH % 2 == 0 && CH >= 8)
+	{
+		// two lanes per frame, each with CH / 2 channels
+		s.split[0] = (poly_fn)k_poly<CH / 2, TT, MODE, NORM, GEOMETRY[4].threads, GEOMETRY[4].vecs, 1, 1, 0, 0, 0, 1, 2>;
+		s.split[1] = (poly_fn)k_poly<CH / 2, TT, MODE, NORM, GEOMETRY[2].threads, GEOMETRY[2].vecs, 1, 1, 0, 0, 0, 1, 2>;
+		s.split[2] = (poly_fn)k_poly<CH / 2, TT, MODE, NORM, GEOMETRY[4].threads, GEOMETRY[4].vecs, 1, 1, 0, 0, 0, 0, 2>;
+		s.split[3] = (poly_fn)k_poly<CH / 2, TT, MODE, NORM, GEOMETRY[2].threads, GEOMETRY[2].vecs, 1, 1, 0, 0, 0, 0, 2>;
+	}
 	if constexpr (WAVE)
 	{
 		s.wave[0] = (poly_fn)k_wave<CH, TT, MODE, NORM, WAVE_WAVES, WAVE_NVW, WAVE_ITER, 0, 1>;
@@ -1424,10 +1470,14 @@ static uint32_t resolve_variant(const special *sp, uint32_t variant, uint32_t ou
 		return WAVE_VARIANT;                                  // diagnostic k_wave instance: k_wave geometry
 	if (variant >= 1000u && variant < 1010u)
 		return 3u;                                            // diagnostic k_poly instances: headline geometry
-	if (variant >= (uint32_t)VARIANTS + 2u)
+	if (variant >= SPLIT_VARIANT + 4u)
 		variant = sp->default_variant;
-	if (variant >= WAVE_VARIANT && sp->wave[0] == nullptr)
+	if (variant >= SPLIT_VARIANT && sp->split[0] == nullptr)
 		variant = 13u;
+	if (variant >= WAVE_VARIANT && variant < SPLIT_VARIANT && sp->wave[0] == nullptr)
+		variant = 13u;
+	if (out_s16 && variant >= SPLIT_VARIANT)
+		variant = sp->default_variant < WAVE_VARIANT ? sp->default_variant : 13u;
 	if (out_s16 && variant < WAVE_VARIANT)
 		return sp->default_variant < WAVE_VARIANT ? sp->default_variant : 13u;   // the k_poly int16 form exists for one variant
 	return variant;
@@ -1443,7 +1493,7 @@ int crhip_poly_swizzled(uint32_t channels, uint32_t slots, uint32_t row_mode, ui
 
 int crhip_poly_variants(void)
 {
-	return VARIANTS + 2;   // + the two k_wave variants
+	return VARIANTS + 6;   // + the two k_wave variants and the four two-lanes-per-frame variants
 }
 
 int crhip_poly_dynamic_default(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
@@ -1462,6 +1512,15 @@ void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, u
 {
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
 	const uint32_t v = sp != nullptr ? resolve_variant(sp, variant) : (uint32_t)runtime_geo((int)channels);
+
+	if (sp != nullptr && v >= SPLIT_VARIANT)
+	{
+		// two lanes per frame: a group of threads covers half as many frames
+		*threads = (uint32_t)GEOMETRY[SPLIT_GEO[v - SPLIT_VARIANT]].threads;
+		*vecs = (uint32_t)GEOMETRY[SPLIT_GEO[v - SPLIT_VARIANT]].vecs;
+		*frames_multiple = *threads / 2u;
+		return;
+	}
 
 	if (sp != nullptr && v >= WAVE_VARIANT)
 	{
@@ -1483,6 +1542,12 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 	const special *sp = launch->specialised ? find_special(launch->channels, launch->slots, launch->row_mode, launch->norm_mode) : nullptr;
 	const uint32_t v = resolve_variant(sp, launch->variant, launch->out_s16);
 	poly_fn fn;
+
+	if (sp != nullptr && v >= SPLIT_VARIANT)
+	{
+		*geo = (uint32_t)SPLIT_GEO[v - SPLIT_VARIANT];
+		return sp->split[v - SPLIT_VARIANT];
+	}
 
 	if (sp != nullptr && v >= WAVE_VARIANT)
 	{

@@ -391,3 +391,18 @@ def test_random_configurations_bit_exact(products):
         kernels[p.api.PlanGetInfo(p.api.PlanCreate(st.raw, p.pre)).kernel] += 1
         done += 1
     assert kernels[0] > 0 and kernels[1] > 0, kernels      # both the generic and the polyphase kernels were exercised
+
+
+@pytest.mark.parametrize("variant", [2, 4, 14, 22, 23, 24, 25])
+@pytest.mark.parametrize("name", ["cfg4_1min", "ch8_down"])
+def test_eight_channel_variants_bit_exact(golden, products, name, variant):
+    """8-channel frames: one lane per frame (two 16-byte stores 32 bytes apart) and two lanes per frame (variants 22-25: each
+    lane 4 channels, every store instruction of a wave one contiguous KiB) give the same bits."""
+    case = _cases.CASE_BY_NAME[name]
+    p = products[case["radius"]]
+    p.api.DebugSetVariant(variant)
+    try:
+        res = _cases.run_case(p, case)
+    finally:
+        p.api.DebugSetVariant(0xFFFF)
+    assert res == golden["cases"][name]

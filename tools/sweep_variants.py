@@ -38,14 +38,14 @@ def main():
         sets.append((pcm, torch.empty(n_out * ch, dtype=torch.int32, device=dev)))
     stream = torch.cuda.current_stream(dev)
     nvar = api.lib.crhip_poly_variants() if hasattr(api.lib, "crhip_poly_variants") else 48
-    variants = [int(v) for v in args.variants.split(",")] if args.variants else list(range(22))
+    variants = [int(v) for v in args.variants.split(",")] if args.variants else list(range(26))
     plans, infos = {}, {}
     for v in variants:
         api.DebugSetVariant(v)
         plans[v] = api.PlanCreate(st0, pre)
         infos[v] = api.PlanGetInfo(plans[v])
 
-    stamp = torch.zeros(4 * 4096, dtype=torch.int64, device=dev)
+    stamp = torch.zeros(4 * 4096 + 4 * 64, dtype=torch.int64, device=dev)
     api.lib.ClownResamplerAMD_DebugSetStampBuffer.argtypes = [__import__('ctypes').c_void_p]
     api.lib.ClownResamplerAMD_DebugSetStampBuffer(stamp.data_ptr())
 
@@ -88,7 +88,9 @@ def main():
             extra = ""
             if v in (1006, 1007):
                 import numpy as _np
-                st = stamp.cpu().numpy().reshape(-1, 4)
+                raw = stamp.cpu().numpy()
+                ph = raw[4 * 4096:].reshape(-1, 4).astype(float)
+                st = raw[:4 * 4096].reshape(-1, 4)
                 st = st[st[:, 2] != 0]
                 t0 = st[:, 1].min()
                 life = (st[:, 2] - st[:, 1]) / 100.0
@@ -96,11 +98,18 @@ def main():
                 clk = st[:, 0] / _np.maximum(st[:, 2] - st[:, 1], 1) / 10.0
                 extra = "\n   %d workgroups: clock %.2f-%.2f GHz; start spread %.1f us; lifetime us min/median/max %.1f/%.1f/%.1f; end time us min/median/max %.1f/%.1f/%.1f" % (
                     len(st), clk.min(), clk.max(), (st[:, 1].max() - t0) / 100.0, life.min(), _np.median(life), life.max(), endt.min(), _np.median(endt), endt.max())
+                if v == 1006 and ph.sum() > 0:
+                    tot = ph.sum(axis=1).mean()
+                    extra += "\n   wave 0 of workgroups 0-63, cycles per workgroup: issue next DMA+ticket %.0f (%.0f%%), arithmetic+stores %.0f (%.0f%%), wait DMA %.0f (%.0f%%), barrier %.0f (%.0f%%)" % tuple(
+                        x for k in range(4) for x in (ph[:, k].mean(), 100 * ph[:, k].mean() / tot))
                 for x in range(8):
                     m = st[:, 3] == x
                     if m.any():
                         extra += "\n   XCC %d: %3d workgroups, end time median %.1f max %.1f us" % (x, m.sum(), _np.median(endt[m]), endt[m].max())
             print("ablation %d (timing only%s): %7.1f us median %7.1f min%s" % (v - 1000, "" if v in (1006, 1007) else ", results wrong by design", med, mn, extra))
+            continue
+        if v >= 22 and v < 26:
+            print("%3d  2 lanes/frame geo %s nt=%d %5d %6d %4d | %7.1f %7.1f | %7.0f  %.3f %s" % (v, [(1024, 2), (512, 2)][(v - 22) % 2], 1 - (v - 22) // 2, i.tile_frames, i.lds_bytes, i.max_blocks, med, mn, nbytes / med / 1e3, nbytes / med / 1e3 / 8000, "MISMATCH" if v in bad else ""))
             continue
         if v in (20, 21):
             print("%3d  k_wave     nt=%d          %5d %6d %4d | %7.1f %7.1f | %7.0f  %.3f %s" % (v, 21 - v, i.tile_frames, i.lds_bytes, i.max_blocks, med, mn, nbytes / med / 1e3, nbytes / med / 1e3 / 8000, "MISMATCH" if v in bad else ""))

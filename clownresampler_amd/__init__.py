@@ -74,6 +74,10 @@ class Shard(C.Structure):  # ClownResamplerAMD_Shard
                 ("input_frames", C.c_size_t), ("halo_frames", C.c_size_t), ("state", LowLevel_State)]
 
 
+class Segment(C.Structure):  # ClownResamplerAMD_Segment
+    _fields_ = [("input_frames", C.c_size_t), ("input_sample_rate", cc_u32f), ("output_sample_rate", cc_u32f), ("low_pass_filter_sample_rate", cc_u32f)]
+
+
 class PlanInfo(C.Structure):  # ClownResamplerAMD_PlanInfo
     _fields_ = [(n, C.c_uint32) for n in ("kernel", "channels", "slots", "first_slot", "rows", "row_stride", "row_mode", "threads",
                                           "tile_frames", "lds_bytes", "max_blocks", "specialised", "variant")]
@@ -171,6 +175,10 @@ class Api:
         self._PlanRowOf = fn("ClownResamplerAMD_PlanRowOf", C.c_uint32, [C.c_void_p, C.c_uint32], False)
         self._ResampleDevice = fn("ClownResamplerAMD_ResampleDevice", C.c_size_t, [C.c_void_p, P(LowLevel_State), C.c_void_p, P(C.c_size_t), C.c_void_p, C.c_size_t, C.c_void_p, P(cc_bool)], False)
         self._ResampleDeviceS16 = fn("ClownResamplerAMD_ResampleDeviceS16", C.c_size_t, [C.c_void_p, P(LowLevel_State), C.c_void_p, P(C.c_size_t), C.c_void_p, C.c_size_t, C.c_void_p, P(cc_bool)], False)
+        self._SetPlanCacheLimit = fn("ClownResamplerAMD_SetPlanCacheLimit", None, [C.c_size_t], False)
+        self._PlanCacheCount = fn("ClownResamplerAMD_PlanCacheCount", C.c_size_t, [], False)
+        self._ResampleSegmentsDevice = fn("ClownResamplerAMD_ResampleSegmentsDevice", C.c_size_t, [P(LowLevel_State), P(self.Precomputed), C.c_void_p, C.c_size_t, P(Segment), C.c_size_t,
+                                                                                                      C.c_void_p, C.c_size_t, C.c_int, P(C.c_size_t), C.c_void_p])
         self._Count = fn("ClownResamplerAMD_CountOutputFrames", C.c_size_t, [P(LowLevel_State), C.c_size_t], False)
         self._Advance = fn("ClownResamplerAMD_AdvanceState", None, [P(LowLevel_State), C.c_size_t], False)
         self._PlanShard = fn("ClownResamplerAMD_PlanShard", C.c_int, [P(LowLevel_State), C.c_size_t, C.c_uint, C.c_uint, P(Shard)], False)
@@ -341,6 +349,22 @@ class Api:
                                  output_capacity_frames, C.c_void_p(hip_stream or 0), C.byref(ran_out))
         _raise_if_failed(self.lib)
         return n, left.value, int(ran_out.value)
+
+    def ResampleSegmentsDevice(self, resampler, precomputed, device_timeline, halo_frames, segments, device_output, output_capacity_frames, hip_stream=None, s16=False):
+        """Variable rate on the device (ClownResamplerAMD_ResampleSegmentsDevice).  segments: [(input_frames, in_rate, out_rate, low_pass), ...];
+        device_timeline: device address of input frame 0.  Returns (total_frames, [frames per segment]); not synchronised."""
+        array = (Segment * max(1, len(segments)))(*[Segment(*seg) for seg in segments])
+        counts = (C.c_size_t * max(1, len(segments)))()
+        n = self._ResampleSegmentsDevice(C.byref(resampler), C.byref(precomputed), C.c_void_p(device_timeline), halo_frames, array, len(segments),
+                                         C.c_void_p(device_output), output_capacity_frames, 1 if s16 else 0, counts, C.c_void_p(hip_stream or 0))
+        _raise_if_failed(self.lib)
+        return n, list(counts)[:len(segments)]
+
+    def SetPlanCacheLimit(self, plans):
+        self._SetPlanCacheLimit(plans)
+
+    def PlanCacheCount(self):
+        return self._PlanCacheCount()
 
     def SetStreamingWindow(self, frames):
         self._SetStreamingWindow(frames)

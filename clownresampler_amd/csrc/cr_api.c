@@ -157,20 +157,34 @@ static void config_of(const ClownResampler_LowestLevel_Configuration *configurat
 	cfg->step = configuration->kernel_step_size;
 }
 
-static ClownResamplerAMD_Plan *plan_for(const ClownResampler_LowestLevel_Configuration *configuration, const ClownResampler_Precomputed *precomputed, cc_u8f channels, cc_u32f increment)
+/* Plans are keyed by the CONTENTS of the caller's table (48 KB to hash): a caller may legitimately keep several
+   tables, or const-initialise one from a dump (clownresampler.h:677-681). */
+static uint64_t table_hash_of(const ClownResampler_Precomputed *precomputed)
+{
+	return cr_hash_bytes(precomputed->lanczos_kernel_table, sizeof(precomputed->lanczos_kernel_table), RADIUS);
+}
+
+/* The caller holds the plan until cr_plan_release. */
+static ClownResamplerAMD_Plan *plan_for_hashed(uint64_t table_hash, const ClownResampler_LowestLevel_Configuration *configuration, const ClownResampler_Precomputed *precomputed, cc_u8f channels, cc_u32f increment, int pin)
 {
 	cr_config cfg;
 
 	config_of(configuration, &cfg);
-	/* keyed by the CONTENTS of the caller's table (48 KB to hash): a caller may legitimately keep several
-	   tables, or const-initialise one from a dump (clownresampler.h:677-681) */
-	return cr_plan_get(cr_hash_bytes(precomputed->lanczos_kernel_table, sizeof(precomputed->lanczos_kernel_table), RADIUS),
-	                   TABLE_LEN, fill_table_i32, precomputed, RADIUS, &cfg, channels, increment);
+	return cr_plan_get(table_hash, TABLE_LEN, fill_table_i32, precomputed, RADIUS, &cfg, channels, increment, pin);
+}
+
+static ClownResamplerAMD_Plan *plan_for(const ClownResampler_LowestLevel_Configuration *configuration, const ClownResampler_Precomputed *precomputed, cc_u8f channels, cc_u32f increment, int pin)
+{
+	return plan_for_hashed(table_hash_of(precomputed), configuration, precomputed, channels, increment, pin);
 }
 
 ClownResamplerAMD_Plan *ClownResamplerAMD_PlanCreate(const ClownResampler_LowLevel_State *state, const ClownResampler_Precomputed *precomputed)
 {
-	return plan_for(&state->lowest_level, precomputed, state->channels, state->increment);
+	/* pinned: valid until ClownResamplerAMD_Shutdown, as the header promises */
+	ClownResamplerAMD_Plan *plan = plan_for(&state->lowest_level, precomputed, state->channels, state->increment, 1);
+
+	cr_plan_release(plan);
+	return plan;
 }
 
 /* Host-only view of the polyphase rows a plan would use (no device needed): for tests and tools.
@@ -256,13 +270,16 @@ static size_t resample_bulk(ClownResampler_LowLevel_State *resampler, const Clow
 
 	if (emit != 0)
 	{
-		const ClownResamplerAMD_Plan *plan = plan_for(&resampler->lowest_level, precomputed, resampler->channels, resampler->increment);
+		const ClownResamplerAMD_Plan *plan = plan_for(&resampler->lowest_level, precomputed, resampler->channels, resampler->increment, 0);
+		int failed;
 
 		if (plan == NULL)
 			return 0;
 
-		if (cr_run_host(plan, input_buffer, (uint64_t)*total_input_frames + 2 * resampler->lowest_level.integer_stretched_kernel_radius,
-		                pos_int, pos_frac, emit, output, out_s16) != 0)
+		failed = cr_run_host(plan, input_buffer, (uint64_t)*total_input_frames + 2 * resampler->lowest_level.integer_stretched_kernel_radius,
+		                     pos_int, pos_frac, emit, output, out_s16);
+		cr_plan_release(plan);
+		if (failed != 0)
 			return 0;
 	}
 	else if (stopped)
@@ -286,6 +303,101 @@ size_t ClownResampler_LowLevel_ResampleBulk(ClownResampler_LowLevel_State *resam
 size_t ClownResampler_LowLevel_ResampleBulkS16(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed, const cc_s16l *input_buffer, size_t *total_input_frames, int16_t *output, size_t output_capacity_frames, cc_bool *ran_out_of_input)
 {
 	return resample_bulk(resampler, precomputed, input_buffer, total_input_frames, output, output_capacity_frames, ran_out_of_input, 1);
+}
+
+/* ======================================================================================================= */
+/* Variable rate on the device: a list of constant-rate segments, one launch each, no synchronisation      */
+/* ======================================================================================================= */
+
+/* Equivalent reference sequence, per segment s covering input frames [a_s, a_s + n_s) of one contiguous timeline:
+     ClownResampler_LowLevel_Adjust(state, rates_s);                                   clownresampler.h:1052-1056
+     total = n_s;  ClownResampler_LowLevel_Resample(state, precomputed,                clownresampler.h:1058-1092
+                       timeline + (a_s - integer_stretched_kernel_radius_s) * channels, &total, append, 0);
+   i.e. each segment's "padding" is the real neighbouring frames (legal per clownresampler.h:725-733), the position
+   (overshoot + fraction) is carried across the re-configuration exactly as the state struct carries it. */
+size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed,
+                                                const void *device_timeline, size_t halo_frames, const ClownResamplerAMD_Segment *segments, size_t segment_count,
+                                                void *device_output, size_t output_capacity_frames, int output_is_s16, size_t *segment_output_frames, void *hip_stream)
+{
+	const unsigned long errors_before = cr_error_serial();
+	ClownResampler_LowLevel_State state = *resampler;
+	uint64_t total_out = 0, in_frame = 0, out_frame = 0, table_hash;
+	size_t s;
+
+	/* pass 1, host only: every segment must be acceptable before anything is enqueued */
+	for (s = 0; s < segment_count; ++s)
+	{
+		uint64_t n, pos_int, pos_frac;
+
+		if (!ClownResampler_LowLevel_Adjust(&state, segments[s].input_sample_rate, segments[s].output_sample_rate, segments[s].low_pass_filter_sample_rate))
+		{
+			cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "segment %lu: ClownResampler_LowLevel_Adjust rejects the rates %lu -> %lu (low-pass %lu)", (unsigned long)s,
+			        (unsigned long)segments[s].input_sample_rate, (unsigned long)segments[s].output_sample_rate, (unsigned long)segments[s].low_pass_filter_sample_rate);
+			return 0;
+		}
+		if (state.lowest_level.integer_stretched_kernel_radius > halo_frames)
+		{
+			cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "segment %lu needs %lu frames of halo, the timeline has %lu", (unsigned long)s,
+			        (unsigned long)state.lowest_level.integer_stretched_kernel_radius, (unsigned long)halo_frames);
+			return 0;
+		}
+
+		pos_int = state.position_integer;
+		pos_frac = state.position_fractional;
+		n = cr_count_output_frames(pos_int, pos_frac, state.increment, segments[s].input_frames);
+		cr_advance(&pos_int, &pos_frac, state.increment, n);
+		state.position_integer = (size_t)(pos_int - segments[s].input_frames);     /* :1065 */
+		state.position_fractional = (cc_u32f)pos_frac;
+		total_out += n;
+	}
+
+	if (total_out > output_capacity_frames)
+	{
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "the segments produce %lu frames, the output has room for %lu", (unsigned long)total_out, (unsigned long)output_capacity_frames);
+		return 0;
+	}
+
+	/* pass 2: one launch per segment, back to back on the caller's stream */
+	table_hash = table_hash_of(precomputed);
+	state = *resampler;
+	for (s = 0; s < segment_count; ++s)
+	{
+		uint64_t n;
+		size_t total = segments[s].input_frames;
+
+		ClownResampler_LowLevel_Adjust(&state, segments[s].input_sample_rate, segments[s].output_sample_rate, segments[s].low_pass_filter_sample_rate);
+		n = cr_count_output_frames(state.position_integer, state.position_fractional, state.increment, total);
+
+		if (n != 0)
+		{
+			const size_t radius_frames = state.lowest_level.integer_stretched_kernel_radius;
+			const cc_s16l *window = (const cc_s16l *)device_timeline + ((ptrdiff_t)in_frame - (ptrdiff_t)radius_frames) * (ptrdiff_t)state.channels;
+			unsigned char *out = (unsigned char *)device_output + out_frame * state.channels * (output_is_s16 ? sizeof(int16_t) : sizeof(int32_t));
+			const ClownResamplerAMD_Plan *plan = plan_for_hashed(table_hash, &state.lowest_level, precomputed, state.channels, state.increment, 0);
+			int failed;
+
+			if (plan == NULL)
+				return 0;
+			/* released as soon as the launch is enqueued: rows are only ever freed with hipFree, which waits for it */
+			failed = cr_plan_launch(plan, window, ((uint64_t)total + 2 * radius_frames) * state.channels * sizeof(cc_s16l), out,
+			                        state.position_integer, state.position_fractional, n, hip_stream, output_is_s16);
+			cr_plan_release(plan);
+			if (failed != 0)
+				return 0;
+		}
+
+		settle_exhausted(&state, &total, state.position_integer, state.position_fractional, n);
+		if (segment_output_frames != NULL)
+			segment_output_frames[s] = (size_t)n;
+		in_frame += segments[s].input_frames;
+		out_frame += n;
+	}
+
+	if (cr_error_serial() != errors_before)
+		return 0;
+
+	*resampler = state;
+	return (size_t)out_frame;
 }
 
 /* ======================================================================================================= */
@@ -314,13 +426,14 @@ cc_bool ClownResampler_LowLevel_Resample(ClownResampler_LowLevel_State *resample
 		return cc_true;
 	}
 
-	plan = plan_for(&resampler->lowest_level, precomputed, channels, resampler->increment);
+	plan = plan_for(&resampler->lowest_level, precomputed, channels, resampler->increment, 0);
 	if (plan == NULL)
 		return cc_true;
 
 	batch_out = (int32_t *)malloc((size_t)(available < batch_limit ? available : batch_limit) * channels * sizeof(int32_t));
 	if (batch_out == NULL)
 	{
+		cr_plan_release(plan);
 		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
 		return cc_true;
 	}
@@ -354,6 +467,7 @@ cc_bool ClownResampler_LowLevel_Resample(ClownResampler_LowLevel_State *resample
 			if (!output_callback((void *)user_data, frame, channels))
 			{
 				free(batch_out);
+				cr_plan_release(plan);
 				settle_stopped(resampler, total_input_frames, start_int, start_frac, done + i + 1);
 				return cc_false;
 			}
@@ -367,6 +481,7 @@ cc_bool ClownResampler_LowLevel_Resample(ClownResampler_LowLevel_State *resample
 	}
 
 	free(batch_out);
+	cr_plan_release(plan);
 
 	if (done < available)
 	{
@@ -387,7 +502,7 @@ cc_bool ClownResampler_LowLevel_Resample(ClownResampler_LowLevel_State *resample
 void ClownResampler_LowestLevel_Resample(const ClownResampler_LowestLevel_Configuration *configuration, const ClownResampler_Precomputed *precomputed, cc_s32f *output_frame, cc_u8f channels, const cc_s16l *input_buffer, size_t position_integer, cc_u32f position_fractional)
 {
 	/* increment is irrelevant for a single frame; 65536 keeps the plan key well-formed */
-	const ClownResamplerAMD_Plan *plan = plan_for(configuration, precomputed, channels, ONE);
+	const ClownResamplerAMD_Plan *plan = plan_for(configuration, precomputed, channels, ONE, 0);
 	int64_t acc_in[CLOWNRESAMPLER_MAXIMUM_CHANNELS], acc_out[CLOWNRESAMPLER_MAXIMUM_CHANNELS];
 	cc_u8f c;
 
@@ -398,9 +513,13 @@ void ClownResampler_LowestLevel_Resample(const ClownResampler_LowestLevel_Config
 		acc_in[c] = output_frame[c];
 
 	/* the frame reads padded-buffer frames [position_integer, position_integer + 2 * radius) at most (:995-996, :1003-1004) */
-	if (cr_run_single_frame(plan, input_buffer + position_integer * channels, 2 * (uint64_t)configuration->integer_stretched_kernel_radius,
-	                        position_fractional, acc_in, acc_out) != 0)
-		return;
+	{
+		const int failed = cr_run_single_frame(plan, input_buffer + position_integer * channels, 2 * (uint64_t)configuration->integer_stretched_kernel_radius,
+		                                       position_fractional, acc_in, acc_out);
+		cr_plan_release(plan);
+		if (failed != 0)
+			return;
+	}
 
 	for (c = 0; c < channels; ++c)
 		output_frame[c] = (cc_s32f)acc_out[c];

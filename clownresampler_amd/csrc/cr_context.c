@@ -94,6 +94,8 @@ static int g_device = 0;
 static int g_device_ready = 0;
 static crhip_device_info g_info;
 static ClownResamplerAMD_Plan *g_plans = NULL;
+static uint64_t g_plan_clock = 0;
+static size_t g_plan_limit = 64;   /* unpinned plans kept; ClownResamplerAMD_SetPlanCacheLimit */
 static cr_workspace g_workspace;
 static int g_workspace_busy = 0;
 static int g_force_generic = 0;
@@ -172,6 +174,21 @@ static cr_stream *g_streams = NULL;
 static uint64_t g_stream_serial = 0;
 static size_t g_stream_max_frames = (size_t)1 << 18;
 
+static void store_release(cr_plan_store *store, int device_usable)
+{
+	if (store == NULL || --store->refs > 0)
+		return;
+
+	if (device_usable)
+	{
+		/* hipFree waits for the device: a launch that was enqueued with these rows has finished by the time they go */
+		crhip_free(store->d_table);
+		crhip_free(store->d_rows);
+	}
+	cr_poly_free(&store->poly);
+	free(store);
+}
+
 static void release_everything_locked(void)
 {
 	/* streaming side windows are host memory: they stay valid across device changes and are only dropped by Shutdown */
@@ -181,12 +198,7 @@ static void release_everything_locked(void)
 	{
 		ClownResamplerAMD_Plan *next = p->next;
 
-		if (g_device_ready)
-		{
-			crhip_free(p->d_table);
-			crhip_free(p->d_rows);
-		}
-		cr_poly_free(&p->poly);
+		store_release(p->store, g_device_ready);
 		free(p);
 		p = next;
 	}
@@ -420,10 +432,80 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	plan->max_blocks = per_cu * (uint32_t)(g_info.compute_units > 0 ? g_info.compute_units : 256);
 }
 
-ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_table_fill fill_table, const void *user,
-                                    unsigned radius, const cr_config *cfg, uint32_t channels, uint64_t increment)
+static int plan_key_matches(const ClownResamplerAMD_Plan *plan, uint64_t table_hash, unsigned radius, const cr_config *cfg, uint32_t channels)
 {
-	ClownResamplerAMD_Plan *plan;
+	return plan->table_hash == table_hash && plan->radius == radius && plan->channels == channels
+	    && plan->key_variant == current_variant() && plan->device == g_device && memcmp(&plan->cfg, cfg, sizeof(*cfg)) == 0;
+}
+
+/* Drops unpinned, unheld plans, least recently used first, until at most g_plan_limit unpinned plans remain. */
+static void evict_plans_locked(void)
+{
+	for (;;)
+	{
+		ClownResamplerAMD_Plan **link, **victim = NULL;
+		size_t unpinned = 0;
+
+		for (link = &g_plans; *link != NULL; link = &(*link)->next)
+		{
+			if ((*link)->pinned)
+				continue;
+			++unpinned;
+			if ((*link)->users == 0 && (victim == NULL || (*link)->last_use < (*victim)->last_use))
+				victim = link;
+		}
+
+		if (unpinned <= g_plan_limit || victim == NULL)
+			return;
+
+		{
+			ClownResamplerAMD_Plan *plan = *victim;
+			*victim = plan->next;
+			store_release(plan->store, g_device_ready);
+			free(plan);
+		}
+	}
+}
+
+void ClownResamplerAMD_SetPlanCacheLimit(size_t plans)
+{
+	pthread_mutex_lock(&g_lock);
+	g_plan_limit = plans;
+	evict_plans_locked();
+	pthread_mutex_unlock(&g_lock);
+}
+
+size_t ClownResamplerAMD_PlanCacheCount(void)
+{
+	const ClownResamplerAMD_Plan *plan;
+	size_t n = 0;
+
+	pthread_mutex_lock(&g_lock);
+	for (plan = g_plans; plan != NULL; plan = plan->next)
+		++n;
+	pthread_mutex_unlock(&g_lock);
+	return n;
+}
+
+void cr_plan_release(const ClownResamplerAMD_Plan *plan_in)
+{
+	ClownResamplerAMD_Plan *plan = (ClownResamplerAMD_Plan *)plan_in;
+
+	if (plan == NULL)
+		return;
+
+	pthread_mutex_lock(&g_lock);
+	if (plan->users != 0)
+		--plan->users;
+	evict_plans_locked();
+	pthread_mutex_unlock(&g_lock);
+}
+
+ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_table_fill fill_table, const void *user,
+                                    unsigned radius, const cr_config *cfg, uint32_t channels, uint64_t increment, int pin)
+{
+	ClownResamplerAMD_Plan *plan, *sibling = NULL;
+	cr_plan_store *store = NULL;
 	int32_t *table = NULL;
 
 	pthread_mutex_lock(&g_lock);
@@ -433,12 +515,19 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 
 	for (plan = g_plans; plan != NULL; plan = plan->next)
 	{
-		if (plan->table_hash == table_hash && plan->radius == radius && plan->channels == channels && plan->increment == increment
-		 && plan->variant == current_variant() && plan->device == g_device && memcmp(&plan->cfg, cfg, sizeof(*cfg)) == 0)
+		if (!plan_key_matches(plan, table_hash, radius, cfg, channels))
+			continue;
+
+		if (plan->increment == increment)
 		{
+			plan->last_use = ++g_plan_clock;
+			plan->users += 1;
+			plan->pinned |= pin;
 			pthread_mutex_unlock(&g_lock);
 			return plan;
 		}
+
+		sibling = plan; /* same rows, different increment */
 	}
 
 	if (channels == 0 || channels > CRHIP_MAX_CHANNELS)
@@ -453,20 +542,10 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 		goto fail;
 	}
 
-	table = (int32_t *)malloc(table_len * sizeof(int32_t));
 	plan = (ClownResamplerAMD_Plan *)calloc(1, sizeof(*plan));
-
-	if (table == NULL || plan == NULL)
+	if (plan == NULL)
 	{
-		free(plan);
 		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
-		goto fail;
-	}
-
-	if (fill_table(user, table, table_len) != 0)
-	{
-		free(plan);
-		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "a Lanczos table entry does not fit 32 bits");
 		goto fail;
 	}
 
@@ -476,16 +555,58 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 	plan->channels = channels;
 	plan->increment = increment;
 	plan->device = g_device;
-	plan->variant = current_variant();
+	plan->key_variant = current_variant();
+	plan->variant = plan->key_variant;
 	plan->table_len = (uint32_t)table_len;
 
-	if (cr_poly_build(table, table_len, cfg, &plan->poly) != 0)
+	if (sibling != NULL)
 	{
-		/* the reference itself would trap or read outside its table with this configuration */
-		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "unusable configuration: %s", plan->poly.reason);
-		free(plan);
-		goto fail;
+		store = sibling->store;
+		store->refs += 1;
 	}
+	else
+	{
+		table = (int32_t *)malloc(table_len * sizeof(int32_t));
+		store = (cr_plan_store *)calloc(1, sizeof(*store));
+
+		if (table == NULL || store == NULL)
+		{
+			free(store);
+			free(plan);
+			cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
+			goto fail;
+		}
+
+		store->refs = 1;
+		store->table_len = (uint32_t)table_len;
+		store->rows_layout = -1;
+
+		if (fill_table(user, table, table_len) != 0)
+		{
+			free(store);
+			free(plan);
+			cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "a Lanczos table entry does not fit 32 bits");
+			goto fail;
+		}
+
+		if (cr_poly_build(table, table_len, cfg, &store->poly) != 0)
+		{
+			/* the reference itself would trap or read outside its table with this configuration */
+			cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "unusable configuration: %s", store->poly.reason);
+			free(store);
+			free(plan);
+			goto fail;
+		}
+
+		if (cr_check_hip(crhip_malloc((void **)&store->d_table, table_len * sizeof(int32_t)), "hipMalloc(table)") != 0
+		 || cr_check_hip(crhip_memcpy_h2d(store->d_table, table, table_len * sizeof(int32_t), NULL), "hipMemcpy(table)") != 0
+		 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
+			goto fail_plan;
+	}
+
+	plan->store = store;
+	plan->poly = store->poly;       /* view: the arrays belong to the store */
+	plan->d_table = store->d_table;
 
 	plan->use_poly = plan->poly.eligible && plan->poly.weights != NULL;
 	plan->generic_reason = plan->poly.reason;
@@ -505,37 +626,55 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 	if (plan->use_poly)
 		plan_geometry(plan);
 
-	if (cr_check_hip(crhip_malloc((void **)&plan->d_table, table_len * sizeof(int32_t)), "hipMalloc(table)") != 0
-	 || cr_check_hip(crhip_memcpy_h2d(plan->d_table, table, table_len * sizeof(int32_t), NULL), "hipMemcpy(table)") != 0)
-		goto fail_plan;
+	if (plan->use_poly)
+	{
+		const int layout = plan->specialised ? CR_IMAGE_COMPACT : CR_IMAGE_SPLIT;
+
+		/* the bank-conflict model walks a few thousand wave footprints (~0.4 ms): only worth running for an instance that
+		   can read a swizzled image, and none is built at present */
+		plan->swizzle = 0;
+		if (crhip_poly_swizzled(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant))
+			plan->swizzle = cr_poly_pick_swizzle(&plan->poly, increment, &plan->conflict_plain, &plan->conflict_best);
+
+		if (store->d_rows != NULL && (store->rows_layout != layout || store->swizzle != plan->swizzle))
+		{
+			/* cannot happen while the layout is a function of (channels, slots, row mode, normalisation), which siblings
+			   share; if a tuning hook ever breaks that, the generic kernel is still right */
+			plan->use_poly = 0;
+			plan->generic_reason = "plans of one configuration disagree on the layout of their rows";
+		}
+		else if (store->d_rows == NULL)
+		{
+			int32_t *image = cr_poly_device_image(&store->poly, plan->swizzle, layout, &store->device_row_stride);
+			const size_t bytes = (size_t)cr_poly_plane_rows(&store->poly) * store->device_row_stride * sizeof(int32_t);
+
+			if (image == NULL)
+			{
+				cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
+				goto fail_plan;
+			}
+
+			if (cr_check_hip(crhip_malloc((void **)&store->d_rows, bytes), "hipMalloc(rows)") != 0
+			 || cr_check_hip(crhip_memcpy_h2d(store->d_rows, image, bytes, NULL), "hipMemcpy(rows)") != 0
+			 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
+			{
+				free(image);
+				goto fail_plan;
+			}
+
+			free(image);
+			store->rows_layout = layout;
+			store->swizzle = plan->swizzle;
+			store->plane_rows = cr_poly_plane_rows(&store->poly);
+		}
+
+	}
 
 	if (plan->use_poly)
 	{
-		int32_t *image;
-		size_t bytes;
-
-		plan->plane_rows = cr_poly_plane_rows(&plan->poly);
-		plan->swizzle = cr_poly_pick_swizzle(&plan->poly, increment, &plan->conflict_plain, &plan->conflict_best);
-		if (!crhip_poly_swizzled(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant))
-			plan->swizzle = 0; /* the selected instance reads the plain image */
-		image = cr_poly_device_image(&plan->poly, plan->swizzle, plan->specialised ? CR_IMAGE_COMPACT : CR_IMAGE_SPLIT, &plan->device_row_stride);
-		bytes = (size_t)plan->plane_rows * plan->device_row_stride * sizeof(int32_t);
-
-		if (image == NULL)
-		{
-			cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
-			goto fail_plan;
-		}
-
-		if (cr_check_hip(crhip_malloc((void **)&plan->d_rows, bytes), "hipMalloc(rows)") != 0
-		 || cr_check_hip(crhip_memcpy_h2d(plan->d_rows, image, bytes, NULL), "hipMemcpy(rows)") != 0
-		 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
-		{
-			free(image);
-			goto fail_plan;
-		}
-
-		free(image);
+		plan->d_rows = store->d_rows;
+		plan->plane_rows = store->plane_rows;
+		plan->device_row_stride = store->device_row_stride;
 
 		{
 			/* once per plan, never inside a caller's stream capture */
@@ -549,19 +688,18 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 		}
 	}
 
-	if (cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
-		goto fail_plan;
-
 	free(table);
+	plan->pinned = pin;
+	plan->users = 1;
+	plan->last_use = ++g_plan_clock;
 	plan->next = g_plans;
 	g_plans = plan;
+	evict_plans_locked();
 	pthread_mutex_unlock(&g_lock);
 	return plan;
 
 fail_plan:
-	crhip_free(plan->d_table);
-	crhip_free(plan->d_rows);
-	cr_poly_free(&plan->poly);
+	store_release(store, 1);
 	free(plan);
 fail:
 	free(table);

@@ -27,6 +27,21 @@ int cr_check_hip(int hip_code, const char *what);
 int cr_ensure_device(void);
 const crhip_device_info *cr_device_info(void);
 
+/* What plans that differ only in their increment share: the polyphase rows are a function of the fractional position,
+   the configuration and the table - not of the increment, which only decides which fractions a stream visits.  A
+   variable-rate client that keeps its low-pass (every pure upsampler: clownresampler.h:968 gives the same
+   configuration for any output rate >= the input rate) therefore pays for the rows once.  Reference-counted. */
+typedef struct cr_plan_store
+{
+	int refs;
+	uint32_t table_len;
+	int32_t *d_table;       /* caller's table as int32 (generic kernel) */
+	cr_poly poly;           /* host copy of the rows + row-index form (owns its arrays) */
+	int32_t *d_rows;        /* device image of the rows, NULL until a plan needs it */
+	int rows_layout;        /* CR_IMAGE_* of d_rows */
+	uint32_t plane_rows, swizzle, device_row_stride;
+} cr_plan_store;
+
 /* The plan object behind the public opaque ClownResamplerAMD_Plan. */
 typedef struct ClownResamplerAMD_Plan
 {
@@ -38,10 +53,16 @@ typedef struct ClownResamplerAMD_Plan
 	uint32_t channels;
 	uint64_t increment;
 	int device;
-	/* contents */
+	uint32_t key_variant;   /* the variant that was current when the plan was made (`variant` below is the one it ended up with) */
+	/* cache bookkeeping (under the context lock) */
+	int pinned;             /* handed out by ClownResamplerAMD_PlanCreate: never evicted */
+	unsigned users;         /* calls in progress that hold the plan (cr_plan_get .. cr_plan_release) */
+	uint64_t last_use;
+	/* contents: `poly`, `d_table` and `d_rows` are VIEWS of the store's */
+	cr_plan_store *store;
 	uint32_t table_len;
-	int32_t *d_table;       /* caller's table as int32 (generic kernel) */
-	cr_poly poly;           /* host copy of the rows + row-index form */
+	int32_t *d_table;
+	cr_poly poly;
 	int use_poly;
 	const char *generic_reason;
 	int32_t *d_rows;
@@ -52,11 +73,15 @@ typedef struct ClownResamplerAMD_Plan
 } ClownResamplerAMD_Plan;
 
 /* Cache lookup by (hash of the caller's raw table bytes, radius, configuration, channels, increment); on a miss
-   `fill_table(user, dst)` is asked to write the table as int32 and the plan is built and uploaded.
-   NULL after cr_fail. */
+   `fill_table(user, dst)` is asked to write the table as int32 and the plan is built (sharing the rows of a plan that
+   differs only in its increment, if there is one) and uploaded.  NULL after cr_fail.
+   The caller holds the plan until cr_plan_release; with `pin` the plan additionally stays valid until Shutdown.
+   Unpinned plans nobody holds are dropped, least recently used first, once there are more than
+   ClownResamplerAMD_SetPlanCacheLimit of them. */
 typedef int (*cr_table_fill)(const void *user, int32_t *dst, size_t count);
 ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_table_fill fill_table, const void *user,
-                                    unsigned radius, const cr_config *cfg, uint32_t channels, uint64_t increment);
+                                    unsigned radius, const cr_config *cfg, uint32_t channels, uint64_t increment, int pin);
+void cr_plan_release(const ClownResamplerAMD_Plan *plan);
 
 /* Enqueues the computation of output frames [0, n_out) starting at (pos_int, pos_frac) on `stream`. 0 on success. */
 int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_t in_valid_bytes, void *d_out,

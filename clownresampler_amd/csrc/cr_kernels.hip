@@ -39,7 +39,10 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "crhip.h"
 
@@ -1580,7 +1583,25 @@ int crhip_poly_prepare(const crhip_poly_launch *launch)
 	if (fn == nullptr)
 		return (int)hipErrorInvalidValue;
 
-	return (int)hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)launch->lds_bytes);
+	// hipFuncSetAttribute costs ~0.2 ms: remember, per device, the largest size each instance has been opened up to, so that
+	// a client walking through many ratios (a new plan each) pays it once per instance
+	{
+		static std::mutex lock;
+		static std::map<std::pair<int, const void *>, uint32_t> opened;
+		int device = 0;
+		const hipError_t e = hipGetDevice(&device);
+		if (e != hipSuccess)
+			return (int)e;
+
+		std::lock_guard<std::mutex> guard(lock);
+		uint32_t &bytes = opened[std::make_pair(device, (const void *)fn)];
+		if (bytes >= launch->lds_bytes)
+			return 0;
+		const hipError_t r = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)launch->lds_bytes);
+		if (r == hipSuccess)
+			bytes = launch->lds_bytes;
+		return (int)r;
+	}
 }
 
 int crhip_launch_poly(const crhip_poly_launch *launch, void *stream)

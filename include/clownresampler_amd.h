@@ -106,6 +106,7 @@ int ClownResamplerAMD_PlanShard(const ClownResampler_LowLevel_State *state, size
  #define ClownResampler_LowLevel_ResampleBulk CLOWNRESAMPLER_AMD_SYM(ClownResampler_LowLevel_ResampleBulk)
  #define ClownResampler_LowLevel_ResampleBulkS16 CLOWNRESAMPLER_AMD_SYM(ClownResampler_LowLevel_ResampleBulkS16)
  #define ClownResamplerAMD_PlanCreate          CLOWNRESAMPLER_AMD_SYM(ClownResamplerAMD_PlanCreate)
+ #define ClownResamplerAMD_ResampleSegmentsDevice CLOWNRESAMPLER_AMD_SYM(ClownResamplerAMD_ResampleSegmentsDevice)
 #endif
 
 /* Same arguments as ClownResampler_LowLevel_Resample with (output, output_capacity_frames) in place of the
@@ -146,6 +147,13 @@ typedef struct ClownResamplerAMD_PlanInfo
 ClownResamplerAMD_Plan *ClownResamplerAMD_PlanCreate(const ClownResampler_LowLevel_State *state, const ClownResampler_Precomputed *precomputed);
 void ClownResamplerAMD_PlanGetInfo(const ClownResamplerAMD_Plan *plan, ClownResamplerAMD_PlanInfo *info);
 
+/* Plans are cached by the CONTENTS of (table, configuration, channels, increment); plans that differ only in their
+   increment share one copy of the rows.  Plans made by the library on behalf of the reference-signature calls are
+   dropped, least recently used first, once there are more than `plans` of them (default 64; their device memory is
+   released with hipFree, which waits for the device).  Plans returned by ClownResamplerAMD_PlanCreate are never dropped. */
+void ClownResamplerAMD_SetPlanCacheLimit(size_t plans);
+size_t ClownResamplerAMD_PlanCacheCount(void);
+
 /* Debug/test access to the host copy of the polyphase rows (rows * row_stride int32). */
 const int32_t *ClownResamplerAMD_PlanRows(const ClownResamplerAMD_Plan *plan);
 /* Row index the kernels compute for a fractional position (host mirror of the device formula). */
@@ -170,6 +178,33 @@ size_t ClownResamplerAMD_ResampleDevice(ClownResamplerAMD_Plan *plan, ClownResam
 /* As ClownResamplerAMD_ResampleDevice, with device_output an int16 buffer and the clamp of
    ClownResampler_LowLevel_ResampleBulkS16 (4 bytes less write traffic per output sample). */
 size_t ClownResamplerAMD_ResampleDeviceS16(ClownResamplerAMD_Plan *plan, ClownResampler_LowLevel_State *resampler, const void *device_input, size_t *total_input_frames, void *device_output, size_t output_capacity_frames, void *hip_stream, cc_bool *ran_out_of_input);
+
+/* ---------------------------------------------------------------------------------------------
+ * Variable rate (mid-stream ClownResampler_LowLevel_Adjust, clownresampler.h:1052-1056) on the device.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ClownResamplerAMD_Segment
+{
+	size_t input_frames;                    /* frames of the input timeline this segment covers */
+	cc_u32f input_sample_rate;              /* arguments of the ClownResampler_LowLevel_Adjust applied before it */
+	cc_u32f output_sample_rate;
+	cc_u32f low_pass_filter_sample_rate;
+} ClownResamplerAMD_Segment;
+
+/* Resamples one contiguous device-resident timeline piecewise: for each segment, in order, the state is re-configured
+   with ClownResampler_LowLevel_Adjust and the segment's input frames are resampled until they run out, the position
+   (overshoot and fraction) carrying over - frame for frame what the reference produces when a caller alternates
+   ClownResampler_LowLevel_Adjust and ClownResampler_LowLevel_Resample over consecutive chunks of one buffer.
+   device_timeline points at input frame 0 (NOT at a padding); halo_frames frames must be readable before it and after
+   the last segment's end, and every segment's integer_stretched_kernel_radius must fit in them (the caller zeroes the
+   halo for the reference's zero padding at the ends of the stream).  device_output receives the segments' frames back
+   to back: int32, or clamped int16 when output_is_s16.  segment_output_frames (may be NULL) receives the frame count
+   of each segment.  One launch per non-empty segment on hip_stream, no synchronisation; everything is validated
+   before the first launch (a rejected rate triple, a halo too small or an output too small is reported through the
+   error handler, 0 is returned and nothing is enqueued).  On success *resampler is left as the reference leaves it
+   after the last chunk, and the total frame count is returned. */
+size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed,
+                                                const void *device_timeline, size_t halo_frames, const ClownResamplerAMD_Segment *segments, size_t segment_count,
+                                                void *device_output, size_t output_capacity_frames, int output_is_s16, size_t *segment_output_frames, void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -244,6 +244,107 @@ def test_adjust_between_calls(products):
     assert np.array_equal(np.concatenate(got), np.concatenate(want))
 
 
+def _oracle_segments(o, ch, pcm, frames, halo, segments, first_rates):
+    """The reference sequence ClownResamplerAMD_ResampleSegmentsDevice stands for: Adjust, then a low-level call on the next chunk
+    of ONE timeline whose padding is the real neighbouring frames (clownresampler.h:725-733, :1052-1056)."""
+    ok, st = o.low_init(ch, *first_rates)
+    padded = ck.pad_frames(pcm, ch, halo)
+    pos, out, counts = 0, [], []
+    for n, *rates in segments:
+        assert o.low_adjust(st, *rates)
+        R = int(st.cfg.radius_frames)
+        x, left, ran_out = o.low_resample_i32(st, padded[(pos + halo - R) * ch:], n)
+        assert left == 0 and ran_out == 1
+        out.append(x); counts.append(len(x) // ch)
+        pos += n
+    return np.concatenate(out), counts, st
+
+
+@pytest.mark.parametrize("radius,ch,s16", [(3, 2, False), (3, 1, False), (3, 5, True), (8, 2, False)])
+def test_variable_rate_segments_on_device(products, radius, ch, s16):
+    """a list of constant-rate segments over one device-resident timeline = Adjust + LowLevel_Resample per chunk
+    in the reference, position carried across every re-configuration; one launch per segment, nothing synchronised in between."""
+    import torch
+    p, o = products[radius], ck.oracle(radius)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77 + radius + ch)
+    first = (44100, 48000, 44100)
+    segments = [(20000, 44100, 48000, 44100), (1, 48000, 44100, 44100), (0, 44100, 44100, 44100), (15000, 48000, 44100, 44100),
+                (9000, 44100, 44100, 22050), (3, 44100, 8000, 8000), (16000, 44100, 88200, 44100), (2, 8000, 44100, 8000)]
+    segments += [(int(rng.integers(1, 4000)), int(rng.integers(8000, 96000)), int(rng.integers(8000, 96000)), int(rng.integers(8000, 96000))) for _ in range(24)]
+    frames = sum(s[0] for s in segments)
+    halo = 8 * 12 + 2                                     # 8000 -> 96000 with a low-pass of 8000 on radius 8 needs 96 frames
+    pcm = ck.noise_pcm(frames * ch, 5)
+    want, want_counts, ost = _oracle_segments(o, ch, pcm, frames, halo, segments, first)
+    if s16:
+        want = np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16)
+
+    st = p.api.LowLevel_State()
+    p.api.LowLevel_Init(st, ch, *first)
+    d_in = torch.from_numpy(ck.pad_frames(pcm, ch, halo)).to(dev)
+    d_out = torch.zeros(len(want) + 64, dtype=torch.int16 if s16 else torch.int32, device=dev)
+    n, counts = p.api.ResampleSegmentsDevice(st, p.pre, d_in.data_ptr() + halo * ch * 2, halo, segments, d_out.data_ptr(), len(want) // ch, s16=s16)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert n == len(want) // ch and counts == want_counts
+    assert np.array_equal(got[:len(want)], want) and not got[len(want):].any()
+    assert (st.lowest_level.stretched_kernel_radius, st.position_integer, st.position_fractional, st.increment) == \
+           (ost.cfg.stretched_radius, ost.pos_int, ost.pos_frac, ost.increment)
+
+
+def test_variable_rate_segments_validate_before_launching(products):
+    """A rejected rate triple, a halo too small for one of the segments or an output too small: reported, state untouched, nothing written."""
+    import torch
+    p = products[3]
+    dev = torch.device("cuda", 0)
+    ch, halo = 2, 3
+    d_in = torch.zeros((1000 + 2 * halo) * ch, dtype=torch.int16, device=dev)
+    d_out = torch.full((4000 * ch,), 12345, dtype=torch.int32, device=dev)
+    for segments, capacity in [([(500, 44100, 48000, 44100), (500, 44100, 0, 44100)], 4000),          # zero rate: LowLevel_Adjust says no
+                               ([(500, 44100, 48000, 44100), (500, 48000, 8000, 8000)], 4000),        # needs 18 frames of halo
+                               ([(500, 44100, 48000, 44100), (500, 44100, 88200, 44100)], 1000)]:     # 1,545 frames do not fit
+        st = p.api.LowLevel_State()
+        p.api.LowLevel_Init(st, ch, 44100, 48000, 44100)
+        before = bytes(st)
+        with pytest.raises(cr.ClownResamplerError):
+            p.api.ResampleSegmentsDevice(st, p.pre, d_in.data_ptr() + halo * ch * 2, halo, segments, d_out.data_ptr(), capacity)
+        torch.cuda.synchronize()
+        assert bytes(st) == before and bool((d_out == 12345).all())
+
+
+def test_plan_cache_is_bounded_and_shares_rows(products):
+    """A variable-rate client walks through many ratios: plans the library makes for the reference-signature calls are dropped
+    least-recently-used beyond the limit (results unaffected), plans from PlanCreate stay, and the results of a plan whose rows
+    are shared with a sibling of another increment are still the oracle's."""
+    p, o = products[3], ck.oracle(3)
+    ch, frames = 2, 3000
+    pcm = ck.noise_pcm(frames * ch, 9)
+    p.api.Shutdown()
+    p.api.SetPlanCacheLimit(5)
+    try:
+        pinned_state = p.api.LowLevel_State()
+        p.api.LowLevel_Init(pinned_state, ch, 44100, 50000, 44100)
+        pinned = p.api.PlanCreate(pinned_state, p.pre)
+        assert p.api.PlanCacheCount() == 1
+        for k in range(40):
+            # even k: pure upsampling, one configuration, 20 increments (shared rows); odd k: 20 different configurations
+            rates = (44100, 48000 + k, 44100) if k % 2 == 0 else (48000 + k, 44100, 44100)
+            ok, a = p.low_init(ch, *rates)
+            ok, b = o.low_init(ch, *rates)
+            padded = ck.pad_frames(pcm, ch, int(b.cfg.radius_frames))
+            xa, la, ra = p.low_resample_i32(a, padded, frames)
+            xb, lb, rb = o.low_resample_i32(b, padded, frames)
+            assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple()
+            assert p.api.PlanCacheCount() <= 1 + 5
+        assert p.api.PlanCacheCount() == 1 + 5
+        info = p.api.PlanGetInfo(pinned)                 # still alive
+        assert info.channels == ch and info.rows > 0
+        p.api.SetPlanCacheLimit(0)
+        assert p.api.PlanCacheCount() == 1
+    finally:
+        p.api.SetPlanCacheLimit(64)
+
+
 @pytest.mark.parametrize("window", [0, 5000, 1 << 18])
 def test_highlevel_stop_and_resume_any_window(products, window):
     """ClownResampler_HighLevel_Resample with the output callback stopping every 1,000 frames, then ResampleEnd; the input is

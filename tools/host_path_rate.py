@@ -10,6 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ctypes as C  # noqa: E402
+import torch  # noqa: E402
+torch.cuda.init()   # before the library's own first HIP call: torch refuses to initialise afterwards on this image
 import numpy as np  # noqa: E402
 import _checkers as ck  # noqa: E402
 import _product  # noqa: E402
@@ -89,3 +91,24 @@ for rep in range(2):
     f2(C.addressof(hs), C.addressof(p.pre), C.cast(hl.push, C.c_void_p), C.addressof(io))
     dt = time.perf_counter() - t0
     print("HighLevel_Resample + ResampleEnd (1 min stereo, C callbacks, %d input pulls): %.1f ms  %.0f Msamples/s" % (io.pulls, dt * 1e3, io.n / dt / 1e6))
+
+# variable rate on the device (ClownResamplerAMD_ResampleSegmentsDevice): the cfg 2 timeline cut into constant-rate segments
+# whose output rate wanders around 48 kHz (clock drift, pitch bend), device-resident buffers, one launch per segment
+dev = torch.device("cuda", 0)
+halo = 4
+d_in = torch.from_numpy(ck.pad_frames(padded[3 * ch: (3 + frames) * ch], ch, halo)).to(dev)
+for seg_frames in (4410000, 441000, 44100, 4410):
+    nseg = frames // seg_frames
+    segs = [(seg_frames, 44100, 48000 + (k % 997) - 498, 44100) for k in range(nseg)]    # up to 997 distinct ratios, one configuration
+    d_out = torch.empty(int(frames * 48003 / 44100 + 16) * ch, dtype=torch.int32, device=dev)
+    for rep in range(3):
+        st = p.api.LowLevel_State()
+        p.api.LowLevel_Init(st, ch, *rates)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n, counts = p.api.ResampleSegmentsDevice(st, p.pre, d_in.data_ptr() + halo * ch * 2, halo, segs, d_out.data_ptr(), d_out.numel() // ch)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print("ResampleSegmentsDevice: %5d segments of %7d frames, up to 997 distinct ratios: host %.2f ms, done %.2f ms  %.0f Msamples/s"
+          % (nseg, seg_frames, (t1 - t0) * 1e3, dt * 1e3, n * ch / dt / 1e6))

@@ -344,6 +344,62 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	if (getenv("CLOWNRESAMPLER_AMD_NO_SPECIAL") != NULL) /* tuning hook: time the run-time-slot instance instead */
 		plan->specialised = 0;
 	crhip_poly_geometry(plan->channels, plan->specialised ? plan->poly.slots : 0xFFFFu, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
+	if (plan->vecs >= 200u)
+	{
+		/* k_up: a lane owns one input position and produces all of its output frames; a wave-tile is as many output
+		   frames as 64 positions are sure to cover, staged through LDS for coalesced stores.  Qualifies when there are
+		   at least two frames per position, the weight signs per slot are the ones the instance was compiled for, and
+		   rows + staging fit the LDS. */
+		uint32_t negmask = 0, pos_bits = 0, neg_bits = 0;
+		const uint32_t unit = plan->channels * 4u;
+		uint64_t wave_tile = ((uint64_t)63u << 16) / plan->increment + 1u;   /* 65535 + (wave_tile - 1) * increment < 64 * 65536 */
+		int ok = plan->increment <= 32768u && plan->increment >= 4096u
+		      && crhip_poly_up_negmask(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, &negmask);
+
+		if (ok)
+		{
+			cr_poly_slot_signs(&plan->poly, &pos_bits, &neg_bits);
+			ok = (neg_bits & ~negmask) == 0 && (pos_bits & negmask) == 0;
+		}
+
+		if (wave_tile > frames_multiple)
+			wave_tile = frames_multiple;
+		{
+			/* ... and no larger than the staging space one workgroup per CU leaves each wave */
+			const uint32_t waves = plan->threads / 64u;
+			const uint32_t fixed = rows_bytes + 16u + waves * 2u * 1024u;
+			const uint32_t lds = (uint32_t)g_info.max_lds_per_block < 160u * 1024u ? (uint32_t)g_info.max_lds_per_block : 160u * 1024u;
+			const uint64_t room = lds > fixed ? ((lds - fixed) / waves & ~15u) / unit : 0;
+
+			if (wave_tile > room)
+				wave_tile = room;
+			if (wave_tile < 64u)
+				ok = 0;
+		}
+
+		if (ok)
+		{
+			const uint32_t stage_bytes = ((uint32_t)wave_tile * unit + 15u) & ~15u;
+
+			plan->lds_bytes = rows_bytes + (plan->threads / 64u) * (2u * 1024u + stage_bytes) + 16u;
+			plan->tile_frames = (uint32_t)wave_tile * 4u;
+			per_cu = (160u * 1024u) / plan->lds_bytes;
+			if (per_cu > 2048u / plan->threads)
+				per_cu = 2048u / plan->threads;
+			if (per_cu >= 1u && plan->lds_bytes <= (uint32_t)g_info.max_lds_per_block)
+			{
+				plan->max_blocks = per_cu * (uint32_t)(g_info.compute_units > 0 ? g_info.compute_units : 256);
+				return;
+			}
+		}
+
+		if (getenv("CLOWNRESAMPLER_AMD_DEBUG") != NULL)
+			fprintf(stderr, "clownresampler_amd: k_up not used: increment %llu, ok %d, signs +%#x -%#x against mask %#x, wave tile %llu, lds %u of %d\n",
+			        (unsigned long long)plan->increment, ok, pos_bits, neg_bits, negmask, (unsigned long long)wave_tile, plan->lds_bytes, g_info.max_lds_per_block);
+		plan->variant = crhip_poly_up_fallback_variant(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
+		crhip_poly_geometry(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
+	}
+
 	if (plan->vecs >= 100u)
 	{
 		/* k_wave: every wave streams wave-tiles of 64 * 4 frames through a private, double-buffered (vecs - 100) KiB
@@ -943,7 +999,7 @@ int cr_run_single_frame(const ClownResamplerAMD_Plan *plan, const int16_t *host_
 void ClownResamplerAMD_PlanGetInfo(const ClownResamplerAMD_Plan *plan, ClownResamplerAMD_PlanInfo *info)
 {
 	memset(info, 0, sizeof(*info));
-	info->kernel = plan->use_poly ? (plan->vecs >= 100u ? 2u : 1u) : 0u;
+	info->kernel = plan->use_poly ? (plan->vecs >= 200u ? 3u : plan->vecs >= 100u ? 2u : 1u) : 0u;
 	info->variant = plan->variant;
 	info->channels = plan->channels;
 	info->slots = plan->poly.slots;

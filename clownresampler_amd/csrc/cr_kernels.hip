@@ -1149,6 +1149,355 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave(const crhip_poly_launch a)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_up - input-stationary form for strong pure upsampling (increment <= 32768: two or more output frames per input
+// position).  k_poly / k_wave give every output frame its own lane, which then unpacks its whole tap window from LDS
+// and fixes up the truncation of every product from the product's sign (4 VALU per tap and channel, ~15 cycles).
+// When several output frames share one integer position they share the WINDOW, and in pure upsampling the weight a
+// window frame meets always comes from the same lobe of the kernel, so its sign is known per slot at compile time
+// (NEGMASK; the host checks the plan's rows against it).  So here a lane owns one INPUT position: it unpacks the
+// window once into sign-extended samples S and truncation biases B (0xFFFF where sample * weight will be negative,
+// decided by the sample's sign alone), and then every frame of that position costs per tap and channel
+//     x = v_mad_i32_i24(S, w, B);   acc += x >> 16          (2-3 VALU, ~8.5 cycles)
+// which is the reference's (sample * weight) / 65536 with C truncation (clownresampler.h:1020 via :625), exactly.
+// A lane's frames are consecutive in the output, so results are staged through LDS and leave as coalesced stores.
+// Wave-autonomous like k_wave: no barrier after the rows are staged; work is drawn in chunks of 4 wave-tiles.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wait_vmcnt_at_most(unsigned n)
+{
+	// s_waitcnt takes a literal: one arm per count (n is wave-uniform)
+	switch (n)
+	{
+#define CRHIP_WAIT_ARM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+		CRHIP_WAIT_ARM(1) CRHIP_WAIT_ARM(2) CRHIP_WAIT_ARM(3) CRHIP_WAIT_ARM(4) CRHIP_WAIT_ARM(5) CRHIP_WAIT_ARM(6) CRHIP_WAIT_ARM(7) CRHIP_WAIT_ARM(8)
+		CRHIP_WAIT_ARM(9) CRHIP_WAIT_ARM(10) CRHIP_WAIT_ARM(11) CRHIP_WAIT_ARM(12) CRHIP_WAIT_ARM(13) CRHIP_WAIT_ARM(14) CRHIP_WAIT_ARM(15) CRHIP_WAIT_ARM(16)
+		CRHIP_WAIT_ARM(17) CRHIP_WAIT_ARM(18) CRHIP_WAIT_ARM(19) CRHIP_WAIT_ARM(20) CRHIP_WAIT_ARM(21) CRHIP_WAIT_ARM(22) CRHIP_WAIT_ARM(23) CRHIP_WAIT_ARM(24)
+		CRHIP_WAIT_ARM(25) CRHIP_WAIT_ARM(26) CRHIP_WAIT_ARM(27) CRHIP_WAIT_ARM(28) CRHIP_WAIT_ARM(29) CRHIP_WAIT_ARM(30) CRHIP_WAIT_ARM(31) CRHIP_WAIT_ARM(32)
+#undef CRHIP_WAIT_ARM
+		default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+	}
+}
+
+template <int CH, int TT, int NORM, unsigned NEGMASK, int WAVES, int OUT16, int NT>
+__global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
+{
+	constexpr unsigned NTHREADS = WAVES * 64u;
+	constexpr unsigned FB = CH * 2;                // bytes per input frame
+	constexpr unsigned CW = 4;                     // wave-tiles per chunk (ticket)
+	constexpr unsigned BUF = 1024u;                // bytes per window buffer: one 16-byte DMA per lane
+	constexpr unsigned UNIT = OUT16 ? CH * 2 : CH * 4;   // bytes per output frame
+	constexpr int RS = (TT + 1 + 3) & ~3;
+	static_assert((63 + TT) * FB + 16 <= BUF, "the window of 64 input positions must fit one DMA piece");
+	static_assert(UNIT % 4 == 0, "output frames are moved as dwords");
+	constexpr unsigned VEC = UNIT % 8 == 0 ? 8 : 4;   // bytes per lane per store
+
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+	const unsigned tid = threadIdx.x;
+	const unsigned lane = tid & 63u;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+	const unsigned CHUNK = a.tile_frames;          // output frames per ticket
+	const unsigned WT = CHUNK / CW;                // output frames per wave-tile: at most 64 input positions (host)
+	const unsigned stage_bytes = (WT * UNIT + 15u) & ~15u;
+
+	const unsigned rows_bytes = a.plane_rows * a.row_stride * 4u;
+	const int *rows = reinterpret_cast<const int *>(smem);
+	unsigned char *my_buf = smem + rows_bytes + wave * (2u * BUF + stage_bytes);
+	unsigned char *my_stage = my_buf + 2u * BUF;
+
+	unsigned *waves_done = reinterpret_cast<unsigned *>(smem + rows_bytes + WAVES * (2u * BUF + stage_bytes));
+	if (tid == 0)
+		*waves_done = 0;
+
+	// stage the polyphase rows once per workgroup: the only barrier of the kernel
+	{
+		const unsigned nvec = rows_bytes / 16u;
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.d_rows);
+		u32x4 *dst = reinterpret_cast<u32x4 *>(smem);
+		for (unsigned i = tid; i < nvec; i += NTHREADS)
+			dst[i] = src[i];
+	}
+	__syncthreads();
+
+	const uint64_t n_chunks = (a.n_out + CHUNK - 1) / CHUNK;
+	const uint64_t global_wave = (uint64_t)blockIdx.x * WAVES + wave;
+	const uint64_t global_waves = (uint64_t)gridDim.x * WAVES;
+
+	// tickets: as in k_wave
+	const unsigned LANES = global_waves < 32u ? (unsigned)global_waves : 32u;
+	const unsigned lane_id = (unsigned)(global_wave % LANES);
+	const uint64_t lane_chunks = n_chunks > lane_id ? (n_chunks - lane_id + LANES - 1u) / LANES : 0;
+	const unsigned lane_waves = (unsigned)((global_waves - lane_id + LANES - 1u) / LANES);
+	unsigned *lane_counter = a.d_tickets + lane_id * 32u;
+	auto draw_issue = [&]() -> unsigned {
+		unsigned got = 0;
+		if (lane == 0)
+			got = __hip_atomic_fetch_add(lane_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return got;
+	};
+	auto draw_resolve = [&](unsigned got) -> uint64_t {
+		const uint64_t k = (uint64_t)lane_waves + __builtin_amdgcn_readfirstlane(got);
+		return k < lane_chunks ? lane_id + (uint64_t)LANES * k : ~0ull;
+	};
+	auto retire = [&]() {
+		if (lane == 0 && __hip_atomic_fetch_add(waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == WAVES - 1u)
+		{
+			unsigned *finished = a.d_tickets + 32u * 32u;
+			if (__hip_atomic_fetch_add(finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u)
+			{
+				for (unsigned c = 0; c < 32u; ++c)
+					__hip_atomic_store(a.d_tickets + c * 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	};
+
+	const uint64_t in_base = reinterpret_cast<uint64_t>(a.d_in);
+	const uint64_t in_end = in_base + a.in_valid_bytes;
+	const float inv_increment = __builtin_amdgcn_rcpf((float)a.increment);
+
+	// LDS-DMA of the input window of the wave-tile of `n` frames starting at output frame `first` into `buf`; returns the
+	// byte offset of the window's first frame inside the buffer.  Not waited for.
+	auto fetch = [&](uint64_t first, unsigned n, unsigned char *buf) -> unsigned {
+		const uint64_t pos = a.pos0 + first * (uint64_t)a.increment;
+		const uint64_t first_byte = in_base + ((pos >> 16) + a.first_slot) * FB;
+		const uint64_t aligned = first_byte & ~(uint64_t)15;
+		const unsigned shift = (unsigned)(first_byte - aligned);
+		const unsigned last_rel = (unsigned)(((pos & 0xFFFFu) + (uint64_t)(n - 1) * a.increment) >> 16);
+		uint64_t want = (uint64_t)shift + (uint64_t)(last_rel + TT) * FB;
+		uint64_t avail = in_end > aligned ? in_end - aligned : 0;
+		if (want > avail)
+			want = avail;
+		want = (want + 3u) & ~(uint64_t)3u;   // whole dwords: see k_poly
+		const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)aligned);
+		const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(aligned >> 32));
+		const unsigned rec = __builtin_amdgcn_readfirstlane((unsigned)want);
+		const __amdgpu_buffer_rsrc_t rsrc =
+		    __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)rec, 0x00020000);
+		__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)buf, 16, (int)(lane * 16u), 0, 0, 0);
+		return shift;
+	};
+
+	// smallest k with frac0 + k * increment >= l * 65536: the first frame (relative to the wave-tile) of input position l
+	auto first_frame_of = [&](unsigned l, unsigned frac0) -> unsigned {
+		if (l == 0)
+			return 0;
+		const unsigned x = (l << 16) - frac0;                     // 1 .. 2^22
+		unsigned k = (unsigned)((float)x * inv_increment);        // within one of the quotient; made exact below
+		k += (__umul24(k, a.increment) < x) ? 1u : 0u;
+		k += (__umul24(k, a.increment) < x) ? 1u : 0u;
+		k -= (k != 0 && __umul24(k - 1u, a.increment) >= x) ? 1u : 0u;
+		k -= (k != 0 && __umul24(k - 1u, a.increment) >= x) ? 1u : 0u;
+		return k;
+	};
+
+	// one wave-tile: n output frames from `first`, window at `base`; returns the number of store instructions issued
+	auto wave_tile = [&](uint64_t first, unsigned n, const unsigned char *base) -> unsigned {
+		const uint64_t pos = a.pos0 + first * (uint64_t)a.increment;
+		const unsigned frac0 = (unsigned)(pos & 0xFFFFu);
+		unsigned k = first_frame_of(lane, frac0);
+		unsigned k_end = first_frame_of(lane + 1u, frac0);
+		k = k < n ? k : n;
+		k_end = k_end < n ? k_end : n;
+
+		// the window of this lane's input position, unpacked once
+		int S[TT][CH], B[TT][CH];
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+		{
+			Frame<CH> f;
+			f.load(base + (lane + (unsigned)s) * FB);
+#pragma unroll
+			for (int c = 0; c < CH; ++c)
+			{
+				int sample;
+				if constexpr (Frame<CH>::PACKED)
+					sample = (c & 1) ? (f.v[c / 2] >> 16) : (int)(short)f.v[c / 2];
+				else
+					sample = f.v[c];
+				S[s][c] = sample;
+				// the product with this slot's weight is negative iff the sample's sign differs from the slot's
+				B[s][c] = (int)((unsigned)(((NEGMASK >> s) & 1u) ? -sample : sample) >> 16);
+				asm volatile("" : "+v"(B[s][c]));   // keep it in a register: hipcc otherwise recomputes the shift in every frame
+			}
+		}
+
+		unsigned frac = frac0 + __umul24(k, a.increment) - (lane << 16);   // fraction of frame k: its integer position is lane's
+
+		auto read_row = [&](unsigned fraction, int (&w)[RS]) {
+			const unsigned row = (65536u - (fraction & 0xFFFFu)) >> 6;   // (the masked case is a prefetch past the lane's last frame)
+			const i32x4 *plane0 = reinterpret_cast<const i32x4 *>(rows) + row;
+#pragma unroll
+			for (int q = 0; q < RS / 4; ++q)
+			{
+				const i32x4 v = plane0[q * a.plane_rows];
+				w[4 * q] = v.x;
+				w[4 * q + 1] = v.y;
+				w[4 * q + 2] = v.z;
+				w[4 * q + 3] = v.w;
+			}
+		};
+		auto one = [&](const int (&w)[RS], unsigned at) {
+			int acc[CH], acc2[CH];
+#pragma unroll
+			for (int c = 0; c < CH; ++c)
+				acc[c] = acc2[c] = 0;
+#pragma unroll
+			for (int s = 0; s < TT; ++s)
+			{
+#pragma unroll
+				for (int c = 0; c < CH; ++c)
+				{
+					const int term = (__mul24(S[s][c], w[s]) + B[s][c]) >> 16;
+					if (s & 1)
+						acc2[c] += term;
+					else
+						acc[c] += term;
+				}
+			}
+
+			int outv[CH];
+#pragma unroll
+			for (int c = 0; c < CH; ++c)
+				outv[c] = normalise<NORM>(acc[c] + acc2[c], w[TT]);
+
+			if constexpr (OUT16)
+			{
+				int *dst = reinterpret_cast<int *>(my_stage) + at * (CH / 2);
+#pragma unroll
+				for (int c = 0; c < CH; c += 2)
+					dst[c / 2] = (clamp_s16(outv[c]) & 0xFFFF) | (clamp_s16(outv[c + 1]) << 16);
+			}
+			else
+			{
+				int *dst = reinterpret_cast<int *>(my_stage) + at * CH;
+#pragma unroll
+				for (int c = 0; c < CH; ++c)
+					dst[c] = outv[c];
+			}
+		};
+
+		// the row of frame k + 1 is read before the arithmetic of frame k (two register sets, loop unrolled by two)
+		int wa[RS], wb[RS];
+		if (k < k_end)
+			read_row(frac, wa);
+		while (k < k_end)
+		{
+			read_row(frac + a.increment, wb);
+			__builtin_amdgcn_sched_barrier(0);
+			one(wa, k);
+			++k;
+			frac += a.increment;
+			if (k >= k_end)
+				break;
+			read_row(frac + a.increment, wa);
+			__builtin_amdgcn_sched_barrier(0);
+			one(wb, k);
+			++k;
+			frac += a.increment;
+		}
+
+		// the staged frames of the other lanes: same wave, LDS operations of a wave complete in order
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+		const unsigned vectors = n * UNIT / VEC;
+		unsigned char *out = reinterpret_cast<unsigned char *>(a.d_out) + first * UNIT;
+		unsigned stores = 0;
+		typedef typename std::conditional<VEC == 8, i32x2, int>::type vec_t;
+		const vec_t *staged = reinterpret_cast<const vec_t *>(my_stage);
+		vec_t *dst = reinterpret_cast<vec_t *>(out);
+		auto put = [&](unsigned i, vec_t v) {
+			if constexpr (NT)
+				__builtin_nontemporal_store(v, dst + i);
+			else
+				dst[i] = v;
+		};
+		unsigned done = 0;   // wave-uniform
+		// four LDS reads in flight per trip: a read-then-store pair at a time would pay the LDS latency per store
+		for (; done + 256u <= vectors; done += 256u)
+		{
+			const unsigned i = done + lane;
+			const vec_t v0 = staged[i], v1 = staged[i + 64u], v2 = staged[i + 128u], v3 = staged[i + 192u];
+			put(i, v0);
+			put(i + 64u, v1);
+			put(i + 128u, v2);
+			put(i + 192u, v3);
+		}
+		for (unsigned i = done + lane; i < vectors; i += 64u)
+			put(i, staged[i]);
+		stores = (vectors + 63u) / 64u;
+		__builtin_amdgcn_wave_barrier();
+		return __builtin_amdgcn_readfirstlane(stores);
+	};
+
+	if (global_wave >= n_chunks)
+	{
+		retire();
+		return;
+	}
+
+	uint64_t chunk = global_wave;
+	unsigned cur = 0, shift = 0;
+	{
+		const uint64_t first = chunk * CHUNK;
+		const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
+		shift = fetch(first, n, my_buf);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+
+	for (;;)
+	{
+		const unsigned ticket = draw_issue();          // one chunk ahead; resolved at the end of this chunk
+		uint64_t next_chunk = ~0ull;
+		const uint64_t chunk_first = chunk * CHUNK;
+		const uint64_t chunk_end = (chunk_first + CHUNK < a.n_out) ? chunk_first + CHUNK : a.n_out;
+
+		for (uint64_t first = chunk_first; first < chunk_end; first += WT)
+		{
+			const unsigned n = (unsigned)((chunk_end - first < WT) ? (chunk_end - first) : WT);
+			unsigned shift_next = 0;
+			bool have_next = true;
+
+			// start the DMA of the wave-tile after this one (its buffer was consumed one step ago)
+			if (first + WT < chunk_end)
+			{
+				const uint64_t nf = first + WT;
+				const unsigned nn = (unsigned)((chunk_end - nf < WT) ? (chunk_end - nf) : WT);
+				shift_next = fetch(nf, nn, my_buf + (cur ^ 1u) * BUF);
+			}
+			else
+			{
+				next_chunk = draw_resolve(ticket);
+				if (next_chunk != ~0ull)
+				{
+					const uint64_t nf = next_chunk * CHUNK;
+					const unsigned nn = (unsigned)((a.n_out - nf < WT) ? (a.n_out - nf) : WT);
+					shift_next = fetch(nf, nn, my_buf + (cur ^ 1u) * BUF);
+				}
+				else
+					have_next = false;
+			}
+
+			const unsigned stores = wave_tile(first, n, my_buf + cur * BUF + shift);
+
+			// the DMA was issued before this wave-tile's stores and vmcnt retires in order
+			if (have_next)
+				wait_vmcnt_at_most(stores);
+			cur ^= 1u;
+			shift = shift_next;
+		}
+
+		if (next_chunk == ~0ull)
+			break;
+		chunk = next_chunk;
+	}
+
+	retire();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // k_generic - reference arithmetic, 64-bit, one lane per output frame (clownresampler.h:986-1035)
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_generic(const crhip_generic_launch a)
@@ -1256,7 +1605,14 @@ struct special
 	poly_fn wave16;             // k_wave, int16 output
 	bool dynamic_tiles;         // k_poly: draw tiles as tickets (measured per instance; see crhip_poly_launch.dynamic_tiles)
 	poly_fn split[4];           // k_poly with two lanes per frame (variants SPLIT_VARIANT + i: geometry {4, 2} x nt {1, 0}); nullptr if none
+	poly_fn up[2];              // k_up (variants UP_VARIANT + {0: non-temporal stores, 1: plain}); nullptr if none
+	poly_fn up16;               // k_up, int16 output
+	uint32_t up_negmask;        // k_up: bit s set = the weights of slot s are <= 0 in every row, clear = >= 0 (checked by the host per plan)
 };
+
+constexpr uint32_t UP_VARIANT = 26;     // variant ids 26, 27 select k_up where the instance has one and the plan qualifies
+constexpr int UP_WAVES = 12;
+constexpr uint32_t UP_MAX_WAVE_TILE = 1024;   // output frames per wave-tile (LDS staging)
 
 constexpr uint32_t SPLIT_VARIANT = 22;   // variant ids 22..25
 constexpr int SPLIT_GEO[4] = {4, 2, 4, 2};
@@ -1265,10 +1621,17 @@ constexpr int SPLIT_NT[4] = {1, 1, 0, 0};
 constexpr uint32_t WAVE_VARIANT = 20;   // variant ids 20, 21 select k_wave where the instance has one
 constexpr int WAVE_WAVES = 16, WAVE_NVW = 1, WAVE_ITER = 4;
 
-template <int CH, int TT, int MODE, int NORM, int DV, bool WAVE = false, bool DYNAMIC = false>
+template <int CH, int TT, int MODE, int NORM, int DV, bool WAVE = false, bool DYNAMIC = false, unsigned UPMASK = 0>
 special make_special()
 {
-	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}};
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, UPMASK};
+	if constexpr (UPMASK != 0)
+	{
+		static_assert(MODE == CRHIP_ROWMODE_UPSAMPLE, "k_up is for pure upsampling");
+		s.up[0] = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 0, 1>;
+		s.up[1] = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 0, 0>;
+		s.up16 = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 1, 1>;
+	}
 	variant_table<CH, TT, MODE, NORM, 0>::fill(s.fn);
 	constexpr int KV = DV < 20 ? DV : 13;   // the k_poly variant behind a k_wave default (its fallback and int16 geometry)
 	s.fn16 = instance<CH, TT, MODE, NORM, KV % 5, 1, (KV / 5) % 2, (KV / 10) % 2, 1>();
@@ -1292,8 +1655,9 @@ special make_special()
 const special *specials(int *count)
 {
 	static const special table[] = {
-	    make_special<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 13, true, true>(),   // cfg 2 / cfg 5: stereo 44.1 -> 48 kHz, 3 lobes
-	    make_special<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 20, true>(),  // cfg 3: stereo 8 -> 96 kHz, 8 lobes
+	    // the k_up sign masks are those of a Lanczos window whose lobes are one input frame wide (slot 0 = first_slot)
+	    make_special<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 13, true, true, 0x12u>(),   // cfg 2 / cfg 5: stereo 44.1 -> 48 kHz, 3 lobes
+	    make_special<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 26, true, false, 0x2A55u>(),  // cfg 3: stereo 8 -> 96 kHz, 8 lobes (k_up from 2x upsampling on, k_wave below)
 	    make_special<8, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 2>(),     // cfg 4: 8 channels 48 -> 44.1 kHz
 	    make_special<1, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 13, true, true>(),   // mono upsampling, 3 lobes
 	    make_special<2, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>(),     // stereo mild downsampling, 3 lobes
@@ -1473,8 +1837,14 @@ static uint32_t resolve_variant(const special *sp, uint32_t variant, uint32_t ou
 		return WAVE_VARIANT;                                  // diagnostic k_wave instance: k_wave geometry
 	if (variant >= 1000u && variant < 1010u)
 		return 3u;                                            // diagnostic k_poly instances: headline geometry
-	if (variant >= SPLIT_VARIANT + 4u)
+	if (variant >= UP_VARIANT + 2u)
 		variant = sp->default_variant;
+	if (variant >= UP_VARIANT)
+	{
+		if (sp->up[0] != nullptr)
+			return variant;
+		variant = sp->wave[0] != nullptr ? WAVE_VARIANT : 13u;
+	}
 	if (variant >= SPLIT_VARIANT && sp->split[0] == nullptr)
 		variant = 13u;
 	if (variant >= WAVE_VARIANT && variant < SPLIT_VARIANT && sp->wave[0] == nullptr)
@@ -1496,7 +1866,22 @@ int crhip_poly_swizzled(uint32_t channels, uint32_t slots, uint32_t row_mode, ui
 
 int crhip_poly_variants(void)
 {
-	return VARIANTS + 6;   // + the two k_wave variants and the four two-lanes-per-frame variants
+	return VARIANTS + 8;   // + the two k_wave variants, the four two-lanes-per-frame variants and the two k_up variants
+}
+
+int crhip_poly_up_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t *negmask)
+{
+	const special *sp = find_special(channels, slots, row_mode, norm_mode);
+	if (sp == nullptr || sp->up[0] == nullptr)
+		return 0;
+	*negmask = sp->up_negmask;
+	return 1;
+}
+
+uint32_t crhip_poly_up_fallback_variant(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
+{
+	const special *sp = find_special(channels, slots, row_mode, norm_mode);
+	return sp != nullptr && sp->wave[0] != nullptr ? WAVE_VARIANT : 13u;
 }
 
 int crhip_poly_dynamic_default(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
@@ -1515,6 +1900,16 @@ void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, u
 {
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
 	const uint32_t v = sp != nullptr ? resolve_variant(sp, variant) : (uint32_t)runtime_geo((int)channels);
+
+	if (sp != nullptr && v >= UP_VARIANT)
+	{
+		// k_up: vecs = 200; frames_multiple = the cap on output frames per wave-tile (the host sizes the wave-tile so that
+		// it spans at most 64 input positions)
+		*threads = UP_WAVES * 64u;
+		*vecs = 200u;
+		*frames_multiple = UP_MAX_WAVE_TILE;
+		return;
+	}
 
 	if (sp != nullptr && v >= SPLIT_VARIANT)
 	{
@@ -1539,12 +1934,18 @@ void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, u
 	*frames_multiple = *threads * (1u << ((v / 5) % 2));
 }
 
-// geo: index into GEOMETRY, or 100 for k_wave
+// geo: index into GEOMETRY, 100 for k_wave, 200 for k_up
 static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 {
 	const special *sp = launch->specialised ? find_special(launch->channels, launch->slots, launch->row_mode, launch->norm_mode) : nullptr;
 	const uint32_t v = resolve_variant(sp, launch->variant, launch->out_s16);
 	poly_fn fn;
+
+	if (sp != nullptr && v >= UP_VARIANT)
+	{
+		*geo = 200u;
+		return launch->out_s16 ? sp->up16 : sp->up[v - UP_VARIANT];
+	}
 
 	if (sp != nullptr && v >= SPLIT_VARIANT)
 	{
@@ -1611,7 +2012,8 @@ int crhip_launch_poly(const crhip_poly_launch *launch, void *stream)
 
 	if (fn == nullptr)
 		return (int)hipErrorInvalidValue;
-	if (geo == 100u ? (launch->threads != WAVE_WAVES * 64u || launch->vecs != 100u + WAVE_NVW)
+	if (geo == 200u ? (launch->threads != UP_WAVES * 64u || launch->vecs != 200u || launch->tile_frames % 4u != 0 || launch->tile_frames / 4u > UP_MAX_WAVE_TILE)
+	  : geo == 100u ? (launch->threads != WAVE_WAVES * 64u || launch->vecs != 100u + WAVE_NVW)
 	                : (launch->threads != (uint32_t)GEOMETRY[geo].threads || launch->vecs != (uint32_t)GEOMETRY[geo].vecs))
 		return (int)hipErrorInvalidValue;
 	if (launch->n_out == 0)

@@ -451,6 +451,27 @@ static double swizzle_cost(const cr_poly *poly, uint64_t increment, uint32_t swi
 	return extra / 128.0;
 }
 
+void cr_poly_slot_signs(const cr_poly *poly, uint32_t *positive, uint32_t *negative)
+{
+	uint32_t row, slot;
+
+	*positive = 0;
+	*negative = 0;
+
+	for (row = 0; row < poly->rows; ++row)
+	{
+		for (slot = 0; slot < poly->slots && slot < 32u; ++slot)
+		{
+			const int32_t w = poly->weights[(size_t)row * poly->row_stride + slot];
+
+			if (w > 0)
+				*positive |= 1u << slot;
+			else if (w < 0)
+				*negative |= 1u << slot;
+		}
+	}
+}
+
 uint32_t cr_poly_pick_swizzle(const cr_poly *poly, uint64_t increment, double *conflict_plain, double *conflict_best)
 {
 	uint32_t best = 0, k;

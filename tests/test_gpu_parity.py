@@ -54,7 +54,7 @@ def test_fast_kernel_is_what_runs(products):
         p = products[radius]
         ok, st = p.low_init(ch, *rates)
         info = p.api.PlanGetInfo(p.api.PlanCreate(st.raw, p.pre))
-        assert info.kernel in (1, 2) and info.slots == slots and info.specialised == 1, info.asdict()
+        assert info.kernel in (1, 2, 3) and info.slots == slots and info.specialised == 1, info.asdict()
         assert info.lds_bytes <= 160 * 1024 and info.tile_frames >= info.threads
 
 
@@ -459,7 +459,7 @@ def test_random_configurations_bit_exact(products):
     whatever kernel the plan picks (specialised, run-time-slot, wave-autonomous, generic), the stream equals the oracle's."""
     import random
     rng = random.Random(20261002)
-    kernels = {0: 0, 1: 0, 2: 0}
+    kernels = {0: 0, 1: 0, 2: 0, 3: 0}
     done = 0
     while done < 300:
         radius = rng.choice([3, 3, 8])
@@ -492,6 +492,60 @@ def test_random_configurations_bit_exact(products):
         kernels[p.api.PlanGetInfo(p.api.PlanCreate(st.raw, p.pre)).kernel] += 1
         done += 1
     assert kernels[0] > 0 and kernels[1] > 0, kernels      # both the generic and the polyphase kernels were exercised
+
+
+@pytest.mark.parametrize("variant", [26, 27])
+@pytest.mark.parametrize("name", ["cfg3_1min", "cfg2_1min", "tiny_257"])
+def test_input_stationary_variants_on_golden_cases(golden, products, name, variant):
+    """Variants 26/27 ask for k_up; cfg 3 (12x) qualifies, cfg 2 (1.09x) does not and falls back - same bits either way."""
+    case = _cases.CASE_BY_NAME[name]
+    p = products[case["radius"]]
+    p.api.DebugSetVariant(variant)
+    try:
+        res = _cases.run_case(p, case)
+    finally:
+        p.api.DebugSetVariant(0xFFFF)
+    assert res == golden["cases"][name]
+
+
+@pytest.mark.parametrize("radius,rates", [(8, (8000, 96000, 8000)), (8, (22050, 44100, 22050)), (8, (8000, 127999, 8000)), (3, (11025, 44100, 11025)),
+                                         (3, (8000, 24000, 8000)), (3, (12000, 191999, 12000)), (3, (16000, 32001, 16000)), (3, (8000, 44100, 8000))])
+def test_input_stationary_kernel_bit_exact(products, radius, rates):
+    """k_up (one lane per INPUT position, truncation bias from the sample's sign and the slot's compile-time weight sign) against the
+    oracle: ratios 2x-16x, both radii, ragged lengths, a carried start position, a capacity stop, and the clamped int16 output."""
+    p, o = products[radius], ck.oracle(radius)
+    ch = 2
+    p.api.DebugSetVariant(26)
+    try:
+        for frames, first_call in [(1, 0), (63, 0), (4099, 0), (30011, 777)]:
+            pcm = ck.noise_pcm(frames * ch, 31 + frames)
+            ok, a = p.low_init(ch, *rates)
+            ok, b = o.low_init(ch, *rates)
+            info = p.api.PlanGetInfo(p.api.PlanCreate(a.raw, p.pre))
+            assert info.kernel == 3, (rates, info.kernel)
+            R = int(b.cfg.radius_frames)
+            padded = ck.pad_frames(pcm, ch, R)
+            if first_call:
+                # a first call stopped by its capacity leaves a fractional start position for the second
+                xa, la, ra = p.low_resample_i32(a, padded, frames, capacity=first_call)
+                xb, lb, rb = o.low_resample_i32(b, padded, frames, capacity=first_call)
+                assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple()
+                padded = padded[(frames - la) * ch:]
+                frames = la
+            xa, la, ra = p.low_resample_i32(a, padded, frames)
+            xb, lb, rb = o.low_resample_i32(b, padded, frames)
+            assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple()
+        # int16 form
+        frames = 20001
+        pcm = ck.noise_pcm(frames * ch, 5)
+        ok, a = p.low_init(ch, *rates)
+        ok, b = o.low_init(ch, *rates)
+        padded = ck.pad_frames(pcm, ch, int(b.cfg.radius_frames))
+        want32, _, _ = o.low_resample_i32(b, padded, frames)
+        got, left, ran_out = p.api.LowLevel_ResampleBulkS16(a.raw, p.pre, padded, frames)
+        assert np.array_equal(got, np.clip(want32, -0x7FFF, 0x7FFF).astype(np.int16))
+    finally:
+        p.api.DebugSetVariant(0xFFFF)
 
 
 @pytest.mark.parametrize("variant", [2, 4, 14, 22, 23, 24, 25])

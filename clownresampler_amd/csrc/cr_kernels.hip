@@ -1160,8 +1160,24 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave(const crhip_poly_launch a)
 //     x = v_mad_i32_i24(S, w, B);   acc += x >> 16          (2-3 VALU, ~8.5 cycles)
 // which is the reference's (sample * weight) / 65536 with C truncation (clownresampler.h:1020 via :625), exactly.
 // A lane's frames are consecutive in the output, so results are staged through LDS and leave as coalesced stores.
-// Wave-autonomous like k_wave: no barrier after the rows are staged; work is drawn in chunks of 4 wave-tiles.
+// Wave-autonomous like k_wave: no barrier after the rows are staged; wave-tiles are dealt round-robin.
 // ---------------------------------------------------------------------------------------------------------
+// k_up: one tap of two channels as one statement: x = sample * weight + bias (24-bit multiply-add, exact), acc += x >> 16
+// taken as the sign-extended high word of x.
+__device__ __forceinline__ void up_tap_pair(int &acc0, int &acc1, int sample0, int sample1, int weight, int bias0, int bias1)
+{
+	int x0, x1;
+	asm("v_mad_i32_i24 %2, %4, %6, %7\n\t"
+	    "v_mad_i32_i24 %3, %5, %6, %8\n\t"
+	    "v_add_u32_sdwa %0, %0, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_add_u32_sdwa %1, %1, sext(%3) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+	    : "+v"(acc0), "+v"(acc1), "=&v"(x0), "=&v"(x1)
+	    : "v"(sample0), "v"(sample1), "v"(weight), "v"(bias0), "v"(bias1));
+}
+
+// rows of a plane of the device image in pure-upsampling row mode: 1,025 rows ((65536 - fraction) >> 6), rounded up to 16
+constexpr unsigned UP_PLANE_ROWS = 1040;
+
 __device__ __forceinline__ void wait_vmcnt_at_most(unsigned n)
 {
 	// s_waitcnt takes a literal: one arm per count (n is wave-uniform)
@@ -1177,12 +1193,11 @@ __device__ __forceinline__ void wait_vmcnt_at_most(unsigned n)
 	}
 }
 
-template <int CH, int TT, int NORM, unsigned NEGMASK, int WAVES, int OUT16, int NT>
+template <int CH, int TT, int NORM, unsigned NEGMASK, int WAVES, int OUT16, int NT, int ABL = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 {
 	constexpr unsigned NTHREADS = WAVES * 64u;
 	constexpr unsigned FB = CH * 2;                // bytes per input frame
-	constexpr unsigned CW = 4;                     // wave-tiles per chunk (ticket)
 	constexpr unsigned BUF = 1024u;                // bytes per window buffer: one 16-byte DMA per lane
 	constexpr unsigned UNIT = OUT16 ? CH * 2 : CH * 4;   // bytes per output frame
 	constexpr int RS = (TT + 1 + 3) & ~3;
@@ -1196,8 +1211,29 @@ __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 	const unsigned lane = tid & 63u;
 	const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-	const unsigned CHUNK = a.tile_frames;          // output frames per ticket
-	const unsigned WT = CHUNK / CW;                // output frames per wave-tile: at most 64 input positions (host)
+	// diagnostic instance (ABL == 6, variant 1008) only: where wave 0's cycles go, summed over its wave-tiles - [0] DMA issue,
+	// ticket, the lane's frame range and the window unpack, [1] the frames, [2] staged results to global memory, [3] waiting
+	// for the next window (vmcnt)
+	unsigned long long stamp_cycles = 0, stamp_ticks = 0, phase[4] = {0, 0, 0, 0}, t_mark = 0;
+	if constexpr (ABL == 6)
+	{
+		stamp_cycles = __builtin_amdgcn_s_memtime();
+		stamp_ticks = __builtin_amdgcn_s_memrealtime();
+	}
+	auto mark = [&](int which) {
+		if constexpr (ABL == 6)
+		{
+			__builtin_amdgcn_sched_barrier(0);
+			const unsigned long long now = __builtin_amdgcn_s_memtime();
+			__builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): s_memtime returns through the scalar data path
+			if (which >= 0)
+				phase[which] += now - t_mark;
+			t_mark = now;
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	};
+
+	const unsigned WT = a.tile_frames / 4u;        // output frames per wave-tile: at most 64 input positions (the host passes 4 wave-tiles)
 	const unsigned stage_bytes = (WT * UNIT + 15u) & ~15u;
 
 	const unsigned rows_bytes = a.plane_rows * a.row_stride * 4u;
@@ -1205,9 +1241,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 	unsigned char *my_buf = smem + rows_bytes + wave * (2u * BUF + stage_bytes);
 	unsigned char *my_stage = my_buf + 2u * BUF;
 
-	unsigned *waves_done = reinterpret_cast<unsigned *>(smem + rows_bytes + WAVES * (2u * BUF + stage_bytes));
 	if (tid == 0)
-		*waves_done = 0;
+		*reinterpret_cast<unsigned *>(smem + rows_bytes + WAVES * (2u * BUF + stage_bytes)) = 0;
 
 	// stage the polyphase rows once per workgroup: the only barrier of the kernel
 	{
@@ -1219,35 +1254,32 @@ __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 	}
 	__syncthreads();
 
-	const uint64_t n_chunks = (a.n_out + CHUNK - 1) / CHUNK;
-	const uint64_t global_wave = (uint64_t)blockIdx.x * WAVES + wave;
-	const uint64_t global_waves = (uint64_t)gridDim.x * WAVES;
-
-	// tickets: as in k_wave
-	const unsigned LANES = global_waves < 32u ? (unsigned)global_waves : 32u;
-	const unsigned lane_id = (unsigned)(global_wave % LANES);
-	const uint64_t lane_chunks = n_chunks > lane_id ? (n_chunks - lane_id + LANES - 1u) / LANES : 0;
-	const unsigned lane_waves = (unsigned)((global_waves - lane_id + LANES - 1u) / LANES);
-	unsigned *lane_counter = a.d_tickets + lane_id * 32u;
-	auto draw_issue = [&]() -> unsigned {
-		unsigned got = 0;
+	// Wave-tiles are dealt round-robin to the WORKGROUPS of the persistent grid, and inside a workgroup its waves draw them
+	// from a counter in LDS.  The kernel is VALU-bound, so workgroups progress alike; waves of one SIMD do not (the oldest
+	// wave is issued first), and with a fixed share per wave the favoured waves leave early and the rest run on an
+	// under-occupied SIMD (measured: 199 us against 182).  Global tickets as in k_wave would balance that too, but reading a
+	// ticket's result costs a full vmcnt(0) drain - the atomic returns through the same counter as the wave-tile's stores -
+	// which measured at ~30 % of the kernel; an LDS atomic returns through lgkmcnt.
+	const uint64_t n_tiles = (a.n_out + WT - 1) / WT;
+	unsigned *next_draw = reinterpret_cast<unsigned *>(smem + rows_bytes + WAVES * (2u * BUF + stage_bytes));
+	auto draw = [&]() -> uint64_t {   // this workgroup's next wave-tile, or >= n_tiles
+		unsigned d = 0;
 		if (lane == 0)
-			got = __hip_atomic_fetch_add(lane_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		return got;
+			d = __hip_atomic_fetch_add(next_draw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		return (uint64_t)blockIdx.x + (uint64_t)gridDim.x * __builtin_amdgcn_readfirstlane(d);
 	};
-	auto draw_resolve = [&](unsigned got) -> uint64_t {
-		const uint64_t k = (uint64_t)lane_waves + __builtin_amdgcn_readfirstlane(got);
-		return k < lane_chunks ? lane_id + (uint64_t)LANES * k : ~0ull;
-	};
-	auto retire = [&]() {
-		if (lane == 0 && __hip_atomic_fetch_add(waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == WAVES - 1u)
+	auto finish = [&]() {
+		if constexpr (ABL == 6)
 		{
-			unsigned *finished = a.d_tickets + 32u * 32u;
-			if (__hip_atomic_fetch_add(finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u)
+			if (lane == 0 && wave == 0 && a.debug_stamps != nullptr)
 			{
-				for (unsigned c = 0; c < 32u; ++c)
-					__hip_atomic_store(a.d_tickets + c * 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				__hip_atomic_store(finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				a.debug_stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - stamp_cycles;
+				a.debug_stamps[4 * blockIdx.x + 1] = stamp_ticks;
+				a.debug_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+				a.debug_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(63508) & 0xF;
+				if (blockIdx.x < 64u)
+					for (int q = 0; q < 4; ++q)
+						a.debug_stamps[4 * 4096 + 4 * blockIdx.x + q] = phase[q];
 			}
 		}
 	};
@@ -1330,7 +1362,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 #pragma unroll
 			for (int q = 0; q < RS / 4; ++q)
 			{
-				const i32x4 v = plane0[q * a.plane_rows];
+				const i32x4 v = plane0[q * UP_PLANE_ROWS];   // compile-time stride: the three further planes are immediate offsets
 				w[4 * q] = v.x;
 				w[4 * q + 1] = v.y;
 				w[4 * q + 2] = v.z;
@@ -1338,28 +1370,35 @@ __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 			}
 		};
 		auto one = [&](const int (&w)[RS], unsigned at) {
-			int acc[CH], acc2[CH];
+			// The loop is VALU-bound, so instruction cycles are what matters.  Per tap and channel: one 24-bit multiply-add and one
+			// SDWA add that takes the high word of the product (the shift by 16) directly - 8.4 cycles per wave.  (A single
+			// full-rate v_mad_i64_i32 on (sample << 16) with the bias in the low dword of the addend, plus a plain add, is 6.6
+			// cycles on paper and bit-exact too, but measured slower: 168 VGPRs, spills, and a lower clock.)
+			int acc[CH];
 #pragma unroll
 			for (int c = 0; c < CH; ++c)
-				acc[c] = acc2[c] = 0;
+				acc[c] = (__mul24(S[0][c], w[0]) + B[0][c]) >> 16;
 #pragma unroll
-			for (int s = 0; s < TT; ++s)
+			for (int s = 1; s < TT; ++s)
 			{
-#pragma unroll
-				for (int c = 0; c < CH; ++c)
+				if constexpr (CH % 2 == 0)
 				{
-					const int term = (__mul24(S[s][c], w[s]) + B[s][c]) >> 16;
-					if (s & 1)
-						acc2[c] += term;
-					else
-						acc[c] += term;
+#pragma unroll
+					for (int c = 0; c < CH; c += 2)
+						up_tap_pair(acc[c], acc[c + 1], S[s][c], S[s][c + 1], w[s], B[s][c], B[s][c + 1]);
+				}
+				else
+				{
+#pragma unroll
+					for (int c = 0; c < CH; ++c)
+						acc[c] = sdwa_add_word1_signed(acc[c], __mul24(S[s][c], w[s]) + B[s][c]);
 				}
 			}
 
 			int outv[CH];
 #pragma unroll
 			for (int c = 0; c < CH; ++c)
-				outv[c] = normalise<NORM>(acc[c] + acc2[c], w[TT]);
+				outv[c] = normalise<NORM>(acc[c], w[TT]);
 
 			if constexpr (OUT16)
 			{
@@ -1377,6 +1416,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 			}
 		};
 
+		mark(0);
 		// the row of frame k + 1 is read before the arithmetic of frame k (two register sets, loop unrolled by two)
 		int wa[RS], wb[RS];
 		if (k < k_end)
@@ -1397,6 +1437,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 			frac += a.increment;
 		}
 
+		mark(1);
 		// the staged frames of the other lanes: same wave, LDS operations of a wave complete in order
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
@@ -1429,75 +1470,57 @@ __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 			put(i, staged[i]);
 		stores = (vectors + 63u) / 64u;
 		__builtin_amdgcn_wave_barrier();
+		mark(2);
 		return __builtin_amdgcn_readfirstlane(stores);
 	};
 
-	if (global_wave >= n_chunks)
+	uint64_t tile = draw();
+	if (tile >= n_tiles)
 	{
-		retire();
+		finish();
 		return;
 	}
 
-	uint64_t chunk = global_wave;
 	unsigned cur = 0, shift = 0;
 	{
-		const uint64_t first = chunk * CHUNK;
+		const uint64_t first = tile * WT;
 		const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
 		shift = fetch(first, n, my_buf);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	}
+	mark(-1);
 
 	for (;;)
 	{
-		const unsigned ticket = draw_issue();          // one chunk ahead; resolved at the end of this chunk
-		uint64_t next_chunk = ~0ull;
-		const uint64_t chunk_first = chunk * CHUNK;
-		const uint64_t chunk_end = (chunk_first + CHUNK < a.n_out) ? chunk_first + CHUNK : a.n_out;
+		const uint64_t first = tile * WT;
+		const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
+		const uint64_t next = draw();
+		const bool have_next = next < n_tiles;
+		unsigned shift_next = 0;
 
-		for (uint64_t first = chunk_first; first < chunk_end; first += WT)
+		// start the DMA of this wave's next wave-tile (its buffer was consumed one step ago)
+		if (have_next)
 		{
-			const unsigned n = (unsigned)((chunk_end - first < WT) ? (chunk_end - first) : WT);
-			unsigned shift_next = 0;
-			bool have_next = true;
-
-			// start the DMA of the wave-tile after this one (its buffer was consumed one step ago)
-			if (first + WT < chunk_end)
-			{
-				const uint64_t nf = first + WT;
-				const unsigned nn = (unsigned)((chunk_end - nf < WT) ? (chunk_end - nf) : WT);
-				shift_next = fetch(nf, nn, my_buf + (cur ^ 1u) * BUF);
-			}
-			else
-			{
-				next_chunk = draw_resolve(ticket);
-				if (next_chunk != ~0ull)
-				{
-					const uint64_t nf = next_chunk * CHUNK;
-					const unsigned nn = (unsigned)((a.n_out - nf < WT) ? (a.n_out - nf) : WT);
-					shift_next = fetch(nf, nn, my_buf + (cur ^ 1u) * BUF);
-				}
-				else
-					have_next = false;
-			}
-
-			const unsigned stores = wave_tile(first, n, my_buf + cur * BUF + shift);
-
-			// the DMA was issued before this wave-tile's stores and vmcnt retires in order
-			if (have_next)
-				wait_vmcnt_at_most(stores);
-			cur ^= 1u;
-			shift = shift_next;
+			const uint64_t nf = next * WT;
+			const unsigned nn = (unsigned)((a.n_out - nf < WT) ? (a.n_out - nf) : WT);
+			shift_next = fetch(nf, nn, my_buf + (cur ^ 1u) * BUF);
 		}
 
-		if (next_chunk == ~0ull)
+		const unsigned stores = wave_tile(first, n, my_buf + cur * BUF + shift);
+
+		if (!have_next)
 			break;
-		chunk = next_chunk;
+		// the DMA was issued before this wave-tile's stores and vmcnt retires in order
+		wait_vmcnt_at_most(stores);
+		mark(3);
+		cur ^= 1u;
+		shift = shift_next;
+		tile = next;
 	}
 
-	retire();
+	finish();
 }
 
-// ---------------------------------------------------------------------------------------------------------
 // k_generic - reference arithmetic, 64-bit, one lane per output frame (clownresampler.h:986-1035)
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_generic(const crhip_generic_launch a)
@@ -1678,6 +1701,7 @@ poly_fn ablation_instance(int abl)
 		case 5: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 4, 0, 1>;   // as 4, non-temporal stores
 		case 6: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 6, 0, 1>;   // the real kernel (variant 13) + clock stamps
 		case 7: return (poly_fn)k_wave<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, WAVE_WAVES, WAVE_NVW, WAVE_ITER, 0, 1, 6>;   // k_wave + stamps
+		case 8: return (poly_fn)k_up<2, 15, CRHIP_NORM_U32, 0x2A55u, UP_WAVES, 0, 1, 6>;   // k_up of the 8-lobe stereo instance + stamps
 		default: return nullptr;
 	}
 }
@@ -1833,6 +1857,8 @@ static uint32_t resolve_variant(const special *sp, uint32_t variant, uint32_t ou
 {
 	if (sp == nullptr)
 		return 0u;
+	if (variant == 1008u)
+		return sp->up[0] != nullptr ? UP_VARIANT : (sp->wave[0] != nullptr ? WAVE_VARIANT : 13u);   // diagnostic k_up instance
 	if (variant == 1007u && sp->wave[0] != nullptr)
 		return WAVE_VARIANT;                                  // diagnostic k_wave instance: k_wave geometry
 	if (variant >= 1000u && variant < 1010u)
@@ -1944,6 +1970,8 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 	if (sp != nullptr && v >= UP_VARIANT)
 	{
 		*geo = 200u;
+		if (launch->variant == 1008u && !launch->out_s16 && launch->channels == 2 && launch->slots == 15)
+			return ablation_instance(8);
 		return launch->out_s16 ? sp->up16 : sp->up[v - UP_VARIANT];
 	}
 
@@ -2012,7 +2040,7 @@ int crhip_launch_poly(const crhip_poly_launch *launch, void *stream)
 
 	if (fn == nullptr)
 		return (int)hipErrorInvalidValue;
-	if (geo == 200u ? (launch->threads != UP_WAVES * 64u || launch->vecs != 200u || launch->tile_frames % 4u != 0 || launch->tile_frames / 4u > UP_MAX_WAVE_TILE)
+	if (geo == 200u ? (launch->threads != UP_WAVES * 64u || launch->vecs != 200u || launch->tile_frames % 4u != 0 || launch->tile_frames / 4u > UP_MAX_WAVE_TILE || launch->plane_rows != UP_PLANE_ROWS)
 	  : geo == 100u ? (launch->threads != WAVE_WAVES * 64u || launch->vecs != 100u + WAVE_NVW)
 	                : (launch->threads != (uint32_t)GEOMETRY[geo].threads || launch->vecs != (uint32_t)GEOMETRY[geo].vecs))
 		return (int)hipErrorInvalidValue;

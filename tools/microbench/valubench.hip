@@ -18,6 +18,10 @@ __global__ __launch_bounds__(512) void k(int *out, int iters, int seed, unsigned
 	for (int i = 0; i < 8; ++i)
 		a[i] = seed + threadIdx.x * (i + 1);
 	int w = seed * 3 + 1;
+	long long b[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i)
+		b[i] = a[i];
 	for (int it = 0; it < iters; ++it)
 	{
 #define ADD(i) asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(w));
@@ -39,6 +43,12 @@ __global__ __launch_bounds__(512) void k(int *out, int iters, int seed, unsigned
 #define CNDM(i) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(w));
 #define MADU16(i) asm volatile("v_mad_u32_u16 %0, %0, %1, %1" : "+v"(a[i]) : "v"(w));
 #define ADDC(i) asm volatile("v_add_co_u32_e32 %0, vcc, %0, %1" : "+v"(a[i]) : "v"(w) : "vcc");
+#define MULHI(i) asm volatile("v_mul_hi_i32 %0, %0, %1" : "+v"(a[i]) : "v"(w));
+#define MULHI24(i) asm volatile("v_mul_hi_i32_i24_e32 %0, %0, %1" : "+v"(a[i]) : "v"(w));
+#define MAD64(i) asm volatile("v_mad_i64_i32 %0, vcc, %1, %1, %0" : "+v"(b[i]) : "v"(w) : "vcc");
+#define DOT2(i) asm volatile("v_dot2_i32_i16 %0, %0, %1, %1" : "+v"(a[i]) : "v"(w));
+#define XAD(i) asm volatile("v_xad_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(w));
+#define LSHLADD(i) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[i]) : "v"(w));
 		if constexpr (KIND == 0) { REP64(ADD) }
 		if constexpr (KIND == 1) { REP64(MUL) }
 		if constexpr (KIND == 2) { REP64(ASHR) }
@@ -58,6 +68,12 @@ __global__ __launch_bounds__(512) void k(int *out, int iters, int seed, unsigned
 		if constexpr (KIND == 16) { REP64(CNDM) }
 		if constexpr (KIND == 17) { REP64(MADU16) }
 		if constexpr (KIND == 18) { REP64(ADDC) }
+		if constexpr (KIND == 19) { REP64(MULHI) }
+		if constexpr (KIND == 20) { REP64(MULHI24) }
+		if constexpr (KIND == 21) { REP64(MAD64) }
+		if constexpr (KIND == 22) { REP64(DOT2) }
+		if constexpr (KIND == 23) { REP64(XAD) }
+		if constexpr (KIND == 24) { REP64(LSHLADD) }
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 	{
@@ -67,7 +83,7 @@ __global__ __launch_bounds__(512) void k(int *out, int iters, int seed, unsigned
 	int r = 0;
 #pragma unroll
 	for (int i = 0; i < 8; ++i)
-		r ^= a[i];
+		r ^= a[i] ^ (int)b[i] ^ (int)(b[i] >> 32);
 	if (r == 0x12345678)
 		out[threadIdx.x] = r;
 }
@@ -121,5 +137,11 @@ int main()
 	run<16>("v_cndmask_b32", d);
 	run<17>("v_mad_u32_u16", d);
 	run<18>("v_add_co_u32", d);
+	run<19>("v_mul_hi_i32", d);
+	run<20>("v_mul_hi_i32_i24", d);
+	run<21>("v_mad_i64_i32", d);
+	run<22>("v_dot2_i32_i16", d);
+	run<23>("v_xad_u32", d);
+	run<24>("v_lshl_add_u32", d);
 	return 0;
 }

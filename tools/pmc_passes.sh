@@ -4,7 +4,7 @@
 set -u
 OUT=$1; shift
 export TMPDIR=/tmp
-mkdir -p "$OUT"
+mkdir -p "$OUT"; OUT=$(cd "$OUT" && pwd)
 cd /tmp
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
@@ -20,7 +20,7 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_poly" in r["Kernel_Name"] or "k_generic" in r["Kernel_Name"]:
+        if any(k in r["Kernel_Name"] for k in ("k_poly", "k_wave", "k_up", "k_generic")):
             a = agg[r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += 1
 with open(out + "/pmc_summary.txt", "w") as w:

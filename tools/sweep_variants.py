@@ -86,7 +86,7 @@ def main():
         i = infos[v]
         if v >= 1000:
             extra = ""
-            if v in (1006, 1007):
+            if v in (1006, 1007, 1008):
                 import numpy as _np
                 raw = stamp.cpu().numpy()
                 ph = raw[4 * 4096:].reshape(-1, 4).astype(float)
@@ -102,11 +102,15 @@ def main():
                     tot = ph.sum(axis=1).mean()
                     extra += "\n   wave 0 of workgroups 0-63, cycles per workgroup: issue next DMA+ticket %.0f (%.0f%%), arithmetic+stores %.0f (%.0f%%), wait DMA %.0f (%.0f%%), barrier %.0f (%.0f%%)" % tuple(
                         x for k in range(4) for x in (ph[:, k].mean(), 100 * ph[:, k].mean() / tot))
+                if v == 1008 and ph.sum() > 0:
+                    tot = ph.sum(axis=1).mean()
+                    extra += "\n   wave 0 of workgroups 0-63, cycles per wave: tile setup + window unpack %.0f (%.0f%%), frames %.0f (%.0f%%), staged results to global %.0f (%.0f%%), waiting for the next window %.0f (%.0f%%)" % tuple(
+                        x for k in range(4) for x in (ph[:, k].mean(), 100 * ph[:, k].mean() / tot))
                 for x in range(8):
                     m = st[:, 3] == x
                     if m.any():
                         extra += "\n   XCC %d: %3d workgroups, end time median %.1f max %.1f us" % (x, m.sum(), _np.median(endt[m]), endt[m].max())
-            print("ablation %d (timing only%s): %7.1f us median %7.1f min%s" % (v - 1000, "" if v in (1006, 1007) else ", results wrong by design", med, mn, extra))
+            print("ablation %d (timing only%s): %7.1f us median %7.1f min%s" % (v - 1000, "" if v in (1006, 1007, 1008) else ", results wrong by design", med, mn, extra))
             continue
         if v >= 22 and v < 26:
             print("%3d  2 lanes/frame geo %s nt=%d %5d %6d %4d | %7.1f %7.1f | %7.0f  %.3f %s" % (v, [(1024, 2), (512, 2)][(v - 22) % 2], 1 - (v - 22) // 2, i.tile_frames, i.lds_bytes, i.max_blocks, med, mn, nbytes / med / 1e3, nbytes / med / 1e3 / 8000, "MISMATCH" if v in bad else ""))

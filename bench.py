@@ -32,6 +32,8 @@ WORKLOADS = {
     "cfg3": (8, 2, (8000, 96000, 8000), 4800000),      # configs[2] (10 min assumed)
     "cfg4": (3, 8, (48000, 44100, 44100), 28800000),   # configs[3] (10 min assumed)
     "cfg5": (3, 2, (44100, 48000, 44100), 158760000),  # configs[4] on ONE GPU (1 hour)
+    # not a BASELINE configuration: the headline conversion with the reference's high-quality 8-lobe build (tuning only)
+    "hq48": (8, 2, (44100, 48000, 44100), 26460000),
 }
 
 

@@ -344,6 +344,25 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	if (getenv("CLOWNRESAMPLER_AMD_NO_SPECIAL") != NULL) /* tuning hook: time the run-time-slot instance instead */
 		plan->specialised = 0;
 	crhip_poly_geometry(plan->channels, plan->specialised ? plan->poly.slots : 0xFFFFu, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
+	if (plan->variant == 28u || plan->variant == 29u || (plan->variant == 0xFFFFu && crhip_poly_default_is_mad(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode)))
+	{
+		/* k_poly with the 64-bit multiply-add chain: compiled for fixed weight signs per slot, like k_up */
+		uint32_t negmask = 0, pos_bits = 0, neg_bits = 0;
+		int ok = crhip_poly_up_negmask(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, &negmask);
+
+		if (ok)
+		{
+			cr_poly_slot_signs(&plan->poly, &pos_bits, &neg_bits);
+			ok = (neg_bits & ~negmask) == 0 && (pos_bits & negmask) == 0;
+		}
+
+		if (!ok)
+		{
+			plan->variant = crhip_poly_fallback_variant();
+			crhip_poly_geometry(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
+		}
+	}
+
 	if (plan->vecs >= 200u)
 	{
 		/* k_up: a lane owns one input position and produces all of its output frames; a wave-tile is as many output

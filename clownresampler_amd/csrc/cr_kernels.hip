@@ -414,9 +414,84 @@ __device__ __forceinline__ void fetch_frame(const crhip_poly_launch &a, const in
 		d.f[s].load(src + s * FB);
 }
 
+// The tap arithmetic as a chain of full-rate 64-bit multiply-adds (ASM mode 2; pure upsampling only, where the sign of a
+// slot's weights is a compile-time property - NEGMASK in ASM >> 8, checked by the host against the plan's rows):
+//     P = (accumulator : bias)          high dword: the running sum; low dword: 0xFFFF0000 where sample * weight < 0, else 0
+//     P = v_mad_i64_i32(sample << 16, weight, P)
+// The product lands as (sample * weight) << 16, so with the bias beside it the carry into the high dword is exactly the
+// reference's (sample * weight) / 65536 with C truncation (clownresampler.h:1020 via :625) added to the running sum; what
+// is left in the low dword is overwritten by the next tap's bias.  Per packed pair of channels and tap: one v_pk_ashrrev_i16
+// (the sign masks of both samples; a zero sample may carry the bias too: (0 + 0xFFFF) >> 16 == 0), two shifts/masks for the
+// samples, two for the biases, two multiply-adds: ~22 cycles per wave against ~30 for the SDWA form.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// p = (sample << 16) * weight + p, 64 bits, one instruction.  Inline asm: left to itself hipcc re-associates the bias out of the
+// addend and adds it with a separate 64-bit add.
+__device__ __forceinline__ void mad64(i32x2 &p, int sample_shifted, int weight)
+{
+	long long carry;
+	asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(p), "=&s"(carry) : "v"(sample_shifted), "v"(weight));
+}
+
+template <bool NEGATIVE_SLOT, bool FIRST>
+__device__ __forceinline__ void mad64_tap_pair(i32x2 &p_lo, i32x2 &p_hi, int frame, int weight)
+{
+	const int seen = NEGATIVE_SLOT ? ~frame : frame;   // negative slot: the product is negative where the sample is positive
+	const s16x2 masks = __builtin_bit_cast(s16x2, seen) >> (short)15;
+	const unsigned pm = __builtin_bit_cast(unsigned, masks);
+	// the bias goes straight into the low dword of the accumulator pair (x); the high dword (y) is the running sum
+	p_lo.x = (int)(pm << 16);
+	p_hi.x = (int)(pm & 0xFFFF0000u);
+	if (FIRST)
+	{
+		p_lo.y = 0;
+		p_hi.y = 0;
+	}
+	mad64(p_lo, (int)((unsigned)frame << 16), weight);
+	mad64(p_hi, (int)((unsigned)frame & 0xFFFF0000u), weight);
+}
+
+template <unsigned NEGMASK, bool FIRST>
+__device__ __forceinline__ void mad64_tap_pair_dispatch(int slot, i32x2 &p_lo, i32x2 &p_hi, int frame, int weight)
+{
+	if ((NEGMASK >> slot) & 1u)
+		mad64_tap_pair<true, FIRST>(p_lo, p_hi, frame, weight);
+	else
+		mad64_tap_pair<false, FIRST>(p_lo, p_hi, frame, weight);
+}
+
 template <int CH, int TT, int NORM, int ASM>
 __device__ __forceinline__ void compute_frame(const FrameData<CH, TT> &d, int *out)
 {
+	if constexpr ((ASM & 0xFF) == 2)
+	{
+		static_assert(CH % 2 == 0, "the 64-bit chain works on packed pairs of channels");
+		constexpr unsigned NEGMASK = (unsigned)ASM >> 8;
+		i32x2 p[CH], p2[CH];   // two chains, taps alternating: consecutive multiply-adds are independent
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+		{
+#pragma unroll
+			for (int k = 0; k < CH / 2; ++k)
+			{
+				if (s == 0)
+					mad64_tap_pair_dispatch<NEGMASK, true>(s, p[2 * k], p[2 * k + 1], d.f[s].v[k], d.w[s]);
+				else if (s == 1)
+					mad64_tap_pair_dispatch<NEGMASK, true>(s, p2[2 * k], p2[2 * k + 1], d.f[s].v[k], d.w[s]);
+				else if (s & 1)
+					mad64_tap_pair_dispatch<NEGMASK, false>(s, p2[2 * k], p2[2 * k + 1], d.f[s].v[k], d.w[s]);
+				else
+					mad64_tap_pair_dispatch<NEGMASK, false>(s, p[2 * k], p[2 * k + 1], d.f[s].v[k], d.w[s]);
+			}
+		}
+#pragma unroll
+		for (int c = 0; c < CH; ++c)
+		{
+			const int acc = p[c].y + (TT > 1 ? p2[c].y : 0);
+			out[c] = normalise<NORM>(acc, d.w[TT]);
+		}
+		return;
+	}
 	// two accumulator sets, taps alternating between them: consecutive tap statements are independent (no asm boundary
 	// pad, more overlap); integer addition is associative, so the sum is the same
 	int acc[CH], acc2[CH];
@@ -896,7 +971,8 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 // frames): the first chunk by global wave number, the rest by atomic tickets over 32 counter lanes (see k_poly), drawn
 // one chunk ahead.
 //   WAVES  waves per workgroup          NVW  1 KiB DMA pieces per wave-tile          ITER  frames per lane per wave-tile
-template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, int OUT16, int NT, int ABL = 0>
+// ASM: arithmetic form of full wave-tiles, as in k_poly (1 = SDWA, 2 | NEGMASK << 8 = 64-bit multiply-add chain)
+template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, int OUT16, int NT, int ABL = 0, int ASM = 1>
 __global__ __launch_bounds__(WAVES * 64) void k_wave(const crhip_poly_launch a)
 {
 	static_assert(TT > 0, "k_wave exists for specialised slot counts only");
@@ -1030,7 +1106,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave(const crhip_poly_launch a)
 			if (i + 1 < ITER)
 				fetch_frame<CH, TT, MODE, 0>(a, rows, base, lane_rel + (unsigned)(i + 1) * 64u * a.increment, d[(i + 1) & 1]);
 			__builtin_amdgcn_sched_barrier(0);
-			compute_frame<CH, TT, NORM, 1>(d[i & 1], outv);
+			compute_frame<CH, TT, NORM, ASM>(d[i & 1], outv);
 			if constexpr (OUT16)
 				store_shorts<CH, NT>(out16 + (size_t)(i * 64u) * CH + lane * CH, outv);
 			else
@@ -1630,8 +1706,12 @@ struct special
 	poly_fn split[4];           // k_poly with two lanes per frame (variants SPLIT_VARIANT + i: geometry {4, 2} x nt {1, 0}); nullptr if none
 	poly_fn up[2];              // k_up (variants UP_VARIANT + {0: non-temporal stores, 1: plain}); nullptr if none
 	poly_fn up16;               // k_up, int16 output
-	uint32_t up_negmask;        // k_up: bit s set = the weights of slot s are <= 0 in every row, clear = >= 0 (checked by the host per plan)
+	uint32_t up_negmask;        // k_up / mad: bit s set = the weights of slot s are <= 0 in every row, clear = >= 0 (checked by the host per plan)
+	poly_fn mad[2];             // the 64-bit multiply-add chain (compute_frame, ASM mode 2): variant MAD_VARIANT = k_poly geometry 3 with non-temporal stores,
+	                            // MAD_VARIANT + 1 = k_wave where the instance has one, else k_poly geometry 3 with plain stores
 };
+
+constexpr uint32_t MAD_VARIANT = 28;    // variant ids 28, 29
 
 constexpr uint32_t UP_VARIANT = 26;     // variant ids 26, 27 select k_up where the instance has one and the plan qualifies
 constexpr int UP_WAVES = 12;
@@ -1647,7 +1727,14 @@ constexpr int WAVE_WAVES = 16, WAVE_NVW = 1, WAVE_ITER = 4;
 template <int CH, int TT, int MODE, int NORM, int DV, bool WAVE = false, bool DYNAMIC = false, unsigned UPMASK = 0>
 special make_special()
 {
-	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, UPMASK};
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, UPMASK, {nullptr, nullptr}};
+	if constexpr (UPMASK != 0 && CH % 2 == 0)
+	{
+		s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 1>;
+		s.mad[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 0>;
+		if constexpr (WAVE)
+			s.mad[1] = (poly_fn)k_wave<CH, TT, MODE, NORM, WAVE_WAVES, WAVE_NVW, WAVE_ITER, 0, 1, 0, (int)(2u | (UPMASK << 8))>;   // where the instance has a k_wave form, 29 is k_wave with the chain
+	}
 	if constexpr (UPMASK != 0)
 	{
 		static_assert(MODE == CRHIP_ROWMODE_UPSAMPLE, "k_up is for pure upsampling");
@@ -1863,8 +1950,14 @@ static uint32_t resolve_variant(const special *sp, uint32_t variant, uint32_t ou
 		return WAVE_VARIANT;                                  // diagnostic k_wave instance: k_wave geometry
 	if (variant >= 1000u && variant < 1010u)
 		return 3u;                                            // diagnostic k_poly instances: headline geometry
-	if (variant >= UP_VARIANT + 2u)
+	if (variant >= MAD_VARIANT + 2u)
 		variant = sp->default_variant;
+	if (variant >= MAD_VARIANT)
+	{
+		if (sp->mad[0] != nullptr && !out_s16)
+			return variant;
+		variant = 13u;
+	}
 	if (variant >= UP_VARIANT)
 	{
 		if (sp->up[0] != nullptr)
@@ -1892,16 +1985,22 @@ int crhip_poly_swizzled(uint32_t channels, uint32_t slots, uint32_t row_mode, ui
 
 int crhip_poly_variants(void)
 {
-	return VARIANTS + 8;   // + the two k_wave variants, the four two-lanes-per-frame variants and the two k_up variants
+	return VARIANTS + 10;   // + the two k_wave variants, the four two-lanes-per-frame variants, the two k_up variants and the two 64-bit-chain variants
 }
 
 int crhip_poly_up_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t *negmask)
 {
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
-	if (sp == nullptr || sp->up[0] == nullptr)
+	if (sp == nullptr || (sp->up[0] == nullptr && sp->mad[0] == nullptr))
 		return 0;
 	*negmask = sp->up_negmask;
 	return 1;
+}
+
+int crhip_poly_default_is_mad(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
+{
+	const special *sp = find_special(channels, slots, row_mode, norm_mode);
+	return sp != nullptr && sp->default_variant >= MAD_VARIANT && sp->default_variant < MAD_VARIANT + 2u && sp->mad[0] != nullptr ? 1 : 0;
 }
 
 uint32_t crhip_poly_up_fallback_variant(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
@@ -1926,6 +2025,22 @@ void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, u
 {
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
 	const uint32_t v = sp != nullptr ? resolve_variant(sp, variant) : (uint32_t)runtime_geo((int)channels);
+
+	if (sp != nullptr && v == MAD_VARIANT + 1u && sp->wave[0] != nullptr)
+	{
+		*threads = WAVE_WAVES * 64u;
+		*vecs = 100u + WAVE_NVW;
+		*frames_multiple = 64u * WAVE_ITER * 4u;
+		return;
+	}
+
+	if (sp != nullptr && v >= MAD_VARIANT)
+	{
+		*threads = (uint32_t)GEOMETRY[3].threads;
+		*vecs = (uint32_t)GEOMETRY[3].vecs;
+		*frames_multiple = *threads;
+		return;
+	}
 
 	if (sp != nullptr && v >= UP_VARIANT)
 	{
@@ -1966,6 +2081,12 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 	const special *sp = launch->specialised ? find_special(launch->channels, launch->slots, launch->row_mode, launch->norm_mode) : nullptr;
 	const uint32_t v = resolve_variant(sp, launch->variant, launch->out_s16);
 	poly_fn fn;
+
+	if (sp != nullptr && v >= MAD_VARIANT)
+	{
+		*geo = (v == MAD_VARIANT + 1u && sp->wave[0] != nullptr) ? 100u : 3u;
+		return sp->mad[v - MAD_VARIANT];
+	}
 
 	if (sp != nullptr && v >= UP_VARIANT)
 	{

@@ -130,8 +130,11 @@ int crhip_poly_dynamic_default(uint32_t channels, uint32_t slots, uint32_t row_m
 uint32_t crhip_poly_fallback_variant(void);
 /* k_up (input-stationary upsampling kernel): 1 and *negmask = the per-slot weight signs the instance was built for
    (bit s set: every weight of slot s must be <= 0, clear: >= 0), or 0 when the instance has no k_up form. */
+/* ... also the mask of the 64-bit-chain variants of k_poly (variants 28, 29) */
 int crhip_poly_up_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t *negmask);
 /* the variant to use when a plan does not qualify for k_up */
+/* 1 when the instance's default variant is one of the 64-bit-chain variants (whose sign precondition the host must check) */
+int crhip_poly_default_is_mad(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
 uint32_t crhip_poly_up_fallback_variant(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
 /* Number of tuning variants of the specialised instances (crhip_poly_launch.variant). */
 int crhip_poly_variants(void);

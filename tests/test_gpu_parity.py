@@ -440,7 +440,7 @@ def test_highlevel_reinit_reuses_window(products):
     assert len(keys) == 1
 
 
-@pytest.mark.parametrize("variant", [13, 18, 3, 20, 21])
+@pytest.mark.parametrize("variant", [13, 18, 3, 20, 21, 28, 29])
 @pytest.mark.parametrize("name", ["cfg2_1min", "cfg3_1min", "ch1_up", "tiny_257", "cfg2_chunked", "amp_square_up"])
 def test_kernel_variants_bit_exact(golden, products, name, variant):
     """Every tuning variant computes the same bits: k_poly geometries and the wave-autonomous k_wave (variants 20, 21)."""

@@ -548,6 +548,42 @@ def test_input_stationary_kernel_bit_exact(products, radius, rates):
         p.api.DebugSetVariant(0xFFFF)
 
 
+def test_input_stationary_kernel_random_ratios(products):
+    """k_up over 80 random pure-upsampling ratios between 2x and 16x (random rates, so the increments are arbitrary), random lengths,
+    and a random split into two calls (the second starts at a fractional position): every stream equals the oracle's."""
+    import random
+    rng = random.Random(4711)
+    used = 0
+    for draw in range(80):
+        radius = rng.choice([3, 8])
+        p, o = products[radius], ck.oracle(radius)
+        i = rng.randrange(4000, 48000)
+        out = int(i * rng.uniform(2.0, 16.0))
+        frames = rng.choice([rng.randrange(1, 200), rng.randrange(200, 5000), rng.randrange(5000, 40000)])
+        ok, a = p.low_init(2, i, out, i)
+        ok2, b = o.low_init(2, i, out, i)
+        assert ok == ok2 and a.astuple() == b.astuple()
+        p.api.DebugSetVariant(26)
+        try:
+            info = p.api.PlanGetInfo(p.api.PlanCreate(a.raw, p.pre))
+            used += info.kernel == 3
+            padded = ck.pad_frames(ck.noise_pcm(frames * 2, 1000 + draw), 2, int(b.cfg.radius_frames))
+            total = ck.count_output_frames(b, frames)
+            cut = rng.randrange(1, total) if total > 1 else None
+            if cut is not None:
+                xa, la, ra = p.low_resample_i32(a, padded, frames, capacity=cut)
+                xb, lb, rb = o.low_resample_i32(b, padded, frames, capacity=cut)
+                assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple(), (radius, i, out, frames, cut)
+                padded = padded[(frames - la) * 2:]
+                frames = la
+            xa, la, ra = p.low_resample_i32(a, padded, frames)
+            xb, lb, rb = o.low_resample_i32(b, padded, frames)
+            assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple(), (radius, i, out, frames)
+        finally:
+            p.api.DebugSetVariant(0xFFFF)
+    assert used >= 70, used       # nearly all draws qualify (increment within 4096..32768)
+
+
 @pytest.mark.parametrize("variant", [2, 4, 14, 22, 23, 24, 25])
 @pytest.mark.parametrize("name", ["cfg4_1min", "ch8_down"])
 def test_eight_channel_variants_bit_exact(golden, products, name, variant):

@@ -242,7 +242,7 @@ def main():
             traffic = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
             traffic_note = "bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes: profiles/" + os.path.basename(pmc_file)
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_note": traffic_note, "kernel": ("k_wave<%d,%d>" if info.kernel == 2 else "k_poly<%d,%d>") % (ch, info.slots) if info.kernel else "k_generic",
+                "traffic": traffic, "traffic_note": traffic_note, "kernel": {1: "k_poly<%d,%d>", 2: "k_wave<%d,%d>", 3: "k_up<%d,%d>"}[info.kernel] % (ch, info.slots) if info.kernel else "k_generic",
                 "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_ms": dev_ms / args.steps,
                 "read_only_GBs": shard.input_frames * ch * 2 / (dev_ms / args.steps * 1e-3) / 1e9}
 

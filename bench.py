@@ -34,6 +34,9 @@ WORKLOADS = {
     "cfg5": (3, 2, (44100, 48000, 44100), 158760000),  # configs[4] on ONE GPU (1 hour)
     # not a BASELINE configuration: the headline conversion with the reference's high-quality 8-lobe build (tuning only)
     "hq48": (8, 2, (44100, 48000, 44100), 26460000),
+    "up55": (3, 2, (8000, 44100, 8000), 4800000),      # one of the reference's ctest triples (tests/CMakeLists.txt), 10 min, 3 lobes
+    "ch6": (3, 6, (44100, 48000, 44100), 8820000),     # 5.1 surround through the run-time-slot instance
+    "ch3": (3, 3, (48000, 44100, 44100), 14400000),
 }
 
 

@@ -760,6 +760,33 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 			l.out_s16 = 1; /* the int16-output instance is a different function */
 			if (cr_check_hip(crhip_poly_prepare(&l), "hipFuncSetAttribute(dynamic LDS, int16 form)") != 0)
 				goto fail_plan;
+
+			/* The persistent grid must not be larger than what is resident at once: workgroups that start after the first
+			   batch has left find their statically dealt tiles still waiting (twice the time) or no tickets (harmless).
+			   LDS and thread count were accounted for above; registers are the runtime's to know - e.g. above 96 SGPRs a
+			   SIMD holds 7 waves, not 8, and a 1024-thread workgroup then has the CU to itself. */
+			{
+				int form;
+				plan->max_blocks_s16 = plan->max_blocks;
+				for (form = 0; form < 2; ++form)
+				{
+					int per_cu = 0, vgprs = 0, static_lds = 0;
+					l.out_s16 = (uint32_t)form;
+					if (crhip_poly_occupancy(&l, &per_cu, &vgprs, &static_lds) == 0 && per_cu >= 1)
+					{
+						const uint32_t resident = (uint32_t)per_cu * (uint32_t)(g_info.compute_units > 0 ? g_info.compute_units : 256);
+						if (getenv("CLOWNRESAMPLER_AMD_DEBUG") != NULL)
+							fprintf(stderr, "clownresampler_amd: plan variant %u (%s output): %u threads, %u B dynamic LDS, %d VGPRs: %d workgroups per CU, grid cap %u -> %u\n",
+							        plan->variant, form ? "int16" : "int32", plan->threads, plan->lds_bytes, vgprs, per_cu, form ? plan->max_blocks_s16 : plan->max_blocks, resident);
+						if (getenv("CLOWNRESAMPLER_AMD_NO_OCCUPANCY_CLAMP") != NULL) /* (tuning hook: measure without) */
+							continue;
+						if (form == 0 && resident < plan->max_blocks)
+							plan->max_blocks = resident;
+						if (form == 1 && resident < plan->max_blocks_s16)
+							plan->max_blocks_s16 = resident;
+					}
+				}
+			}
 		}
 	}
 
@@ -835,8 +862,8 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		blocks = (n_out + plan->tile_frames - 1) / plan->tile_frames;
 		if (plan->vecs >= 100u)
 			blocks = (blocks + plan->threads / 64u - 1) / (plan->threads / 64u); /* k_wave hands chunks to WAVES */
-		if (blocks > plan->max_blocks)
-			blocks = plan->max_blocks;
+		if (blocks > (out_s16 ? plan->max_blocks_s16 : plan->max_blocks))
+			blocks = out_s16 ? plan->max_blocks_s16 : plan->max_blocks;
 		l.blocks = (uint32_t)blocks;
 		{
 			/* tickets pay off where workgroups drift apart over many medium-sized tiles; measured on MI355X (profiles/):

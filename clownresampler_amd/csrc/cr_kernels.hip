@@ -610,6 +610,17 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// SGPR budget.  Two 1024-thread workgroups per CU are 8 waves per SIMD, and on gfx950 a SIMD admits
+// min(8, 800 / (ceil(sgpr_count / 16) * 16 + 16)) waves (MI355X_MICROARCH.md, "Residency"): 8 only up to .sgpr_count 80,
+// 7 up to 96 - while the compiler's "Occupancy: 8" and hipOccupancyMaxActiveBlocksPerMultiprocessor still say 8 / two
+// workgroups.  Left alone hipcc gave most instances 82-106 SGPRs (wave-uniform 64-bit addresses, tile bookkeeping), so the
+// second workgroup of a CU only started when the first had finished - seen in the start ticks of the stamped diagnostic
+// instance.  80 includes VCC, FLAT_SCRATCH and XNACK_MASK; what does not fit is spilled to VGPR lanes, of which there are
+// plenty (38-63 of 64 used).
+// ---------------------------------------------------------------------------------------------------------
+#define CRHIP_SGPR_BUDGET 80
+
+// ---------------------------------------------------------------------------------------------------------
 // k_poly
 // ---------------------------------------------------------------------------------------------------------
 // CH        channels (compile time)
@@ -628,7 +639,7 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 // SPLIT     lanes per frame: CH is then the channels of ONE lane and a frame has CH * SPLIT channels (8-channel
 //           frames as two lanes of 4: every store instruction of a wave is one contiguous 1 KiB)
 template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0, int OUT16 = 0, int NT = 0, int SPLIT = 1>
-__global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR_BUDGET))) void k_poly(const crhip_poly_launch a)
 {
 	constexpr unsigned FB = CH * 2 * SPLIT;               // bytes per input frame (all channels)
 	constexpr unsigned FBL = CH * 2;                      // bytes of one lane's share of a frame
@@ -637,12 +648,15 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 	const unsigned tid = threadIdx.x;
-	unsigned long long stamp_cycles = 0, stamp_ticks = 0;
+	unsigned stamp_cycles = 0;
 	if constexpr (ABL == 6)
 	{
-		// diagnostic build only: in-kernel clock = cycles / (ticks / 100 MHz)  (MI355X_MICROARCH.md, DVFS give-back item 6)
-		stamp_cycles = __builtin_amdgcn_s_memtime();
-		stamp_ticks = __builtin_amdgcn_s_memrealtime();
+		// diagnostic build only: in-kernel clock = cycles / (ticks / 100 MHz)  (MI355X_MICROARCH.md, DVFS give-back item 6).
+		// 32 bits of the cycle counter, and the start tick goes out at once: the instance has to stay at or below 96 SGPRs
+		// to be the same kernel as the one it stands for (see the note at `phase` below).
+		stamp_cycles = (unsigned)__builtin_amdgcn_s_memtime();
+		if (tid == 0 && a.debug_stamps != nullptr)
+			a.debug_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 	}
 	const unsigned rows_bytes = a.plane_rows * a.row_stride * 4u;   // planes of plane_rows x 16 bytes
 	const int *rows = reinterpret_cast<const int *>(smem);
@@ -768,16 +782,18 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 	// diagnostic instance (ABL == 6) only: where a tile's cycles go, summed over the tiles of this workgroup as seen by
 	// wave 0 - [0] issuing the next tile's DMA + ticket, [1] arithmetic + stores, [2] waiting for the DMA (vmcnt),
 	// [3] waiting at the barrier (+ mailbox)
-	unsigned long long phase[4] = {0, 0, 0, 0};
-	unsigned long long t_mark = 0;
+	// The sums live in VGPRs on purpose: as wave-uniform 64-bit values they took the instance from 80 to 106 SGPRs, and above
+	// 96 SGPRs a SIMD holds 7 waves instead of 8 - one 1024-thread workgroup per CU instead of two, i.e. a different kernel.
+	unsigned phase[4] = {0, 0, 0, 0};
+	unsigned t_mark = 0;
 	auto mark = [&](int which) {
 		if constexpr (ABL == 6)
 		{
 			__builtin_amdgcn_sched_barrier(0);
-			const unsigned long long now = __builtin_amdgcn_s_memtime();
+			const unsigned now = (unsigned)__builtin_amdgcn_s_memtime();
 			__builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): s_memtime returns through the scalar data path
 			if (which >= 0)
-				phase[which] += now - t_mark;
+				asm volatile("v_add_u32 %0, %0, %1" : "+v"(phase[which]) : "s"(now - t_mark));
 			t_mark = now;
 			__builtin_amdgcn_sched_barrier(0);
 		}
@@ -925,6 +941,12 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		}
 
+		if constexpr (ABL == 6)
+		{
+			// per tile of every workgroup (first 32): tile index << 48 | tick at which wave 0 had issued the tile's last store
+			if (tid == 0 && a.debug_stamps != nullptr && it < 32u)
+				a.debug_stamps[4 * 4096 + 4 * 64 + 32 * blockIdx.x + it] = (tile_index << 48) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFFFFFull);
+		}
 		if (!more)
 		{
 			if constexpr (ABL == 6)
@@ -932,8 +954,7 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 				if (tid == 0 && a.debug_stamps != nullptr)
 				{
 					// per workgroup: {shader cycles of its lifetime, start tick, end tick, XCC id}
-					a.debug_stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - stamp_cycles;
-					a.debug_stamps[4 * blockIdx.x + 1] = stamp_ticks;
+					a.debug_stamps[4 * blockIdx.x + 0] = (unsigned)__builtin_amdgcn_s_memtime() - stamp_cycles;
 					a.debug_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
 					a.debug_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(63508 /* HW_REG_XCC_ID, bits 0..3 */) & 0xF;
 					if (blockIdx.x < 64u)
@@ -973,7 +994,7 @@ __global__ __launch_bounds__(NTHREADS) void k_poly(const crhip_poly_launch a)
 //   WAVES  waves per workgroup          NVW  1 KiB DMA pieces per wave-tile          ITER  frames per lane per wave-tile
 // ASM: arithmetic form of full wave-tiles, as in k_poly (1 = SDWA, 2 | NEGMASK << 8 = 64-bit multiply-add chain)
 template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, int OUT16, int NT, int ABL = 0, int ASM = 1>
-__global__ __launch_bounds__(WAVES * 64) void k_wave(const crhip_poly_launch a)
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR_BUDGET))) void k_wave(const crhip_poly_launch a)
 {
 	static_assert(TT > 0, "k_wave exists for specialised slot counts only");
 	constexpr unsigned FB = CH * 2;
@@ -2152,6 +2173,25 @@ int crhip_poly_prepare(const crhip_poly_launch *launch)
 			bytes = launch->lds_bytes;
 		return (int)r;
 	}
+}
+
+// What the runtime says about the instance a launch would use: workgroups of launch->threads threads and launch->lds_bytes of
+// dynamic LDS that fit one CU at a time, and the instance's register / static LDS footprint.
+int crhip_poly_occupancy(const crhip_poly_launch *launch, int *workgroups_per_cu, int *vgprs, int *static_lds)
+{
+	uint32_t geo;
+	const poly_fn fn = select_poly(launch, &geo);
+	hipFuncAttributes attr;
+	hipError_t e;
+
+	if (fn == nullptr)
+		return (int)hipErrorInvalidValue;
+	e = hipFuncGetAttributes(&attr, (const void *)fn);
+	if (e != hipSuccess)
+		return (int)e;
+	*vgprs = attr.numRegs;
+	*static_lds = (int)attr.sharedSizeBytes;
+	return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(workgroups_per_cu, (const void *)fn, (int)launch->threads, launch->lds_bytes);
 }
 
 int crhip_launch_poly(const crhip_poly_launch *launch, void *stream)

@@ -117,6 +117,7 @@ int crhip_stream_sync(void *stream);
 
 /* One-time setup of the instance a launch selects (raises its dynamic-LDS limit); call once per plan, outside any capture. */
 int crhip_poly_prepare(const crhip_poly_launch *launch);
+int crhip_poly_occupancy(const crhip_poly_launch *launch, int *workgroups_per_cu, int *vgprs, int *static_lds);
 int crhip_launch_poly(const crhip_poly_launch *launch, void *stream);
 int crhip_launch_generic(const crhip_generic_launch *launch, void *stream);
 

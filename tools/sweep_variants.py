@@ -45,7 +45,7 @@ def main():
         plans[v] = api.PlanCreate(st0, pre)
         infos[v] = api.PlanGetInfo(plans[v])
 
-    stamp = torch.zeros(4 * 4096 + 4 * 64, dtype=torch.int64, device=dev)
+    stamp = torch.zeros(4 * 4096 + 4 * 64 + 32 * 4096, dtype=torch.int64, device=dev)
     api.lib.ClownResamplerAMD_DebugSetStampBuffer.argtypes = [__import__('ctypes').c_void_p]
     api.lib.ClownResamplerAMD_DebugSetStampBuffer(stamp.data_ptr())
 

@@ -37,6 +37,9 @@ WORKLOADS = {
     "up55": (3, 2, (8000, 44100, 8000), 4800000),      # one of the reference's ctest triples (tests/CMakeLists.txt), 10 min, 3 lobes
     "ch6": (3, 6, (44100, 48000, 44100), 8820000),     # 5.1 surround through the run-time-slot instance
     "ch3": (3, 3, (48000, 44100, 44100), 14400000),
+    "ch16": (3, 16, (44100, 48000, 44100), 3307500),   # the reference's maximum channel count
+    "dn8": (3, 2, (44100, 8000, 8000), 26460000),      # ctest triple 44100 -> 8000: 33-tap windows
+    "mono": (3, 1, (44100, 48000, 44100), 52920000),
 }
 
 

@@ -1290,7 +1290,9 @@ __device__ __forceinline__ void wait_vmcnt_at_most(unsigned n)
 	}
 }
 
-template <int CH, int TT, int NORM, unsigned NEGMASK, int WAVES, int OUT16, int NT, int ABL = 0>
+// CHAIN: 1 = the tap as one 64-bit multiply-add on (sample << 16) whose addend pair is {bias << 16, running sum}: the carry out
+//        of the low dword IS the truncation, the high dword the accumulator; the low dword is re-armed with a plain move per tap
+template <int CH, int TT, int NORM, unsigned NEGMASK, int WAVES, int OUT16, int NT, int ABL = 0, int CHAIN = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 {
 	constexpr unsigned NTHREADS = WAVES * 64u;
@@ -1444,10 +1446,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 					sample = (c & 1) ? (f.v[c / 2] >> 16) : (int)(short)f.v[c / 2];
 				else
 					sample = f.v[c];
-				S[s][c] = sample;
 				// the product with this slot's weight is negative iff the sample's sign differs from the slot's
-				B[s][c] = (int)((unsigned)(((NEGMASK >> s) & 1u) ? -sample : sample) >> 16);
+				const unsigned bias = (unsigned)(((NEGMASK >> s) & 1u) ? -sample : sample) >> 16;
+				S[s][c] = CHAIN ? (int)((unsigned)sample << 16) : sample;
+				B[s][c] = CHAIN ? (int)(bias << 16) : (int)bias;
 				asm volatile("" : "+v"(B[s][c]));   // keep it in a register: hipcc otherwise recomputes the shift in every frame
+				if constexpr (CHAIN)
+					asm volatile("" : "+v"(S[s][c]));
 			}
 		}
 
@@ -1472,6 +1477,36 @@ __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 			// full-rate v_mad_i64_i32 on (sample << 16) with the bias in the low dword of the addend, plus a plain add, is 6.6
 			// cycles on paper and bit-exact too, but measured slower: 168 VGPRs, spills, and a lower clock.)
 			int acc[CH];
+			if constexpr (CHAIN)
+			{
+				// Two chains per channel (even / odd slots): neighbouring multiply-adds are independent.  The accumulator pairs are
+				// pinned to physical registers: the re-arming of the low dword is then ONE plain v_mov_b32 (given a 64-bit asm operand
+				// hipcc copies the whole pair twice per tap instead).
+				static_assert(CH == 2, "the chain form of k_up is written for stereo");
+				int lo[4], hi[4] = {0, 0, 0, 0};
+#define CRHIP_CHAIN_STEP(K, LO, HI, SAMPLE, WEIGHT, BIAS)                                                                  \
+	lo[K] = (BIAS);                                                                                                    \
+	asm("v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]" : "+{v" #LO "}"(lo[K]), "+{v" #HI "}"(hi[K]) : "v"(SAMPLE), "v"(WEIGHT) : "vcc")
+#pragma unroll
+				for (int s = 0; s < TT; ++s)
+				{
+					if (s & 1)
+					{
+						CRHIP_CHAIN_STEP(1, 122, 123, S[s][0], w[s], B[s][0]);
+						CRHIP_CHAIN_STEP(3, 126, 127, S[s][1], w[s], B[s][1]);
+					}
+					else
+					{
+						CRHIP_CHAIN_STEP(0, 120, 121, S[s][0], w[s], B[s][0]);
+						CRHIP_CHAIN_STEP(2, 124, 125, S[s][1], w[s], B[s][1]);
+					}
+				}
+#undef CRHIP_CHAIN_STEP
+				acc[0] = hi[0] + hi[1];
+				acc[1] = hi[2] + hi[3];
+			}
+			else
+			{
 #pragma unroll
 			for (int c = 0; c < CH; ++c)
 				acc[c] = (__mul24(S[0][c], w[0]) + B[0][c]) >> 16;
@@ -1490,6 +1525,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 					for (int c = 0; c < CH; ++c)
 						acc[c] = sdwa_add_word1_signed(acc[c], __mul24(S[s][c], w[s]) + B[s][c]);
 				}
+			}
 			}
 
 			int outv[CH];
@@ -1725,7 +1761,7 @@ struct special
 	poly_fn wave16;             // k_wave, int16 output
 	bool dynamic_tiles;         // k_poly: draw tiles as tickets (measured per instance; see crhip_poly_launch.dynamic_tiles)
 	poly_fn split[4];           // k_poly with two lanes per frame (variants SPLIT_VARIANT + i: geometry {4, 2} x nt {1, 0}); nullptr if none
-	poly_fn up[2];              // k_up (variants UP_VARIANT + {0: non-temporal stores, 1: plain}); nullptr if none
+	poly_fn up[2];              // k_up (variants UP_VARIANT + {0: 24-bit multiply-add + SDWA add per tap, 1: 64-bit multiply-add chain}); nullptr if none
 	poly_fn up16;               // k_up, int16 output
 	uint32_t up_negmask;        // k_up / mad: bit s set = the weights of slot s are <= 0 in every row, clear = >= 0 (checked by the host per plan)
 	poly_fn mad[2];             // the 64-bit multiply-add chain (compute_frame, ASM mode 2): variant MAD_VARIANT = k_poly geometry 3 with non-temporal stores,
@@ -1760,8 +1796,8 @@ special make_special()
 	{
 		static_assert(MODE == CRHIP_ROWMODE_UPSAMPLE, "k_up is for pure upsampling");
 		s.up[0] = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 0, 1>;
-		s.up[1] = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 0, 0>;
-		s.up16 = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 1, 1>;
+		s.up[1] = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 0, 1, 0, 1>;   // the 64-bit chain form
+		s.up16 = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 1, 1, 0, 1>;
 	}
 	variant_table<CH, TT, MODE, NORM, 0>::fill(s.fn);
 	constexpr int KV = DV < 20 ? DV : 13;   // the k_poly variant behind a k_wave default (its fallback and int16 geometry)
@@ -1788,7 +1824,7 @@ const special *specials(int *count)
 	static const special table[] = {
 	    // the k_up sign masks are those of a Lanczos window whose lobes are one input frame wide (slot 0 = first_slot)
 	    make_special<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 13, true, true, 0x12u>(),   // cfg 2 / cfg 5: stereo 44.1 -> 48 kHz, 3 lobes
-	    make_special<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 26, true, false, 0x2A55u>(),  // cfg 3: stereo 8 -> 96 kHz, 8 lobes (k_up from 2x upsampling on, k_wave below)
+	    make_special<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 27, true, false, 0x2A55u>(),  // cfg 3: stereo 8 -> 96 kHz, 8 lobes (k_up, chain form, from 2x upsampling on; k_wave below)
 	    make_special<8, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 2>(),     // cfg 4: 8 channels 48 -> 44.1 kHz
 	    make_special<1, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 13, true, true>(),   // mono upsampling, 3 lobes
 	    make_special<2, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>(),     // stereo mild downsampling, 3 lobes
@@ -1809,7 +1845,7 @@ poly_fn ablation_instance(int abl)
 		case 5: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 4, 0, 1>;   // as 4, non-temporal stores
 		case 6: return (poly_fn)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 6, 0, 1>;   // the real kernel (variant 13) + clock stamps
 		case 7: return (poly_fn)k_wave<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, WAVE_WAVES, WAVE_NVW, WAVE_ITER, 0, 1, 6>;   // k_wave + stamps
-		case 8: return (poly_fn)k_up<2, 15, CRHIP_NORM_U32, 0x2A55u, UP_WAVES, 0, 1, 6>;   // k_up of the 8-lobe stereo instance + stamps
+		case 8: return (poly_fn)k_up<2, 15, CRHIP_NORM_U32, 0x2A55u, UP_WAVES, 0, 1, 6, 1>;   // k_up of the 8-lobe stereo instance (chain form, the default) + stamps
 		default: return nullptr;
 	}
 }
@@ -1824,12 +1860,18 @@ const special *find_special(uint32_t channels, uint32_t slots, uint32_t mode, ui
 	return nullptr;
 }
 
-// run-time slot count: every channel count 1..8, both row modes, both normalisations, both output forms.  One geometry
-// per channel count - 1024 threads; 16 KiB tiles for up to 4 channels, 32 KiB above (an 8-channel frame is 16 bytes) -
-// SDWA arithmetic, one frame in flight, non-temporal stores.
+// run-time slot count: every channel count 1..8 and the even counts 10..16 (the reference's maximum,
+// CLOWNRESAMPLER_MAXIMUM_CHANNELS, clownresampler.h:462), both row modes, both normalisations, both output forms.  One
+// geometry per channel count - 1024 threads; 16 KiB tiles for up to 4 channels, 32 KiB above (an 8-channel frame is 16
+// bytes) - SDWA arithmetic, one frame in flight, non-temporal stores.  Above 8 channels a frame is shared by TWO neighbouring
+// lanes (k_poly's SPLIT), each taking half of its channels: the per-lane code is that of 5..8 channels.
 constexpr int runtime_geo(int channels)
 {
 	return channels <= 4 ? 3 : 4;
+}
+constexpr int runtime_split(int channels)
+{
+	return channels > 8 ? 2 : 1;
 }
 
 template <int CH, int OUT16>
@@ -1841,6 +1883,18 @@ poly_fn pick_runtime(uint32_t mode, uint32_t norm)
 		                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, GEO, 1, 0, 1, OUT16>();
 	return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, GEO, 1, 0, 1, OUT16>()
 	                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, GEO, 1, 0, 1, OUT16>();
+}
+
+// two lanes per frame, HALF channels each (run-time slot count, geometry 4)
+template <int HALF, int OUT16>
+poly_fn pick_runtime_split(uint32_t mode, uint32_t norm)
+{
+	constexpr int T = GEOMETRY[4].threads, V = GEOMETRY[4].vecs;
+	if (norm == CRHIP_NORM_S31)
+		return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, T, V, 1, 1, 0, 0, OUT16, 1, 2>
+		                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, T, V, 1, 1, 0, 0, OUT16, 1, 2>;
+	return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, T, V, 1, 1, 0, 0, OUT16, 1, 2>
+	                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, T, V, 1, 1, 0, 0, OUT16, 1, 2>;
 }
 
 template <int OUT16>
@@ -1856,6 +1910,10 @@ poly_fn pick_runtime_channels(uint32_t channels, uint32_t mode, uint32_t norm)
 		case 6: return pick_runtime<6, OUT16>(mode, norm);
 		case 7: return pick_runtime<7, OUT16>(mode, norm);
 		case 8: return pick_runtime<8, OUT16>(mode, norm);
+		case 10: return pick_runtime_split<5, OUT16>(mode, norm);
+		case 12: return pick_runtime_split<6, OUT16>(mode, norm);
+		case 14: return pick_runtime_split<7, OUT16>(mode, norm);
+		case 16: return pick_runtime_split<8, OUT16>(mode, norm);
 		default: return nullptr;
 	}
 }
@@ -2094,6 +2152,8 @@ void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, u
 	*threads = (uint32_t)GEOMETRY[v % 5].threads;
 	*vecs = (uint32_t)GEOMETRY[v % 5].vecs;
 	*frames_multiple = *threads * (1u << ((v / 5) % 2));
+	if (sp == nullptr)
+		*frames_multiple /= (uint32_t)runtime_split((int)channels);   // a group of threads covers half as many frames
 }
 
 // geo: index into GEOMETRY, 100 for k_wave, 200 for k_up

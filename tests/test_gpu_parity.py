@@ -463,7 +463,7 @@ def test_random_configurations_bit_exact(products):
     done = 0
     while done < 300:
         radius = rng.choice([3, 3, 8])
-        ch = rng.choice([1, 2, 2, 2, 3, 4, 5, 6, 7, 8, 8, 11, 16])
+        ch = rng.choice([1, 2, 2, 2, 3, 4, 5, 6, 7, 8, 8, 10, 11, 12, 14, 16])
         i, o = rng.randrange(1, 200000), rng.randrange(1, 200000)
         if rng.random() < 0.5:
             o = max(1, int(i * rng.choice([0.03, 0.25, 0.5, 0.9, 0.999, 1.0, 1.001, 1.0884, 1.1, 2, 3, 12, 40])))
@@ -492,6 +492,29 @@ def test_random_configurations_bit_exact(products):
         kernels[p.api.PlanGetInfo(p.api.PlanCreate(st.raw, p.pre)).kernel] += 1
         done += 1
     assert kernels[0] > 0 and kernels[1] > 0, kernels      # both the generic and the polyphase kernels were exercised
+
+
+@pytest.mark.parametrize("ch", [9, 10, 11, 12, 13, 14, 15, 16])
+def test_nine_to_sixteen_channels(products, ch):
+    """Up to CLOWNRESAMPLER_MAXIMUM_CHANNELS (clownresampler.h:462): even counts run on the polyphase kernel with two lanes
+    per frame, odd ones on the generic kernel - int32 and clamped int16 output, up- and downsampling, both radii, ragged
+    lengths, unaligned device pointers via the bulk API - all equal to the oracle."""
+    for radius, rates, frames in ((3, (44100, 48000, 44100), 30011), (3, (48000, 44100, 44100), 25013), (8, (8000, 44100, 8000), 4099),
+                                  (3, (44100, 8000, 8000), 60007), (8, (96000, 44100, 44100), 20011), (3, (32000, 48000, 16000), 777)):
+        p, orc = products[radius], ck.oracle(radius)
+        ok_a, a = p.low_init(ch, *rates)
+        ok_b, b = orc.low_init(ch, *rates)
+        assert ok_a and ok_b and a.astuple() == b.astuple()
+        info = p.api.PlanGetInfo(p.api.PlanCreate(a.raw, p.pre))
+        assert info.kernel == (1 if ch % 2 == 0 else 0), (ch, rates, info.asdict())
+        R = int(b.cfg.radius_frames)
+        padded = ck.pad_frames(ck.noise_pcm(frames * ch, 900 + ch), ch, R)
+        got, la, ra = p.low_resample_i32(a, padded, frames)
+        want, lb, rb = orc.low_resample_i32(b, padded, frames)
+        assert (la, ra) == (lb, rb) and np.array_equal(got, want) and a.astuple() == b.astuple(), (ch, radius, rates)
+        ok_a, a = p.low_init(ch, *rates)
+        got16, left, ran_out = p.api.LowLevel_ResampleBulkS16(a.raw, p.pre, padded, frames)
+        assert ran_out == 1 and left == 0 and np.array_equal(got16, np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16)), (ch, radius, rates, "int16")
 
 
 @pytest.mark.parametrize("variant", [26, 27])

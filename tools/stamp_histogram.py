@@ -20,10 +20,17 @@ stream = torch.cuda.current_stream(dev)
 for rep in range(30):
     st = cr.LowLevel_State.from_buffer_copy(st0)
     api.ResampleDevice(plan, st, pcm.data_ptr(), frames, out.data_ptr(), n_out, stream.cuda_stream)
-torch.cuda.synchronize()
-stamp.zero_()
-st = cr.LowLevel_State.from_buffer_copy(st0)
-api.ResampleDevice(plan, st, pcm.data_ptr(), frames, out.data_ptr(), n_out, stream.cuda_stream)
+if os.environ.get("STAMP_COLD"):
+    # one launch from idle
+    torch.cuda.synchronize()
+    stamp.zero_()
+    st = cr.LowLevel_State.from_buffer_copy(st0)
+    api.ResampleDevice(plan, st, pcm.data_ptr(), frames, out.data_ptr(), n_out, stream.cuda_stream)
+else:
+    # the last of a sustained series (every launch overwrites the stamps of the one before)
+    for rep in range(300):
+        st = cr.LowLevel_State.from_buffer_copy(st0)
+        api.ResampleDevice(plan, st, pcm.data_ptr(), frames, out.data_ptr(), n_out, stream.cuda_stream)
 torch.cuda.synchronize()
 raw = stamp.cpu().numpy()[:4 * 4096].reshape(-1, 4)
 raw = raw[raw[:, 2] != 0]
@@ -39,6 +46,7 @@ print("late starters per XCC:", [int((late & (raw[:, 3] == x)).sum()) for x in r
 # per-tile stamps (k_poly diagnostic instance): tile index << 48 | tick
 pt = stamp.cpu().numpy()[4 * 4096 + 4 * 64:].reshape(4096, 32)[:len(raw)]
 idx = (pt >> 48).astype(np.int64); tick = (pt & 0xFFFFFFFFFFFF).astype(np.int64)
+tick = np.where(tick >= (t0 & 0xFFFFFFFFFFFF), tick, 0)   # older launches' entries
 ntile = (tick != 0).sum(axis=1)
 print("tiles per workgroup histogram:", np.bincount(ntile).tolist())
 tt = np.where(tick != 0, (tick - t0) / 100.0, np.nan)

@@ -89,7 +89,7 @@ def main():
             if v in (1006, 1007, 1008):
                 import numpy as _np
                 raw = stamp.cpu().numpy()
-                ph = raw[4 * 4096:].reshape(-1, 4).astype(float)
+                ph = raw[4 * 4096:4 * 4096 + 4 * 64].reshape(-1, 4).astype(float)
                 st = raw[:4 * 4096].reshape(-1, 4)
                 st = st[st[:, 2] != 0]
                 t0 = st[:, 1].min()
@@ -116,7 +116,7 @@ def main():
             print("%3d  2 lanes/frame geo %s nt=%d %5d %6d %4d | %7.1f %7.1f | %7.0f  %.3f %s" % (v, [(1024, 2), (512, 2)][(v - 22) % 2], 1 - (v - 22) // 2, i.tile_frames, i.lds_bytes, i.max_blocks, med, mn, nbytes / med / 1e3, nbytes / med / 1e3 / 8000, "MISMATCH" if v in bad else ""))
             continue
         if v in (26, 27, 28, 29):
-            kind = {26: "k_up nt=1", 27: "k_up nt=0", 28: "k_poly 64-bit chain", 29: "k_wave/k_poly 64-bit chain"}[v]
+            kind = {26: "k_up nt=1", 27: "k_up 64-bit chain", 28: "k_poly 64-bit chain", 29: "k_wave/k_poly 64-bit chain"}[v]
             print("%3d  %-26s kernel %d %5d %6d %4d | %7.1f %7.1f | %7.0f  %.3f %s" % (v, kind, i.kernel, i.tile_frames, i.lds_bytes, i.max_blocks, med, mn, nbytes / med / 1e3, nbytes / med / 1e3 / 8000, "MISMATCH" if v in bad else ""))
             continue
         if v in (20, 21):

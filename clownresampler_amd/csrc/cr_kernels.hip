@@ -164,6 +164,52 @@ __device__ __forceinline__ void sdwa_tap_single(int &acc, int sample, int weight
 	    : "v"(sample), "v"(weight));
 }
 
+// One tap of the sample in the LOW word of a dword (the odd channel that is left over when a frame is read as dwords).
+__device__ __forceinline__ void sdwa_tap_word0(int &acc, int frame, int weight)
+{
+	int x, t;
+	asm("v_mul_i32_i24_sdwa %1, sext(%3), %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
+	    "v_ashrrev_i32_e32 %2, 31, %1\n\t"
+	    "v_add_u32_sdwa %1, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_add_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+	    : "+v"(acc), "=&v"(x), "=&v"(t)
+	    : "v"(frame), "v"(weight));
+}
+
+__device__ __forceinline__ void sdwa_tap_word0_first(int &acc, int frame, int weight)
+{
+	int t;
+	asm("v_mul_i32_i24_sdwa %0, sext(%2), %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
+	    "v_ashrrev_i32_e32 %1, 31, %0\n\t"
+	    "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_ashrrev_i32_e32 %0, 16, %0"
+	    : "=&v"(acc), "=&v"(t)
+	    : "v"(frame), "v"(weight));
+}
+
+// ... and in the HIGH word (mono: two neighbouring frames of the window share a dword).
+__device__ __forceinline__ void sdwa_tap_word1(int &acc, int frame, int weight)
+{
+	int x, t;
+	asm("v_mul_i32_i24_sdwa %1, sext(%3), %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+	    "v_ashrrev_i32_e32 %2, 31, %1\n\t"
+	    "v_add_u32_sdwa %1, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_add_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+	    : "+v"(acc), "=&v"(x), "=&v"(t)
+	    : "v"(frame), "v"(weight));
+}
+
+__device__ __forceinline__ void sdwa_tap_word1_first(int &acc, int frame, int weight)
+{
+	int t;
+	asm("v_mul_i32_i24_sdwa %0, sext(%2), %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+	    "v_ashrrev_i32_e32 %1, 31, %0\n\t"
+	    "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_ashrrev_i32_e32 %0, 16, %0"
+	    : "=&v"(acc), "=&v"(t)
+	    : "v"(frame), "v"(weight));
+}
+
 // acc += trunc(product / 65536)
 template <int ASM>
 __device__ __forceinline__ int accumulate_product(int acc, int product)
@@ -174,13 +220,18 @@ __device__ __forceinline__ int accumulate_product(int acc, int product)
 		return acc + ((product + (int)((unsigned)(product >> 31) >> 16)) >> 16);
 }
 
-// One input frame from LDS.  Even channel counts stay PACKED (two int16 per dword) and are multiplied straight out
-// of the dword; odd counts are read sample by sample.
+// One input frame from LDS, kept PACKED (two int16 per dword) and multiplied straight out of the dwords by the SDWA
+// forms.  An odd channel count leaves one sample over: it sits in the low word of the last dword.
+// Frames of an odd channel count start on 2-byte boundaries, and LDS reads that are not naturally aligned are SLOW on
+// gfx950: hipcc merges neighbouring 16-bit reads into ds_read_b64 / b32 on 2-byte boundaries, and the mono and 3-channel
+// kernels measured 1.5-1.7x slower for it (profiles/).  So an odd frame is read as the ALIGNED dwords that cover it and
+// funnel-shifted into place (v_alignbit_b32 by 0 or 16): one instruction per dword, which also replaces the per-sample
+// sign extension the unpacked form needed.
 template <int CH>
 struct Frame
 {
 	static constexpr bool PACKED = (CH % 2) == 0;
-	static constexpr int WORDS = PACKED ? CH / 2 : CH;
+	static constexpr int WORDS = (CH + 1) / 2;
 	int v[WORDS];
 
 	__device__ __forceinline__ void load(const unsigned char *p)
@@ -211,9 +262,16 @@ struct Frame
 		}
 		else
 		{
+			const unsigned odd = (unsigned)reinterpret_cast<uintptr_t>(p) & 2u;   // the frame starts in the high half of a dword
+			const unsigned *q = reinterpret_cast<const unsigned *>(p - odd);
+			unsigned d[WORDS];
 #pragma unroll
-			for (int c = 0; c < CH; ++c)
-				v[c] = reinterpret_cast<const short *>(p)[c];
+			for (int k = 0; k < WORDS; ++k)
+				d[k] = q[k];
+#pragma unroll
+			for (int k = 0; k + 1 < WORDS; ++k)
+				v[k] = (int)__builtin_amdgcn_alignbit(d[k + 1], d[k], odd * 8u);
+			v[WORDS - 1] = (int)(d[WORDS - 1] >> (odd * 8u));
 		}
 	}
 
@@ -228,50 +286,116 @@ struct Frame
 				acc[c] = 0;
 			mac<0>(acc, weight);
 		}
-		else if constexpr (PACKED)
-		{
-#pragma unroll
-			for (int k = 0; k < WORDS; ++k)
-				sdwa_tap_pair_first(acc[2 * k], acc[2 * k + 1], v[k], weight);
-		}
 		else
 		{
 #pragma unroll
-			for (int c = 0; c < CH; ++c)
-				sdwa_tap_single_first(acc[c], v[c], weight);
+			for (int k = 0; k < CH / 2; ++k)
+				sdwa_tap_pair_first(acc[2 * k], acc[2 * k + 1], v[k], weight);
+			if constexpr (!PACKED)
+				sdwa_tap_word0_first(acc[CH - 1], v[WORDS - 1], weight);
 		}
 	}
 
 	template <int ASM>
 	__device__ __forceinline__ void mac(int (&acc)[CH], int weight) const
 	{
-		if constexpr (PACKED)
-		{
 #pragma unroll
-			for (int k = 0; k < WORDS; ++k)
+		for (int k = 0; k < CH / 2; ++k)
+		{
+			if constexpr (ASM)
 			{
-				if constexpr (ASM)
-				{
-					sdwa_tap_pair(acc[2 * k], acc[2 * k + 1], v[k], weight);
-				}
-				else
-				{
-					acc[2 * k] = accumulate_product<0>(acc[2 * k], __mul24((int)(short)v[k], weight));
-					acc[2 * k + 1] = accumulate_product<0>(acc[2 * k + 1], __mul24(v[k] >> 16, weight));
-				}
+				sdwa_tap_pair(acc[2 * k], acc[2 * k + 1], v[k], weight);
+			}
+			else
+			{
+				acc[2 * k] = accumulate_product<0>(acc[2 * k], __mul24((int)(short)v[k], weight));
+				acc[2 * k + 1] = accumulate_product<0>(acc[2 * k + 1], __mul24(v[k] >> 16, weight));
 			}
 		}
+		if constexpr (!PACKED)
+		{
+			if constexpr (ASM)
+				sdwa_tap_word0(acc[CH - 1], v[WORDS - 1], weight);
+			else
+				acc[CH - 1] = accumulate_product<0>(acc[CH - 1], __mul24((int)(short)v[WORDS - 1], weight));
+		}
+	}
+};
+
+// N consecutive MONO frames (int16) starting at p, packed two per dword: pw[k] = frames 2k (low word) and 2k + 1 (high word).
+// Aligned dword reads + one funnel shift per dword (see Frame); pw must have (N + 1) / 2 elements.
+template <int N>
+__device__ __forceinline__ void load_mono_window(const unsigned char *p, int *pw)
+{
+	constexpr int NPW = (N + 1) / 2, NW = (N + 2) / 2;
+	const unsigned odd = (unsigned)reinterpret_cast<uintptr_t>(p) & 2u;
+	const unsigned *q = reinterpret_cast<const unsigned *>(p - odd);
+	unsigned d[NW];
+#pragma unroll
+	for (int k = 0; k < NW; ++k)
+		d[k] = q[k];
+#pragma unroll
+	for (int k = 0; k < NPW; ++k)
+		pw[k] = k + 1 < NW ? (int)__builtin_amdgcn_alignbit(d[k + 1], d[k], odd * 8u) : (int)(d[k] >> (odd * 8u));
+}
+
+// One mono tap out of a packed window: frame s of the window, weight w.
+template <int ASM, bool FIRST>
+__device__ __forceinline__ void mono_tap(int &acc, const int *pw, int s, int weight)
+{
+	if constexpr (!ASM)
+	{
+		const int sample = (s & 1) ? (pw[s / 2] >> 16) : (int)(short)pw[s / 2];
+		acc = accumulate_product<0>(FIRST ? 0 : acc, __mul24(sample, weight));
+	}
+	else if (s & 1)
+	{
+		if constexpr (FIRST)
+			sdwa_tap_word1_first(acc, pw[s / 2], weight);
 		else
-		{
+			sdwa_tap_word1(acc, pw[s / 2], weight);
+	}
+	else
+	{
+		if constexpr (FIRST)
+			sdwa_tap_word0_first(acc, pw[s / 2], weight);
+		else
+			sdwa_tap_word0(acc, pw[s / 2], weight);
+	}
+}
+
+// The frames of a tap window for an ODD channel count above one.  A frame is CH * 2 = 2 (mod 4) bytes, so consecutive frames
+// alternate between starting on a dword and in the middle of one; both aligned bases and both funnel shifts are formed once
+// per window, and every frame is then read at an immediate offset.
+template <int CH, int FB>
+struct OddWindow
+{
+	const unsigned char *even_base, *odd_base;   // aligned base of frame s is {even,odd}_base + s * FB for even / odd s
+	unsigned even_shift, odd_shift;
+
+	__device__ __forceinline__ explicit OddWindow(const unsigned char *p)
+	{
+		static_assert(CH % 2 == 1 && FB % 4 == 2, "frames of an odd channel count, one lane per frame");
+		const unsigned odd = (unsigned)reinterpret_cast<uintptr_t>(p) & 2u;
+		even_base = p - odd;
+		odd_base = p - 2u + odd;         // frame 1 starts FB = 2 (mod 4) bytes on: in the other half
+		even_shift = odd * 8u;
+		odd_shift = 16u - odd * 8u;
+	}
+
+	__device__ __forceinline__ void load(Frame<CH> &f, int slot) const
+	{
+		constexpr int WORDS = Frame<CH>::WORDS;
+		const unsigned *q = reinterpret_cast<const unsigned *>(((slot & 1) ? odd_base : even_base) + slot * FB);
+		const unsigned shift = (slot & 1) ? odd_shift : even_shift;
+		unsigned d[WORDS];
 #pragma unroll
-			for (int c = 0; c < CH; ++c)
-			{
-				if constexpr (ASM)
-					sdwa_tap_single(acc[c], v[c], weight);
-				else
-					acc[c] = accumulate_product<0>(acc[c], __mul24(v[c], weight));
-			}
-		}
+		for (int k = 0; k < WORDS; ++k)
+			d[k] = q[k];
+#pragma unroll
+		for (int k = 0; k + 1 < WORDS; ++k)
+			f.v[k] = (int)__builtin_amdgcn_alignbit(d[k + 1], d[k], shift);
+		f.v[WORDS - 1] = (int)(d[WORDS - 1] >> shift);
 	}
 };
 
@@ -409,9 +533,28 @@ __device__ __forceinline__ void fetch_frame(const crhip_poly_launch &a, const in
 		d.w[4 * q + 2] = v.z;
 		d.w[4 * q + 3] = v.w;
 	}
+	if constexpr (CH == 1 && SPLIT == 1)
+	{
+		// mono: the window as packed pairs in f[0 .. (TT + 1) / 2) (see compute_frame)
+		int pw[(TT + 1) / 2];
+		load_mono_window<TT>(src, pw);
 #pragma unroll
-	for (int s = 0; s < TT; ++s)
-		d.f[s].load(src + s * FB);
+		for (int k = 0; k < (TT + 1) / 2; ++k)
+			d.f[k].v[0] = pw[k];
+	}
+	else if constexpr (CH % 2 == 1 && SPLIT == 1)
+	{
+		const OddWindow<CH, (int)FB> window(src);
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+			window.load(d.f[s], s);
+	}
+	else
+	{
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+			d.f[s].load(src + s * FB);
+	}
 }
 
 // The tap arithmetic as a chain of full-rate 64-bit multiply-adds (ASM mode 2; pure upsampling only, where the sign of a
@@ -492,6 +635,29 @@ __device__ __forceinline__ void compute_frame(const FrameData<CH, TT> &d, int *o
 		}
 		return;
 	}
+	if constexpr (CH == 1)
+	{
+		// mono: fetch_frame left the window packed, two frames per dword
+		int pw[(TT + 1) / 2];
+#pragma unroll
+		for (int k = 0; k < (TT + 1) / 2; ++k)
+			pw[k] = d.f[k].v[0];
+		int a0 = 0, a1 = 0;
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+		{
+			if (s == 0)
+				mono_tap<ASM, true>(a0, pw, s, d.w[s]);
+			else if (s == 1)
+				mono_tap<ASM, true>(a1, pw, s, d.w[s]);
+			else if (s & 1)
+				mono_tap<ASM, false>(a1, pw, s, d.w[s]);
+			else
+				mono_tap<ASM, false>(a0, pw, s, d.w[s]);
+		}
+		out[0] = normalise<NORM>(a0 + a1, d.w[TT]);
+		return;
+	}
 	// two accumulator sets, taps alternating between them: consecutive tap statements are independent (no asm boundary
 	// pad, more overlap); integer addition is associative, so the sum is the same
 	int acc[CH], acc2[CH];
@@ -559,11 +725,27 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 		// two accumulator sets, taps alternating between them: consecutive tap statements are then independent (no asm
 		// boundary pad, more overlap); integer addition is associative, so the sum is the same
 		int acc2[CH];
+		int pw[CH == 1 && SPLIT == 1 ? (TT + 1) / 2 : 1];
+		if constexpr (CH == 1 && SPLIT == 1)
+			load_mono_window<TT>(src, pw);
 #pragma unroll
 		for (int s = 0; s < TT; ++s)
 		{
+			if constexpr (CH == 1 && SPLIT == 1)
+			{
+				if (s == 0)
+					mono_tap<ASM, true>(acc[0], pw, s, w[s]);
+				else if (s == 1)
+					mono_tap<ASM, true>(acc2[0], pw, s, w[s]);
+				else
+					mono_tap<ASM, false>((s & 1) ? acc2[0] : acc[0], pw, s, w[s]);
+				continue;
+			}
 			Frame<CH> f;
-			f.load(src + s * FB);
+			if constexpr (CH % 2 == 1 && SPLIT == 1)
+				OddWindow<CH, (int)FB>(src).load(f, s);
+			else
+				f.load(src + s * FB);
 			if (s == 0)
 				f.template mac_first<ASM>(acc, w[s]);
 			else if (s == 1)
@@ -591,11 +773,35 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 		for (unsigned q = 0; q < weight_planes; ++q)
 		{
 			const i32x4 v = plane0[q * a.plane_rows];
+			if constexpr (CH == 1 && SPLIT == 1)
+			{
+				// mono: the four frames of this trip as two packed dwords (the parity of the window's start is the same in every
+				// trip: four frames are 8 bytes)
+				int pw[2];
+				load_mono_window<4>(src + 4u * q * FB, pw);
+				mono_tap<ASM, false>(acc[0], pw, 0, v.x);
+				mono_tap<ASM, false>(acc[0], pw, 1, v.y);
+				mono_tap<ASM, false>(acc[0], pw, 2, v.z);
+				mono_tap<ASM, false>(acc[0], pw, 3, v.w);
+				continue;
+			}
 			Frame<CH> f0, f1, f2, f3;
+			if constexpr (CH % 2 == 1 && SPLIT == 1)
+			{
+				// four frames of an odd channel count are 4 * FB = 0 (mod 8) bytes: the window of every trip starts alike
+				const OddWindow<CH, (int)FB> window(src + 4u * q * FB);
+				window.load(f0, 0);
+				window.load(f1, 1);
+				window.load(f2, 2);
+				window.load(f3, 3);
+			}
+			else
+			{
 			f0.load(src + (4u * q + 0u) * FB);
 			f1.load(src + (4u * q + 1u) * FB);
 			f2.load(src + (4u * q + 2u) * FB);
 			f3.load(src + (4u * q + 3u) * FB);
+			}
 			f0.template mac<ASM>(acc, v.x);
 			f1.template mac<ASM>(acc, v.y);
 			f2.template mac<ASM>(acc, v.z);

@@ -318,8 +318,8 @@ static uint32_t current_variant(void)
 
 static uint32_t supported_poly_channels(uint32_t channels)
 {
-	/* 1..8 one lane per frame; 10, 12, 14, 16 two lanes per frame (cr_kernels.hip runtime_split); odd counts above 8: k_generic */
-	return (channels >= 1 && channels <= 8) || (channels <= 16 && channels % 2u == 0);
+	/* 1..8 one lane per frame; 9..16 two lanes per frame (cr_kernels.hip runtime_split; odd counts with a phantom channel) */
+	return channels >= 1 && channels <= 16;
 }
 
 static uint32_t plan_image_stride(const ClownResamplerAMD_Plan *plan)

@@ -275,6 +275,28 @@ struct Frame
 		}
 	}
 
+	// the same for a frame that may start on ANY 2-byte boundary whatever its channel count (frames of an odd total channel
+	// count shared by two lanes): aligned dwords + funnel shift, as above
+	__device__ __forceinline__ void load_any(const unsigned char *p)
+	{
+		if constexpr (!PACKED)
+		{
+			load(p);
+		}
+		else
+		{
+			const unsigned odd = (unsigned)reinterpret_cast<uintptr_t>(p) & 2u;
+			const unsigned *q = reinterpret_cast<const unsigned *>(p - odd);
+			unsigned d[WORDS + 1];
+#pragma unroll
+			for (int k = 0; k < WORDS + 1; ++k)
+				d[k] = q[k];
+#pragma unroll
+			for (int k = 0; k < WORDS; ++k)
+				v[k] = (int)__builtin_amdgcn_alignbit(d[k + 1], d[k], odd * 8u);
+		}
+	}
+
 	// acc = first tap's terms (no previous contents)
 	template <int ASM>
 	__device__ __forceinline__ void mac_first(int (&acc)[CH], int weight) const
@@ -687,10 +709,11 @@ __device__ __forceinline__ void compute_frame(const FrameData<CH, TT> &d, int *o
 // One output frame: CH normalised int32 into out[0..CH).
 //   rel   16.16 position relative to the tile's first integer position
 //   base  LDS address of the tile's first window frame (tile + shift)
-template <int CH, int TT, int MODE, int NORM, int ASM, int SWZ, int SPLIT = 1>
+template <int CH, int TT, int MODE, int NORM, int ASM, int SWZ, int SPLIT = 1, int PH = 0>
 __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int *rows, const unsigned char *base, unsigned rel, int *out)
 {
-	constexpr unsigned FB = CH * 2 * SPLIT;
+	static_assert(PH == 0 || (TT == 0 && SPLIT == 2), "the phantom channel exists for run-time-slot instances with two lanes per frame");
+	constexpr unsigned FB = (CH * SPLIT - PH) * 2;
 	constexpr int RS_CT = (TT + 1 + 3) & ~3;
 
 	const unsigned frac = rel & 0xFFFFu;
@@ -795,6 +818,13 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 				window.load(f2, 2);
 				window.load(f3, 3);
 			}
+			else if constexpr (PH)
+			{
+				f0.load_any(src + (4u * q + 0u) * FB);
+				f1.load_any(src + (4u * q + 1u) * FB);
+				f2.load_any(src + (4u * q + 2u) * FB);
+				f3.load_any(src + (4u * q + 3u) * FB);
+			}
 			else
 			{
 			f0.load(src + (4u * q + 0u) * FB);
@@ -844,10 +874,13 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 // NT        1 = non-temporal output stores
 // SPLIT     lanes per frame: CH is then the channels of ONE lane and a frame has CH * SPLIT channels (8-channel
 //           frames as two lanes of 4: every store instruction of a wave is one contiguous 1 KiB)
-template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0, int OUT16 = 0, int NT = 0, int SPLIT = 1>
+// PH        1 = the frame has CH * SPLIT - 1 channels (odd totals above 8, SPLIT == 2): the second lane's last channel is a
+//           PHANTOM - it multiplies whatever follows the frame in the window and its result is never stored
+template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0, int OUT16 = 0, int NT = 0, int SPLIT = 1, int PH = 0>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR_BUDGET))) void k_poly(const crhip_poly_launch a)
 {
-	constexpr unsigned FB = CH * 2 * SPLIT;               // bytes per input frame (all channels)
+	constexpr unsigned CHT = CH * SPLIT - PH;             // channels of a frame
+	constexpr unsigned FB = CHT * 2;                      // bytes per input frame (all channels)
 	constexpr unsigned FBL = CH * 2;                      // bytes of one lane's share of a frame
 	constexpr unsigned TILE_BYTES = NV * 16u * NTHREADS;
 
@@ -882,15 +915,6 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 	if (blockIdx.x >= n_tiles)
 		return;
 	volatile unsigned *mailbox = reinterpret_cast<volatile unsigned *>(smem + rows_bytes + 2u * TILE_BYTES);
-
-	// stage the polyphase rows once per workgroup (L2-resident after the first workgroups)
-	{
-		const unsigned nvec = rows_bytes / 16u;
-		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.d_rows);
-		u32x4 *dst = reinterpret_cast<u32x4 *>(smem);
-		for (unsigned i = tid; i < nvec; i += NTHREADS)
-			dst[i] = src[i];
-	}
 
 	const uint64_t in_base = reinterpret_cast<uint64_t>(a.d_in);
 	const uint64_t in_end = in_base + a.in_valid_bytes;
@@ -937,7 +961,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 	// as straight-line code for that reason; a ragged tile drains everything.
 	constexpr unsigned GROUP = NTHREADS * U;
 	constexpr int ADJ = 0;   // a lane's U frames are NTHREADS apart: every store instruction is coalesced across the wave
-	constexpr int STORES_PER_GROUP = U * (OUT16 ? (CH % 2 == 0 ? stores_of_ints(CH / 2) : CH) : stores_of_ints(CH));
+	constexpr int STORES_PER_GROUP = PH ? U * CH : U * (OUT16 ? (CH % 2 == 0 ? stores_of_ints(CH / 2) : CH) : stores_of_ints(CH));
 
 	// Tickets.  One global counter would serialise: a single word sustains ~88 atomic draws per microsecond on this
 	// chip (MI355X_MICROARCH.md, "dequeue") and a 10-minute stereo launch draws 7,000 of them - measured 92 us instead
@@ -981,6 +1005,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 	const bool dynamic = a.dynamic_tiles != 0;
 	if (dynamic && tid == 0)
 		mailbox[0] = draw();
+	// stage the polyphase rows once per workgroup (L2-resident after the first workgroups) - AFTER the first tile's DMA and
+	// the first ticket are on their way, so that the three round trips of a workgroup's start overlap
+	{
+		const unsigned nvec = rows_bytes / 16u;
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.d_rows);
+		u32x4 *dst = reinterpret_cast<u32x4 *>(smem);
+		for (unsigned i = tid; i < nvec; i += NTHREADS)
+			dst[i] = src[i];
+	}
 	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 	__syncthreads();   // rows staged (plain stores to LDS), first tile landed and first ticket posted, for every wave
 	uint64_t next_index = dynamic ? __builtin_amdgcn_readfirstlane(mailbox[0]) : tile_index + gridDim.x;   // wave-uniform
@@ -1028,8 +1061,26 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 		const unsigned frac0 = (unsigned)(pos & 0xFFFFu);
 		// lane-frames: a frame shared by SPLIT lanes counts SPLIT times; lane-frame L is lane share L % SPLIT of frame L / SPLIT
 		const unsigned nl = n * SPLIT;
-		int *out_tile = reinterpret_cast<int *>(a.d_out) + jt * (CH * SPLIT);             // OUT16 == 0
-		short *out_tile16 = reinterpret_cast<short *>(a.d_out) + jt * (CH * SPLIT);       // OUT16 == 1
+		int *out_tile = reinterpret_cast<int *>(a.d_out) + jt * CHT;             // OUT16 == 0
+		short *out_tile16 = reinterpret_cast<short *>(a.d_out) + jt * CHT;       // OUT16 == 1
+		// phantom instances: lane-frame L is share L % 2 of frame L / 2; the shares are CH and CH - 1 channels, stored sample by
+		// sample (an odd channel count leaves nothing wider aligned), the last one only by the first lane of a pair - one store
+		// instruction per wave either way, so the counted vmcnt below holds
+		auto store_phantom = [&](unsigned L, const int *v) {
+			const size_t at = (size_t)(L >> 1) * CHT + (L & 1u) * CH;
+#pragma unroll
+			for (int c = 0; c < CH; ++c)
+			{
+				if (c == CH - 1 && (L & 1u))
+					break;
+				if constexpr (OUT16)
+					out_tile16[at + c] = (short)clamp_s16(v[c]);
+				else if constexpr (NT)
+					__builtin_nontemporal_store(v[c], out_tile + at + c);
+				else
+					out_tile[at + c] = v[c];
+			}
+		};
 		const unsigned char *base = tile + shift + (tid % SPLIT) * FBL;
 
 		// One group = NTHREADS * U frames: U independent frames per lane, no bounds checks.
@@ -1049,7 +1100,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 						outv[u * CH + c] = (int)(first + tid);
 				}
 				else
-					one_frame<CH, TT, MODE, NORM, ASM, SWZ, SPLIT>(a, rows, base, lane_rel + (first / SPLIT) * a.increment, outv + u * CH);
+					one_frame<CH, TT, MODE, NORM, ASM, SWZ, SPLIT, PH>(a, rows, base, lane_rel + (first / SPLIT) * a.increment, outv + u * CH);
 			}
 			if constexpr (ABL == 1 || ABL == 3)
 			{
@@ -1062,7 +1113,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 #pragma unroll
 			for (int u = 0; u < U; ++u)
 			{
-				if constexpr (OUT16)
+				if constexpr (PH)
+				{
+					store_phantom(g + u * NTHREADS + tid, outv + u * CH);
+				}
+				else if constexpr (OUT16)
 				{
 					short *group_out = out_tile16 + (size_t)(g + u * NTHREADS) * CH;   // uniform
 					store_shorts<CH, NT>(group_out + tid * CH, outv + u * CH);
@@ -1138,8 +1193,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 			for (unsigned jl = g + tid; jl < nl; jl += NTHREADS)
 			{
 				int outv[CH];
-				one_frame<CH, TT, MODE, NORM, ASM, SWZ, SPLIT>(a, rows, base, __umul24(jl / SPLIT, a.increment) + frac0, outv);
-				if constexpr (OUT16)
+				one_frame<CH, TT, MODE, NORM, ASM, SWZ, SPLIT, PH>(a, rows, base, __umul24(jl / SPLIT, a.increment) + frac0, outv);
+				if constexpr (PH)
+					store_phantom(jl, outv);
+				else if constexpr (OUT16)
 					store_shorts<CH, NT>(out_tile16 + (size_t)jl * CH, outv);
 				else
 					store_ints<CH, NT>(out_tile + (size_t)jl * CH, outv);
@@ -2091,16 +2148,16 @@ poly_fn pick_runtime(uint32_t mode, uint32_t norm)
 	                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, GEO, 1, 0, 1, OUT16>();
 }
 
-// two lanes per frame, HALF channels each (run-time slot count, geometry 4)
-template <int HALF, int OUT16>
+// two lanes per frame, HALF channels each (run-time slot count, geometry 4); PH = 1: 2 * HALF - 1 channels (see k_poly)
+template <int HALF, int OUT16, int PH = 0>
 poly_fn pick_runtime_split(uint32_t mode, uint32_t norm)
 {
 	constexpr int T = GEOMETRY[4].threads, V = GEOMETRY[4].vecs;
 	if (norm == CRHIP_NORM_S31)
-		return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, T, V, 1, 1, 0, 0, OUT16, 1, 2>
-		                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, T, V, 1, 1, 0, 0, OUT16, 1, 2>;
-	return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, T, V, 1, 1, 0, 0, OUT16, 1, 2>
-	                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, T, V, 1, 1, 0, 0, OUT16, 1, 2>;
+		return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, T, V, 1, 1, 0, 0, OUT16, 1, 2, PH>
+		                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, T, V, 1, 1, 0, 0, OUT16, 1, 2, PH>;
+	return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, T, V, 1, 1, 0, 0, OUT16, 1, 2, PH>
+	                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, T, V, 1, 1, 0, 0, OUT16, 1, 2, PH>;
 }
 
 template <int OUT16>
@@ -2116,7 +2173,11 @@ poly_fn pick_runtime_channels(uint32_t channels, uint32_t mode, uint32_t norm)
 		case 6: return pick_runtime<6, OUT16>(mode, norm);
 		case 7: return pick_runtime<7, OUT16>(mode, norm);
 		case 8: return pick_runtime<8, OUT16>(mode, norm);
+		case 9: return pick_runtime_split<5, OUT16, 1>(mode, norm);
 		case 10: return pick_runtime_split<5, OUT16>(mode, norm);
+		case 11: return pick_runtime_split<6, OUT16, 1>(mode, norm);
+		case 13: return pick_runtime_split<7, OUT16, 1>(mode, norm);
+		case 15: return pick_runtime_split<8, OUT16, 1>(mode, norm);
 		case 12: return pick_runtime_split<6, OUT16>(mode, norm);
 		case 14: return pick_runtime_split<7, OUT16>(mode, norm);
 		case 16: return pick_runtime_split<8, OUT16>(mode, norm);

@@ -113,12 +113,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE %d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the GPU: the product has no CPU path")
+    # CRA_BENCH_BACKEND=gloo is a validation hook for boxes with fewer GPUs than ranks: the ranks share the GPUs there are
+    # and synchronise over gloo (everything but RCCL itself is exercised); the driver's runs use nccl = RCCL, one GPU per rank
+    backend = os.environ.get("CRA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     radius, ch, rates, frames_per_gpu = WORKLOADS[args.workload]
     api = cr.load(radius)
@@ -221,7 +229,7 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)
     ms_rank = max(dev_ms, 0.0)
     if world > 1:
-        t = torch.tensor([ms_rank, wall * 1e3], dtype=torch.float64, device=device)
+        t = torch.tensor([ms_rank, wall * 1e3], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms_rank, wall_ms = float(t[0]), float(t[1])
     else:
@@ -272,7 +280,7 @@ def main():
             raise SystemExit("bench: device output differs from the oracle - numbers void")
 
     gather = None
-    if world > 1 and not args.s16:
+    if world > 1 and not args.s16 and backend == "nccl":
         # the final concatenate (north_star): all ranks' int32 shards gathered over xGMI by RCCL; timed apart from the kernel
         per = (out_frames_all + world - 1) // world * ch
         send = torch.zeros(per, dtype=torch.int32, device=device)

@@ -65,6 +65,39 @@ int main()
 		CHECK(hipHostUnregister(out));
 		printf("registered, both directions at once: %.2f ms (%.1f GB/s aggregate)\n", (t1 - t0) * 1e3, (in_bytes + out_bytes) / (t1 - t0) / 1e9);
 	}
+	for (int rep = 0; rep < 3; ++rep)
+	{
+		// the same from PAGEABLE memory, one host thread: do the async calls return before the copy is done?
+		double t0 = now();
+		CHECK(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, s0));
+		double t1 = now();
+		CHECK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s1));
+		double t2 = now();
+		CHECK(hipStreamSynchronize(s0));
+		CHECK(hipStreamSynchronize(s1));
+		double t3 = now();
+		printf("pageable, both directions at once: H2D call %.2f ms, D2H call %.2f ms, all done after %.2f ms (%.1f GB/s aggregate)\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t0) * 1e3,
+		       (in_bytes + out_bytes) / (t3 - t0) / 1e9);
+	}
+	for (int rep = 0; rep < 3; ++rep)
+	{
+		// pipelined chunks, pageable, one host thread, two streams: chunk c = H2D(c) then D2H(c) on stream c % 2 (what
+		// cr_run_host would do with two workspaces)
+		const int chunks = 8;
+		const size_t ci = in_bytes / chunks & ~(size_t)15, co = out_bytes / chunks & ~(size_t)15;
+		double t0 = now();
+		for (int c = 0; c < chunks; ++c)
+		{
+			hipStream_t s = (c & 1) ? s1 : s0;
+			CHECK(hipMemcpyAsync((char *)d_in + c * ci, in + c * ci, ci, hipMemcpyHostToDevice, s));
+			CHECK(hipMemcpyAsync(out + c * co, (char *)d_out + c * co, co, hipMemcpyDeviceToHost, s));
+		}
+		double t1 = now();
+		CHECK(hipStreamSynchronize(s0));
+		CHECK(hipStreamSynchronize(s1));
+		double t2 = now();
+		printf("pageable, 8 chunks on two streams: calls returned after %.2f ms, all done after %.2f ms (%.1f GB/s aggregate)\n", (t1 - t0) * 1e3, (t2 - t0) * 1e3, (ci + co) * chunks / (t2 - t0) / 1e9);
+	}
 	// a single host thread copying into / out of a pinned bounce buffer
 	{
 		char *bounce;

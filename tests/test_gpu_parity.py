@@ -1,6 +1,7 @@
 """GPU (MI355X): the HIP path, called through the C ABI, against the committed known answers of the real reference
 (tests/golden/golden.json) and against the oracle run on the same inputs.  Bit-exact: this is integer work."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -458,12 +459,14 @@ def test_random_configurations_bit_exact(products):
     """300 random (radius, channels, rates, low-pass, length) draws, incl. carried state across two calls and capacity stops:
     whatever kernel the plan picks (specialised, run-time-slot, wave-autonomous, generic), the stream equals the oracle's."""
     import random
-    rng = random.Random(20261002)
+    # CRA_SOAK_SEED / CRA_SOAK_DRAWS: a longer one-off soak with another seed (the committed run is 300 draws of the fixed seed)
+    rng = random.Random(int(os.environ.get("CRA_SOAK_SEED", "20261002")))
+    draws = int(os.environ.get("CRA_SOAK_DRAWS", "300"))
     kernels = {0: 0, 1: 0, 2: 0, 3: 0}
     done = 0
-    while done < 300:
+    while done < draws:
         radius = rng.choice([3, 3, 8])
-        ch = rng.choice([1, 2, 2, 2, 3, 4, 5, 6, 7, 8, 8, 10, 11, 12, 14, 16])
+        ch = rng.choice([1, 2, 2, 2, 3, 4, 5, 6, 7, 8, 8, 9, 10, 11, 12, 13, 14, 15, 16])
         i, o = rng.randrange(1, 200000), rng.randrange(1, 200000)
         if rng.random() < 0.5:
             o = max(1, int(i * rng.choice([0.03, 0.25, 0.5, 0.9, 0.999, 1.0, 1.001, 1.0884, 1.1, 2, 3, 12, 40])))

@@ -790,52 +790,69 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 	{
 		// Run-time slot count.  The device image of the rows is laid out for this loop (cr_plan.c, SPLIT layout):
 		// ceil(slots / 4) planes of weights, zero-padded, then one plane that holds only the reciprocal.  Four taps
-		// per trip - one ds_read_b128 of weights, four frame reads, four independent multiply-accumulates - and no
-		// per-slot bounds test: a padded slot has weight 0 and contributes exactly 0 whatever the LDS read returns.
+		// per trip - one ds_read_b128 of weights, four frame reads, four independent multiply-accumulates - and, where it
+		// measured faster (TAIL below), a last SHORTER trip for slots % 4 taps (a wave-uniform switch): 5 slots - every pure
+		// upsampling with three lobes - are then 5 taps of arithmetic, not 8.
 		const unsigned weight_planes = a.row_stride / 4u - 1u;
-		for (unsigned q = 0; q < weight_planes; ++q)
-		{
+		auto trip = [&](unsigned q, auto count_tag) {
+			constexpr int N = decltype(count_tag)::value;   // taps of this trip, 1..4
 			const i32x4 v = plane0[q * a.plane_rows];
+			const int wv[4] = {v.x, v.y, v.z, v.w};
 			if constexpr (CH == 1 && SPLIT == 1)
 			{
-				// mono: the four frames of this trip as two packed dwords (the parity of the window's start is the same in every
-				// trip: four frames are 8 bytes)
+				// mono: the frames of this trip as packed dwords (the parity of the window's start is the same in every trip:
+				// four frames are 8 bytes)
 				int pw[2];
-				load_mono_window<4>(src + 4u * q * FB, pw);
-				mono_tap<ASM, false>(acc[0], pw, 0, v.x);
-				mono_tap<ASM, false>(acc[0], pw, 1, v.y);
-				mono_tap<ASM, false>(acc[0], pw, 2, v.z);
-				mono_tap<ASM, false>(acc[0], pw, 3, v.w);
-				continue;
-			}
-			Frame<CH> f0, f1, f2, f3;
-			if constexpr (CH % 2 == 1 && SPLIT == 1)
-			{
-				// four frames of an odd channel count are 4 * FB = 0 (mod 8) bytes: the window of every trip starts alike
-				const OddWindow<CH, (int)FB> window(src + 4u * q * FB);
-				window.load(f0, 0);
-				window.load(f1, 1);
-				window.load(f2, 2);
-				window.load(f3, 3);
-			}
-			else if constexpr (PH)
-			{
-				f0.load_any(src + (4u * q + 0u) * FB);
-				f1.load_any(src + (4u * q + 1u) * FB);
-				f2.load_any(src + (4u * q + 2u) * FB);
-				f3.load_any(src + (4u * q + 3u) * FB);
+				load_mono_window<N>(src + 4u * q * FB, pw);
+#pragma unroll
+				for (int k = 0; k < N; ++k)
+					mono_tap<ASM, false>(acc[0], pw, k, wv[k]);
 			}
 			else
 			{
-			f0.load(src + (4u * q + 0u) * FB);
-			f1.load(src + (4u * q + 1u) * FB);
-			f2.load(src + (4u * q + 2u) * FB);
-			f3.load(src + (4u * q + 3u) * FB);
+				Frame<CH> f[N];
+				if constexpr (CH % 2 == 1 && SPLIT == 1)
+				{
+					// four frames of an odd channel count are 4 * FB = 0 (mod 8) bytes: the window of every trip starts alike
+					const OddWindow<CH, (int)FB> window(src + 4u * q * FB);
+#pragma unroll
+					for (int k = 0; k < N; ++k)
+						window.load(f[k], k);
+				}
+				else
+				{
+#pragma unroll
+					for (int k = 0; k < N; ++k)
+					{
+						if constexpr (PH)
+							f[k].load_any(src + (4u * q + (unsigned)k) * FB);
+						else
+							f[k].load(src + (4u * q + (unsigned)k) * FB);
+					}
+				}
+#pragma unroll
+				for (int k = 0; k < N; ++k)
+					f[k].template mac<ASM>(acc, wv[k]);
 			}
-			f0.template mac<ASM>(acc, v.x);
-			f1.template mac<ASM>(acc, v.y);
-			f2.template mac<ASM>(acc, v.z);
-			f3.template mac<ASM>(acc, v.w);
+		};
+		// What to do with the slots % 4 taps of the last plane was MEASURED per lane shape (profiles/r01_channel_table.log;
+		// 44.1 -> 48 kHz, 5 slots): the shorter last trip gains 10-30 % up to 6 channels per lane; 7-8 channels per lane and
+		// most phantom shapes LOSE 10-30 % with it (three more unrolled trip bodies in every straight-line frame of a tile),
+		// so there the zero-padded full trip stays (a padded slot has weight 0 and contributes exactly 0 whatever the LDS
+		// read returns).
+		constexpr bool SHORT_TAIL = (CH <= 6 && !PH) || (CH == 5 && PH);
+		const unsigned full_trips = SHORT_TAIL ? a.slots / 4u : weight_planes;
+		for (unsigned q = 0; q < full_trips; ++q)
+			trip(q, std::integral_constant<int, 4>());
+		if constexpr (SHORT_TAIL)
+		{
+			switch (a.slots & 3u)
+			{
+				case 1: trip(full_trips, std::integral_constant<int, 1>()); break;
+				case 2: trip(full_trips, std::integral_constant<int, 2>()); break;
+				case 3: trip(full_trips, std::integral_constant<int, 3>()); break;
+				default: break;
+			}
 		}
 		reciprocal = reinterpret_cast<const int *>(plane0 + weight_planes * a.plane_rows)[0];
 	}

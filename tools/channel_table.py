@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel time and fraction of the HBM roofline for every channel count 1..16, up- and downsampling (device-resident,
-synthetic noise, ~10 M input samples per launch, HIP events around 30 sustained launches after 30 warm-up launches)."""
+synthetic noise, ~10 M input samples per launch, HIP events around 60 launches after ~200 ms of warm-up launches)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -31,14 +31,18 @@ for rates in ((44100, 48000, 44100), (48000, 44100, 44100), (44100, 8000, 8000),
             st = cr.LowLevel_State.from_buffer_copy(st0)
             pcm, out = sets[k % 3]
             api.ResampleDevice(plan, st, pcm.data_ptr(), frames, out.data_ptr(), n_out, stream.cuda_stream)
-        for k in range(30):
-            launch(k)
+        import time
+        t0 = time.perf_counter(); k = 0
+        while time.perf_counter() - t0 < 0.2:      # sustained clocks: ~200 ms of launches before the timed ones
+            for _ in range(10):
+                launch(k); k += 1
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        for k in range(30):
+        for k in range(60):
             launch(k)
         e1.record(stream); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1000 / 30
+        us = e0.elapsed_time(e1) * 1000 / 60
         nbytes = frames * ch * 2 + n_out * ch * 4
         print("%2d | %5d -> %5d | %d %3d %5d | %8.1f | %8.0f | %5.0f | %.3f" % (ch, rates[0], rates[1], info.kernel, info.slots, info.tile_frames, us, n_out * ch / us, nbytes / us / 1e3, nbytes / us / 1e3 / 8000))
         del sets

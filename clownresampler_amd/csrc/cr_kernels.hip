@@ -421,6 +421,53 @@ struct OddWindow
 	}
 };
 
+// NINT consecutive int32 to a destination that is only DWORD-aligned: 16-byte, then 8-byte, then 4-byte stores
+// (stores_of_ints_dword_aligned(NINT) instructions).
+typedef i32x4 i32x4_dword_aligned __attribute__((aligned(4)));
+typedef i32x2 i32x2_dword_aligned __attribute__((aligned(4)));
+
+template <int NINT, int NT>
+__device__ __forceinline__ void store_ints_dword_aligned(int *dst, const int *v)
+{
+	int c = 0;
+#pragma unroll
+	for (; c + 4 <= NINT; c += 4)
+	{
+		i32x4 q;
+		q.x = v[c];
+		q.y = v[c + 1];
+		q.z = v[c + 2];
+		q.w = v[c + 3];
+		if constexpr (NT)
+			__builtin_nontemporal_store(q, reinterpret_cast<i32x4_dword_aligned *>(dst + c));
+		else
+			*reinterpret_cast<i32x4_dword_aligned *>(dst + c) = q;
+	}
+	if constexpr (NINT % 4 >= 2)
+	{
+		i32x2 q;
+		q.x = v[c];
+		q.y = v[c + 1];
+		if constexpr (NT)
+			__builtin_nontemporal_store(q, reinterpret_cast<i32x2_dword_aligned *>(dst + c));
+		else
+			*reinterpret_cast<i32x2_dword_aligned *>(dst + c) = q;
+		c += 2;
+	}
+	if constexpr (NINT % 2 == 1)
+	{
+		if constexpr (NT)
+			__builtin_nontemporal_store(v[c], dst + c);
+		else
+			dst[c] = v[c];
+	}
+}
+
+constexpr int stores_of_ints_dword_aligned(int n)
+{
+	return n / 4 + (n % 4) / 2 + n % 2;
+}
+
 // NINT consecutive int32 -> global memory, widest stores the size allows.  NT = 1 marks them non-temporal: the output
 // is written once and never read by the kernel; on MI355X that is worth ~7 % of HBM throughput for the stereo stream
 // (8-byte stores) and costs a few % with 16-byte stores, so it is part of the per-instance tuning.
@@ -459,14 +506,8 @@ __device__ __forceinline__ void store_ints(int *dst, const int *v)
 	}
 	else
 	{
-#pragma unroll
-		for (int c = 0; c < NINT; ++c)
-		{
-			if constexpr (NT)
-				__builtin_nontemporal_store(v[c], dst + c);
-			else
-				dst[c] = v[c];
-		}
+		// an odd count: the frames are only dword-aligned; 16- and 8-byte stores need no more than that on gfx950
+		store_ints_dword_aligned<NINT, NT>(dst, v);
 	}
 }
 
@@ -499,7 +540,7 @@ __device__ __forceinline__ void store_shorts(short *dst, const int *v)
 
 constexpr int stores_of_ints(int n)
 {
-	return n % 4 == 0 ? n / 4 : (n % 2 == 0 ? n / 2 : n);
+	return n % 4 == 0 ? n / 4 : (n % 2 == 0 ? n / 2 : stores_of_ints_dword_aligned(n));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -978,7 +1019,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 	// as straight-line code for that reason; a ragged tile drains everything.
 	constexpr unsigned GROUP = NTHREADS * U;
 	constexpr int ADJ = 0;   // a lane's U frames are NTHREADS apart: every store instruction is coalesced across the wave
-	constexpr int STORES_PER_GROUP = PH ? U * CH : U * (OUT16 ? (CH % 2 == 0 ? stores_of_ints(CH / 2) : CH) : stores_of_ints(CH));
+	constexpr int STORES_PER_GROUP = PH ? U * (OUT16 ? CH : stores_of_ints_dword_aligned(CH - 1) + 1)
+	                                    : U * (OUT16 ? (CH % 2 == 0 ? stores_of_ints(CH / 2) : CH) : stores_of_ints(CH));
 
 	// Tickets.  One global counter would serialise: a single word sustains ~88 atomic draws per microsecond on this
 	// chip (MI355X_MICROARCH.md, "dequeue") and a 10-minute stereo launch draws 7,000 of them - measured 92 us instead
@@ -1085,17 +1127,26 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 		// instruction per wave either way, so the counted vmcnt below holds
 		auto store_phantom = [&](unsigned L, const int *v) {
 			const size_t at = (size_t)(L >> 1) * CHT + (L & 1u) * CH;
-#pragma unroll
-			for (int c = 0; c < CH; ++c)
+			if constexpr (OUT16)
 			{
-				if (c == CH - 1 && (L & 1u))
-					break;
-				if constexpr (OUT16)
+#pragma unroll
+				for (int c = 0; c < CH; ++c)
+				{
+					if (c == CH - 1 && (L & 1u))
+						break;
 					out_tile16[at + c] = (short)clamp_s16(v[c]);
-				else if constexpr (NT)
-					__builtin_nontemporal_store(v[c], out_tile + at + c);
-				else
-					out_tile[at + c] = v[c];
+				}
+			}
+			else
+			{
+				store_ints_dword_aligned<CH - 1, NT>(out_tile + at, v);
+				if (!(L & 1u))
+				{
+					if constexpr (NT)
+						__builtin_nontemporal_store(v[CH - 1], out_tile + at + CH - 1);
+					else
+						out_tile[at + CH - 1] = v[CH - 1];
+				}
 			}
 		};
 		const unsigned char *base = tile + shift + (tid % SPLIT) * FBL;

@@ -2159,6 +2159,7 @@ const special *specials(int *count)
 	    make_special<8, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 2>(),     // cfg 4: 8 channels 48 -> 44.1 kHz
 	    make_special<1, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 13, true, true>(),   // mono upsampling, 3 lobes
 	    make_special<2, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>(),     // stereo mild downsampling, 3 lobes
+	    make_special<1, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>(),     // mono mild downsampling, 3 lobes
 	};
 	*count = (int)(sizeof(table) / sizeof(table[0]));
 	return table;

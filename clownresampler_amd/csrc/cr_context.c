@@ -340,6 +340,8 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	uint64_t tile;
 
 	uint32_t frames_multiple = 0;
+	/* frames of one tap window as a tile has to hold it: the slots plus the largest shift of a phase's window (shifted rows) */
+	const uint32_t window_slots = plan->poly.slots + plan->poly.window_extra;
 
 	plan->specialised = (uint32_t)crhip_poly_has_instance(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
 	if (getenv("CLOWNRESAMPLER_AMD_NO_SPECIAL") != NULL) /* tuning hook: time the run-time-slot instance instead */
@@ -427,7 +429,7 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 		const uint32_t piece_bytes = (plan->vecs - 100u) * 1024u;
 		const uint32_t wave_tile = frames_multiple / 4u;
 		const uint64_t last_rel = (65535u + (uint64_t)(wave_tile - 1u) * plan->increment) >> 16;
-		const uint64_t window = 12u + (last_rel + plan->poly.slots) * frame_bytes;
+		const uint64_t window = 12u + (last_rel + window_slots) * frame_bytes;
 
 		if (window <= piece_bytes && (uint64_t)wave_tile * plan->increment < (1ull << 32) - 65536u)
 		{
@@ -461,7 +463,7 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	/* frames the tile image can hold after the (< 16 byte) alignment shift */
 	cap_frames = (tile_bytes - 16u) / frame_bytes;
 
-	if (cap_frames <= plan->poly.slots)
+	if (cap_frames <= window_slots)
 	{
 		plan->use_poly = 0;
 		plan->generic_reason = "tap window longer than an LDS tile";
@@ -469,7 +471,7 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	}
 
 	/* largest tile with ((65535 + (tile - 1) * increment) >> 16) + slots <= cap_frames */
-	tile = ((uint64_t)(cap_frames - plan->poly.slots) << 16) / plan->increment + 1u;
+	tile = ((uint64_t)(cap_frames - window_slots) << 16) / plan->increment + 1u;
 
 	/* 32-bit relative positions and the 24-bit multiplier of the kernel */
 	if (tile > ((1ull << 32) - 65536u) / plan->increment)
@@ -818,6 +820,8 @@ static void fill_poly_launch(const ClownResamplerAMD_Plan *plan, crhip_poly_laun
 	l->increment = (uint32_t)plan->increment;
 	l->channels = plan->channels;
 	l->slots = plan->poly.slots;
+	l->first_mr = plan->poly.first_mr;
+	l->window_extra = plan->poly.window_extra;
 	l->first_slot = plan->poly.first_slot;
 	l->rows = plan->poly.rows;
 	l->row_stride = plan->device_row_stride;

@@ -546,11 +546,14 @@ constexpr int stores_of_ints(int n)
 // ---------------------------------------------------------------------------------------------------------
 // Row index of a fractional position (host mirror: cr_plan.c cr_poly_row_of)
 // ---------------------------------------------------------------------------------------------------------
+// `shift` receives the number of frames this phase's window starts after the tile's first window frame: affine rows are laid
+// out from their own first tap (cr_plan.c, "SHIFTED windows"), and min_relative is computed here anyway.
 template <int MODE>
-__device__ __forceinline__ unsigned row_of(const crhip_poly_launch &a, unsigned frac)
+__device__ __forceinline__ unsigned row_of(const crhip_poly_launch &a, unsigned frac, unsigned &shift)
 {
 	if constexpr (MODE == CRHIP_ROWMODE_UPSAMPLE)
 	{
+		shift = 0;
 		return (65536u - frac) >> 6;
 	}
 	else
@@ -559,6 +562,7 @@ __device__ __forceinline__ unsigned row_of(const crhip_poly_launch &a, unsigned 
 		const unsigned mr = (frac + a.delta + 65535u) >> 16;
 		const unsigned xr = (frac + a.skr) >> 16;
 		const unsigned kstart = __umul24(a.step, (mr << 16) - frac) >> 16;
+		shift = mr - a.first_mr;
 		return (unsigned)((int)kstart + a.aff_a * (int)mr + a.aff_b * (int)xr + a.aff_c);
 	}
 }
@@ -582,9 +586,10 @@ template <int CH, int TT, int MODE, int SWZ, int SPLIT = 1>
 __device__ __forceinline__ void fetch_frame(const crhip_poly_launch &a, const int *rows, const unsigned char *base, unsigned rel, FrameData<CH, TT> &d)
 {
 	constexpr unsigned FB = CH * 2 * SPLIT;
-	const unsigned row = row_of<MODE>(a, rel & 0xFFFFu);
+	unsigned shift;
+	const unsigned row = row_of<MODE>(a, rel & 0xFFFFu, shift);
 	const unsigned phys = SWZ ? ((row & ~15u) | ((__umul24(row >> 4, a.swizzle) + row) & 15u)) : row;
-	const unsigned char *src = base + (rel >> 16) * FB;
+	const unsigned char *src = base + ((rel >> 16) + shift) * FB;
 	const i32x4 *plane0 = reinterpret_cast<const i32x4 *>(rows) + phys;
 
 #pragma unroll
@@ -758,13 +763,14 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 	constexpr int RS_CT = (TT + 1 + 3) & ~3;
 
 	const unsigned frac = rel & 0xFFFFu;
-	const unsigned row = row_of<MODE>(a, frac);
+	unsigned shift;
+	const unsigned row = row_of<MODE>(a, frac, shift);
 	// LDS image of the rows: PLANAR (plane q holds int32 [4q, 4q+4) of every row, 16 bytes per row) and SWIZZLED
 	// within each block of 16 rows by a host-chosen multiple of the block number, so that the 16 lanes a
 	// ds_read_b128 services together fall on 16 different 16-byte bank slots instead of the 5-8 the plain layout
 	// gives for a fixed increment (cr_plan.c cr_poly_pick_swizzle).
 	const unsigned phys = SWZ ? ((row & ~15u) | ((__umul24(row >> 4, a.swizzle) + row) & 15u)) : row;
-	const unsigned char *src = base + (rel >> 16) * FB;
+	const unsigned char *src = base + ((rel >> 16) + shift) * FB;
 	const i32x4 *plane0 = reinterpret_cast<const i32x4 *>(rows) + phys;
 
 	int acc[CH];
@@ -976,7 +982,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 
 	const uint64_t in_base = reinterpret_cast<uint64_t>(a.d_in);
 	const uint64_t in_end = in_base + a.in_valid_bytes;
-	const unsigned T = TT > 0 ? (unsigned)TT : a.slots;
+	const unsigned T = (TT > 0 ? (unsigned)TT : a.slots) + a.window_extra;   // frames of a tap window, the largest shift included
 
 	// Starts the LDS-DMA of the input window of the tile that begins at output frame jt: 16-byte buffer loads that
 	// land directly in `tile` (no register staging, no ds_write), each wave filling a contiguous 1 KiB piece per
@@ -1425,7 +1431,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(CRHIP_SG
 		const uint64_t aligned = first_byte & ~(uint64_t)15;
 		const unsigned shift = (unsigned)(first_byte - aligned);
 		const unsigned last_rel = (unsigned)(((pos & 0xFFFFu) + (uint64_t)(n - 1) * a.increment) >> 16);
-		uint64_t want = (uint64_t)shift + (uint64_t)(last_rel + TT) * FB;
+		uint64_t want = (uint64_t)shift + (uint64_t)(last_rel + TT + a.window_extra) * FB;
 		uint64_t avail = in_end > aligned ? in_end - aligned : 0;
 		if (want > avail)
 			want = avail;
@@ -1726,7 +1732,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 		const uint64_t aligned = first_byte & ~(uint64_t)15;
 		const unsigned shift = (unsigned)(first_byte - aligned);
 		const unsigned last_rel = (unsigned)(((pos & 0xFFFFu) + (uint64_t)(n - 1) * a.increment) >> 16);
-		uint64_t want = (uint64_t)shift + (uint64_t)(last_rel + TT) * FB;
+		uint64_t want = (uint64_t)shift + (uint64_t)(last_rel + TT + a.window_extra) * FB;
 		uint64_t avail = in_end > aligned ? in_end - aligned : 0;
 		if (want > avail)
 			want = avail;
@@ -2156,10 +2162,10 @@ const special *specials(int *count)
 	    // the k_up sign masks are those of a Lanczos window whose lobes are one input frame wide (slot 0 = first_slot)
 	    make_special<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 13, true, true, 0x12u>(),   // cfg 2 / cfg 5: stereo 44.1 -> 48 kHz, 3 lobes
 	    make_special<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 27, true, false, 0x2A55u>(),  // cfg 3: stereo 8 -> 96 kHz, 8 lobes (k_up, chain form, from 2x upsampling on; k_wave below)
-	    make_special<8, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 2>(),     // cfg 4: 8 channels 48 -> 44.1 kHz
+	    make_special<8, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 2>(),     // cfg 4: 8 channels 48 -> 44.1 kHz (5-6 taps; 6 slots on shifted windows)
 	    make_special<1, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 13, true, true>(),   // mono upsampling, 3 lobes
-	    make_special<2, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>(),     // stereo mild downsampling, 3 lobes
-	    make_special<1, 7, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>(),     // mono mild downsampling, 3 lobes
+	    make_special<2, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>(),     // stereo mild downsampling, 3 lobes
+	    make_special<1, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>(),     // mono mild downsampling, 3 lobes
 	};
 	*count = (int)(sizeof(table) / sizeof(table[0]));
 	return table;

@@ -96,6 +96,8 @@ int cr_poly_build(const int32_t *table, size_t table_len, const cr_config *cfg, 
 	uint32_t frac;
 	uint32_t nz_lo = 0xFFFFFFFFu, nz_hi = 0; /* frame-offset range [nz_lo, nz_hi) holding non-zero weights */
 	uint32_t off_lo = 0xFFFFFFFFu, off_hi = 0; /* frame-offset range holding taps at all */
+	uint32_t rel_lo = 0xFFFFFFFFu, rel_hi = 0; /* the same non-zero range counted from each phase's OWN first tap (min_relative) */
+	uint32_t mr_lo = 0xFFFFFFFFu, mr_hi = 0;   /* range of min_relative */
 	int64_t max_abs_weight = 0;
 
 	memset(out, 0, sizeof(*out));
@@ -153,6 +155,10 @@ int cr_poly_build(const int32_t *table, size_t table_len, const cr_config *cfg, 
 					combos[c].khi = ph.table_at;
 			}
 
+			if (ph.first_rel < mr_lo)
+				mr_lo = ph.first_rel;
+			if (ph.first_rel > mr_hi)
+				mr_hi = ph.first_rel;
 			if (ph.first_rel < off_lo)
 				off_lo = ph.first_rel;
 			if (ph.first_rel + ph.taps > off_hi)
@@ -174,6 +180,10 @@ int cr_poly_build(const int32_t *table, size_t table_len, const cr_config *cfg, 
 						nz_lo = ph.first_rel + t;
 					if (ph.first_rel + t + 1 > nz_hi)
 						nz_hi = ph.first_rel + t + 1;
+					if (t < rel_lo)
+						rel_lo = t;
+					if (t + 1 > rel_hi)
+						rel_hi = t + 1;
 				}
 			}
 
@@ -250,6 +260,24 @@ int cr_poly_build(const int32_t *table, size_t table_len, const cr_config *cfg, 
 		out->aff_b = (int32_t)b;
 		out->aff_c = (int32_t)cc;
 		out->rows = next;
+
+		/* SHIFTED windows.  The phases of a stretched kernel start at different frames (min_relative takes two values), so a
+		   window common to all of them is one slot longer than the longest phase: 48 -> 44.1 kHz has 5-6 taps on 7 common
+		   slots.  The affine row index already computes min_relative on the device, so every row is laid out from ITS OWN
+		   first tap instead and the device starts a frame's window (min_relative - first_mr) frames later: one slot - a
+		   seventh of cfg 4's multiplies - less.  The window a tile must hold grows by window_extra frames at its end. */
+		if (rel_lo < rel_hi)
+		{
+			out->first_mr = mr_lo;
+			out->window_extra = mr_hi - mr_lo;
+			out->rel_first = rel_lo;
+			out->first_slot = mr_lo + rel_lo;
+			out->slots = rel_hi - rel_lo;
+			out->row_stride = (out->slots + 1u + 3u) & ~3u;
+			out->shifted = 1;
+		}
+		else
+			return fail(out, 0, "no non-zero weight");   /* (cannot happen once every phase's sum is non-zero) */
 	}
 
 	if ((uint64_t)out->rows * out->row_stride > (1u << 24))
@@ -324,12 +352,15 @@ int cr_poly_build(const int32_t *table, size_t table_len, const cr_config *cfg, 
 
 				if (w != 0)
 				{
-					if (offset < out->first_slot || offset - out->first_slot >= out->slots)
+					/* slot of this tap: counted from the common window's first frame, or - shifted rows - from the phase's own */
+					const uint32_t slot = out->shifted ? t - out->rel_first : offset - out->first_slot;
+
+					if ((out->shifted ? t < out->rel_first : offset < out->first_slot) || slot >= out->slots)
 					{
 						ok = 0;
 						break;
 					}
-					scratch[offset - out->first_slot] = (int32_t)w;
+					scratch[slot] = (int32_t)w;
 				}
 			}
 

@@ -39,8 +39,13 @@ typedef struct cr_poly
 	const char *reason;     /* why not, when eligible == 0 (static string) */
 	int fatal;              /* 1: the reference itself would trap / read outside the table for some phase */
 
-	uint32_t slots;         /* taps evaluated per frame (common window, zero weights included) */
-	uint32_t first_slot;    /* frame offset of slot 0 from position_integer */
+	uint32_t slots;         /* taps evaluated per frame (zero weights included) */
+	uint32_t first_slot;    /* frame offset of slot 0 from position_integer (shifted rows: for the phases with the smallest min_relative) */
+	uint32_t shifted;       /* 1 (affine row mode): a row's slot 0 is rel_first taps after ITS phase's first tap, i.e. the window of a
+	                           frame starts (min_relative - first_mr) frames after first_slot; 0: one window common to all phases */
+	uint32_t first_mr;      /* smallest min_relative over all phases */
+	uint32_t window_extra;  /* largest shift: frames a tile's input window must hold beyond first_slot + slots */
+	uint32_t rel_first;     /* all-zero leading taps trimmed from every row */
 	uint32_t rows;
 	uint32_t row_stride;    /* int32 per row: [slots weights][reciprocal][zero padding], multiple of 4 */
 	uint32_t row_mode;      /* CRHIP_ROWMODE_* */

@@ -36,6 +36,8 @@ typedef struct crhip_poly_launch
 	uint32_t increment;         /* 16.16, < 2^24 */
 	uint32_t channels;
 	uint32_t slots;             /* taps evaluated per frame */
+	uint32_t first_mr;          /* affine row mode: a frame's window starts (min_relative - first_mr) frames after first_slot */
+	uint32_t window_extra;      /* largest such shift: the tile's input window holds slots + window_extra frames beyond the last frame's position */
 	uint32_t first_slot;        /* frame offset of slot 0 relative to the integer position */
 	uint32_t rows;
 	uint32_t row_stride;        /* int32 per row, multiple of 4 */

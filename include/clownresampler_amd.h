@@ -129,7 +129,8 @@ typedef struct ClownResamplerAMD_PlanInfo
 	uint32_t kernel;            /* 1 = k_poly (polyphase rows in LDS, workgroup tiles), 2 = k_wave (same, wave-autonomous), 3 = k_up (input-stationary, strong upsampling), 0 = generic 64-bit kernel */
 	uint32_t channels;
 	uint32_t slots;             /* taps evaluated per output frame (zero-weight slots included) */
-	uint32_t first_slot;        /* frame offset of slot 0 relative to position_integer, in padded-buffer frames */
+	uint32_t first_slot;        /* frame offset of slot 0 relative to position_integer, in padded-buffer frames (row_mode 0: of the
+	                               phases with the smallest min_relative; the rows of the others start that much later) */
 	uint32_t rows;              /* polyphase rows */
 	uint32_t row_stride;        /* int32 per row: slots weights, then the 17.15 reciprocal, then padding */
 	uint32_t row_mode;          /* 0 = affine row index, 1 = pure-upsampling row index ((65536 - frac) >> 6) */

@@ -192,7 +192,9 @@ def test_polyphase_rows_equal_reference_taps(radius, rates):
     for t in range(int(taps.max())):
         active = t < taps
         w = np.where(active, table[np.minimum(ks + step * t, len(table) - 1)], 0)
-        slot = mr + t - first
+        # pure-upsampling rows lie on ONE window common to all phases; affine rows start at their own phase's first tap
+        # (cr_plan.c "SHIFTED windows": first_slot is then the window start of the phases with the smallest min_relative)
+        slot = mr + t - first if info.row_mode == 1 else t - (first - int(mr.min())) + 0 * mr
         inside = active & (slot >= 0) & (slot < T)
         assert np.all(w[active & ~inside] == 0)      # everything trimmed away is a zero weight
         exp[frac[inside], slot[inside]] = w[inside]
@@ -211,7 +213,7 @@ def test_polyphase_shapes_of_baseline_configs():
     info, rows, el, _ = p8.api.BuildRows(p8.configure(8000, 96000, 8000)[1], p8.pre)
     assert (info.slots, info.first_slot, info.rows, info.row_stride, info.row_mode, el) == (15, 1, 1025, 16, 1, True)  # cfg 3
     info, rows, el, _ = p3.api.BuildRows(p3.configure(48000, 44100, 44100)[1], p3.pre)
-    assert (info.slots, info.row_stride, info.row_mode, el) == (7, 8, 0, True)                                       # cfg 4
+    assert (info.slots, info.row_stride, info.row_mode, el) == (6, 8, 0, True)                                       # cfg 4: 5-6 taps, shifted windows
 
 
 def test_rejects_what_the_reference_cannot_run():

@@ -59,6 +59,38 @@ def test_fast_kernel_is_what_runs(products):
         assert info.lds_bytes <= 160 * 1024 and info.tile_frames >= info.threads
 
 
+@pytest.mark.parametrize("ch", list(range(1, 17)))
+def test_device_pointers_of_minimal_alignment(products, ch):
+    """Device-resident calls whose input pointer is only int16-aligned and whose output pointer is only int32-aligned (all the
+    reference's types ask for), every channel count, up- and downsampling: frames then start on every 2-byte phase of the
+    LDS tiles and the stores on every dword phase."""
+    p, o = products[3], ck.oracle(3)
+    api = p.api
+    for rates, frames in (((44100, 48000, 44100), 20011), ((48000, 44100, 44100), 20011), ((44100, 8000, 8000), 9001)):
+        ok, st = p.low_init(ch, *rates)
+        ok, ost = o.low_init(ch, *rates)
+        R = int(ost.cfg.radius_frames)
+        padded = ck.pad_frames(ck.noise_pcm(frames * ch, 31 + ch), ch, R)
+        want, _, _ = o.low_resample_i32(ost, padded, frames)
+        total = want.size // ch
+        d_in = api.DeviceAlloc(padded.nbytes + 256)
+        d_out = api.DeviceAlloc(want.nbytes + 256 + 8 * ch * 4)
+        try:
+            for in_off, out_off in ((2, 4), (6, 12), (14, 8)):
+                ok, st = p.low_init(ch, *rates)
+                api.CopyToDevice(d_in + in_off, padded)
+                plan = api.PlanCreate(st.raw, p.pre)
+                n, left, ran_out = api.ResampleDevice(plan, st.raw, d_in + in_off, frames, d_out + out_off, total + 8)
+                api.StreamSynchronize()
+                assert (n, left, ran_out) == (total, 0, 1)
+                got = np.empty_like(want)
+                api.CopyFromDevice(got, d_out + out_off)
+                assert np.array_equal(got, want), (ch, rates, in_off, out_off)
+        finally:
+            api.DeviceFree(d_in)
+            api.DeviceFree(d_out)
+
+
 def test_single_frames(golden, products):
     # ClownResampler_LowestLevel_Resample incl. "+=" into a non-zero accumulator (clownresampler.h:1020,1033)
     for f in golden["single_frames"]:

@@ -2354,6 +2354,29 @@ int crhip_stream_sync(void *stream)
 	return (int)hipStreamSynchronize((hipStream_t)stream);
 }
 
+int crhip_event_create(void **event)
+{
+	hipEvent_t e = nullptr;
+	const hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+	*event = (void *)e;
+	return (int)r;
+}
+
+int crhip_event_destroy(void *event)
+{
+	return (int)hipEventDestroy((hipEvent_t)event);
+}
+
+int crhip_event_record(void *event, void *stream)
+{
+	return (int)hipEventRecord((hipEvent_t)event, (hipStream_t)stream);
+}
+
+int crhip_stream_wait_event(void *stream, void *event)
+{
+	return (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
+}
+
 int crhip_poly_has_instance(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
 {
 	return find_special(channels, slots, row_mode, norm_mode) != nullptr ? 1 : 0;

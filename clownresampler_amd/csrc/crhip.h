@@ -111,6 +111,10 @@ int crhip_memset(void *dst, int value, size_t bytes, void *stream);
 int crhip_stream_create(void **stream);
 int crhip_stream_destroy(void *stream);
 int crhip_stream_sync(void *stream);
+int crhip_event_create(void **event);                   /* timing disabled */
+int crhip_event_destroy(void *event);
+int crhip_event_record(void *event, void *stream);
+int crhip_stream_wait_event(void *stream, void *event);
 
 #define CRHIP_TICKET_WORDS (33u * 32u)   /* up to 32 ticket counters + the finished counter, 128 bytes apart */
 

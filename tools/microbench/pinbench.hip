@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -97,6 +98,30 @@ int main()
 		CHECK(hipStreamSynchronize(s1));
 		double t2 = now();
 		printf("pageable, 8 chunks on two streams: calls returned after %.2f ms, all done after %.2f ms (%.1f GB/s aggregate)\n", (t1 - t0) * 1e3, (t2 - t0) * 1e3, (ci + co) * chunks / (t2 - t0) / 1e9);
+	}
+	for (int rep = 0; rep < 3; ++rep)
+	{
+		// pageable, TWO host threads: one uploads while the other downloads (8 chunks each)
+		const int chunks = 8;
+		const size_t ci = in_bytes / chunks & ~(size_t)15, co = out_bytes / chunks & ~(size_t)15;
+		double t0 = now();
+		std::thread down([&] {
+			CHECK(hipSetDevice(0));
+			for (int c = 0; c < chunks; ++c)
+			{
+				CHECK(hipMemcpyAsync(out + c * co, (char *)d_out + c * co, co, hipMemcpyDeviceToHost, s1));
+				CHECK(hipStreamSynchronize(s1));
+			}
+		});
+		for (int c = 0; c < chunks; ++c)
+		{
+			CHECK(hipMemcpyAsync((char *)d_in + c * ci, in + c * ci, ci, hipMemcpyHostToDevice, s0));
+			CHECK(hipStreamSynchronize(s0));
+		}
+		double t1 = now();
+		down.join();
+		double t2 = now();
+		printf("pageable, two host threads: uploads done after %.2f ms, everything after %.2f ms (%.1f GB/s aggregate)\n", (t1 - t0) * 1e3, (t2 - t0) * 1e3, (ci + co) * chunks / (t2 - t0) / 1e9);
 	}
 	// a single host thread copying into / out of a pinned bounce buffer
 	{

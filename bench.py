@@ -282,20 +282,24 @@ def main():
     gather = None
     if world > 1 and not args.s16 and backend == "nccl":
         # the final concatenate (north_star): all ranks' int32 shards gathered over xGMI by RCCL; timed apart from the kernel
-        per = (out_frames_all + world - 1) // world * ch
-        send = torch.zeros(per, dtype=torch.int32, device=device)
-        send[: shard.output_frames * ch] = sets[0][1]
-        recv = torch.empty(per * world, dtype=torch.int32, device=device)
-        dist.all_gather_into_tensor(recv, send)
-        barrier()
-        g0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
+        # (reported beside the headline; a failure here must not cost the run its bench line)
+        try:
+            per = (out_frames_all + world - 1) // world * ch
+            send = torch.zeros(per, dtype=torch.int32, device=device)
+            send[: shard.output_frames * ch] = sets[0][1]
+            recv = torch.empty(per * world, dtype=torch.int32, device=device)
             dist.all_gather_into_tensor(recv, send)
-        barrier()
-        g_ms = (time.perf_counter() - g0) * 1e3 / reps
-        gather = {"collective": "all_gather_into_tensor (RCCL)", "ms": g_ms, "bytes_per_rank": per * 4,
-                  "value_with_gather": out_samples_all / ((ms_per_step + g_ms) * 1e-3) / 1e6}
+            barrier()
+            g0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                dist.all_gather_into_tensor(recv, send)
+            barrier()
+            g_ms = (time.perf_counter() - g0) * 1e3 / reps
+            gather = {"collective": "all_gather_into_tensor (RCCL)", "ms": g_ms, "bytes_per_rank": per * 4,
+                      "value_with_gather": out_samples_all / ((ms_per_step + g_ms) * 1e-3) / 1e6}
+        except Exception as e:
+            gather = {"collective": "all_gather_into_tensor (RCCL)", "error": str(e)[:200]}
 
     if rank == 0:
         line = {

@@ -217,6 +217,32 @@ def test_cfg2_full_size_bit_exact(products):
     assert np.array_equal(np.concatenate([a, b]), want)
 
 
+@pytest.mark.parametrize("name,radius,ch,rates,frames", [
+    ("cfg3", 8, 2, (8000, 96000, 8000), 4800000),        # 8 -> 96 kHz, 8 lobes, 10 min: 57,603,516 output frames (k_up)
+    ("cfg4", 3, 8, (48000, 44100, 44100), 28800000),     # 8 channels 48 -> 44.1 kHz, 10 min: 26,460,260 output frames
+    ("cfg5", 3, 2, (44100, 48000, 44100), 158760000),    # 1 hour stereo on ONE GPU: 172,800,574 output frames
+])
+def test_baseline_configs_full_size_bit_exact(products, name, radius, ch, rates, frames):
+    """BASELINE configs[2], [3] and [4] at their full sizes against the multi-threaded oracle, plus the size-independent
+    property that splitting the input anywhere (state carried) gives the same stream.  (configs[1]: the test above.)"""
+    p, o = products[radius], ck.oracle(radius)
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    R = int(ost.cfg.radius_frames)
+    padded = ck.pad_frames(ck.noise_pcm(frames * ch, 77), ch, R)
+    want = o.low_resample_i32_mt(ost, padded, frames, threads=min(32, os.cpu_count() or 1))
+    got, left, ran_out = p.low_resample_i32(st, padded, frames)
+    assert got.size == want.size == ck.count_output_frames(ost, frames) * ch and ran_out == 1 and left == 0
+    assert np.array_equal(got, want)
+    del got
+    cut = frames // 3 + 12345
+    ok, st2 = p.low_init(ch, *rates)
+    a, l1, r1 = p.low_resample_i32(st2, padded, cut)
+    b, l2, r2 = p.low_resample_i32(st2, padded[cut * ch:], frames - cut)
+    assert l1 == 0 and l2 == 0 and a.size + b.size == want.size
+    assert np.array_equal(a, want[: a.size]) and np.array_equal(b, want[a.size:])
+
+
 def test_c_harness_reproduces_reference_harness_outputs(golden, tmp_path):
     """tools/cr_resample.c - a plain C client of include/clownresampler.h, shaped like tests/test-low-level.c and
     tests/test-high-level.c - on the reference's own fixture and ctest triples: byte-identical files (sha256 of the real

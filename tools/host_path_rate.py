@@ -13,13 +13,21 @@ import ctypes as C  # noqa: E402
 import torch  # noqa: E402
 torch.cuda.init()   # before the library's own first HIP call: torch refuses to initialise afterwards on this image
 import numpy as np  # noqa: E402
-import _checkers as ck  # noqa: E402
 import _product  # noqa: E402
+
+
+def pad_frames(pcm, channels, radius_frames):
+    z = np.zeros(radius_frames * channels, dtype=np.int16)
+    return np.concatenate([z, np.asarray(pcm, dtype=np.int16), z])
+
+
+def noise_pcm(samples):
+    return np.random.default_rng(20261002).integers(-32768, 32768, samples, dtype=np.int16)
 import clownresampler_amd as cr  # noqa: E402
 
 p = _product.Product(3)
 ch, rates, frames = 2, (44100, 48000, 44100), 26460000
-padded = ck.pad_frames(ck.noise_pcm(frames * ch), ch, 3)
+padded = pad_frames(noise_pcm(frames * ch), ch, 3)
 for rep in range(3):
     ok, st = p.low_init(ch, *rates)
     out = np.zeros((28800096 + 1) * ch, dtype=np.int32)      # fresh, untouched pages: the first write faults them in
@@ -103,7 +111,7 @@ for rep in range(2):
 # whose output rate wanders around 48 kHz (clock drift, pitch bend), device-resident buffers, one launch per segment
 dev = torch.device("cuda", 0)
 halo = 4
-d_in = torch.from_numpy(ck.pad_frames(padded[3 * ch: (3 + frames) * ch], ch, halo)).to(dev)
+d_in = torch.from_numpy(pad_frames(padded[3 * ch: (3 + frames) * ch], ch, halo)).to(dev)
 for seg_frames in (4410000, 441000, 44100, 4410):
     nseg = frames // seg_frames
     segs = [(seg_frames, 44100, 48000 + (k % 997) - 498, 44100) for k in range(nseg)]    # up to 997 distinct ratios, one configuration

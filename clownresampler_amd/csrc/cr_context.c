@@ -100,6 +100,10 @@ static cr_workspace g_workspace;
 #define CR_EXTRA_SETS 2 /* further staging sets of the pipelined host path (cr_run_host): three in all; same lock as g_workspace */
 static cr_workspace g_workspace_more[CR_EXTRA_SETS]; /* ([0].stream is the download stream) */
 static int g_workspace_busy = 0;
+/* small host-buffer calls: one pinned, device-visible block (input at the front, output behind it) that the kernel reads and
+   writes across PCIe itself - see cr_run_host */
+#define CR_SMALL_CALL_BYTES (128u * 1024u)
+static unsigned char *g_small = NULL;
 static int g_force_generic = 0;
 /* ticket slots for k_poly's dynamic tile scheduling: a ring of counter blocks (crhip.h CRHIP_TICKET_WORDS), zeroed
    once; every launch takes the next block (launches that overlap in time - different streams - must not share one) and
@@ -214,6 +218,8 @@ static void release_everything_locked(void)
 		crhip_free(g_workspace.d_out);
 		if (g_workspace.stream != NULL)
 			crhip_stream_destroy(g_workspace.stream);
+		if (g_small != NULL)
+			crhip_host_free(g_small);
 		{
 			int k;
 			for (k = 0; k < CR_EXTRA_SETS; ++k)
@@ -225,6 +231,7 @@ static void release_everything_locked(void)
 			}
 		}
 	}
+	g_small = NULL;
 	memset(&g_workspace, 0, sizeof(g_workspace));
 	memset(g_workspace_more, 0, sizeof(g_workspace_more));
 }
@@ -1052,6 +1059,44 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 
 	if (n_out == 0)
 		return 0;
+
+	/* SMALL calls (a sound-card sized request, a refill of the streaming API): two hipMemcpyAsync and a launch cost ~35 us
+	   whatever the size, most of it in the two copies.  Up to CR_SMALL_CALL_BYTES the kernel therefore works on pinned host
+	   memory directly - the input is copied into it by the CPU, the LDS-DMA reads it and the stores write the result across
+	   PCIe, and one synchronise later the CPU copies the result out: one launch, no copy calls (480 frames: 34 -> ~15 us). */
+	if (n_out <= batch_frames && getenv("CLOWNRESAMPLER_AMD_NO_SMALL_CALL_PATH") == NULL)
+	{
+		uint64_t pi = pos_int, extent = cr_input_extent(&plan->cfg, 0, pos_frac, plan->increment, n_out);
+		size_t in_bytes, out_bytes, out_at;
+
+		if (pi >= in_frames)
+			extent = 0;
+		else if (extent > in_frames - pi)
+			extent = in_frames - pi;
+		in_bytes = (size_t)extent * frame_in;
+		out_bytes = (size_t)n_out * frame_out;
+		out_at = (in_bytes + 255u) & ~(size_t)255u;
+
+		if (out_at + out_bytes + 64u <= CR_SMALL_CALL_BYTES)
+		{
+			ws = cr_workspace_acquire(0, 0); /* (the lock and the stream) */
+			if (ws == NULL)
+				return -1;
+			if (g_small == NULL && cr_check_hip(crhip_host_alloc((void **)&g_small, CR_SMALL_CALL_BYTES), "hipHostMalloc(small-call block)") != 0)
+			{
+				g_small = NULL;
+				cr_workspace_release(ws);
+				return -1;
+			}
+			memcpy(g_small, host_in + pi * plan->channels, in_bytes);
+			bad = cr_plan_launch(plan, g_small, in_bytes, g_small + out_at, 0, pos_frac, n_out, ws->stream, out_s16) != 0
+			   || cr_check_hip(crhip_stream_sync(ws->stream), "hipStreamSynchronize") != 0;
+			if (!bad)
+				memcpy(host_out, g_small + out_at, out_bytes);
+			cr_workspace_release(ws);
+			return bad ? -1 : 0;
+		}
+	}
 
 	/* both staging sets, sized for a full batch, under the one workspace lock for the whole call */
 	{

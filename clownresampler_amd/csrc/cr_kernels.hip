@@ -2100,6 +2100,7 @@ struct special
 	poly_fn split[4];           // k_poly with two lanes per frame (variants SPLIT_VARIANT + i: geometry {4, 2} x nt {1, 0}); nullptr if none
 	poly_fn up[2];              // k_up (variants UP_VARIANT + {0: 24-bit multiply-add + SDWA add per tap, 1: 64-bit multiply-add chain}); nullptr if none
 	poly_fn up16;               // k_up, int16 output
+	bool lite;                  // one k_poly instance only (the default variant, int32 and int16 forms): every variant id resolves to it
 	uint32_t up_negmask;        // k_up / mad: bit s set = the weights of slot s are <= 0 in every row, clear = >= 0 (checked by the host per plan)
 	poly_fn mad[2];             // the 64-bit multiply-add chain (compute_frame, ASM mode 2): variant MAD_VARIANT = k_poly geometry 3 with non-temporal stores,
 	                            // MAD_VARIANT + 1 = k_wave where the instance has one, else k_poly geometry 3 with plain stores
@@ -2121,7 +2122,7 @@ constexpr int WAVE_WAVES = 16, WAVE_NVW = 1, WAVE_ITER = 4;
 template <int CH, int TT, int MODE, int NORM, int DV, bool WAVE = false, bool DYNAMIC = false, unsigned UPMASK = 0>
 special make_special()
 {
-	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, UPMASK, {nullptr, nullptr}};
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, false, UPMASK, {nullptr, nullptr}};
 	if constexpr (UPMASK != 0 && CH % 2 == 0)
 	{
 		s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 1>;
@@ -2156,6 +2157,20 @@ special make_special()
 	return s;
 }
 
+// A specialised instance WITHOUT the tuning variants: one k_poly (compile-time slot count, pipelined LDS reads) at the
+// geometry the run-time-slot instance of that channel count uses, non-temporal stores, int32 and int16 forms.  For the common
+// surround layouts, where the run-time-slot loop leaves 10-20 % behind (profiles/r01_channel_table.log).
+template <int CH, int TT, int MODE, int NORM, int DV = (CH <= 4 ? 13 : 14)>   // default: (1024 threads, 1 or 2 vectors per thread), one frame in flight, non-temporal stores
+special make_special_lite()
+{
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 0u, {nullptr, nullptr}};
+	const poly_fn fn = instance<CH, TT, MODE, NORM, DV % 5, 1, (DV / 5) % 2, (DV / 10) % 2>();
+	for (int v = 0; v < VARIANTS; ++v)
+		s.fn[v] = fn;
+	s.fn16 = instance<CH, TT, MODE, NORM, DV % 5, 1, (DV / 5) % 2, (DV / 10) % 2, 1>();
+	return s;
+}
+
 const special *specials(int *count)
 {
 	static const special table[] = {
@@ -2166,6 +2181,11 @@ const special *specials(int *count)
 	    make_special<1, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 13, true, true>(),   // mono upsampling, 3 lobes
 	    make_special<2, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>(),     // stereo mild downsampling, 3 lobes
 	    make_special<1, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>(),     // mono mild downsampling, 3 lobes
+	    make_special_lite<4, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),               // quad, 5.1 and 7.1 at 44.1 <-> 48 kHz
+	    make_special_lite<4, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<6, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),
+	    make_special_lite<6, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<8, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 2>(),            // (the geometry cfg 4's instance measured best with: 512 threads, plain stores)
 	};
 	*count = (int)(sizeof(table) / sizeof(table[0]));
 	return table;
@@ -2205,7 +2225,7 @@ const special *find_special(uint32_t channels, uint32_t slots, uint32_t mode, ui
 // lanes (k_poly's SPLIT), each taking half of its channels: the per-lane code is that of 5..8 channels.
 constexpr int runtime_geo(int channels)
 {
-	return channels <= 4 ? 3 : 4;
+	return channels <= 4 ? 3 : 4;   // (512 threads x 2 vectors, which the specialised 8-channel instances prefer, measured 10-20 % slower here)
 }
 constexpr int runtime_split(int channels)
 {
@@ -2227,7 +2247,7 @@ poly_fn pick_runtime(uint32_t mode, uint32_t norm)
 template <int HALF, int OUT16, int PH = 0>
 poly_fn pick_runtime_split(uint32_t mode, uint32_t norm)
 {
-	constexpr int T = GEOMETRY[4].threads, V = GEOMETRY[4].vecs;
+	constexpr int T = GEOMETRY[runtime_geo(16)].threads, V = GEOMETRY[runtime_geo(16)].vecs;
 	if (norm == CRHIP_NORM_S31)
 		return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, T, V, 1, 1, 0, 0, OUT16, 1, 2, PH>
 		                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, T, V, 1, 1, 0, 0, OUT16, 1, 2, PH>;
@@ -2388,6 +2408,8 @@ static uint32_t resolve_variant(const special *sp, uint32_t variant, uint32_t ou
 {
 	if (sp == nullptr)
 		return 0u;
+	if (sp->lite)
+		return sp->default_variant;
 	if (variant == 1008u)
 		return sp->up[0] != nullptr ? UP_VARIANT : (sp->wave[0] != nullptr ? WAVE_VARIANT : 13u);   // diagnostic k_up instance
 	if (variant == 1007u && sp->wave[0] != nullptr)

@@ -2186,6 +2186,17 @@ const special *specials(int *count)
 	    make_special_lite<6, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),
 	    make_special_lite<6, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
 	    make_special_lite<8, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 2>(),            // (the geometry cfg 4's instance measured best with: 512 threads, plain stores)
+	    // mono and stereo at the usual downsampling ratios: 2:1 (12 slots), 96 -> 44.1 (13), 3:2 (9), 44.1 -> 32 (8), 3:1 (18)
+	    make_special_lite<1, 12, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<2, 12, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<1, 13, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<2, 13, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<1, 9, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<2, 9, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<1, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<2, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<1, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<2, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
 	};
 	*count = (int)(sizeof(table) / sizeof(table[0]));
 	return table;

@@ -8,13 +8,17 @@ import torch
 import clownresampler_amd as cr
 from bench import device_noise
 
+# usage: channel_table.py [radius] [in:out ...] [channels=1,2,...]   (default: four ratios, channels 1..16)
 radius = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+RATES = [tuple(int(x) for x in a.split(":")) for a in sys.argv[2:] if ":" in a]
+RATES = [(i, o, min(i, o)) for i, o in RATES] or [(44100, 48000, 44100), (48000, 44100, 44100), (44100, 8000, 8000), (8000, 44100, 8000)]
+CHANNELS = [int(x) for a in sys.argv[2:] if a.startswith("channels=") for x in a[9:].split(",")] or list(range(1, 17))
 api = cr.load(radius); dev = torch.device("cuda", 0); pre = api.precomputed()
 stream = torch.cuda.current_stream(dev)
 print("radius %d" % radius)
 print("ch | rates           | kernel slots tile | us/launch | Msamples/s | GB/s | frac of 8 TB/s")
-for rates in ((44100, 48000, 44100), (48000, 44100, 44100), (44100, 8000, 8000), (8000, 44100, 8000)):
-    for ch in range(1, 17):
+for rates in RATES:
+    for ch in CHANNELS:
         frames = 52920000 // ch if rates[0] <= rates[1] * 2 else 26460000 // ch
         if rates[1] > 3 * rates[0]:
             frames //= 5

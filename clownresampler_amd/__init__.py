@@ -80,7 +80,7 @@ class Segment(C.Structure):  # ClownResamplerAMD_Segment
 
 class PlanInfo(C.Structure):  # ClownResamplerAMD_PlanInfo
     _fields_ = [(n, C.c_uint32) for n in ("kernel", "channels", "slots", "first_slot", "rows", "row_stride", "row_mode", "threads",
-                                          "tile_frames", "lds_bytes", "max_blocks", "specialised", "variant")]
+                                          "tile_frames", "lds_bytes", "max_blocks", "specialised", "variant", "norm_mode")]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -221,6 +221,7 @@ int ClownResamplerAMD_BuildRows(const ClownResampler_LowestLevel_Configuration *
 	info->rows = poly.rows;
 	info->row_stride = poly.row_stride;
 	info->row_mode = poly.row_mode;
+	info->norm_mode = poly.norm_mode;
 	*rows_out = poly.weights; /* ownership passes to the caller */
 
 	/* optional: the row every one of the 65536 fractional positions maps to (host mirror of the device formula) */

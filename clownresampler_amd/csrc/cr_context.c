@@ -1290,6 +1290,7 @@ void ClownResamplerAMD_PlanGetInfo(const ClownResamplerAMD_Plan *plan, ClownResa
 	info->kernel = plan->use_poly ? (plan->vecs >= 200u ? 3u : plan->vecs >= 100u ? 2u : 1u) : 0u;
 	info->variant = plan->variant;
 	info->channels = plan->channels;
+	info->norm_mode = plan->poly.norm_mode;
 	info->slots = plan->poly.slots;
 	info->first_slot = plan->poly.first_slot;
 	info->rows = plan->poly.rows;

@@ -2197,6 +2197,10 @@ const special *specials(int *count)
 	    make_special_lite<2, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
 	    make_special_lite<1, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
 	    make_special_lite<2, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    // the 8-lobe build: mono upsampling, mono / stereo 48 -> 44.1 kHz (17 slots)
+	    make_special_lite<1, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32>(),
+	    make_special_lite<1, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<2, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
 	};
 	*count = (int)(sizeof(table) / sizeof(table[0]));
 	return table;

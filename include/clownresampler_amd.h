@@ -140,6 +140,7 @@ typedef struct ClownResamplerAMD_PlanInfo
 	uint32_t max_blocks;        /* persistent grid size used for large launches */
 	uint32_t specialised;       /* 1 when a (channels, slots) template instance is used */
 	uint32_t variant;           /* tuning variant the plan was built for (0xFFFF: the instance's measured default) */
+	uint32_t norm_mode;         /* 0: |accumulator x reciprocal| < 2^31 for every row (signed multiply), 1: < 2^32 (on magnitudes) */
 } ClownResamplerAMD_PlanInfo;
 
 /* Builds (or fetches from the cache) the device-side plan for the configuration, channel count and increment

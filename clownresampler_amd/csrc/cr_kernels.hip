@@ -2186,6 +2186,11 @@ const special *specials(int *count)
 	    make_special_lite<6, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),
 	    make_special_lite<6, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
 	    make_special_lite<8, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 2>(),            // (the geometry cfg 4's instance measured best with: 512 threads, plain stores)
+	    make_special_lite<3, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),               // and the odd layouts in between (2.1, 5.0, 6.1)
+	    make_special_lite<3, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<5, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),
+	    make_special_lite<7, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),
+	    make_special_lite<7, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
 	    // mono and stereo at the usual downsampling ratios: 2:1 (12 slots), 96 -> 44.1 (13), 3:2 (9), 44.1 -> 32 (8), 3:1 (18)
 	    make_special_lite<1, 12, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
 	    make_special_lite<2, 12, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),

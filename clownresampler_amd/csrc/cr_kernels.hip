@@ -69,8 +69,11 @@ __device__ __forceinline__ int normalise(int acc, int reciprocal)
 {
 	if constexpr (NORM == CRHIP_NORM_S31)
 	{
-		const int product = __mul24(acc, reciprocal);
-		return (product + (int)((unsigned)(product >> 31) >> 17)) >> 15;
+		// truncation toward zero = + 0x7FFF before the shift when the product is negative; the reciprocal is positive, so
+		// that is when the ACCUMULATOR is negative: the bias does not wait for the product and the multiply becomes a
+		// multiply-add (4 instructions instead of 5: hipcc otherwise multiplies twice)
+		const int bias = (int)((unsigned)(acc >> 31) >> 17);
+		return (__mul24(acc, reciprocal) + bias) >> 15;
 	}
 	else
 	{

@@ -501,7 +501,11 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	/* whole groups of threads * frames-in-flight; 4, 2 or 1 groups per tile run as straight-line code in the kernel */
 	{
 		const char *e = getenv("CLOWNRESAMPLER_AMD_TILE_GROUPS"); /* tuning hook: cap the groups per tile */
-		const uint64_t cap = (e != NULL && atoi(e) > 0) ? (uint64_t)atoi(e) * frames_multiple : 0;
+		/* 13 and 15 channels (7-8 channels per lane plus the phantom channel): one group per tile.  With four groups - strong
+		   upsampling - the straight-line tile measured 0.18 of the roofline against 0.30 (profiles/r01_channel_table.log);
+		   at 44.1 <-> 48 kHz, where two groups fit, one costs 1-2 % */
+		const uint64_t wide_phantom = (!plan->specialised && plan->channels > 12u && plan->channels % 2u == 1u) ? 1u : 0u;
+		const uint64_t cap = (e != NULL && atoi(e) > 0) ? (uint64_t)atoi(e) * frames_multiple : wide_phantom * frames_multiple;
 		if (cap != 0 && tile > cap)
 			tile = cap;
 	}

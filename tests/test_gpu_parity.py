@@ -486,6 +486,40 @@ def test_concurrent_callers(products):
     assert len(got) == len(jobs)
 
 
+def test_highlevel_random_streams(products):
+    """The streaming API (clownresampler.h:1101-1250: leading padding, refills, ResampleEnd) on random channel counts 1..16,
+    rates, pull sizes and lengths, both radii, with the large side window and with the reference's one pull per GPU call:
+    the same samples as the oracle's restatement of that choreography."""
+    import random
+    rng = random.Random(4711)
+    done = 0
+    try:
+        while done < 60:
+            radius = rng.choice([3, 3, 8])
+            p, o = products[radius], ck.oracle(radius)
+            ch = rng.randrange(1, 17)
+            i = rng.choice([8000, 11025, 22050, 32000, 44100, 48000, 96000, rng.randrange(4000, 200000)])
+            out_rate = rng.choice([8000, 16000, 22050, 44100, 48000, 96000, rng.randrange(4000, 200000)])
+            lp = rng.choice([min(i, out_rate), i, out_rate, max(1, min(i, out_rate) // 2)])
+            frames = rng.choice([rng.randrange(1, 200), rng.randrange(200, 5000), rng.randrange(5000, 40000)])
+            ok_a, a = p.high_init(ch, i, out_rate, lp)
+            ok_b, b = o.high_init(ch, i, out_rate, lp)
+            assert ok_a == ok_b
+            if not ok_a or b.low.cfg.table_step == 0 or 2 * int(b.low.cfg.radius_frames) * ch >= 0x1000:
+                continue
+            if ck.count_output_frames(b.low, frames) * ch > 3_000_000:
+                continue
+            p.api.SetStreamingWindow(rng.choice([0, 1 << 18, 5000]))
+            pcm = ck.noise_pcm(frames * ch, 600 + done)
+            chunk = rng.choice([0, 1, 7, 333, 2042, 100000])
+            got = p.high_run_i32(a, pcm, pull_chunk=chunk)
+            want = o.high_run_i32(b, pcm, pull_chunk=chunk)
+            assert np.array_equal(got, want), (radius, ch, i, out_rate, lp, frames, chunk)
+            done += 1
+    finally:
+        products[3].api.SetStreamingWindow(1 << 18)
+
+
 def test_highlevel_reinit_reuses_window(products):
     p = products[3]
     hs = p.api.HighLevel_State()

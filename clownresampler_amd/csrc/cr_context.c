@@ -105,12 +105,62 @@ static int g_workspace_busy = 0;
 #define CR_SMALL_CALL_BYTES (128u * 1024u)
 static unsigned char *g_small = NULL;
 static int g_force_generic = 0;
-/* ticket slots for k_poly's dynamic tile scheduling: a ring of counter blocks (crhip.h CRHIP_TICKET_WORDS), zeroed
-   once; every launch takes the next block (launches that overlap in time - different streams - must not share one) and
-   leaves it zeroed */
+/* Ticket blocks for k_poly's dynamic tile scheduling (crhip.h CRHIP_TICKET_WORDS counters each), zeroed once; a launch takes
+   a block and leaves it zeroed.  Two launches that may run AT THE SAME TIME must not share a block.  Launches on one stream
+   never do, so the blocks are handed out per stream: every stream seen gets a ring of CR_RING_SLOTS blocks (a ring rather
+   than one block so that the launches of a stream capture - whose graphs may later be replayed side by side - differ too).
+   Up to CR_TICKET_RINGS streams are live at once; one more evicts the ring used longest ago, after a device
+   synchronise (rare, and the only way to know that ring's launches are through without holding on to its stream). */
 #define CR_TICKET_SLOTS 512u
+#define CR_TICKET_RINGS 8u
+#define CR_RING_SLOTS (CR_TICKET_SLOTS / CR_TICKET_RINGS)
 static uint32_t *g_tickets = NULL;
-static unsigned g_ticket_serial = 0;
+static struct
+{
+	void *stream;
+	int used;
+	unsigned next;
+	unsigned long long last_use;
+} g_rings[CR_TICKET_RINGS];
+static unsigned long long g_ring_clock = 0;
+static pthread_mutex_t g_ring_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static uint32_t *ticket_block_for(void *stream)
+{
+	unsigned r, pick = CR_TICKET_RINGS, oldest = 0;
+	uint32_t *block;
+
+	pthread_mutex_lock(&g_ring_lock);
+	for (r = 0; r < CR_TICKET_RINGS; ++r)
+	{
+		if (g_rings[r].used && g_rings[r].stream == stream)
+		{
+			pick = r;
+			break;
+		}
+		if (!g_rings[r].used && pick == CR_TICKET_RINGS)
+			pick = r;
+		if (g_rings[r].used && g_rings[r].last_use < g_rings[oldest].last_use)
+			oldest = r;
+	}
+	if (pick == CR_TICKET_RINGS)
+	{
+		/* all rings belong to other streams: take over the one used longest ago, once nothing can be running on it */
+		crhip_device_sync();
+		pick = oldest;
+		g_rings[pick].used = 0;
+	}
+	if (!g_rings[pick].used)
+	{
+		g_rings[pick].used = 1;
+		g_rings[pick].stream = stream;
+		g_rings[pick].next = 0;
+	}
+	g_rings[pick].last_use = ++g_ring_clock;
+	block = g_tickets + CRHIP_TICKET_WORDS * (pick * CR_RING_SLOTS + g_rings[pick].next++ % CR_RING_SLOTS);
+	pthread_mutex_unlock(&g_ring_lock);
+	return block;
+}
 static unsigned long long *g_debug_stamps = NULL;
 static int g_variant = -1; /* -1: CLOWNRESAMPLER_AMD_VARIANT from the environment, else the default */
 static pthread_mutex_t g_workspace_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -214,6 +264,7 @@ static void release_everything_locked(void)
 	{
 		crhip_free(g_tickets);
 		g_tickets = NULL;
+		memset(g_rings, 0, sizeof(g_rings));
 		crhip_free(g_workspace.d_in);
 		crhip_free(g_workspace.d_out);
 		if (g_workspace.stream != NULL)
@@ -901,7 +952,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			l.dynamic_tiles = e != NULL ? (uint32_t)(atoi(e) != 0)
 			                            : (uint32_t)crhip_poly_dynamic_default(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
 		}
-		l.d_tickets = g_tickets + CRHIP_TICKET_WORDS * (__atomic_fetch_add(&g_ticket_serial, 1u, __ATOMIC_RELAXED) % CR_TICKET_SLOTS);
+		l.d_tickets = ticket_block_for(stream);
 
 		return cr_check_hip(crhip_launch_poly(&l, stream), "k_poly launch");
 	}

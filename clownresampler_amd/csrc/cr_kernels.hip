@@ -2415,6 +2415,11 @@ int crhip_stream_sync(void *stream)
 	return (int)hipStreamSynchronize((hipStream_t)stream);
 }
 
+int crhip_device_sync(void)
+{
+	return (int)hipDeviceSynchronize();
+}
+
 int crhip_event_create(void **event)
 {
 	hipEvent_t e = nullptr;

@@ -111,6 +111,7 @@ int crhip_memset(void *dst, int value, size_t bytes, void *stream);
 int crhip_stream_create(void **stream);
 int crhip_stream_destroy(void *stream);
 int crhip_stream_sync(void *stream);
+int crhip_device_sync(void);
 int crhip_event_create(void **event);                   /* timing disabled */
 int crhip_event_destroy(void *event);
 int crhip_event_record(void *event, void *stream);

@@ -486,6 +486,39 @@ def test_concurrent_callers(products):
     assert len(got) == len(jobs)
 
 
+def test_device_resident_launches_on_many_streams(products):
+    """Device-resident launches spread over 12 HIP streams (more than the library has ticket rings: a ring gets taken over),
+    several launches deep on each, so that kernels of different streams run side by side: every stream's output is its own."""
+    import torch
+    p, o = products[3], ck.oracle(3)
+    api = p.api
+    dev = torch.device("cuda", 0)
+    ch, rates, frames = 2, (44100, 48000, 44100), 300000
+    ok, ost = o.low_init(ch, *rates)
+    R = int(ost.cfg.radius_frames)
+    streams = [torch.cuda.Stream(dev) for _ in range(12)]
+    jobs = []
+    for k, s in enumerate(streams):
+        pcm = ck.pad_frames(ck.noise_pcm(frames * ch, 1000 + k), ch, R)
+        ok, fresh = o.low_init(ch, *rates)
+        want = o.low_resample_i32(fresh, pcm, frames)[0]
+        d_in = torch.from_numpy(pcm).to(dev)
+        d_out = [torch.zeros(want.size, dtype=torch.int32, device=dev) for _ in range(6)]
+        jobs.append((s, d_in, d_out, want))
+    torch.cuda.synchronize()
+    ok, st0 = p.low_init(ch, *rates)
+    plan = api.PlanCreate(st0.raw, p.pre)
+    n_out = jobs[0][3].size // ch
+    for rep in range(6):
+        for s, d_in, d_out, want in jobs:
+            st = cr.LowLevel_State.from_buffer_copy(st0.raw)
+            api.ResampleDevice(plan, st, d_in.data_ptr(), frames, d_out[rep].data_ptr(), n_out + 8, s.cuda_stream)
+    torch.cuda.synchronize()
+    for k, (s, d_in, d_out, want) in enumerate(jobs):
+        for rep in range(6):
+            assert np.array_equal(d_out[rep].cpu().numpy(), want), (k, rep)
+
+
 def test_highlevel_random_streams(products):
     """The streaming API (clownresampler.h:1101-1250: leading padding, refills, ResampleEnd) on random channel counts 1..16,
     rates, pull sizes and lengths, both radii, with the large side window and with the reference's one pull per GPU call:

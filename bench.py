@@ -40,6 +40,8 @@ WORKLOADS = {
     "ch16": (3, 16, (44100, 48000, 44100), 3307500),   # the reference's maximum channel count
     "dn8": (3, 2, (44100, 8000, 8000), 26460000),      # ctest triple 44100 -> 8000: 33-tap windows
     "mono": (3, 1, (44100, 48000, 44100), 52920000),
+    "dn2": (3, 2, (48000, 44100, 44100), 28800000),    # stereo 48 -> 44.1 kHz, 10 min
+    "dn1": (3, 1, (48000, 44100, 44100), 57600000),    # mono 48 -> 44.1 kHz, 20 min
 }
 
 

@@ -3,20 +3,33 @@
 
 One "step" = one pass of the hot path (ClownResampler_LowLevel_Resample's per-frame loop, reference
 clownresampler.h:1058-1092 / :986-1035, as the HIP kernel k_poly) over one batch of synthetic PCM, inputs and outputs
-resident in HBM.  At N=1 the batch is BASELINE configs[1]: stereo int16, 44.1 -> 48 kHz, 3-lobe Lanczos, 10 minutes
-(26,460,000 -> 28,800,096 frames).  With N ranks every rank owns one such 10-minute shard of an N x 10-minute stream
-(output-timeline sharding, input halo replicated, no collective in the data path): weak scaling.
+resident in HBM.
 
-Prints ONE JSON line (rank 0).  `value` = output Msamples/s of the whole job, kernel time only (HIP events on the
-launch stream, barrier + synchronize on both sides, max over ranks).  `roofline` prices the same kernel against the
-8 TB/s HBM peak with ALGORITHMIC bytes (each input sample read once + each int32 output written once).
-`cpu_baseline` is the reference C path (oracle/_ref, the real header compiled in place, when that prebuilt checker is
-present; else the oracle restatement) timed on this box's host cores on the same workload - a baseline, not a target.
+N = 1 (default): the batch is BASELINE configs[1]: stereo int16, 44.1 -> 48 kHz, 3-lobe Lanczos, 10 minutes
+(26,460,000 -> 28,800,096 frames).
+N > 1 (default): BASELINE configs[4]: ONE 1-hour stereo 44.1 -> 48 kHz stream (158,760,000 -> 172,800,574 frames) whose
+output timeline is split into N contiguous blocks by ClownResamplerAMD_PlanShard, one rank (= one process, one GPU) per
+block, input halo replicated, no collective in the data path: STRONG scaling.  `--scaling weak` gives every rank its own
+10-minute shard of an N x 10-minute stream instead.  The final concatenate (north_star) is timed apart from the kernel:
+gather-to-root and all-gather over RCCL, reported as `gather` beside the kernel-only `value`.
+
+`python bench.py --gpus N` starts its own N workers (a child `python -m torch.distributed.run`, started before this
+process has touched the GPU); under an existing torch.distributed.run (RANK/WORLD_SIZE in the environment) it is a worker.
+
+Prints ONE JSON line (rank 0).  `value` = output Msamples/s of the whole job, kernel time only: one HIP event pair on
+the launch stream around exactly K launches, barrier + synchronize on both sides, max over ranks (`ms_per_step`); a second
+region of 10 blocks of launches gives the distribution (`launch_us`: median / min / p95) and `value_at_median`.  `roofline` prices the same kernel against the
+8 TB/s HBM peak with ALGORITHMIC bytes (each input sample read once + each int32 output written once, SURVEY.md 8(d));
+for workloads that PMC counters show to be bound by the integer VALU, a second object `roofline_valu` prices the measured
+VALU wave-instructions against the SIMDs' measured issue rate.  `cpu_baseline` is the reference C path (oracle/_ref, the
+real header compiled in place, when that prebuilt checker is present; else the oracle restatement) timed on this box's
+host cores on the same workload - a baseline, not a target.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,13 +38,17 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+# integer VALU: 256 CUs x 4 SIMDs; a wave64 multiply / multiply-add / SDWA form issues every 4.2 cycles, a plain add / shift
+# every 2.3 (profiles/r01_valubench.log), at the ~2.25 GHz the chip sustains under this load (profiles/r01_sweeps_final.log)
+SIMDS = 1024
+VALU_CLOCK_GHZ = 2.25
 
 WORKLOADS = {
-    # name: (radius, channels, (in, out, lowpass), input frames per GPU)
+    # name: (radius, channels, (in, out, lowpass), input frames)
     "cfg2": (3, 2, (44100, 48000, 44100), 26460000),   # BASELINE configs[1] - the headline
     "cfg3": (8, 2, (8000, 96000, 8000), 4800000),      # configs[2] (10 min assumed)
     "cfg4": (3, 8, (48000, 44100, 44100), 28800000),   # configs[3] (10 min assumed)
-    "cfg5": (3, 2, (44100, 48000, 44100), 158760000),  # configs[4] on ONE GPU (1 hour)
+    "cfg5": (3, 2, (44100, 48000, 44100), 158760000),  # configs[4]: the 1-hour stream
     # not a BASELINE configuration: the headline conversion with the reference's high-quality 8-lobe build (tuning only)
     "hq48": (8, 2, (44100, 48000, 44100), 26460000),
     "up55": (3, 2, (8000, 44100, 8000), 4800000),      # one of the reference's ctest triples (tests/CMakeLists.txt), 10 min, 3 lobes
@@ -42,7 +59,28 @@ WORKLOADS = {
     "mono": (3, 1, (44100, 48000, 44100), 52920000),
     "dn2": (3, 2, (48000, 44100, 44100), 28800000),    # stereo 48 -> 44.1 kHz, 10 min
     "dn1": (3, 1, (48000, 44100, 44100), 57600000),    # mono 48 -> 44.1 kHz, 20 min
+    "hq44": (8, 2, (48000, 44100, 44100), 28800000),   # 8 lobes, 48 -> 44.1 kHz (17-tap windows)
 }
+CONFIG_NAMES = {"cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2]", "cfg4": "BASELINE configs[3]", "cfg5": "BASELINE configs[4]"}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_workers(n):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as children of THIS process, which has
+    not initialised the GPU (no torch import, no HIP call - never an exec of a process that has), wait, pass on their status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def device_noise(n_samples, first_index, device):
@@ -61,10 +99,25 @@ def device_noise(n_samples, first_index, device):
     return out
 
 
+def stream_slice(first_logical, frames, ch, total_frames, salt, device):
+    """Padded-buffer view of the whole stream: logical frames [first_logical, first_logical + frames), zeros outside
+    [0, total_frames) (the reference's zero padding at the two ends of the stream, clownresampler.h:725-733)."""
+    pcm = device_noise(frames * ch, first_logical * ch + salt, device)
+    lo_pad = min(frames, max(0, -first_logical))
+    hi_pad = min(frames, max(0, first_logical + frames - total_frames))
+    if lo_pad:
+        pcm[: lo_pad * ch] = 0
+    if hi_pad:
+        pcm[(frames - hi_pad) * ch:] = 0
+    return pcm
+
+
 def cpu_baseline(radius, ch, rates, frames, max_seconds=30.0):
-    """Times the reference C path on the host: real reference (.so prebuilt from /root/reference) if present, else oracle."""
+    """Times the reference C path on the host: real reference (.so prebuilt from /root/reference) if present, else oracle.
+    Bounded sample: at most 10 minutes of the workload's stream (the 1-thread leg takes ~0.5 s per minute of stereo)."""
     import numpy as np
     import _checkers as ck
+    frames = min(frames, 28800000)
     ref = ck.reference(radius)
     eng, kind = (ref, "reference") if ref is not None else (ck.oracle(radius), "port")
     ok, st = eng.low_init(ch, *rates)
@@ -76,7 +129,7 @@ def cpu_baseline(radius, ch, rates, frames, max_seconds=30.0):
     got, left, ran_out = eng.low_resample_i32(st, padded, frames, out=out)
     dt = time.perf_counter() - t0
     res = {"value": got.size / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": kind,
-           "sample": "full workload, %d -> %d frames x %d ch, callback API storing int32, gcc -O2, 1 thread, %.2f s" % (frames, n_out, ch, dt)}
+           "sample": "%d -> %d frames x %d ch of the workload, callback API storing int32, gcc -O2, 1 thread, %.2f s" % (frames, n_out, ch, dt)}
     # all host cores, independent states over contiguous input ranges (oracle driver)
     cores = os.cpu_count() or 1
     if cores > 1:
@@ -89,37 +142,65 @@ def cpu_baseline(radius, ch, rates, frames, max_seconds=30.0):
     return res
 
 
+def pmc_summary(workload):
+    """Per-dispatch PMC means committed under profiles/ for this workload (latest round first): (dict, file name) or (None, None)."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.txt" % (rnd, workload))
+        if os.path.exists(path):
+            vals = {}
+            for ln in open(path):
+                f = ln.split()
+                if len(f) > 3 and f[1] == "per-dispatch":
+                    vals[f[0]] = float(f[3])
+            return vals, os.path.basename(path)
+    return None, None
+
+
+def percentile(sorted_values, q):
+    if not sorted_values:
+        return None
+    i = min(len(sorted_values) - 1, max(0, int(round(q * (len(sorted_values) - 1)))))
+    return sorted_values[i]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--prewarm-ms", type=float, default=250.0, help="untimed launches before the W warmup steps, until this much wall time has passed: the chip needs ~100 ms of load to leave its idle clocks")
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: cfg2 at N=1, cfg5 (the 1-hour stream, sharded) at N>1")
+    ap.add_argument("--scaling", default=None, choices=("strong", "weak"), help="N>1: strong = ONE stream of the workload's length split over the ranks (default); weak = every rank one stream-length shard of an N times longer stream")
     ap.add_argument("--sets", type=int, default=3, help="rotating buffer sets (defeats the 256 MiB Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--s16", action="store_true", help="opt-in extension: clamped int16 output (NOT the BASELINE metric; writes 2 B per sample instead of 4)")
     ap.add_argument("--graph", action="store_true", help="time one hipGraph replay of the K steps instead of eager launches (measured SLOWER on ROCm 7.2 for this kernel)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_workers(args.gpus))
+
     import numpy as np
     import torch
     import clownresampler_amd as cr
-    from clownresampler_amd import distributed as crd
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE %d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the GPU: the product has no CPU path")
-    # CRA_BENCH_BACKEND=gloo is a validation hook for boxes with fewer GPUs than ranks: the ranks share the GPUs there are
-    # and synchronise over gloo (everything but RCCL itself is exercised); the driver's runs use nccl = RCCL, one GPU per rank
-    backend = os.environ.get("CRA_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
+    # Fewer GPUs than ranks (a 1-GPU box asked for --gpus 8), or CRA_BENCH_BACKEND=gloo: VALIDATION mode - the ranks share the
+    # GPUs there are and synchronise over gloo; everything but RCCL itself is exercised, and the line says so (its timings
+    # are those of ranks contending for one GPU).  The driver's multi-GPU runs have one GPU per rank and use nccl = RCCL.
+    n_dev = torch.cuda.device_count()
+    backend = os.environ.get("CRA_BENCH_BACKEND", "nccl" if n_dev >= world else "gloo")
+    shared_gpus = backend != "nccl"
+    if shared_gpus:
+        local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -130,17 +211,21 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    radius, ch, rates, frames_per_gpu = WORKLOADS[args.workload]
+    workload = args.workload or ("cfg2" if world == 1 else "cfg5")
+    scaling = args.scaling or "strong"
+    radius, ch, rates, frames = WORKLOADS[workload]
     api = cr.load(radius)
     api.SetDevice(local_rank)
     pre = api.precomputed()
     whole = api.LowLevel_State()
     assert api.LowLevel_Init(whole, ch, *rates)
     R = whole.lowest_level.integer_stretched_kernel_radius
-    total_frames = frames_per_gpu * world
-    shard = crd.shard_of(api, whole, total_frames, rank, world)
+    total_frames = frames * world if (scaling == "weak" and world > 1) else frames
+    shard = api.PlanShard(whole, total_frames, rank, world)
     plan = api.PlanCreate(whole, pre)
     info = api.PlanGetInfo(plan)
+    out_frames_all = int(api.CountOutputFrames(whole, total_frames))
+    out_samples_all = out_frames_all * ch
 
     # this rank's slice of the stream + halo; logical frame f of the stream is padded frame f + R; the zero padding of the
     # stream's two ends is materialised only where a shard touches it
@@ -148,29 +233,30 @@ def main():
     first_logical = shard.first_input_frame - R
     sets = []
     for s in range(max(1, args.sets)):
-        pcm = device_noise(in_frames * ch, (first_logical * ch) + s * 7919, device)
-        lo_pad = max(0, -first_logical)
-        hi_pad = max(0, first_logical + in_frames - total_frames)
-        if lo_pad:
-            pcm[: lo_pad * ch] = 0
-        if hi_pad:
-            pcm[(in_frames - hi_pad) * ch:] = 0
-        out = torch.empty(shard.output_frames * ch, dtype=torch.int16 if args.s16 else torch.int32, device=device)
+        pcm = stream_slice(first_logical, in_frames, ch, total_frames, s * 7919, device)
+        out = torch.empty(max(1, shard.output_frames) * ch, dtype=torch.int16 if args.s16 else torch.int32, device=device)
         sets.append((pcm, out))
     stream = torch.cuda.current_stream(device)
 
     def step(i):
         pcm, out = sets[i % len(sets)]
-        if args.s16:
-            st = cr.LowLevel_State.from_buffer_copy(shard.state)
-            return api.ResampleDevice(plan, st, pcm.data_ptr(), shard.input_frames, out.data_ptr(), shard.output_frames, stream.cuda_stream, s16=True)[0]
-        return crd.resample_shard_device(api, plan, shard, pcm.data_ptr(), out.data_ptr(), stream.cuda_stream)
+        st = cr.LowLevel_State.from_buffer_copy(shard.state)
+        n = api.ResampleDevice(plan, st, pcm.data_ptr(), shard.input_frames, out.data_ptr(), shard.output_frames, stream.cuda_stream, s16=args.s16)[0]
+        assert n == shard.output_frames
+        return n
 
     def barrier():
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize(device)
+
+    def host_tensor_max(values):
+        if world == 1:
+            return [float(v) for v in values]
+        t = torch.tensor(values, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.cpu()]
 
     # Clock ramp: untimed launches until --prewarm-ms have passed (then the W warmup steps, then the K timed ones).
     t_pre = time.perf_counter()
@@ -205,125 +291,210 @@ def main():
             graph = None
             stream = torch.cuda.current_stream(device)
 
+    # (1) The contract's timed region: EXACTLY K steps between one event pair on the launch stream, barrier + synchronize on
+    #     both sides -> ms_per_step (mean of the K launches) and `value`.
+    # (2) A second region for the DISTRIBUTION: 10 blocks of K/10 more launches (at least 2 per block), an event between blocks
+    #     -> median / min / p95 of the per-block mean launch time.  Not an event around every launch: an event record between
+    #     two launches costs ~3 us of marker packet on this stack (measured: 67.6 us per launch with, 64.7 us without,
+    #     profiles/r02_event_overhead.log), i.e. it would be measuring itself.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
     def run_steps():
+        ev0.record(stream)
         if graph is not None:
             graph.replay()
         else:
             for i in range(args.steps):
                 step(i)
+        ev1.record(stream)
 
     if graph is not None:
         with torch.cuda.stream(stream):
             for _ in range(max(1, args.warmup // max(1, args.steps))):
-                run_steps()
+                graph.replay()
     else:
         for i in range(args.warmup):
             step(i)
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
-        ev0.record(stream)
         run_steps()
-        ev1.record(stream)
     barrier()
     wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    ms_rank = max(dev_ms, 0.0)
-    if world > 1:
-        t = torch.tensor([ms_rank, wall * 1e3], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms_rank, wall_ms = float(t[0]), float(t[1])
-    else:
-        wall_ms = wall * 1e3
+    dev_ms = max(ev0.elapsed_time(ev1), 0.0)
+    mean_ms = dev_ms / args.steps
 
-    out_frames_all = int(api.CountOutputFrames(whole, total_frames))
-    out_samples_all = out_frames_all * ch
-    ms_per_step = ms_rank / args.steps
+    blocks, block_len = 10, max(2, args.steps // 10)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(blocks + 1)]
+    with torch.cuda.stream(stream):
+        marks[0].record(stream)
+        for b in range(blocks):
+            for i in range(block_len):
+                step(b * block_len + i)
+            marks[b + 1].record(stream)
+    barrier()
+    each = sorted(marks[b].elapsed_time(marks[b + 1]) / block_len for b in range(blocks))
+    median_ms, min_ms, p95_ms, max_ms = percentile(each, 0.5), each[0], percentile(each, 0.95), each[-1]
+    # max over ranks of each rank's statistic
+    mean_all, median_all, wall_ms = host_tensor_max([mean_ms, median_ms, wall * 1e3])
+    ms_per_step = mean_all
     value = out_samples_all / (ms_per_step * 1e-3) / 1e6
 
-    # the dominant (only) kernel: algorithmic bytes of THIS rank's launch / its average duration
+    # the dominant (only) kernel: algorithmic bytes of THIS rank's launch / its launch duration
     launch_bytes = shard.input_frames * ch * 2 + shard.output_frames * ch * (2 if args.s16 else 4)
-    achieved = launch_bytes / (dev_ms / args.steps * 1e-3) / 1e9
+    achieved = launch_bytes / (mean_ms * 1e-3) / 1e9
+    kernel_name = {1: "k_poly<%d,%d>", 2: "k_wave<%d,%d>", 3: "k_up<%d,%d>"}[info.kernel] % (ch, info.slots) if info.kernel else "k_generic"
     traffic, traffic_note = None, "no PMC summary for this workload under profiles/"
-    pmc_file = os.path.join(ROOT, "profiles", "r01_%s_pmc_summary.txt" % args.workload)
-    if world == 1 and os.path.exists(pmc_file):
-        vals = {}
-        for ln in open(pmc_file):
-            f = ln.split()
-            if len(f) > 3 and f[1] == "per-dispatch":
-                vals[f[0]] = float(f[3])
-        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-            # KiB units; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads: x2 (MI355X_MICROARCH.md, HBM)
-            traffic = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-            traffic_note = "bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes: profiles/" + os.path.basename(pmc_file)
+    pmc, pmc_file = pmc_summary(workload) if (world == 1 and not args.s16) else (None, None)
+    if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        # KiB units; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads: x2 (MI355X_MICROARCH.md, HBM)
+        traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+        traffic_note = ("NOT measured in this run: bytes per launch from an earlier rocprofv3 --pmc run of this command (FETCH_SIZE x2 gfx950 "
+                        "correction + WRITE_SIZE, separate passes), committed as profiles/" + pmc_file)
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_note": traffic_note, "kernel": {1: "k_poly<%d,%d>", 2: "k_wave<%d,%d>", 3: "k_up<%d,%d>"}[info.kernel] % (ch, info.slots) if info.kernel else "k_generic",
-                "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_ms": dev_ms / args.steps,
-                "read_only_GBs": shard.input_frames * ch * 2 / (dev_ms / args.steps * 1e-3) / 1e9}
+                "traffic": traffic, "traffic_note": traffic_note, "kernel": kernel_name,
+                "algorithmic_bytes_per_launch": launch_bytes, "launch_ms": mean_ms, "launch_ms_is": "mean of the %d timed launches (one HIP event pair on the launch stream)" % args.steps,
+                "read_only_GBs": shard.input_frames * ch * 2 / (mean_ms * 1e-3) / 1e9}
+    roofline_valu = None
+    if pmc and "SQ_INSTS_VALU" in pmc:
+        # Which ceiling binds?  The launch's VALU wave-instructions (PMC) at the SIMDs' measured issue rate, against the launch
+        # time.  Instruction mix of the tap arithmetic: multiplies / multiply-adds / SDWA adds at 4.2 cycles; taken as the rate
+        # of every instruction this is a LOWER bound of the VALU time (plain adds and shifts issue in 2.3).
+        insts = pmc["SQ_INSTS_VALU"]
+        peak = SIMDS * VALU_CLOCK_GHZ * 1e9 / 4.2
+        ach = insts / (mean_ms * 1e-3)
+        roofline_valu = {"bound": "valu", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s", "frac": ach / peak,
+                         "valu_wave_instructions_per_launch": insts, "per_tap_channel": insts * 64.0 / (shard.output_frames * ch * max(1, info.slots)),
+                         "note": "SQ_INSTS_VALU per launch from profiles/%s (not measured in this run); peak = %d SIMDs x %.2f GHz / 4.2 cycles per wave64 multiply-class instruction (profiles/r01_valubench.log)" % (pmc_file, SIMDS, VALU_CLOCK_GHZ)}
+        if roofline_valu["frac"] > roofline["frac"]:
+            roofline["binding"] = "valu (see roofline_valu): the integer VALU ceiling is below the HBM ceiling for this workload"
 
-    # correctness of what was just timed: spot-check a window of this rank's output against the oracle
-    check = None
-    if not args.no_check and rank == 0:
+    def oracle_window(first_out, n_chk, salt):
+        """Frames [first_out, first_out + n_chk) of the WHOLE stream's output from the oracle: closed-form state at first_out
+        (clownresampler.h:1076-1078 applied first_out times), input slice regenerated from the stream function."""
         import _checkers as ck
         o = ck.oracle(radius)
-        n_chk = min(200000, shard.output_frames)
-        pcm, out = sets[(args.steps - 1) % len(sets)]
+        st = cr.LowLevel_State.from_buffer_copy(whole)
+        api.AdvanceState(st, first_out)
+        pi, pf = st.position_integer, st.position_fractional
+        need = int(n_chk * whole.increment / 65536) + 4 * R + 8
+        host_in = stream_slice(pi - R, need, ch, total_frames, salt, device).cpu().numpy()
         ok, ost = o.low_init(ch, *rates)
-        ost.pos_int, ost.pos_frac = shard.state.position_integer, shard.state.position_fractional
-        need = min(in_frames, int(n_chk * whole.increment / 65536) + 4 * R + 8)
-        host_in = pcm[: need * ch].cpu().numpy()
+        ost.pos_int, ost.pos_frac = 0, pf
         want, _, _ = o.low_resample_i32(ost, host_in, need - 2 * R, capacity=n_chk)
-        got = out[: want.size].cpu().numpy()
-        if args.s16:
-            want = np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16)
-        check = bool(np.array_equal(got, want))
+        return want
+
+    # correctness of what was just timed: EVERY rank checks the head and the tail of its shard against the oracle
+    check = None
+    if not args.no_check:
+        last = (args.steps - 1) % len(sets)
+        out = sets[last][1]
+        ok_here = True
+        n_chk = min(100000, shard.output_frames)
+        for first in sorted({0, shard.output_frames - n_chk}):
+            want = oracle_window(shard.first_output_frame + first, n_chk, last * 7919)
+            got = out[first * ch: first * ch + want.size].cpu().numpy()
+            if args.s16:
+                want = np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16)
+            ok_here = ok_here and want.size == n_chk * ch and bool(np.array_equal(got, want))
+        if world > 1:
+            t = torch.tensor([1 if ok_here else 0])
+            tt = t.to(device) if backend == "nccl" else t
+            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+            check = bool(int(tt.cpu()[0]))
+        else:
+            check = ok_here
         if not check:
-            raise SystemExit("bench: device output differs from the oracle - numbers void")
+            raise SystemExit("bench: device output differs from the oracle on rank %d (ok here: %s) - numbers void" % (rank, ok_here))
 
     gather = None
-    if world > 1 and not args.s16 and backend == "nccl":
-        # the final concatenate (north_star): all ranks' int32 shards gathered over xGMI by RCCL; timed apart from the kernel
-        # (reported beside the headline; a failure here must not cost the run its bench line)
+    if world > 1 and not args.s16 and not args.no_gather:
+        # The final concatenate (north_star; SURVEY.md 8(e)): the ranks' int32 shards, padded to the common per-rank size
+        # PlanShard uses, (a) gathered to rank 0 - ncclGather semantics, RCCL send/recv: each peer -> root transfer rides its
+        # own xGMI link - and (b) all-gathered (every rank gets the stream).  Timed apart from the kernel; a failure here must
+        # not cost the run its bench line.
         try:
             per = (out_frames_all + world - 1) // world * ch
-            send = torch.zeros(per, dtype=torch.int32, device=device)
-            send[: shard.output_frames * ch] = sets[0][1]
-            recv = torch.empty(per * world, dtype=torch.int32, device=device)
-            dist.all_gather_into_tensor(recv, send)
-            barrier()
-            g0 = time.perf_counter()
-            reps = 5
-            for _ in range(reps):
-                dist.all_gather_into_tensor(recv, send)
-            barrier()
-            g_ms = (time.perf_counter() - g0) * 1e3 / reps
-            gather = {"collective": "all_gather_into_tensor (RCCL)", "ms": g_ms, "bytes_per_rank": per * 4,
-                      "value_with_gather": out_samples_all / ((ms_per_step + g_ms) * 1e-3) / 1e6}
+            on_device = backend == "nccl"
+            src = sets[0][1][: shard.output_frames * ch]
+            send = torch.zeros(per, dtype=torch.int32, device=device if on_device else "cpu")
+            send[: shard.output_frames * ch] = src if on_device else src.cpu()
+            recv = torch.empty(per * world, dtype=torch.int32, device=send.device)  # (root's gather target; everyone's all-gather target)
+            pieces = list(recv.split(per)) if rank == 0 else None
+            reps = 5 if on_device else 1
+
+            def timed(fn):
+                fn()
+                barrier()
+                ts = []
+                for _ in range(reps):
+                    g0 = time.perf_counter()
+                    fn()
+                    barrier()
+                    ts.append((time.perf_counter() - g0) * 1e3)
+                return host_tensor_max([sorted(ts)[len(ts) // 2]])[0]
+
+            root_ms = timed(lambda: dist.gather(send, pieces, dst=0))
+            # what arrived is the one-shot stream (PlanShard's blocks are `per` frames each, so the pieces are contiguous):
+            # the root checks a window across every shard boundary against the oracle
+            seams_ok = None
+            if rank == 0 and not args.no_check:
+                seams_ok = True
+                half = 2000
+                for r in range(1, world):
+                    b = api.PlanShard(whole, total_frames, r, world).first_output_frame
+                    if b < half or b + half > out_frames_all:
+                        continue
+                    want = oracle_window(b - half, 2 * half, 0)
+                    got = recv[(b - half) * ch: (b + half) * ch].cpu().numpy()
+                    seams_ok = seams_ok and bool(np.array_equal(got, want))
+            all_ms = timed(lambda: dist.all_gather_into_tensor(recv, send))
+            gather = {"to_root": {"collective": "gather (RCCL send/recv, ncclGather semantics)" if on_device else "gather (gloo, host copies: validation only)", "ms": root_ms},
+                      "all_gather": {"collective": "all_gather_into_tensor (RCCL)" if on_device else "all_gather_into_tensor (gloo, host copies: validation only)", "ms": all_ms},
+                      "ms": root_ms, "bytes_per_rank": per * 4, "seams_match_oracle": seams_ok,
+                      "value_with_gather": out_samples_all / ((ms_per_step + root_ms) * 1e-3) / 1e6,
+                      "value_with_all_gather": out_samples_all / ((ms_per_step + all_ms) * 1e-3) / 1e6}
+            if seams_ok is False:
+                raise SystemExit("bench: gathered stream differs from the oracle at a shard boundary - numbers void")
+        except SystemExit:
+            raise
         except Exception as e:
-            gather = {"collective": "all_gather_into_tensor (RCCL)", "error": str(e)[:200]}
+            gather = {"error": str(e)[:300]}
 
     if rank == 0:
+        named = CONFIG_NAMES.get(workload)
         line = {
-            "metric": ("output Msamples/s at 44.1->48 kHz stereo" if args.workload in ("cfg2", "cfg5") else "output Msamples/s (%s)" % args.workload) + (" [int16-clamped output extension]" if args.s16 else ""),
+            "metric": ("output Msamples/s at 44.1->48 kHz stereo" if workload in ("cfg2", "cfg5") else "output Msamples/s (%s)" % workload) + (" [int16-clamped output extension]" if args.s16 else ""),
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "s16 in / int32 16.16 fixed-point arithmetic / int32 out", "data": "synthetic",
-            "config": {"workload": "%s: %d-ch int16 %d->%d Hz, %d-lobe Lanczos, %d input frames per GPU (%d -> %d frames in all), device-resident, %d rotating buffer sets"
-                                   % (args.workload, ch, rates[0], rates[1], radius, frames_per_gpu, total_frames, out_frames_all, len(sets)),
-                       "sharding": "output timeline split in %d contiguous blocks, input halo of %d frames replicated, no data-path collective" % (world, R),
+            "config": {"workload": "%s%s: %d-ch int16 %d->%d Hz, %d-lobe Lanczos, ONE stream of %d -> %d frames%s, device-resident, %d rotating buffer sets"
+                                   % (workload, " (%s)" % named if named else "", ch, rates[0], rates[1], radius, total_frames, out_frames_all,
+                                      " split over %d ranks (%s scaling: %d input frames per rank)" % (world, scaling, shard.input_frames) if world > 1 else "", len(sets)),
+                       "sharding": "output timeline split in %d contiguous blocks (ClownResamplerAMD_PlanShard), input halo of %d frames replicated, no data-path collective" % (world, R),
                        "plan": info.asdict()},
+            "ms_per_step_is": "max over ranks of (one HIP event pair around the K launches on the launch stream) / K",
+            "launch_us": {"median": median_ms * 1e3, "min": min_ms * 1e3, "p95": p95_ms * 1e3, "max": max_ms * 1e3, "mean_of_timed_region": mean_ms * 1e3,
+                          "of": "rank 0; median / min / p95 / max over %d blocks of %d further launches each (per-block mean; an event per launch would add ~3 us to each)" % (blocks, block_len)},
+            "value_at_median": out_samples_all / (median_all * 1e-3) / 1e6,
             "roofline": roofline,
             "launch_mode": "hipGraph replay of the K steps" if graph is not None else "eager",
             "wall_ms_per_step": wall_ms / args.steps,
             "parity_spot_check": check,
+            "parity_spot_check_is": "every rank: first and last 100,000 frames of its shard of the last timed launch == oracle; all ranks agree",
         }
+        if roofline_valu:
+            line["roofline_valu"] = roofline_valu
+        if world > 1:
+            line["backend"] = "nccl (RCCL), one GPU per rank" if backend == "nccl" else \
+                "%s; VALIDATION ONLY: %d ranks share %d GPU(s), timings are those of ranks contending for a GPU" % (backend, world, n_dev)
         if gather:
             line["gather"] = gather
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(radius, ch, rates, frames_per_gpu)
-        print(json.dumps(line))
+            line["cpu_baseline"] = cpu_baseline(radius, ch, rates, frames)
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -39,3 +39,20 @@ def gather_output(local_out, shard, total_output_frames, channels, world_size, g
     else:
         dist.all_gather_into_tensor(recv, send, group=group)
     return recv[: total_output_frames * channels]
+
+
+def gather_output_to_root(local_out, shard, total_output_frames, channels, world_size, root=0, group=None):
+    """Concatenates the ranks' int32 outputs on `root` only (ncclGather semantics: with RCCL every peer -> root transfer is a
+    point-to-point send over its own xGMI link).  Returns the whole stream on root, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    per = (total_output_frames + world_size - 1) // world_size
+    send = torch.zeros(per * channels, dtype=torch.int32, device=local_out.device)
+    send[: shard.output_frames * channels] = local_out[: shard.output_frames * channels]
+    if world_size == 1:
+        return send[: total_output_frames * channels]
+    rank = dist.get_rank(group)
+    recv = torch.empty(per * channels * world_size, dtype=torch.int32, device=local_out.device) if rank == root else None
+    dist.gather(send, list(recv.split(per * channels)) if rank == root else None, dst=root, group=group)
+    return recv[: total_output_frames * channels] if rank == root else None

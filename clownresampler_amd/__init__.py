@@ -74,6 +74,13 @@ class Shard(C.Structure):  # ClownResamplerAMD_Shard
                 ("input_frames", C.c_size_t), ("halo_frames", C.c_size_t), ("state", LowLevel_State)]
 
 
+class DeviceShard(C.Structure):  # ClownResamplerAMD_DeviceShard
+    _fields_ = [("device", C.c_int), ("device_input", C.c_void_p), ("device_output", C.c_void_p), ("hip_stream", C.c_void_p)]
+
+
+GATHER_NONE, GATHER_PEER_COPY, GATHER_RCCL = 0, 1, 2
+
+
 class Segment(C.Structure):  # ClownResamplerAMD_Segment
     _fields_ = [("input_frames", C.c_size_t), ("input_sample_rate", cc_u32f), ("output_sample_rate", cc_u32f), ("low_pass_filter_sample_rate", cc_u32f)]
 
@@ -179,6 +186,15 @@ class Api:
         self._PlanCacheCount = fn("ClownResamplerAMD_PlanCacheCount", C.c_size_t, [], False)
         self._ResampleSegmentsDevice = fn("ClownResamplerAMD_ResampleSegmentsDevice", C.c_size_t, [P(LowLevel_State), P(self.Precomputed), C.c_void_p, C.c_size_t, P(Segment), C.c_size_t,
                                                                                                       C.c_void_p, C.c_size_t, C.c_int, P(C.c_size_t), C.c_void_p])
+        self._ResampleSharded = fn("ClownResamplerAMD_ResampleShardedDevice", C.c_size_t, [P(LowLevel_State), P(self.Precomputed), C.c_size_t, P(DeviceShard), C.c_uint, C.c_int,
+                                                                                              C.c_int, C.c_uint, C.c_void_p])
+        self._ShardedSync = fn("ClownResamplerAMD_ShardedSynchronize", C.c_int, [P(DeviceShard), C.c_uint], False)
+        self._SetThreadDevice = fn("ClownResamplerAMD_SetThreadDevice", C.c_int, [C.c_int], False)
+        self._GetDevice = fn("ClownResamplerAMD_GetDevice", C.c_int, [], False)
+        self._ReserveCapture = fn("ClownResamplerAMD_ReserveCaptureLaunches", C.c_int, [C.c_size_t], False)
+        self._HighRelease = fn("ClownResamplerAMD_HighLevel_Release", None, [P(HighLevel_State)], False)
+        self._WindowCount = fn("ClownResamplerAMD_StreamingWindowCount", C.c_size_t, [], False)
+        self._DeviceAllocOn = fn("ClownResamplerAMD_DeviceAllocOn", C.c_void_p, [C.c_int, C.c_size_t], False)
         self._Count = fn("ClownResamplerAMD_CountOutputFrames", C.c_size_t, [P(LowLevel_State), C.c_size_t], False)
         self._Advance = fn("ClownResamplerAMD_AdvanceState", None, [P(LowLevel_State), C.c_size_t], False)
         self._PlanShard = fn("ClownResamplerAMD_PlanShard", C.c_int, [P(LowLevel_State), C.c_size_t, C.c_uint, C.c_uint, P(Shard)], False)
@@ -359,6 +375,45 @@ class Api:
                                          C.c_void_p(device_output), output_capacity_frames, 1 if s16 else 0, counts, C.c_void_p(hip_stream or 0))
         _raise_if_failed(self.lib)
         return n, list(counts)[:len(segments)]
+
+    def ResampleShardedDevice(self, resampler, precomputed, total_input_frames, shards, s16=False, gather_mode=GATHER_NONE, root_shard=0, root_output=None):
+        """One stream over several devices (ClownResamplerAMD_ResampleShardedDevice).  shards: [(device, device_input, device_output, hip_stream), ...].
+        Returns the total number of output frames; nothing is synchronised (ShardedSynchronize)."""
+        array = (DeviceShard * len(shards))(*[DeviceShard(d, C.c_void_p(i), C.c_void_p(o), C.c_void_p(s or 0)) for d, i, o, s in shards])
+        n = self._ResampleSharded(C.byref(resampler), C.byref(precomputed), total_input_frames, array, len(shards), 1 if s16 else 0,
+                                  gather_mode, root_shard, C.c_void_p(root_output or 0))
+        _raise_if_failed(self.lib)
+        return n
+
+    def ShardedSynchronize(self, shards):
+        array = (DeviceShard * len(shards))(*[DeviceShard(d, C.c_void_p(i), C.c_void_p(o), C.c_void_p(s or 0)) for d, i, o, s in shards])
+        r = self._ShardedSync(array, len(shards))
+        _raise_if_failed(self.lib)
+        return r
+
+    def SetThreadDevice(self, ordinal):
+        r = self._SetThreadDevice(ordinal)
+        _raise_if_failed(self.lib)
+        return r
+
+    def GetDevice(self):
+        return self._GetDevice()
+
+    def ReserveCaptureLaunches(self, launches):
+        r = self._ReserveCapture(launches)
+        _raise_if_failed(self.lib)
+        return r
+
+    def HighLevel_Release(self, resampler):
+        self._HighRelease(C.byref(resampler))
+
+    def StreamingWindowCount(self):
+        return self._WindowCount()
+
+    def DeviceAllocOn(self, device, nbytes):
+        p = self._DeviceAllocOn(device, nbytes)
+        _raise_if_failed(self.lib)
+        return p
 
     def SetPlanCacheLimit(self, plans):
         self._SetPlanCacheLimit(plans)

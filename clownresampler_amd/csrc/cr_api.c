@@ -138,9 +138,9 @@ static int fill_table_i32(const void *user, int32_t *dst, size_t count)
 
 	for (i = 0; i < count; ++i)
 	{
-		const cc_s32l v = precomputed->lanczos_kernel_table[i];
+		const long long v = precomputed->lanczos_kernel_table[i];   /* cc_s32l: long (C89 types) or int_least32_t */
 
-		if (v < -2147483647L - 1 || v > 2147483647L)
+		if (v < -2147483647LL - 1 || v > 2147483647LL)
 			return -1;
 
 		dst[i] = (int32_t)v;
@@ -402,6 +402,18 @@ size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *r
 }
 
 /* ======================================================================================================= */
+/* Several GPUs, one call (cr_multi.c)                                                                      */
+/* ======================================================================================================= */
+
+size_t ClownResamplerAMD_ResampleShardedDevice(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed, size_t total_input_frames,
+                                               const ClownResamplerAMD_DeviceShard *shards, unsigned shard_count, int output_is_s16,
+                                               int gather_mode, unsigned root_shard, void *root_output)
+{
+	return cr_resample_sharded(resampler, table_hash_of(precomputed), TABLE_LEN, fill_table_i32, precomputed, RADIUS, total_input_frames,
+	                           shards, shard_count, output_is_s16, gather_mode, root_shard, root_output);
+}
+
+/* ======================================================================================================= */
 /* The callback form (the reference's own signature)                                                       */
 /* ======================================================================================================= */
 
@@ -535,8 +547,11 @@ void ClownResampler_LowestLevel_Resample(const ClownResampler_LowestLevel_Config
 #define STAGING_SAMPLES CLOWNRESAMPLER_COUNT_OF(((ClownResampler_HighLevel_State *)0)->input_buffer)
 
 /* The state's own 0x1000-sample buffer (clownresampler.h:654) is not used for audio here: the staging lives in a side
-   window that can grow (cr_stream, cr_context.c).  The buffer's first bytes carry the key of that window, so the state
-   stays a plain struct the caller owns (a byte copy of the state shares the window with the original). */
+   window that can grow (cr_stream, cr_context.c), registered under the state's ADDRESS.  The buffer's first bytes carry the
+   key of that window, so the state stays a plain struct the caller owns.  Like the reference's state - whose
+   input_buffer_start / _end point into itself (clownresampler.h:655-656) - it cannot be moved by a byte copy: the key is
+   only honoured at the address it was issued for.  ClownResampler_HighLevel_Init never reads the caller's (possibly
+   uninitialised) struct to find a window; it asks the registry for the one of that address. */
 #define STREAM_MAGIC 0x314C48444D415243ull /* "CRAMDHL1" */
 
 static void stream_key_store(ClownResampler_HighLevel_State *resampler, uint64_t id)
@@ -553,7 +568,7 @@ static cr_stream *stream_of(ClownResampler_HighLevel_State *resampler)
 
 	memcpy(&magic, (unsigned char *)resampler->input_buffer, sizeof(magic));
 	memcpy(&id, (unsigned char *)resampler->input_buffer + sizeof(magic), sizeof(id));
-	return magic == STREAM_MAGIC ? cr_stream_lookup(id) : NULL;
+	return magic == STREAM_MAGIC ? cr_stream_lookup(id, resampler) : NULL;
 }
 
 /* frames the reference asks its input callback for per refill (clownresampler.h:1154) */
@@ -580,11 +595,10 @@ cc_bool ClownResampler_HighLevel_Init(ClownResampler_HighLevel_State *resampler,
 
 	/* silence where the frames before the stream would be; empty window right behind it (:1112-1115) */
 	halo_samples = resampler->maximum_integer_stretched_kernel_radius * channels;
-	/* re-initialising a state that already owns a side window reuses it (there is no Deinit to free it) */
-	stream = stream_of(resampler);
+	/* re-initialising a state - or initialising one at an address a discarded state used - reuses that address's window
+	   (the reference has no Deinit; ClownResamplerAMD_HighLevel_Release frees a window explicitly) */
 	memset(resampler->input_buffer, 0, sizeof(resampler->input_buffer));
-	if (stream == NULL)
-		stream = cr_stream_create();
+	stream = cr_stream_claim(resampler);
 
 	if (stream == NULL || channels == 0 || cr_stream_reserve(stream, 2 * halo_samples + reference_pull_frames(resampler) * channels) != 0)
 	{

@@ -86,84 +86,109 @@ void ClownResamplerAMD_ClearError(void)
 }
 
 /* ------------------------------------------------------------------------------------------------------- */
-/* device                                                                                                  */
+/* devices                                                                                                 */
 /* ------------------------------------------------------------------------------------------------------- */
 
-static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
-static int g_device = 0;
-static int g_device_ready = 0;
-static crhip_device_info g_info;
-static ClownResamplerAMD_Plan *g_plans = NULL;
-static uint64_t g_plan_clock = 0;
-static size_t g_plan_limit = 64;   /* unpinned plans kept; ClownResamplerAMD_SetPlanCacheLimit */
-static cr_workspace g_workspace;
-#define CR_EXTRA_SETS 2 /* further staging sets of the pipelined host path (cr_run_host): three in all; same lock as g_workspace */
-static cr_workspace g_workspace_more[CR_EXTRA_SETS]; /* ([0].stream is the download stream) */
-static int g_workspace_busy = 0;
+/* One context per HIP device, created on first use and kept until ClownResamplerAMD_Shutdown: its properties, its ticket
+   blocks and its staging workspace.  Plans carry the ordinal of the device their rows live on.  Which device a call uses:
+   the plan's, where the call is given a plan; otherwise the calling thread's (ClownResamplerAMD_SetThreadDevice) or, when the
+   thread has none, the process default (ClownResamplerAMD_SetDevice).  Nothing here is torn down when the current device
+   changes: a C client can drive all the GPUs of a node from one process, one thread per GPU or one thread for all. */
+#define CR_MAX_DEVICES 64
+#define CR_EXTRA_SETS 2 /* further staging sets of the pipelined host path (cr_run_host): three in all */
 /* small host-buffer calls: one pinned, device-visible block (input at the front, output behind it) that the kernel reads and
    writes across PCIe itself - see cr_run_host */
 #define CR_SMALL_CALL_BYTES (128u * 1024u)
-static unsigned char *g_small = NULL;
-static int g_force_generic = 0;
-/* Ticket blocks for k_poly's dynamic tile scheduling (crhip.h CRHIP_TICKET_WORDS counters each), zeroed once; a launch takes
-   a block and leaves it zeroed.  Two launches that may run AT THE SAME TIME must not share a block.  Launches on one stream
-   never do, so the blocks are handed out per stream: every stream seen gets a ring of CR_RING_SLOTS blocks (a ring rather
-   than one block so that the launches of a stream capture - whose graphs may later be replayed side by side - differ too).
-   Up to CR_TICKET_RINGS streams are live at once; one more evicts the ring used longest ago, after a device
-   synchronise (rare, and the only way to know that ring's launches are through without holding on to its stream). */
-#define CR_TICKET_SLOTS 512u
-#define CR_TICKET_RINGS 8u
-#define CR_RING_SLOTS (CR_TICKET_SLOTS / CR_TICKET_RINGS)
-static uint32_t *g_tickets = NULL;
-static struct
+
+/* Ticket blocks for the dynamic tile scheduling of k_poly / k_wave (crhip.h CRHIP_TICKET_WORDS counters each), zeroed once; a
+   launch takes a block and leaves it zeroed.  Two launches that may run AT THE SAME TIME must not share a block.  Launches on
+   one stream never do, so the blocks are handed out per stream: every stream seen gets a RING of CR_RING_SLOTS blocks (a ring
+   rather than one block so that back-to-back launches of a stream, whose tails and heads overlap on the device, differ).
+   A stream that has no ring takes an unused one, or takes over the ring of a stream that hipStreamQuery reports idle (its
+   launches are through, their blocks are zeroed again; a stream the caller has destroyed counts as idle) - no device
+   synchronise, ever - and when every ring belongs to a busy stream the table GROWS.
+   Launches issued during a STREAM CAPTURE get blocks from a separate pool that is never recycled: the captured graph will
+   reference its blocks for as long as it is replayed, side by side with whatever else is running then.  The pool is sized
+   ahead of time (ClownResamplerAMD_ReserveCaptureLaunches; device memory cannot be allocated during a capture). */
+#define CR_RING_SLOTS 64u
+#define CR_RINGS_AT_START 8u
+#define CR_CAPTURE_BLOCKS_DEFAULT 256u
+
+typedef struct cr_ring
 {
 	void *stream;
+	uint32_t *blocks;            /* CR_RING_SLOTS blocks of CRHIP_TICKET_WORDS, device memory */
 	int used;
 	unsigned next;
 	unsigned long long last_use;
-} g_rings[CR_TICKET_RINGS];
-static unsigned long long g_ring_clock = 0;
-static pthread_mutex_t g_ring_lock = PTHREAD_MUTEX_INITIALIZER;
+} cr_ring;
 
-static uint32_t *ticket_block_for(void *stream)
+typedef struct cr_device_ctx
 {
-	unsigned r, pick = CR_TICKET_RINGS, oldest = 0;
-	uint32_t *block;
+	int ordinal;
+	int ready;
+	crhip_device_info info;
+	/* tickets */
+	pthread_mutex_t ring_lock;
+	cr_ring *rings;
+	unsigned ring_count;
+	unsigned long long ring_clock;
+	uint32_t **capture_chunks;   /* device allocations of the capture pool */
+	unsigned capture_chunk_count;
+	uint32_t *capture_at;        /* next unused block of the newest chunk */
+	size_t capture_left;         /* blocks left in it */
+	/* staging (host-buffer entry points) */
+	pthread_mutex_t workspace_lock;
+	cr_workspace workspace;
+	cr_workspace workspace_more[CR_EXTRA_SETS]; /* ([0].stream is the download stream) */
+	unsigned char *small;
+} cr_device_ctx;
 
-	pthread_mutex_lock(&g_ring_lock);
-	for (r = 0; r < CR_TICKET_RINGS; ++r)
-	{
-		if (g_rings[r].used && g_rings[r].stream == stream)
-		{
-			pick = r;
-			break;
-		}
-		if (!g_rings[r].used && pick == CR_TICKET_RINGS)
-			pick = r;
-		if (g_rings[r].used && g_rings[r].last_use < g_rings[oldest].last_use)
-			oldest = r;
-	}
-	if (pick == CR_TICKET_RINGS)
-	{
-		/* all rings belong to other streams: take over the one used longest ago, once nothing can be running on it */
-		crhip_device_sync();
-		pick = oldest;
-		g_rings[pick].used = 0;
-	}
-	if (!g_rings[pick].used)
-	{
-		g_rings[pick].used = 1;
-		g_rings[pick].stream = stream;
-		g_rings[pick].next = 0;
-	}
-	g_rings[pick].last_use = ++g_ring_clock;
-	block = g_tickets + CRHIP_TICKET_WORDS * (pick * CR_RING_SLOTS + g_rings[pick].next++ % CR_RING_SLOTS);
-	pthread_mutex_unlock(&g_ring_lock);
-	return block;
-}
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static cr_device_ctx *g_ctx[CR_MAX_DEVICES];
+static int g_device = 0;                       /* process default */
+static __thread int t_device = -1;             /* the calling thread's choice, -1: follow the process default */
+static ClownResamplerAMD_Plan *g_plans = NULL;
+static uint64_t g_plan_clock = 0;
+static size_t g_plan_limit = 64;   /* unpinned plans kept; ClownResamplerAMD_SetPlanCacheLimit */
+static int g_force_generic = 0;
 static unsigned long long *g_debug_stamps = NULL;
 static int g_variant = -1; /* -1: CLOWNRESAMPLER_AMD_VARIANT from the environment, else the default */
-static pthread_mutex_t g_workspace_lock = PTHREAD_MUTEX_INITIALIZER;
+
+/* Environment switches are read ONCE (tuning hooks; none of them changes results). */
+static struct
+{
+	int loaded;
+	int dynamic_tiles;          /* CLOWNRESAMPLER_AMD_DYNAMIC_TILES: -1 unset, else 0 / 1 */
+	int no_special, debug, no_occupancy_clamp, tile_groups, no_host_pipeline, no_small_call_path;
+} g_env;
+static pthread_once_t g_env_once = PTHREAD_ONCE_INIT;
+
+static void load_env(void)
+{
+	const char *e;
+
+	e = getenv("CLOWNRESAMPLER_AMD_DYNAMIC_TILES");
+	g_env.dynamic_tiles = (e != NULL && *e != '\0') ? (atoi(e) != 0) : -1;
+	g_env.no_special = getenv("CLOWNRESAMPLER_AMD_NO_SPECIAL") != NULL;
+	g_env.debug = getenv("CLOWNRESAMPLER_AMD_DEBUG") != NULL;
+	g_env.no_occupancy_clamp = getenv("CLOWNRESAMPLER_AMD_NO_OCCUPANCY_CLAMP") != NULL;
+	e = getenv("CLOWNRESAMPLER_AMD_TILE_GROUPS");
+	g_env.tile_groups = (e != NULL && atoi(e) > 0) ? atoi(e) : 0;
+	g_env.no_host_pipeline = getenv("CLOWNRESAMPLER_AMD_NO_HOST_PIPELINE") != NULL;
+	g_env.no_small_call_path = getenv("CLOWNRESAMPLER_AMD_NO_SMALL_CALL_PATH") != NULL;
+	g_env.loaded = 1;
+}
+
+static void env_ready(void)
+{
+	pthread_once(&g_env_once, load_env);
+}
+
+static int current_device(void)
+{
+	return t_device >= 0 ? t_device : g_device;
+}
 
 int ClownResamplerAMD_DeviceCount(void)
 {
@@ -175,55 +200,249 @@ int ClownResamplerAMD_DeviceCount(void)
 	return count;
 }
 
-static int ensure_device_locked(void)
+static int ring_alloc(cr_ring *ring)
 {
+	const size_t bytes = (size_t)CR_RING_SLOTS * CRHIP_TICKET_WORDS * sizeof(uint32_t);
+
+	memset(ring, 0, sizeof(*ring));
+	if (cr_check_hip(crhip_malloc((void **)&ring->blocks, bytes), "hipMalloc(tickets)") != 0)
+		return -1;
+	if (cr_check_hip(crhip_memset(ring->blocks, 0, bytes, NULL), "hipMemset(tickets)") != 0
+	 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
+	{
+		crhip_free(ring->blocks);
+		ring->blocks = NULL;
+		return -1;
+	}
+	return 0;
+}
+
+/* rings [ctx->ring_count, want) come into being; ring_lock held (or the context not yet published) */
+static int rings_grow(cr_device_ctx *ctx, unsigned want)
+{
+	cr_ring *grown = (cr_ring *)realloc(ctx->rings, (size_t)want * sizeof(cr_ring));
+
+	if (grown == NULL)
+		return cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
+	ctx->rings = grown;
+	while (ctx->ring_count < want)
+	{
+		if (ring_alloc(&ctx->rings[ctx->ring_count]) != 0)
+			return -1;
+		++ctx->ring_count;
+	}
+	return 0;
+}
+
+/* one more chunk of never-recycled blocks for launches issued during stream captures; ring_lock held (or unpublished) */
+static int capture_pool_grow(cr_device_ctx *ctx, size_t blocks)
+{
+	const size_t bytes = blocks * CRHIP_TICKET_WORDS * sizeof(uint32_t);
+	uint32_t **list = (uint32_t **)realloc(ctx->capture_chunks, (ctx->capture_chunk_count + 1u) * sizeof(uint32_t *));
+	uint32_t *chunk = NULL;
+
+	if (list == NULL)
+		return cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
+	ctx->capture_chunks = list;
+	if (cr_check_hip(crhip_malloc((void **)&chunk, bytes), "hipMalloc(capture tickets)") != 0)
+		return -1;
+	if (cr_check_hip(crhip_memset(chunk, 0, bytes, NULL), "hipMemset(capture tickets)") != 0
+	 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
+	{
+		crhip_free(chunk);
+		return -1;
+	}
+	ctx->capture_chunks[ctx->capture_chunk_count++] = chunk;
+	ctx->capture_at = chunk;      /* (what was left of the previous chunk is abandoned: blocks are never handed out twice) */
+	ctx->capture_left = blocks;
+	return 0;
+}
+
+/* g_lock held.  Selects the device for the calling thread (hipSetDevice is per thread) and makes sure its context exists. */
+static cr_device_ctx *ensure_ctx_locked(int ordinal)
+{
+	cr_device_ctx *ctx;
 	int count = 0;
 	int e;
 
-	if (g_device_ready)
-		return cr_check_hip(crhip_set_device(g_device), "hipSetDevice"); /* the current device is per thread */
+	if (ordinal >= 0 && ordinal < CR_MAX_DEVICES && g_ctx[ordinal] != NULL && g_ctx[ordinal]->ready)
+		return cr_check_hip(crhip_set_device(ordinal), "hipSetDevice") == 0 ? g_ctx[ordinal] : NULL;
 
+	env_ready();
 	e = crhip_device_count(&count);
 
 	if (e != 0 || count <= 0)
-		return cr_fail(CLOWNRESAMPLER_AMD_ERROR_NO_DEVICE,
-		               "no usable HIP device (%s); this library has no CPU fallback for the resampling path",
-		               e != 0 ? crhip_error_string(e) : "device count is 0");
-
-	if (g_device >= count)
-		return cr_fail(CLOWNRESAMPLER_AMD_ERROR_NO_DEVICE, "device %d selected but only %d present", g_device, count);
-
-	if (cr_check_hip(crhip_set_device(g_device), "hipSetDevice") != 0)
-		return CLOWNRESAMPLER_AMD_ERROR_HIP;
-
-	if (cr_check_hip(crhip_get_device_info(g_device, &g_info), "hipGetDeviceProperties") != 0)
-		return CLOWNRESAMPLER_AMD_ERROR_HIP;
-
-	if (g_tickets == NULL)
 	{
-		if (cr_check_hip(crhip_malloc((void **)&g_tickets, CR_TICKET_SLOTS * CRHIP_TICKET_WORDS * sizeof(uint32_t)), "hipMalloc(tickets)") != 0
-		 || cr_check_hip(crhip_memset(g_tickets, 0, CR_TICKET_SLOTS * CRHIP_TICKET_WORDS * sizeof(uint32_t), NULL), "hipMemset(tickets)") != 0
-		 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
-			return CLOWNRESAMPLER_AMD_ERROR_HIP;
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_NO_DEVICE,
+		        "no usable HIP device (%s); this library has no CPU fallback for the resampling path",
+		        e != 0 ? crhip_error_string(e) : "device count is 0");
+		return NULL;
 	}
 
-	g_device_ready = 1;
-	return 0;
+	if (ordinal < 0 || ordinal >= count || ordinal >= CR_MAX_DEVICES)
+	{
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_NO_DEVICE, "device %d selected but only %d present", ordinal, count);
+		return NULL;
+	}
+
+	if (cr_check_hip(crhip_set_device(ordinal), "hipSetDevice") != 0)
+		return NULL;
+
+	ctx = g_ctx[ordinal];
+	if (ctx == NULL)
+	{
+		ctx = (cr_device_ctx *)calloc(1, sizeof(*ctx));
+		if (ctx == NULL)
+		{
+			cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
+			return NULL;
+		}
+		ctx->ordinal = ordinal;
+		pthread_mutex_init(&ctx->ring_lock, NULL);
+		pthread_mutex_init(&ctx->workspace_lock, NULL);
+		g_ctx[ordinal] = ctx;
+	}
+
+	if (cr_check_hip(crhip_get_device_info(ordinal, &ctx->info), "hipGetDeviceProperties") != 0)
+		return NULL;
+
+	if (ctx->ring_count < CR_RINGS_AT_START && rings_grow(ctx, CR_RINGS_AT_START) != 0)
+		return NULL;
+	if (ctx->capture_chunk_count == 0 && capture_pool_grow(ctx, CR_CAPTURE_BLOCKS_DEFAULT) != 0)
+		return NULL;
+
+	ctx->ready = 1;
+	return ctx;
+}
+
+static cr_device_ctx *ensure_ctx(int ordinal)
+{
+	cr_device_ctx *ctx;
+
+	/* fast path without the process lock: a context, once ready, stays until Shutdown (which needs a quiescent library) */
+	if (ordinal >= 0 && ordinal < CR_MAX_DEVICES)
+	{
+		ctx = __atomic_load_n(&g_ctx[ordinal], __ATOMIC_ACQUIRE);
+		if (ctx != NULL && __atomic_load_n(&ctx->ready, __ATOMIC_ACQUIRE))
+			return cr_check_hip(crhip_set_device(ordinal), "hipSetDevice") == 0 ? ctx : NULL;
+	}
+
+	pthread_mutex_lock(&g_lock);
+	ctx = ensure_ctx_locked(ordinal);
+	pthread_mutex_unlock(&g_lock);
+	return ctx;
 }
 
 int cr_ensure_device(void)
 {
-	int r;
+	return ensure_ctx(current_device()) != NULL ? 0 : -1;
+}
 
-	pthread_mutex_lock(&g_lock);
-	r = ensure_device_locked();
-	pthread_mutex_unlock(&g_lock);
-	return r;
+int cr_ensure_device_of(const ClownResamplerAMD_Plan *plan)
+{
+	return ensure_ctx(plan->device) != NULL ? 0 : -1;
+}
+
+int cr_current_device(void)
+{
+	return current_device();
+}
+
+static uint32_t *ticket_block_for(cr_device_ctx *ctx, void *stream)
+{
+	unsigned r, pick;
+	uint32_t *block = NULL;
+	int capturing = 0;
+
+	if (stream != NULL && crhip_stream_is_capturing(stream, &capturing) != 0)
+		capturing = 0;
+
+	pthread_mutex_lock(&ctx->ring_lock);
+
+	if (capturing)
+	{
+		if (ctx->capture_left != 0)
+		{
+			block = ctx->capture_at;
+			ctx->capture_at += CRHIP_TICKET_WORDS;
+			--ctx->capture_left;
+		}
+		pthread_mutex_unlock(&ctx->ring_lock);
+		if (block == NULL)
+			cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "more launches captured into graphs than ticket blocks were set aside for (device memory cannot be "
+			        "allocated during a capture): call ClownResamplerAMD_ReserveCaptureLaunches(n) before capturing");
+		return block;
+	}
+
+	pick = ctx->ring_count;
+	for (r = 0; r < ctx->ring_count; ++r)
+	{
+		if (ctx->rings[r].used && ctx->rings[r].stream == stream)
+		{
+			pick = r;
+			break;
+		}
+		if (!ctx->rings[r].used && pick == ctx->ring_count)
+			pick = r;
+	}
+
+	if (pick == ctx->ring_count)
+	{
+		/* every ring belongs to another stream: take over one whose stream has nothing left in flight, least recently used
+		   first (a stream handle the caller has destroyed makes the query fail: that ring is free as well) */
+		unsigned long long oldest = ~0ull;
+
+		for (r = 0; r < ctx->ring_count; ++r)
+			if (ctx->rings[r].last_use < oldest && crhip_stream_busy(ctx->rings[r].stream) == 0)
+			{
+				oldest = ctx->rings[r].last_use;
+				pick = r;
+			}
+
+		if (pick == ctx->ring_count)
+		{
+			/* all busy: more rings (rare: more than ring_count streams with launches in flight at once) */
+			if (rings_grow(ctx, ctx->ring_count + 4u) != 0)
+			{
+				pthread_mutex_unlock(&ctx->ring_lock);
+				return NULL;
+			}
+		}
+		ctx->rings[pick].used = 0;
+	}
+
+	if (!ctx->rings[pick].used)
+	{
+		ctx->rings[pick].used = 1;
+		ctx->rings[pick].stream = stream;
+		ctx->rings[pick].next = 0;
+	}
+	ctx->rings[pick].last_use = ++ctx->ring_clock;
+	block = ctx->rings[pick].blocks + (size_t)CRHIP_TICKET_WORDS * (ctx->rings[pick].next++ % CR_RING_SLOTS);
+	pthread_mutex_unlock(&ctx->ring_lock);
+	return block;
+}
+
+int ClownResamplerAMD_ReserveCaptureLaunches(size_t launches)
+{
+	cr_device_ctx *ctx = ensure_ctx(current_device());
+	int r = 0;
+
+	if (ctx == NULL)
+		return -1;
+	pthread_mutex_lock(&ctx->ring_lock);
+	if (ctx->capture_left < launches)
+		r = capture_pool_grow(ctx, launches);
+	pthread_mutex_unlock(&ctx->ring_lock);
+	return r != 0 ? -1 : 0;
 }
 
 const crhip_device_info *cr_device_info(void)
 {
-	return &g_info;
+	const cr_device_ctx *ctx = ensure_ctx(current_device());
+	static const crhip_device_info none;
+
+	return ctx != NULL ? &ctx->info : &none;
 }
 
 static cr_stream *g_streams = NULL;
@@ -245,86 +464,130 @@ static void store_release(cr_plan_store *store, int device_usable)
 	free(store);
 }
 
-static void release_everything_locked(void)
+/* g_lock held.  Frees what one device holds; fails (returns -1, nothing freed) while a call still holds one of its plans. */
+static int release_device_locked(cr_device_ctx *ctx)
 {
-	/* streaming side windows are host memory: they stay valid across device changes and are only dropped by Shutdown */
-	ClownResamplerAMD_Plan *p = g_plans;
+	ClownResamplerAMD_Plan **link;
+	unsigned k;
 
-	while (p != NULL)
+	for (link = &g_plans; *link != NULL; link = &(*link)->next)
+		if ((*link)->device == ctx->ordinal && (*link)->users != 0)
+			return -1;
+
+	/* no host-buffer call may be inside the staging workspace, no launch may be drawing a ticket block */
+	pthread_mutex_lock(&ctx->workspace_lock);
+	pthread_mutex_lock(&ctx->ring_lock);
+
+	if (ctx->ready)
+		crhip_set_device(ctx->ordinal);
+
+	link = &g_plans;
+	while (*link != NULL)
 	{
-		ClownResamplerAMD_Plan *next = p->next;
+		ClownResamplerAMD_Plan *plan = *link;
 
-		store_release(p->store, g_device_ready);
-		free(p);
-		p = next;
-	}
-	g_plans = NULL;
-
-	if (g_device_ready)
-	{
-		crhip_free(g_tickets);
-		g_tickets = NULL;
-		memset(g_rings, 0, sizeof(g_rings));
-		crhip_free(g_workspace.d_in);
-		crhip_free(g_workspace.d_out);
-		if (g_workspace.stream != NULL)
-			crhip_stream_destroy(g_workspace.stream);
-		if (g_small != NULL)
-			crhip_host_free(g_small);
+		if (plan->device != ctx->ordinal)
 		{
-			int k;
-			for (k = 0; k < CR_EXTRA_SETS; ++k)
-			{
-				crhip_free(g_workspace_more[k].d_in);
-				crhip_free(g_workspace_more[k].d_out);
-				if (g_workspace_more[k].stream != NULL)
-					crhip_stream_destroy(g_workspace_more[k].stream);
-			}
+			link = &plan->next;
+			continue;
+		}
+		*link = plan->next;
+		store_release(plan->store, ctx->ready);
+		free(plan);
+	}
+
+	if (ctx->ready)
+	{
+		for (k = 0; k < ctx->ring_count; ++k)
+			crhip_free(ctx->rings[k].blocks);
+		for (k = 0; k < ctx->capture_chunk_count; ++k)
+			crhip_free(ctx->capture_chunks[k]);
+		crhip_free(ctx->workspace.d_in);
+		crhip_free(ctx->workspace.d_out);
+		if (ctx->workspace.stream != NULL)
+			crhip_stream_destroy(ctx->workspace.stream);
+		if (ctx->small != NULL)
+			crhip_host_free(ctx->small);
+		for (k = 0; k < CR_EXTRA_SETS; ++k)
+		{
+			crhip_free(ctx->workspace_more[k].d_in);
+			crhip_free(ctx->workspace_more[k].d_out);
+			if (ctx->workspace_more[k].stream != NULL)
+				crhip_stream_destroy(ctx->workspace_more[k].stream);
 		}
 	}
-	g_small = NULL;
-	memset(&g_workspace, 0, sizeof(g_workspace));
-	memset(g_workspace_more, 0, sizeof(g_workspace_more));
+	free(ctx->rings);
+	free(ctx->capture_chunks);
+	ctx->rings = NULL;
+	ctx->ring_count = 0;
+	ctx->capture_chunks = NULL;
+	ctx->capture_chunk_count = 0;
+	ctx->capture_at = NULL;
+	ctx->capture_left = 0;
+	ctx->small = NULL;
+	memset(&ctx->workspace, 0, sizeof(ctx->workspace));
+	memset(ctx->workspace_more, 0, sizeof(ctx->workspace_more));
+	__atomic_store_n(&ctx->ready, 0, __ATOMIC_RELEASE);
+
+	pthread_mutex_unlock(&ctx->ring_lock);
+	pthread_mutex_unlock(&ctx->workspace_lock);
+	return 0;
 }
 
 int ClownResamplerAMD_SetDevice(int ordinal)
 {
-	int r = 0;
+	cr_device_ctx *ctx;
 
 	pthread_mutex_lock(&g_lock);
-	if (ordinal != g_device || !g_device_ready)
-	{
-		if (g_device_ready)
-			crhip_set_device(g_device);
-		release_everything_locked(); /* plans and staging belong to the old device */
+	ctx = ensure_ctx_locked(ordinal);
+	if (ctx != NULL)
 		g_device = ordinal;
-		g_device_ready = 0;
-		r = ensure_device_locked();
-	}
 	pthread_mutex_unlock(&g_lock);
-	return r;
+	return ctx != NULL ? 0 : -1;
 }
 
 int ClownResamplerAMD_GetDevice(void)
 {
-	return g_device;
+	return current_device();
 }
 
+int ClownResamplerAMD_SetThreadDevice(int ordinal)
+{
+	if (ordinal < 0)
+	{
+		t_device = -1;
+		return 0;
+	}
+	if (ensure_ctx(ordinal) == NULL)
+		return -1;
+	t_device = ordinal;
+	return 0;
+}
+
+/* Needs a QUIESCENT library: no resample call in progress on any thread (a plan still held by a call makes it fail loudly
+   instead of freeing memory under that call). */
 void ClownResamplerAMD_Shutdown(void)
 {
+	int d, busy = 0;
+
+	cr_multi_shutdown();
 	pthread_mutex_lock(&g_lock);
-	while (g_streams != NULL)
+	for (d = 0; d < CR_MAX_DEVICES; ++d)
+		if (g_ctx[d] != NULL && release_device_locked(g_ctx[d]) != 0)
+			busy = 1;
+	if (!busy)
 	{
-		cr_stream *next = g_streams->next;
-		free(g_streams->window);
-		free(g_streams);
-		g_streams = next;
+		while (g_streams != NULL)
+		{
+			cr_stream *next = g_streams->next;
+			free(g_streams->window);
+			free(g_streams);
+			g_streams = next;
+		}
 	}
-	if (g_device_ready)
-		crhip_set_device(g_device);
-	release_everything_locked();
-	g_device_ready = 0;
 	pthread_mutex_unlock(&g_lock);
+	if (busy)
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "ClownResamplerAMD_Shutdown while a resample call is in progress on another thread: nothing of that device was released");
 }
 
 void *ClownResamplerAMD_DeviceAlloc(size_t bytes)
@@ -396,7 +659,7 @@ static uint32_t supported_poly_channels(uint32_t channels)
 static uint32_t plan_image_stride(const ClownResamplerAMD_Plan *plan)
 {
 	const int special = crhip_poly_has_instance(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode)
-	                    && getenv("CLOWNRESAMPLER_AMD_NO_SPECIAL") == NULL;
+	                    && !g_env.no_special;
 	return special ? plan->poly.row_stride : 4u * ((plan->poly.slots + 3u) / 4u + 1u);
 }
 
@@ -411,11 +674,12 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	uint64_t tile;
 
 	uint32_t frames_multiple = 0;
+	const crhip_device_info *di = &g_ctx[plan->device]->info;
 	/* frames of one tap window as a tile has to hold it: the slots plus the largest shift of a phase's window (shifted rows) */
 	const uint32_t window_slots = plan->poly.slots + plan->poly.window_extra;
 
 	plan->specialised = (uint32_t)crhip_poly_has_instance(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
-	if (getenv("CLOWNRESAMPLER_AMD_NO_SPECIAL") != NULL) /* tuning hook: time the run-time-slot instance instead */
+	if (g_env.no_special) /* tuning hook (CLOWNRESAMPLER_AMD_NO_SPECIAL): time the run-time-slot instance instead */
 		plan->specialised = 0;
 	crhip_poly_geometry(plan->channels, plan->specialised ? plan->poly.slots : 0xFFFFu, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
 	if (plan->variant == 28u || plan->variant == 29u || (plan->variant == 0xFFFFu && crhip_poly_default_is_mad(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode)))
@@ -461,7 +725,7 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 			/* ... and no larger than the staging space one workgroup per CU leaves each wave */
 			const uint32_t waves = plan->threads / 64u;
 			const uint32_t fixed = rows_bytes + 16u + waves * 2u * 1024u;
-			const uint32_t lds = (uint32_t)g_info.max_lds_per_block < 160u * 1024u ? (uint32_t)g_info.max_lds_per_block : 160u * 1024u;
+			const uint32_t lds = (uint32_t)di->max_lds_per_block < 160u * 1024u ? (uint32_t)di->max_lds_per_block : 160u * 1024u;
 			const uint64_t room = lds > fixed ? ((lds - fixed) / waves & ~15u) / unit : 0;
 
 			if (wave_tile > room)
@@ -479,16 +743,16 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 			per_cu = (160u * 1024u) / plan->lds_bytes;
 			if (per_cu > 2048u / plan->threads)
 				per_cu = 2048u / plan->threads;
-			if (per_cu >= 1u && plan->lds_bytes <= (uint32_t)g_info.max_lds_per_block)
+			if (per_cu >= 1u && plan->lds_bytes <= (uint32_t)di->max_lds_per_block)
 			{
-				plan->max_blocks = per_cu * (uint32_t)(g_info.compute_units > 0 ? g_info.compute_units : 256);
+				plan->max_blocks = per_cu * (uint32_t)(di->compute_units > 0 ? di->compute_units : 256);
 				return;
 			}
 		}
 
-		if (getenv("CLOWNRESAMPLER_AMD_DEBUG") != NULL)
+		if (g_env.debug)
 			fprintf(stderr, "clownresampler_amd: k_up not used: increment %llu, ok %d, signs +%#x -%#x against mask %#x, wave tile %llu, lds %u of %d\n",
-			        (unsigned long long)plan->increment, ok, pos_bits, neg_bits, negmask, (unsigned long long)wave_tile, plan->lds_bytes, g_info.max_lds_per_block);
+			        (unsigned long long)plan->increment, ok, pos_bits, neg_bits, negmask, (unsigned long long)wave_tile, plan->lds_bytes, di->max_lds_per_block);
 		plan->variant = crhip_poly_up_fallback_variant(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
 		crhip_poly_geometry(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
 	}
@@ -509,9 +773,9 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 			per_cu = (160u * 1024u) / plan->lds_bytes;
 			if (per_cu > 2048u / plan->threads)
 				per_cu = 2048u / plan->threads;
-			if (per_cu >= 1u && plan->lds_bytes <= (uint32_t)g_info.max_lds_per_block)
+			if (per_cu >= 1u && plan->lds_bytes <= (uint32_t)di->max_lds_per_block)
 			{
-				plan->max_blocks = per_cu * (uint32_t)(g_info.compute_units > 0 ? g_info.compute_units : 256);
+				plan->max_blocks = per_cu * (uint32_t)(di->compute_units > 0 ? di->compute_units : 256);
 				return;
 			}
 		}
@@ -524,7 +788,7 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	tile_bytes = plan->vecs * 16u * plan->threads;
 	plan->lds_bytes = rows_bytes + 2u * tile_bytes + 16u; /* + the ticket mailbox */
 
-	if (plan->lds_bytes > (uint32_t)g_info.max_lds_per_block)
+	if (plan->lds_bytes > (uint32_t)di->max_lds_per_block)
 	{
 		plan->use_poly = 0;
 		plan->generic_reason = "polyphase rows + tiles exceed the LDS of one workgroup";
@@ -551,12 +815,12 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 		tile = (1u << 24) - 1u;
 	/* whole groups of threads * frames-in-flight; 4, 2 or 1 groups per tile run as straight-line code in the kernel */
 	{
-		const char *e = getenv("CLOWNRESAMPLER_AMD_TILE_GROUPS"); /* tuning hook: cap the groups per tile */
+		const int tile_groups = g_env.tile_groups; /* tuning hook (CLOWNRESAMPLER_AMD_TILE_GROUPS): cap the groups per tile */
 		/* 13 and 15 channels (7-8 channels per lane plus the phantom channel): one group per tile.  With four groups - strong
 		   upsampling - the straight-line tile measured 0.18 of the roofline against 0.30 (profiles/r01_channel_table.log);
 		   at 44.1 <-> 48 kHz, where two groups fit, one costs 1-2 % */
 		const uint64_t wide_phantom = (!plan->specialised && plan->channels > 12u && plan->channels % 2u == 1u) ? 1u : 0u;
-		const uint64_t cap = (e != NULL && atoi(e) > 0) ? (uint64_t)atoi(e) * frames_multiple : wide_phantom * frames_multiple;
+		const uint64_t cap = tile_groups > 0 ? (uint64_t)tile_groups * frames_multiple : wide_phantom * frames_multiple;
 		if (cap != 0 && tile > cap)
 			tile = cap;
 	}
@@ -582,13 +846,13 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 		per_cu = 2048u / plan->threads;
 	if (per_cu < 1u)
 		per_cu = 1u;
-	plan->max_blocks = per_cu * (uint32_t)(g_info.compute_units > 0 ? g_info.compute_units : 256);
+	plan->max_blocks = per_cu * (uint32_t)(di->compute_units > 0 ? di->compute_units : 256);
 }
 
-static int plan_key_matches(const ClownResamplerAMD_Plan *plan, uint64_t table_hash, unsigned radius, const cr_config *cfg, uint32_t channels)
+static int plan_key_matches(const ClownResamplerAMD_Plan *plan, uint64_t table_hash, unsigned radius, const cr_config *cfg, uint32_t channels, int device)
 {
 	return plan->table_hash == table_hash && plan->radius == radius && plan->channels == channels
-	    && plan->key_variant == current_variant() && plan->device == g_device && memcmp(&plan->cfg, cfg, sizeof(*cfg)) == 0;
+	    && plan->key_variant == current_variant() && plan->device == device && memcmp(&plan->cfg, cfg, sizeof(*cfg)) == 0;
 }
 
 /* Drops unpinned, unheld plans, least recently used first, until at most g_plan_limit unpinned plans remain. */
@@ -614,7 +878,7 @@ static void evict_plans_locked(void)
 		{
 			ClownResamplerAMD_Plan *plan = *victim;
 			*victim = plan->next;
-			store_release(plan->store, g_device_ready);
+			store_release(plan->store, g_ctx[plan->device] != NULL && g_ctx[plan->device]->ready);
 			free(plan);
 		}
 	}
@@ -657,18 +921,26 @@ void cr_plan_release(const ClownResamplerAMD_Plan *plan_in)
 ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_table_fill fill_table, const void *user,
                                     unsigned radius, const cr_config *cfg, uint32_t channels, uint64_t increment, int pin)
 {
+	return cr_plan_get_on(current_device(), table_hash, table_len, fill_table, user, radius, cfg, channels, increment, pin);
+}
+
+ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t table_len, cr_table_fill fill_table, const void *user,
+                                       unsigned radius, const cr_config *cfg, uint32_t channels, uint64_t increment, int pin)
+{
 	ClownResamplerAMD_Plan *plan, *sibling = NULL;
 	cr_plan_store *store = NULL;
 	int32_t *table = NULL;
+	cr_device_ctx *ctx;
 
 	pthread_mutex_lock(&g_lock);
 
-	if (ensure_device_locked() != 0)
+	ctx = ensure_ctx_locked(device);
+	if (ctx == NULL)
 		goto fail;
 
 	for (plan = g_plans; plan != NULL; plan = plan->next)
 	{
-		if (!plan_key_matches(plan, table_hash, radius, cfg, channels))
+		if (!plan_key_matches(plan, table_hash, radius, cfg, channels, device))
 			continue;
 
 		if (plan->increment == increment)
@@ -707,7 +979,7 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 	plan->cfg = *cfg;
 	plan->channels = channels;
 	plan->increment = increment;
-	plan->device = g_device;
+	plan->device = device;
 	plan->key_variant = current_variant();
 	plan->variant = plan->key_variant;
 	plan->table_len = (uint32_t)table_len;
@@ -852,11 +1124,11 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 					l.out_s16 = (uint32_t)form;
 					if (crhip_poly_occupancy(&l, &per_cu, &vgprs, &static_lds) == 0 && per_cu >= 1)
 					{
-						const uint32_t resident = (uint32_t)per_cu * (uint32_t)(g_info.compute_units > 0 ? g_info.compute_units : 256);
-						if (getenv("CLOWNRESAMPLER_AMD_DEBUG") != NULL)
+						const uint32_t resident = (uint32_t)per_cu * (uint32_t)(ctx->info.compute_units > 0 ? ctx->info.compute_units : 256);
+						if (g_env.debug)
 							fprintf(stderr, "clownresampler_amd: plan variant %u (%s output): %u threads, %u B dynamic LDS, %d VGPRs: %d workgroups per CU, grid cap %u -> %u\n",
 							        plan->variant, form ? "int16" : "int32", plan->threads, plan->lds_bytes, vgprs, per_cu, form ? plan->max_blocks_s16 : plan->max_blocks, resident);
-						if (getenv("CLOWNRESAMPLER_AMD_NO_OCCUPANCY_CLAMP") != NULL) /* (tuning hook: measure without) */
+						if (g_env.no_occupancy_clamp) /* (tuning hook CLOWNRESAMPLER_AMD_NO_OCCUPANCY_CLAMP: measure without) */
 							continue;
 						if (form == 0 && resident < plan->max_blocks)
 							plan->max_blocks = resident;
@@ -948,11 +1220,12 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		{
 			/* tickets pay off where workgroups drift apart over many medium-sized tiles; measured on MI355X (profiles/):
 			   stereo 3-lobe upsampling gains ~4 %, 8-channel and 8-lobe instances lose 1-8 %: a per-instance default */
-			const char *e = getenv("CLOWNRESAMPLER_AMD_DYNAMIC_TILES");
-			l.dynamic_tiles = e != NULL ? (uint32_t)(atoi(e) != 0)
-			                            : (uint32_t)crhip_poly_dynamic_default(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
+			l.dynamic_tiles = g_env.dynamic_tiles >= 0 ? (uint32_t)g_env.dynamic_tiles
+			                                           : (uint32_t)crhip_poly_dynamic_default(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
 		}
-		l.d_tickets = ticket_block_for(stream);
+		l.d_tickets = ticket_block_for(g_ctx[plan->device], stream);
+		if (l.d_tickets == NULL)
+			return -1;
 
 		return cr_check_hip(crhip_launch_poly(&l, stream), "k_poly launch");
 	}
@@ -1005,33 +1278,26 @@ static int grow(unsigned char **p, size_t *have, size_t want)
 	return 0;
 }
 
-cr_workspace *cr_workspace_acquire(size_t in_bytes, size_t out_bytes)
+static cr_workspace *workspace_acquire(cr_device_ctx *ctx, size_t in_bytes, size_t out_bytes)
 {
-	if (cr_ensure_device() != 0)
-		return NULL;
+	pthread_mutex_lock(&ctx->workspace_lock);
 
-	pthread_mutex_lock(&g_workspace_lock);
-	g_workspace_busy = 1;
-
-	if (g_workspace.stream == NULL && cr_check_hip(crhip_stream_create(&g_workspace.stream), "hipStreamCreate") != 0)
+	if (ctx->workspace.stream == NULL && cr_check_hip(crhip_stream_create(&ctx->workspace.stream), "hipStreamCreate") != 0)
 		goto fail;
 
-	if (grow(&g_workspace.d_in, &g_workspace.d_in_bytes, in_bytes + 64) != 0 || grow(&g_workspace.d_out, &g_workspace.d_out_bytes, out_bytes + 64) != 0)
+	if (grow(&ctx->workspace.d_in, &ctx->workspace.d_in_bytes, in_bytes + 64) != 0 || grow(&ctx->workspace.d_out, &ctx->workspace.d_out_bytes, out_bytes + 64) != 0)
 		goto fail;
 
-	return &g_workspace;
+	return &ctx->workspace;
 
 fail:
-	g_workspace_busy = 0;
-	pthread_mutex_unlock(&g_workspace_lock);
+	pthread_mutex_unlock(&ctx->workspace_lock);
 	return NULL;
 }
 
-void cr_workspace_release(cr_workspace *ws)
+static void workspace_release(cr_device_ctx *ctx)
 {
-	(void)ws;
-	g_workspace_busy = 0;
-	pthread_mutex_unlock(&g_workspace_lock);
+	pthread_mutex_unlock(&ctx->workspace_lock);
 }
 
 /* ---- pipelined host path ----
@@ -1057,13 +1323,14 @@ typedef struct cr_download
 	void *stream;     /* the download stream: every D2H of the call, nothing else */
 	uint64_t submitted, completed; /* batches; batch b uses slot (and staging set) b % (1 + CR_EXTRA_SETS) */
 	int quit;
+	int device;
 	int hip_error; /* first failing HIP call of the thread (reported by the caller's thread, whose error state the API exposes) */
 } cr_download;
 
 static void *download_thread(void *arg)
 {
 	cr_download *d = (cr_download *)arg;
-	int code = crhip_set_device(g_device);
+	int code = crhip_set_device(d->device);
 
 	pthread_mutex_lock(&d->lock);
 	if (code != 0 && d->hip_error == 0)
@@ -1105,21 +1372,26 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 	const uint64_t batch_frames = 4u << 20;
 	const size_t frame_in = (size_t)plan->channels * sizeof(int16_t);
 	const size_t frame_out = (size_t)plan->channels * (out_s16 ? sizeof(int16_t) : sizeof(int32_t));
-	const int pipelined = n_out > batch_frames && getenv("CLOWNRESAMPLER_AMD_NO_HOST_PIPELINE") == NULL;
+	const int pipelined = n_out > batch_frames && !g_env.no_host_pipeline;
 	uint64_t done = 0, batch = 0;
 	cr_download dl;
 	pthread_t thread;
 	int have_thread = 0, bad = 0;
 	cr_workspace *ws;
+	cr_device_ctx *ctx;
 
 	if (n_out == 0)
 		return 0;
+
+	ctx = ensure_ctx(plan->device);
+	if (ctx == NULL)
+		return -1;
 
 	/* SMALL calls (a sound-card sized request, a refill of the streaming API): two hipMemcpyAsync and a launch cost ~35 us
 	   whatever the size, most of it in the two copies.  Up to CR_SMALL_CALL_BYTES the kernel therefore works on pinned host
 	   memory directly - the input is copied into it by the CPU, the LDS-DMA reads it and the stores write the result across
 	   PCIe, and one synchronise later the CPU copies the result out: one launch, no copy calls (480 frames: 34 -> ~15 us). */
-	if (n_out <= batch_frames && getenv("CLOWNRESAMPLER_AMD_NO_SMALL_CALL_PATH") == NULL)
+	if (n_out <= batch_frames && !g_env.no_small_call_path)
 	{
 		uint64_t pi = pos_int, extent = cr_input_extent(&plan->cfg, 0, pos_frac, plan->increment, n_out);
 		size_t in_bytes, out_bytes, out_at;
@@ -1134,21 +1406,21 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 
 		if (out_at + out_bytes + 64u <= CR_SMALL_CALL_BYTES)
 		{
-			ws = cr_workspace_acquire(0, 0); /* (the lock and the stream) */
+			ws = workspace_acquire(ctx, 0, 0); /* (the lock and the stream) */
 			if (ws == NULL)
 				return -1;
-			if (g_small == NULL && cr_check_hip(crhip_host_alloc((void **)&g_small, CR_SMALL_CALL_BYTES), "hipHostMalloc(small-call block)") != 0)
+			if (ctx->small == NULL && cr_check_hip(crhip_host_alloc((void **)&ctx->small, CR_SMALL_CALL_BYTES), "hipHostMalloc(small-call block)") != 0)
 			{
-				g_small = NULL;
-				cr_workspace_release(ws);
+				ctx->small = NULL;
+				workspace_release(ctx);
 				return -1;
 			}
-			memcpy(g_small, host_in + pi * plan->channels, in_bytes);
-			bad = cr_plan_launch(plan, g_small, in_bytes, g_small + out_at, 0, pos_frac, n_out, ws->stream, out_s16) != 0
+			memcpy(ctx->small, host_in + pi * plan->channels, in_bytes);
+			bad = cr_plan_launch(plan, ctx->small, in_bytes, ctx->small + out_at, 0, pos_frac, n_out, ws->stream, out_s16) != 0
 			   || cr_check_hip(crhip_stream_sync(ws->stream), "hipStreamSynchronize") != 0;
 			if (!bad)
-				memcpy(host_out, g_small + out_at, out_bytes);
-			cr_workspace_release(ws);
+				memcpy(host_out, ctx->small + out_at, out_bytes);
+			workspace_release(ctx);
 			return bad ? -1 : 0;
 		}
 	}
@@ -1160,30 +1432,31 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 
 		if (extent0 > in_frames)
 			extent0 = in_frames;
-		ws = cr_workspace_acquire((size_t)extent0 * frame_in, (size_t)n0 * frame_out);
+		ws = workspace_acquire(ctx, (size_t)extent0 * frame_in, (size_t)n0 * frame_out);
 		if (ws == NULL)
 			return -1;
 
 		if (pipelined)
 		{
-			int k, failed = g_workspace_more[0].stream == NULL && cr_check_hip(crhip_stream_create(&g_workspace_more[0].stream), "hipStreamCreate") != 0;
+			int k, failed = ctx->workspace_more[0].stream == NULL && cr_check_hip(crhip_stream_create(&ctx->workspace_more[0].stream), "hipStreamCreate") != 0;
 
 			for (k = 0; k < CR_EXTRA_SETS && !failed; ++k)
-				failed = grow(&g_workspace_more[k].d_in, &g_workspace_more[k].d_in_bytes, (size_t)extent0 * frame_in + 64) != 0
-				      || grow(&g_workspace_more[k].d_out, &g_workspace_more[k].d_out_bytes, (size_t)n0 * frame_out + 64) != 0;
+				failed = grow(&ctx->workspace_more[k].d_in, &ctx->workspace_more[k].d_in_bytes, (size_t)extent0 * frame_in + 64) != 0
+				      || grow(&ctx->workspace_more[k].d_out, &ctx->workspace_more[k].d_out_bytes, (size_t)n0 * frame_out + 64) != 0;
 			if (failed)
 			{
-				cr_workspace_release(ws);
+				workspace_release(ctx);
 				return -1;
 			}
 
 			memset(&dl, 0, sizeof(dl));
+			dl.device = plan->device;
 			pthread_mutex_init(&dl.lock, NULL);
 			pthread_cond_init(&dl.changed, NULL);
 			/* uploads and kernels all go to ONE stream (ws->stream), downloads all to another (the second set's): copies
 			   of one direction per stream is what lets the runtime run the two directions side by side (measured: with
 			   each batch's three steps on its own stream the download stalled for as long as the next upload ran) */
-			dl.stream = g_workspace_more[0].stream;
+			dl.stream = ctx->workspace_more[0].stream;
 			for (k = 0; k < 1 + CR_EXTRA_SETS && !failed; ++k)
 				failed = cr_check_hip(crhip_event_create(&dl.slot[k].ready), "hipEventCreate") != 0;
 			if (failed)
@@ -1191,7 +1464,7 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 				for (k = 0; k < 1 + CR_EXTRA_SETS; ++k)
 					if (dl.slot[k].ready != NULL)
 						crhip_event_destroy(dl.slot[k].ready);
-				cr_workspace_release(ws);
+				workspace_release(ctx);
 				return -1;
 			}
 			have_thread = pthread_create(&thread, NULL, download_thread, &dl) == 0;
@@ -1204,7 +1477,7 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 		const uint64_t n = n_out - done < batch_frames ? n_out - done : batch_frames;
 		uint64_t pi = pos_int, pf = pos_frac, extent;
 		const unsigned set = have_thread ? (unsigned)(batch % (1u + CR_EXTRA_SETS)) : 0u;
-		cr_workspace *w = set == 0u ? ws : &g_workspace_more[set - 1u];
+		cr_workspace *w = set == 0u ? ws : &ctx->workspace_more[set - 1u];
 
 		cr_advance(&pi, &pf, plan->increment, done);
 
@@ -1275,7 +1548,7 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 		{
 			/* launches of a failed call may still be running: leave nothing in flight on the staging sets */
 			crhip_stream_sync(ws->stream);
-			crhip_stream_sync(g_workspace_more[0].stream);
+			crhip_stream_sync(ctx->workspace_more[0].stream);
 		}
 		if (code != 0 && !bad)
 			bad = cr_check_hip(code, "download thread (hipMemcpyAsync D2H / hipStreamSynchronize)") != 0;
@@ -1292,7 +1565,7 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 		pthread_mutex_destroy(&dl.lock);
 	}
 
-	cr_workspace_release(ws);
+	workspace_release(ctx);
 	return bad ? -1 : 0;
 }
 
@@ -1301,7 +1574,8 @@ int cr_run_single_frame(const ClownResamplerAMD_Plan *plan, const int16_t *host_
 {
 	const size_t in_bytes = (size_t)window_frames * plan->channels * sizeof(int16_t);
 	const size_t acc_bytes = (size_t)plan->channels * sizeof(int64_t);
-	cr_workspace *ws = cr_workspace_acquire(in_bytes, 2 * acc_bytes);
+	cr_device_ctx *ctx = ensure_ctx(plan->device);
+	cr_workspace *ws = ctx != NULL ? workspace_acquire(ctx, in_bytes, 2 * acc_bytes) : NULL;
 	crhip_generic_launch g;
 	int bad;
 
@@ -1331,7 +1605,7 @@ int cr_run_single_frame(const ClownResamplerAMD_Plan *plan, const int16_t *host_
 	   || cr_check_hip(crhip_memcpy_d2h(acc_out, ws->d_out, acc_bytes, ws->stream), "hipMemcpyAsync(D2H)") != 0
 	   || cr_check_hip(crhip_stream_sync(ws->stream), "hipStreamSynchronize") != 0;
 
-	cr_workspace_release(ws);
+	workspace_release(ctx);
 	return bad ? -1 : 0;
 }
 
@@ -1382,31 +1656,86 @@ void ClownResamplerAMD_DebugForceGenericKernel(int on)
 /* streaming side windows                                                                                  */
 /* ------------------------------------------------------------------------------------------------------- */
 
-cr_stream *cr_stream_create(void)
-{
-	cr_stream *stream = (cr_stream *)calloc(1, sizeof(*stream));
-
-	if (stream == NULL)
-		return NULL;
-
-	pthread_mutex_lock(&g_lock);
-	stream->id = ++g_stream_serial ^ 0x434C4F574E5253ull; /* never 0 */
-	stream->next = g_streams;
-	g_streams = stream;
-	pthread_mutex_unlock(&g_lock);
-	return stream;
-}
-
-cr_stream *cr_stream_lookup(uint64_t id)
+/* The side window of the high-level state at address `owner`: the one already registered for that address (the state is being
+   re-initialised, or a new state lives where a discarded one did - either way the old window's contents are dead), else a new
+   one.  Nothing of the caller's (possibly uninitialised) state is read to find it. */
+cr_stream *cr_stream_claim(const void *owner)
 {
 	cr_stream *stream;
 
 	pthread_mutex_lock(&g_lock);
 	for (stream = g_streams; stream != NULL; stream = stream->next)
-		if (stream->id == id)
+		if (stream->owner == owner)
+			break;
+	if (stream == NULL)
+	{
+		stream = (cr_stream *)calloc(1, sizeof(*stream));
+		if (stream != NULL)
+		{
+			stream->owner = owner;
+			stream->next = g_streams;
+			g_streams = stream;
+		}
+	}
+	if (stream != NULL)
+	{
+		stream->id = ++g_stream_serial ^ 0x434C4F574E5253ull; /* never 0; a new id per claim: keys of the address's past lives die */
+		/* an idle window does not keep its largest size for ever */
+		if (stream->window_samples > (size_t)1 << 16)
+		{
+			free(stream->window);
+			stream->window = NULL;
+			stream->window_samples = 0;
+		}
+	}
+	pthread_mutex_unlock(&g_lock);
+	return stream;
+}
+
+/* the window of the state at `owner` whose key says `id`; NULL when the key is stale or the bytes were copied elsewhere */
+cr_stream *cr_stream_lookup(uint64_t id, const void *owner)
+{
+	cr_stream *stream;
+
+	pthread_mutex_lock(&g_lock);
+	for (stream = g_streams; stream != NULL; stream = stream->next)
+		if (stream->id == id && stream->owner == owner)
 			break;
 	pthread_mutex_unlock(&g_lock);
 	return stream;
+}
+
+size_t ClownResamplerAMD_StreamingWindowCount(void)
+{
+	const cr_stream *stream;
+	size_t n = 0;
+
+	pthread_mutex_lock(&g_lock);
+	for (stream = g_streams; stream != NULL; stream = stream->next)
+		++n;
+	pthread_mutex_unlock(&g_lock);
+	return n;
+}
+
+/* frees the window registered for `owner`, if any */
+void cr_stream_drop(const void *owner)
+{
+	cr_stream **link, *stream = NULL;
+
+	pthread_mutex_lock(&g_lock);
+	for (link = &g_streams; *link != NULL; link = &(*link)->next)
+		if ((*link)->owner == owner)
+		{
+			stream = *link;
+			*link = stream->next;
+			break;
+		}
+	pthread_mutex_unlock(&g_lock);
+	if (stream != NULL)
+	{
+		free(stream->window);
+		free(stream);
+	}
 }
 
 int cr_stream_reserve(cr_stream *stream, size_t samples)

@@ -23,8 +23,10 @@ unsigned long cr_error_serial(void);
 /* cr_fail(CLOWNRESAMPLER_AMD_ERROR_HIP, ...) when hip_code != 0; returns hip_code. */
 int cr_check_hip(int hip_code, const char *what);
 
-/* Makes sure a device is selected and its properties are known.  0 on success. */
+/* Makes the calling thread's device (ClownResamplerAMD_SetThreadDevice, else the process default) current for HIP and makes
+   sure its context exists.  0 on success. */
 int cr_ensure_device(void);
+int cr_current_device(void);
 const crhip_device_info *cr_device_info(void);
 
 /* What plans that differ only in their increment share: the polyphase rows are a function of the fractional position,
@@ -83,12 +85,25 @@ typedef int (*cr_table_fill)(const void *user, int32_t *dst, size_t count);
 ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_table_fill fill_table, const void *user,
                                     unsigned radius, const cr_config *cfg, uint32_t channels, uint64_t increment, int pin);
 void cr_plan_release(const ClownResamplerAMD_Plan *plan);
+/* ... and the same on a given device (the multi-device entry point): the calling thread's HIP device is `device` afterwards */
+ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t table_len, cr_table_fill fill_table, const void *user,
+                                       unsigned radius, const cr_config *cfg, uint32_t channels, uint64_t increment, int pin);
+/* Makes the plan's device current for HIP on the calling thread.  0 on success. */
+int cr_ensure_device_of(const ClownResamplerAMD_Plan *plan);
 
 /* Enqueues the computation of output frames [0, n_out) starting at (pos_int, pos_frac) on `stream`. 0 on success. */
 int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_t in_valid_bytes, void *d_out,
                    uint64_t pos_int, uint64_t pos_frac, uint64_t n_out, void *stream, int out_s16);
 
-/* Staging workspace for the host-buffer entry points: one per process, handed out under a lock. */
+/* cr_multi.c: the multi-device call behind ClownResamplerAMD_ResampleShardedDevice, and its part of Shutdown */
+struct ClownResampler_LowLevel_State;
+struct ClownResamplerAMD_DeviceShard;
+size_t cr_resample_sharded(struct ClownResampler_LowLevel_State *resampler, uint64_t table_hash, size_t table_len, cr_table_fill fill_table, const void *table_user,
+                           unsigned radius, size_t total_input_frames, const struct ClownResamplerAMD_DeviceShard *shards, unsigned shard_count,
+                           int output_is_s16, int gather_mode, unsigned root_shard, void *root_output);
+void cr_multi_shutdown(void);
+
+/* Staging workspace for the host-buffer entry points: one per device, handed out under that device's lock. */
 typedef struct cr_workspace
 {
 	void *stream;
@@ -97,9 +112,6 @@ typedef struct cr_workspace
 	unsigned char *d_out;
 	size_t d_out_bytes;
 } cr_workspace;
-
-cr_workspace *cr_workspace_acquire(size_t in_bytes, size_t out_bytes); /* NULL after cr_fail */
-void cr_workspace_release(cr_workspace *ws);
 
 /* Computes output frames [0, n_out) from HOST input into a HOST int32 buffer: uploads the input window, launches,
    downloads, synchronises.  `host_in` points at padded-buffer frame 0 and in_frames frames are readable. 0 on success. */
@@ -115,6 +127,7 @@ int cr_run_single_frame(const ClownResamplerAMD_Plan *plan, const int16_t *host_
 typedef struct cr_stream
 {
 	uint64_t id;
+	const void *owner;      /* address of the ClownResampler_HighLevel_State the window belongs to */
 	struct cr_stream *next;
 	int16_t *window;        /* [left halo | unconsumed frames ... | look-ahead], same layout as the reference's buffer */
 	size_t window_samples;  /* allocated */
@@ -122,8 +135,9 @@ typedef struct cr_stream
 	size_t target_frames;   /* payload frames to collect per refill; grows while the consumer keeps draining whole windows */
 } cr_stream;
 
-cr_stream *cr_stream_create(void);             /* new id, registered for Shutdown */
-cr_stream *cr_stream_lookup(uint64_t id);
+cr_stream *cr_stream_claim(const void *owner);  /* the window of the state at this address (new id; made if there is none) */
+cr_stream *cr_stream_lookup(uint64_t id, const void *owner);
+void cr_stream_drop(const void *owner);
 int cr_stream_reserve(cr_stream *stream, size_t samples);   /* grows window keeping its contents; 0 on success */
 size_t cr_stream_max_frames(void);             /* ClownResamplerAMD_SetStreamingWindow */
 

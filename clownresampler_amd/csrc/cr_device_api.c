@@ -102,7 +102,7 @@ static size_t resample_device(ClownResamplerAMD_Plan *plan, ClownResampler_LowLe
 	{
 		const uint64_t valid_bytes = ((uint64_t)*total_input_frames + 2 * cfg.radius_frames) * plan->channels * sizeof(cc_s16l);
 
-		if (cr_ensure_device() != 0)
+		if (cr_ensure_device_of(plan) != 0)   /* the plan's rows live on ITS device: that is where the launch goes */
 			return 0;
 
 		if (cr_plan_launch(plan, device_input, valid_bytes, device_output, pos_int, pos_frac, emit, hip_stream, out_s16) != 0)
@@ -140,4 +140,11 @@ size_t ClownResamplerAMD_ResampleDevice(ClownResamplerAMD_Plan *plan, ClownResam
 size_t ClownResamplerAMD_ResampleDeviceS16(ClownResamplerAMD_Plan *plan, ClownResampler_LowLevel_State *resampler, const void *device_input, size_t *total_input_frames, void *device_output, size_t output_capacity_frames, void *hip_stream, cc_bool *ran_out_of_input)
 {
 	return resample_device(plan, resampler, device_input, total_input_frames, device_output, output_capacity_frames, hip_stream, ran_out_of_input, 1);
+}
+
+/* the layout of ClownResampler_HighLevel_State does not depend on the kernel radius: one definition serves every instance */
+void ClownResamplerAMD_HighLevel_Release(ClownResampler_HighLevel_State *resampler)
+{
+	cr_stream_drop(resampler);
+	memset(resampler->input_buffer, 0, 2 * sizeof(uint64_t));   /* the key of the window (cr_api.c, stream_key_store) */
 }

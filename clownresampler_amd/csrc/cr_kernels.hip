@@ -21,7 +21,7 @@
 //             arithmetic is v_mul_i32_i24 + truncate-toward-zero /65536 + add, in that order: the reference
 //             truncates every product BEFORE accumulating (clownresampler.h:1020), which is what rules out
 //             dot-product instructions and MFMA.  All of it is 32-bit: the host only selects this kernel when it has
-//             proved the bounds (|weight| < 2^23, |acc| < 2^23, |acc * reciprocal| < 2^31 or 2^32).
+//             proved the bounds (-65536 < weight <= 65536, |acc| < 2^23, |acc * reciprocal| < 2^31 or 2^32).
 //
 //  k_wave     The same rows and arithmetic without any workgroup barrier after the staging: every wave streams
 //             wave-tiles of 256 frames through its own double-buffered 1 KiB of LDS and draws its own tickets.
@@ -58,8 +58,9 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 // ---------------------------------------------------------------------------------------------------------
 
 // The per-tap term is (sample * weight) / 65536 with C semantics (truncation toward zero), clownresampler.h:1020 via
-// :625.  Both operands fit 24 bits (|sample| <= 2^15; |weight| < 2^23 checked by the host) and the product fits int32
-// (-32768 * 65536 is exactly INT32_MIN), so the full-rate 24-bit multiplier is exact; see accumulate_product below.
+// :625.  Both operands fit 24 bits and the host only selects the 32-bit kernels for -65536 < weight <= 65536 (cr_plan.c): with
+// |sample| <= 2^15 the product then fits int32 (-32768 * 65536 is exactly INT32_MIN), so the low 32 bits the full-rate 24-bit
+// multiplier delivers ARE the product; see accumulate_product below.  Larger weights (a caller's own table) go to k_generic.
 
 // (acc * reciprocal) / 32768 with C semantics, clownresampler.h:1033.  Host-proved: |acc| < 2^23,
 // 0 < reciprocal < 2^23 and either |acc * reciprocal| < 2^31 (NORM_S31) or < 2^32 (NORM_U32: the product of the
@@ -2441,6 +2442,58 @@ int crhip_event_record(void *event, void *stream)
 int crhip_stream_wait_event(void *stream, void *event)
 {
 	return (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
+}
+
+int crhip_stream_is_capturing(void *stream, int *capturing)
+{
+	hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+	const hipError_t e = hipStreamIsCapturing((hipStream_t)stream, &status);
+	*capturing = (e == hipSuccess && status == hipStreamCaptureStatusActive) ? 1 : 0;
+	return (int)e;
+}
+
+int crhip_stream_busy(void *stream)
+{
+	const hipError_t e = hipStreamQuery((hipStream_t)stream);
+	if (e == hipErrorNotReady)
+		return 1;
+	if (e != hipSuccess)
+		(void)hipGetLastError();   // a handle the caller has destroyed: not an error of ours, and certainly not busy
+	return 0;
+}
+
+int crhip_enable_peer_access(int device, int peer)
+{
+	int can = 0, current = 0;
+	hipError_t e = hipGetDevice(&current);
+	if (e != hipSuccess)
+		return (int)e;
+	if (device == peer || hipDeviceCanAccessPeer(&can, device, peer) != hipSuccess || !can)
+		return 0;
+	e = hipSetDevice(device);
+	if (e == hipSuccess)
+	{
+		e = hipDeviceEnablePeerAccess(peer, 0);
+		if (e == hipErrorPeerAccessAlreadyEnabled)
+		{
+			(void)hipGetLastError();
+			e = hipSuccess;
+		}
+	}
+	(void)hipSetDevice(current);
+	return (int)e;
+}
+
+int crhip_memcpy_peer(void *dst, int dst_device, const void *src, int src_device, size_t bytes, void *stream)
+{
+	if (dst_device == src_device)
+		return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+	return (int)hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, (hipStream_t)stream);
+}
+
+int crhip_get_device(int *ordinal)
+{
+	return (int)hipGetDevice(ordinal);
 }
 
 int crhip_poly_has_instance(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)

@@ -1,0 +1,292 @@
+/*
+ * cr_multi.c - several GPUs behind the C ABI, one process: the output timeline of ONE stream split into contiguous blocks
+ * (ClownResamplerAMD_PlanShard), each block an ordinary low-level call on its own device and stream, and the
+ * optional final concatenate onto one device: peer copies (hipMemcpyPeerAsync: each peer -> root transfer is a point-to-point
+ * copy over its own xGMI link) or RCCL's ncclGather (librccl is loaded on first use, never linked).
+ * Host C; HIP through crhip.h only.  The reference has no counterpart (it has no threads and no devices); what is kept is
+ * its contract: the frames are those ONE ClownResampler_LowLevel_Resample call (clownresampler.h:1058-1092) over the whole
+ * input would emit, and the state is left as that call leaves it (:1065-1067).
+ */
+#include "../../include/clownresampler_amd.h"
+
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "cr_context.h"
+
+/* ---- RCCL, loaded lazily ------------------------------------------------------------------------------- */
+
+typedef void *cr_nccl_comm;
+typedef int (*nccl_comm_init_all_fn)(cr_nccl_comm *comms, int ndev, const int *devlist);
+typedef int (*nccl_comm_destroy_fn)(cr_nccl_comm comm);
+typedef int (*nccl_group_fn)(void);
+typedef int (*nccl_gather_fn)(const void *sendbuff, void *recvbuff, size_t sendcount, int datatype, int root, cr_nccl_comm comm, void *stream);
+typedef int (*nccl_sendrecv_fn)(void *buff, size_t count, int datatype, int peer, cr_nccl_comm comm, void *stream);
+typedef const char *(*nccl_error_string_fn)(int result);
+
+#define CR_NCCL_INT8 0 /* ncclInt8 / ncclChar (rccl.h) */
+#define CR_NCCL_MAX_RANKS 64
+
+static struct
+{
+	pthread_mutex_t lock;
+	void *library;
+	int tried;
+	nccl_comm_init_all_fn comm_init_all;
+	nccl_comm_destroy_fn comm_destroy;
+	nccl_group_fn group_start, group_end;
+	nccl_gather_fn gather;                  /* may be NULL in an old librccl: send/recv then */
+	nccl_sendrecv_fn send, recv;
+	nccl_error_string_fn error_string;
+	/* one communicator set, for the device list it was made for (re-made when the list changes) */
+	int ndev;
+	int devices[CR_NCCL_MAX_RANKS];
+	cr_nccl_comm comms[CR_NCCL_MAX_RANKS];
+} g_rccl = {PTHREAD_MUTEX_INITIALIZER, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0, {0}, {NULL}};
+
+static int rccl_check(int result, const char *what)
+{
+	if (result != 0)
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_HIP, "%s failed: %s (ncclResult %d)", what, g_rccl.error_string != NULL ? g_rccl.error_string(result) : "?", result);
+	return result;
+}
+
+/* g_rccl.lock held */
+static int rccl_load(void)
+{
+	static const char *const names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
+	size_t i;
+
+	if (g_rccl.library != NULL)
+		return 0;
+	if (!g_rccl.tried)
+	{
+		g_rccl.tried = 1;
+		for (i = 0; i < sizeof(names) / sizeof(names[0]) && g_rccl.library == NULL; ++i)
+			g_rccl.library = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+		if (g_rccl.library != NULL)
+		{
+			g_rccl.comm_init_all = (nccl_comm_init_all_fn)dlsym(g_rccl.library, "ncclCommInitAll");
+			g_rccl.comm_destroy = (nccl_comm_destroy_fn)dlsym(g_rccl.library, "ncclCommDestroy");
+			g_rccl.group_start = (nccl_group_fn)dlsym(g_rccl.library, "ncclGroupStart");
+			g_rccl.group_end = (nccl_group_fn)dlsym(g_rccl.library, "ncclGroupEnd");
+			g_rccl.gather = (nccl_gather_fn)dlsym(g_rccl.library, "ncclGather");
+			g_rccl.send = (nccl_sendrecv_fn)dlsym(g_rccl.library, "ncclSend");
+			g_rccl.recv = (nccl_sendrecv_fn)dlsym(g_rccl.library, "ncclRecv");
+			g_rccl.error_string = (nccl_error_string_fn)dlsym(g_rccl.library, "ncclGetErrorString");
+			if (g_rccl.comm_init_all == NULL || g_rccl.comm_destroy == NULL || g_rccl.group_start == NULL || g_rccl.group_end == NULL
+			 || (g_rccl.gather == NULL && (g_rccl.send == NULL || g_rccl.recv == NULL)))
+			{
+				dlclose(g_rccl.library);
+				g_rccl.library = NULL;
+			}
+		}
+	}
+	if (g_rccl.library == NULL)
+		return cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "CLOWNRESAMPLER_AMD_GATHER_RCCL: librccl.so with ncclCommInitAll / ncclGather could not be loaded");
+	return 0;
+}
+
+/* g_rccl.lock held */
+static void rccl_drop_comms(void)
+{
+	int r;
+
+	for (r = 0; r < g_rccl.ndev; ++r)
+		if (g_rccl.comms[r] != NULL)
+			g_rccl.comm_destroy(g_rccl.comms[r]);
+	g_rccl.ndev = 0;
+}
+
+/* g_rccl.lock held: communicators for exactly this device list */
+static int rccl_comms_for(const int *devices, int n)
+{
+	if (g_rccl.ndev == n && memcmp(g_rccl.devices, devices, (size_t)n * sizeof(int)) == 0)
+		return 0;
+	rccl_drop_comms();
+	if (rccl_check(g_rccl.comm_init_all(g_rccl.comms, n, devices), "ncclCommInitAll") != 0)
+		return -1;
+	memcpy(g_rccl.devices, devices, (size_t)n * sizeof(int));
+	g_rccl.ndev = n;
+	return 0;
+}
+
+void cr_multi_shutdown(void)
+{
+	pthread_mutex_lock(&g_rccl.lock);
+	if (g_rccl.library != NULL)
+		rccl_drop_comms();
+	pthread_mutex_unlock(&g_rccl.lock);
+}
+
+/* ---- the sharded call ---------------------------------------------------------------------------------- */
+
+size_t cr_resample_sharded(ClownResampler_LowLevel_State *resampler, uint64_t table_hash, size_t table_len, cr_table_fill fill_table, const void *table_user,
+                           unsigned radius, size_t total_input_frames, const ClownResamplerAMD_DeviceShard *shards, unsigned shard_count,
+                           int output_is_s16, int gather_mode, unsigned root_shard, void *root_output)
+{
+	const unsigned long errors_before = cr_error_serial();
+	const size_t unit = (size_t)resampler->channels * (output_is_s16 ? sizeof(int16_t) : sizeof(int32_t));
+	const uint64_t total_out = cr_count_output_frames(resampler->position_integer, resampler->position_fractional, resampler->increment, total_input_frames);
+	const uint64_t per = shard_count != 0 ? (total_out + shard_count - 1) / shard_count : 0;
+	cr_config cfg;
+	int caller_device = 0;
+	unsigned r;
+
+	if (shard_count == 0 || shard_count > CR_NCCL_MAX_RANKS || shards == NULL)
+	{
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "shard count %u outside 1..%d", shard_count, CR_NCCL_MAX_RANKS);
+		return 0;
+	}
+	if (gather_mode != CLOWNRESAMPLER_AMD_GATHER_NONE && (root_shard >= shard_count || root_output == NULL))
+	{
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "a gather needs a root shard below the shard count and a root output buffer");
+		return 0;
+	}
+	if (gather_mode < CLOWNRESAMPLER_AMD_GATHER_NONE || gather_mode > CLOWNRESAMPLER_AMD_GATHER_RCCL)
+	{
+		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "unknown gather mode %d", gather_mode);
+		return 0;
+	}
+
+	cfg.skr = resampler->lowest_level.stretched_kernel_radius;
+	cfg.radius_frames = resampler->lowest_level.integer_stretched_kernel_radius;
+	cfg.delta = resampler->lowest_level.stretched_kernel_radius_delta;
+	cfg.step = resampler->lowest_level.kernel_step_size;
+
+	/* the caller's current HIP device is put back at the end: every step below selects the device it talks to */
+	if (cr_check_hip(crhip_get_device(&caller_device), "hipGetDevice") != 0)
+		return 0;
+
+	/* 1. every shard's kernel, each on its own device and stream, none waited for */
+	for (r = 0; r < shard_count; ++r)
+	{
+		ClownResamplerAMD_Shard shard;
+		const ClownResamplerAMD_Plan *plan;
+		int failed;
+
+		ClownResamplerAMD_PlanShard(resampler, total_input_frames, r, shard_count, &shard);
+		if (shard.output_frames == 0)
+			continue;
+
+		plan = cr_plan_get_on(shards[r].device, table_hash, table_len, fill_table, table_user, radius, &cfg, resampler->channels, resampler->increment, 0);
+		if (plan == NULL)
+			goto out;
+		failed = cr_plan_launch(plan, shards[r].device_input, ((uint64_t)shard.input_frames + 2 * cfg.radius_frames) * resampler->channels * sizeof(cc_s16l),
+		                        shards[r].device_output, shard.state.position_integer, shard.state.position_fractional, shard.output_frames,
+		                        shards[r].hip_stream, output_is_s16);
+		cr_plan_release(plan);
+		if (failed != 0)
+			goto out;
+	}
+
+	/* 2. the concatenate, behind each shard's kernel on that shard's stream */
+	if (gather_mode == CLOWNRESAMPLER_AMD_GATHER_PEER_COPY)
+	{
+		const int root_device = shards[root_shard].device;
+
+		for (r = 0; r < shard_count; ++r)
+		{
+			ClownResamplerAMD_Shard shard;
+			unsigned char *dst;
+
+			ClownResamplerAMD_PlanShard(resampler, total_input_frames, r, shard_count, &shard);
+			dst = (unsigned char *)root_output + shard.first_output_frame * unit;
+			if (shard.output_frames == 0 || (void *)dst == shards[r].device_output) /* (a root that computed in place) */
+				continue;
+			if (cr_check_hip(crhip_enable_peer_access(shards[r].device, root_device), "hipDeviceEnablePeerAccess") != 0
+			 || cr_check_hip(crhip_enable_peer_access(root_device, shards[r].device), "hipDeviceEnablePeerAccess") != 0
+			 || cr_check_hip(crhip_set_device(shards[r].device), "hipSetDevice") != 0
+			 || cr_check_hip(crhip_memcpy_peer(dst, root_device, shards[r].device_output, shards[r].device, shard.output_frames * unit, shards[r].hip_stream), "hipMemcpyPeerAsync") != 0)
+				goto out;
+		}
+	}
+	else if (gather_mode == CLOWNRESAMPLER_AMD_GATHER_RCCL)
+	{
+		/* ncclGather wants the same count from every rank: the common block size `per` (the last shard's buffer must have
+		   room for it too; what lies beyond its frames is carried along and lands behind the stream's end on the root) */
+		int devices[CR_NCCL_MAX_RANKS];
+		const size_t bytes = (size_t)per * unit;
+		int bad = 0;
+
+		for (r = 0; r < shard_count; ++r)
+			devices[r] = shards[r].device;
+
+		pthread_mutex_lock(&g_rccl.lock);
+		bad = rccl_load() != 0 || rccl_comms_for(devices, (int)shard_count) != 0;
+		if (!bad)
+		{
+			bad = rccl_check(g_rccl.group_start(), "ncclGroupStart") != 0;
+			for (r = 0; r < shard_count && !bad; ++r)
+			{
+				bad = cr_check_hip(crhip_set_device(shards[r].device), "hipSetDevice") != 0;
+				if (bad)
+					break;
+				if (g_rccl.gather != NULL)
+				{
+					bad = rccl_check(g_rccl.gather(shards[r].device_output, r == root_shard ? root_output : NULL, bytes, CR_NCCL_INT8, (int)root_shard, g_rccl.comms[r], shards[r].hip_stream), "ncclGather") != 0;
+				}
+				else
+				{
+					unsigned q;
+					bad = rccl_check(g_rccl.send((void *)shards[r].device_output, bytes, CR_NCCL_INT8, (int)root_shard, g_rccl.comms[r], shards[r].hip_stream), "ncclSend") != 0;
+					for (q = 0; q < shard_count && r == root_shard && !bad; ++q)
+						bad = rccl_check(g_rccl.recv((unsigned char *)root_output + (size_t)q * bytes, bytes, CR_NCCL_INT8, (int)q, g_rccl.comms[r], shards[r].hip_stream), "ncclRecv") != 0;
+				}
+			}
+			if (rccl_check(g_rccl.group_end(), "ncclGroupEnd") != 0)
+				bad = 1;
+		}
+		pthread_mutex_unlock(&g_rccl.lock);
+		if (bad)
+			goto out;
+	}
+
+out:
+	crhip_set_device(caller_device);
+
+	if (cr_error_serial() != errors_before)
+		return 0;
+
+	/* the state after ONE call over the whole input that ran out of input (clownresampler.h:1065-1067) */
+	{
+		uint64_t pi = resampler->position_integer, pf = resampler->position_fractional;
+
+		cr_advance(&pi, &pf, resampler->increment, total_out);
+		resampler->position_integer = (size_t)(pi - total_input_frames);
+		resampler->position_fractional = (cc_u32f)pf;
+	}
+	return (size_t)total_out;
+}
+
+int ClownResamplerAMD_ShardedSynchronize(const ClownResamplerAMD_DeviceShard *shards, unsigned shard_count)
+{
+	int caller_device = 0, bad = 0;
+	unsigned r;
+
+	if (cr_check_hip(crhip_get_device(&caller_device), "hipGetDevice") != 0)
+		return -1;
+	for (r = 0; r < shard_count; ++r)
+		if (cr_check_hip(crhip_set_device(shards[r].device), "hipSetDevice") != 0
+		 || cr_check_hip(crhip_stream_sync(shards[r].hip_stream), "hipStreamSynchronize") != 0)
+			bad = 1;
+	crhip_set_device(caller_device);
+	return bad ? -1 : 0;
+}
+
+/* Device memory on a given device, for clients that drive several: alloc / free / copies that do not depend on (or change)
+   the calling thread's current device. */
+void *ClownResamplerAMD_DeviceAllocOn(int device, size_t bytes)
+{
+	int caller_device = 0;
+	void *p = NULL;
+
+	if (cr_check_hip(crhip_get_device(&caller_device), "hipGetDevice") != 0)
+		return NULL;
+	if (cr_check_hip(crhip_set_device(device), "hipSetDevice") == 0)
+		cr_check_hip(crhip_malloc(&p, bytes != 0 ? bytes : 16), "hipMalloc");
+	crhip_set_device(caller_device);
+	return p;
+}

@@ -98,7 +98,7 @@ int cr_poly_build(const int32_t *table, size_t table_len, const cr_config *cfg, 
 	uint32_t off_lo = 0xFFFFFFFFu, off_hi = 0; /* frame-offset range holding taps at all */
 	uint32_t rel_lo = 0xFFFFFFFFu, rel_hi = 0; /* the same non-zero range counted from each phase's OWN first tap (min_relative) */
 	uint32_t mr_lo = 0xFFFFFFFFu, mr_hi = 0;   /* range of min_relative */
-	int64_t max_abs_weight = 0;
+	int64_t max_weight = 0, min_weight = 0;   /* over every tap any phase uses */
 
 	memset(out, 0, sizeof(*out));
 	out->reason = "";
@@ -167,12 +167,13 @@ int cr_poly_build(const int32_t *table, size_t table_len, const cr_config *cfg, 
 			for (t = 0; t < ph.taps; ++t)
 			{
 				const int64_t w = table[ph.table_at + cfg->step * t];
-				const int64_t aw = w < 0 ? -w : w;
 
 				sum += w;
 
-				if (aw > max_abs_weight)
-					max_abs_weight = aw;
+				if (w > max_weight)
+					max_weight = w;
+				if (w < min_weight)
+					min_weight = w;
 
 				if (w != 0)
 				{
@@ -302,10 +303,14 @@ int cr_poly_build(const int32_t *table, size_t table_len, const cr_config *cfg, 
 			return fail(out, 1, "out of host memory");
 		}
 
-		if (max_abs_weight >= (1 << 23))
+		/* The 32-bit kernels form sample * weight with the 24-bit multiplier (low 32 bits of the product) and truncate THAT:
+		   the product must fit int32 for every sample in [-32768, 32767], i.e. -65536 < weight <= 65536 (the one product of
+		   magnitude 2^31 that still fits is -32768 * 65536 = INT32_MIN).  The stock Lanczos tables peak at exactly 65536; a
+		   caller-supplied table with larger weights takes the 64-bit generic kernel. */
+		if (max_weight > 65536 || min_weight <= -65536)
 		{
 			eligible = 0;
-			why = "a table weight does not fit 24 bits";
+			why = "a table weight outside (-65536, 65536]: sample * weight would not fit 32 bits";
 		}
 
 		{

@@ -116,6 +116,12 @@ int crhip_event_create(void **event);                   /* timing disabled */
 int crhip_event_destroy(void *event);
 int crhip_event_record(void *event, void *stream);
 int crhip_stream_wait_event(void *stream, void *event);
+int crhip_stream_is_capturing(void *stream, int *capturing);   /* *capturing = 1 while the stream records into a graph */
+int crhip_stream_busy(void *stream);                    /* 1 = work still in flight, 0 = idle (or the handle is no longer a stream) */
+/* peer access + copies between devices (the multi-device entry point's final concatenate) */
+int crhip_enable_peer_access(int device, int peer);     /* idempotent; 0 also when the pair has no peer path (copies then stage through the host) */
+int crhip_memcpy_peer(void *dst, int dst_device, const void *src, int src_device, size_t bytes, void *stream);
+int crhip_get_device(int *ordinal);
 
 #define CRHIP_TICKET_WORDS (33u * 32u)   /* up to 32 ticket counters + the finished counter, 128 bytes apart */
 

@@ -18,10 +18,10 @@
  * ABI notes (reference clownresampler.h:480-611, :627-662):
  *   - the integer typedefs below are the reference's DEFAULT (C89) choice; on LP64
  *     that makes cc_s32f/cc_s32l 8 bytes, so the output callback receives 8-byte
- *     samples and ClownResampler_Precomputed is 8 bytes per entry.  The library
- *     binary is built with exactly these.  CC_USE_C99_INTEGERS changes widths and
- *     struct layouts; it is honoured only if the library itself is rebuilt with it
- *     (clownresampler_amd/csrc/Makefile, CRA_CFLAGS) - see the #error below.
+ *     samples and ClownResampler_Precomputed is 8 bytes per entry.
+ *     libclownresampler_amd.so is built with exactly these.  CC_USE_C99_INTEGERS changes
+ *     widths and struct layouts (reference clownresampler.h:483-501); that ABI is the
+ *     second build of the same sources, libclownresampler_amd_c99.so - see the #error below.
  *   - CLOWNRESAMPLER_KERNEL_RADIUS changes sizeof(ClownResampler_Precomputed) and the
  *     arithmetic.  The library carries one instance of the API per supported radius;
  *     for a radius other than the default 3 the function names below are redirected to
@@ -61,31 +61,103 @@
 #ifndef CC_INTEGERS_DEFINED
 #define CC_INTEGERS_DEFINED
 
-#if defined(CC_USE_C99_INTEGERS) && !defined(CLOWNRESAMPLER_AMD_BUILT_WITH_C99_INTEGERS)
- #error "CC_USE_C99_INTEGERS changes the ABI; rebuild libclownresampler_amd with CRA_CFLAGS='-DCC_USE_C99_INTEGERS -DCLOWNRESAMPLER_AMD_BUILT_WITH_C99_INTEGERS' and define both here"
+/* CC_USE_C99_INTEGERS changes the widths of the cc_* types, hence struct layouts and the callback's sample width: it is a
+   different ABI.  The library is built in both: libclownresampler_amd.so (C89 types, the reference's default) and
+   libclownresampler_amd_c99.so (`make c99` in clownresampler_amd/csrc).  A client that defines CC_USE_C99_INTEGERS must link
+   the second one, and says so by defining CLOWNRESAMPLER_AMD_LINKS_C99_LIBRARY as well (CMake target clownresampler_c99). */
+#if defined(CC_USE_C99_INTEGERS) && !defined(CLOWNRESAMPLER_AMD_LINKS_C99_LIBRARY) && !defined(CLOWNRESAMPLER_AMD_BUILT_WITH_C99_INTEGERS)
+ #error "CC_USE_C99_INTEGERS: link libclownresampler_amd_c99.so (not libclownresampler_amd.so) and define CLOWNRESAMPLER_AMD_LINKS_C99_LIBRARY"
 #endif
 
 #if defined(CC_USE_C99_INTEGERS)
+/* C99's least / fast types (reference clownresampler.h:483-501).  <inttypes.h> rather than the reference's <stdint.h>: it
+   is what defines the PRI* macros the CC_PRI* names below stand for. */
 #include <inttypes.h>
 typedef int_least8_t cc_s8l;   typedef int_least16_t cc_s16l;   typedef int_least32_t cc_s32l;
 typedef uint_least8_t cc_u8l;  typedef uint_least16_t cc_u16l;  typedef uint_least32_t cc_u32l;
 typedef int_fast8_t cc_s8f;    typedef int_fast16_t cc_s16f;    typedef int_fast32_t cc_s32f;
 typedef uint_fast8_t cc_u8f;   typedef uint_fast16_t cc_u16f;   typedef uint_fast32_t cc_u32f;
+/* printf conversions of those types, CC_PRI<conversion><LEAST|FAST><bits> (reference clownresampler.h:503-543), by conversion */
+#define CC_PRIdLEAST8 PRIdLEAST8
+#define CC_PRIdLEAST16 PRIdLEAST16
 #define CC_PRIdLEAST32 PRIdLEAST32
-#define CC_PRIuLEAST32 PRIuLEAST32
+#define CC_PRIdFAST8 PRIdFAST8
+#define CC_PRIdFAST16 PRIdFAST16
 #define CC_PRIdFAST32 PRIdFAST32
-#define CC_PRIuFAST32 PRIuFAST32
+#define CC_PRIiLEAST8 PRIiLEAST8
+#define CC_PRIiLEAST16 PRIiLEAST16
+#define CC_PRIiLEAST32 PRIiLEAST32
+#define CC_PRIiFAST8 PRIiFAST8
+#define CC_PRIiFAST16 PRIiFAST16
+#define CC_PRIiFAST32 PRIiFAST32
+#define CC_PRIuLEAST8 PRIuLEAST8
+#define CC_PRIuLEAST16 PRIuLEAST16
+#define CC_PRIuLEAST32 PRIuLEAST32
 #define CC_PRIuFAST8 PRIuFAST8
+#define CC_PRIuFAST16 PRIuFAST16
+#define CC_PRIuFAST32 PRIuFAST32
+#define CC_PRIoLEAST8 PRIoLEAST8
+#define CC_PRIoLEAST16 PRIoLEAST16
+#define CC_PRIoLEAST32 PRIoLEAST32
+#define CC_PRIoFAST8 PRIoFAST8
+#define CC_PRIoFAST16 PRIoFAST16
+#define CC_PRIoFAST32 PRIoFAST32
+#define CC_PRIxLEAST8 PRIxLEAST8
+#define CC_PRIxLEAST16 PRIxLEAST16
+#define CC_PRIxLEAST32 PRIxLEAST32
+#define CC_PRIxFAST8 PRIxFAST8
+#define CC_PRIxFAST16 PRIxFAST16
+#define CC_PRIxFAST32 PRIxFAST32
+#define CC_PRIXLEAST8 PRIXLEAST8
+#define CC_PRIXLEAST16 PRIXLEAST16
+#define CC_PRIXLEAST32 PRIXLEAST32
+#define CC_PRIXFAST8 PRIXFAST8
+#define CC_PRIXFAST16 PRIXFAST16
+#define CC_PRIXFAST32 PRIXFAST32
 #else
+/* C89's types (reference clownresampler.h:545-560): 8- and 16-bit values live in char / short (least) and int (fast), 32-bit
+   ones in long either way - 8 bytes on LP64, which is what makes the callback's samples and the table entries 8 bytes wide */
 typedef signed char cc_s8l;    typedef signed short cc_s16l;    typedef signed long cc_s32l;
 typedef unsigned char cc_u8l;  typedef unsigned short cc_u16l;  typedef unsigned long cc_u32l;
 typedef signed int cc_s8f;     typedef signed int cc_s16f;      typedef signed long cc_s32f;
 typedef unsigned int cc_u8f;   typedef unsigned int cc_u16f;    typedef unsigned long cc_u32f;
-#define CC_PRIdLEAST32 "%ld"
-#define CC_PRIuLEAST32 "%lu"
-#define CC_PRIdFAST32 "%ld"
-#define CC_PRIuFAST32 "%lu"
+/* whole conversion specifications here, "%" included (reference clownresampler.h:562-602): int-sized below 32 bits, long at 32 */
+#define CC_PRIdLEAST8 "%d"
+#define CC_PRIdLEAST16 "%d"
+#define CC_PRIdFAST8 "%d"
+#define CC_PRIdFAST16 "%d"
+#define CC_PRIiLEAST8 "%i"
+#define CC_PRIiLEAST16 "%i"
+#define CC_PRIiFAST8 "%i"
+#define CC_PRIiFAST16 "%i"
+#define CC_PRIuLEAST8 "%u"
+#define CC_PRIuLEAST16 "%u"
 #define CC_PRIuFAST8 "%u"
+#define CC_PRIuFAST16 "%u"
+#define CC_PRIoLEAST8 "%o"
+#define CC_PRIoLEAST16 "%o"
+#define CC_PRIoFAST8 "%o"
+#define CC_PRIoFAST16 "%o"
+#define CC_PRIxLEAST8 "%x"
+#define CC_PRIxLEAST16 "%x"
+#define CC_PRIxFAST8 "%x"
+#define CC_PRIxFAST16 "%x"
+#define CC_PRIXLEAST8 "%X"
+#define CC_PRIXLEAST16 "%X"
+#define CC_PRIXFAST8 "%X"
+#define CC_PRIXFAST16 "%X"
+#define CC_PRIdLEAST32 "%ld"
+#define CC_PRIdFAST32 "%ld"
+#define CC_PRIiLEAST32 "%li"
+#define CC_PRIiFAST32 "%li"
+#define CC_PRIuLEAST32 "%lu"
+#define CC_PRIuFAST32 "%lu"
+#define CC_PRIoLEAST32 "%lo"
+#define CC_PRIoFAST32 "%lo"
+#define CC_PRIxLEAST32 "%lx"
+#define CC_PRIxFAST32 "%lx"
+#define CC_PRIXLEAST32 "%lX"
+#define CC_PRIXFAST32 "%lX"
 #endif
 
 typedef cc_u8l cc_bool;
@@ -99,7 +171,14 @@ enum { cc_false = 0, cc_true = 1 };
 #define CLOWNRESAMPLER_MIN(a, b) ((a) < (b) ? (a) : (b))
 #define CLOWNRESAMPLER_MAX(a, b) ((a) > (b) ? (a) : (b))
 #define CLOWNRESAMPLER_CLAMP(min, max, x) (CLOWNRESAMPLER_MAX((min), CLOWNRESAMPLER_MIN((max), (x))))
+/* 16.16 fixed point (reference clownresampler.h:620-625); note that the conversions to integer and the multiply DIVIDE, so
+   for negative values they truncate toward zero - which is the arithmetic the kernels reproduce per tap */
 #define CLOWNRESAMPLER_FIXED_POINT_FRACTIONAL_SIZE (1L << 16)
+#define CLOWNRESAMPLER_TO_FIXED_POINT_FROM_INTEGER(x) ((x) * CLOWNRESAMPLER_FIXED_POINT_FRACTIONAL_SIZE)
+#define CLOWNRESAMPLER_TO_INTEGER_FROM_FIXED_POINT_FLOOR(x) ((x) / CLOWNRESAMPLER_FIXED_POINT_FRACTIONAL_SIZE)
+#define CLOWNRESAMPLER_TO_INTEGER_FROM_FIXED_POINT_ROUND(x) (((x) + (CLOWNRESAMPLER_FIXED_POINT_FRACTIONAL_SIZE / 2)) / CLOWNRESAMPLER_FIXED_POINT_FRACTIONAL_SIZE)
+#define CLOWNRESAMPLER_TO_INTEGER_FROM_FIXED_POINT_CEILING(x) (((x) + (CLOWNRESAMPLER_FIXED_POINT_FRACTIONAL_SIZE - 1)) / CLOWNRESAMPLER_FIXED_POINT_FRACTIONAL_SIZE)
+#define CLOWNRESAMPLER_FIXED_POINT_MULTIPLY(a, b) ((a) * (b) / CLOWNRESAMPLER_FIXED_POINT_FRACTIONAL_SIZE)
 
 /* ---- caller-owned state (reference clownresampler.h:627-662; layouts must match field for field,
         callers read e.g. lowest_level.integer_stretched_kernel_radius to size their padding) ---- */

@@ -55,9 +55,19 @@ void ClownResamplerAMD_ClearError(void);
  * plans keyed by table contents + configuration) and released by Shutdown or at exit.
  * ------------------------------------------------------------------------------------------- */
 int ClownResamplerAMD_DeviceCount(void);                /* 0 when there is none; never calls the error handler */
-int ClownResamplerAMD_SetDevice(int ordinal);           /* device used by subsequent calls of this process; returns 0 on success */
-int ClownResamplerAMD_GetDevice(void);
+int ClownResamplerAMD_SetDevice(int ordinal);           /* process default: device used by calls of threads that have not chosen one; 0 on success */
+int ClownResamplerAMD_SetThreadDevice(int ordinal);     /* device used by subsequent calls of the CALLING THREAD (-1: follow the process default again) */
+int ClownResamplerAMD_GetDevice(void);                  /* what the calling thread's next call would use */
+/* Every device keeps its own context (plans, ticket blocks, staging buffers and streams) from first use on: changing the
+   current device tears nothing down, calls on different devices do not serialise each other, and a plan remembers its
+   device (ClownResamplerAMD_ResampleDevice launches there whatever the current device is).  Shutdown releases everything
+   on every device; it needs a quiescent library (no resample call in progress on any thread). */
 void ClownResamplerAMD_Shutdown(void);
+/* Launches issued while their stream is being captured into a hipGraph draw their scheduling scratch ("ticket blocks") from
+   a pool that is never recycled, because the graph may be replayed at any later time; device memory cannot be allocated
+   during a capture, so the pool is sized ahead: room for 256 captured launches per device by default, more with this call
+   (before the capture; current device).  0 on success. */
+int ClownResamplerAMD_ReserveCaptureLaunches(size_t launches);
 
 /* High-level (streaming) API: how many input frames ClownResampler_HighLevel_Resample may collect from the input callback
    before it resamples them in one GPU call (default 262144).  The reference's 0x1000-sample staging buffer
@@ -66,8 +76,15 @@ void ClownResamplerAMD_Shutdown(void);
    how far ahead of the output the input callback is asked for data (the window grows 4x per refill only while the
    consumer keeps draining whole windows, and falls back to one pull as soon as the output callback stops a call). */
 void ClownResamplerAMD_SetStreamingWindow(size_t frames);
+/* The side window of a high-level state lives in the library, registered under the state's address (the reference API has no
+   Deinit).  A state initialised at an address that had a window before takes that window over, so programs that create and
+   discard resamplers do not accumulate windows; this call frees the window of a state that will not be used again (the state
+   needs a new ClownResampler_HighLevel_Init afterwards).  ClownResamplerAMD_Shutdown frees them all. */
+void ClownResamplerAMD_HighLevel_Release(ClownResampler_HighLevel_State *resampler);
+size_t ClownResamplerAMD_StreamingWindowCount(void);    /* side windows the library holds at the moment */
 
-/* Thin helpers so a C client needs no HIP headers. */
+/* Thin helpers so a C client needs no HIP headers (current device; ...On: a given device). */
+void *ClownResamplerAMD_DeviceAllocOn(int device, size_t bytes);
 void *ClownResamplerAMD_DeviceAlloc(size_t bytes);
 void ClownResamplerAMD_DeviceFree(void *device_pointer);
 int ClownResamplerAMD_CopyToDevice(void *device_destination, const void *host_source, size_t bytes);
@@ -103,6 +120,7 @@ int ClownResamplerAMD_PlanShard(const ClownResampler_LowLevel_State *state, size
  * Bulk resampling, host buffers (radius-specific: redirected like the reference functions).
  * ------------------------------------------------------------------------------------------- */
 #if CLOWNRESAMPLER_KERNEL_RADIUS != 3
+ #define ClownResamplerAMD_ResampleShardedDevice CLOWNRESAMPLER_AMD_SYM(ClownResamplerAMD_ResampleShardedDevice)
  #define ClownResampler_LowLevel_ResampleBulk CLOWNRESAMPLER_AMD_SYM(ClownResampler_LowLevel_ResampleBulk)
  #define ClownResampler_LowLevel_ResampleBulkS16 CLOWNRESAMPLER_AMD_SYM(ClownResampler_LowLevel_ResampleBulkS16)
  #define ClownResamplerAMD_PlanCreate          CLOWNRESAMPLER_AMD_SYM(ClownResamplerAMD_PlanCreate)
@@ -207,6 +225,43 @@ typedef struct ClownResamplerAMD_Segment
 size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed,
                                                 const void *device_timeline, size_t halo_frames, const ClownResamplerAMD_Segment *segments, size_t segment_count,
                                                 void *device_output, size_t output_capacity_frames, int output_is_s16, size_t *segment_output_frames, void *hip_stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Several GPUs, one process, one call (the reference has no counterpart).
+ * The output timeline of ONE stream is split into shard_count contiguous blocks (ClownResamplerAMD_PlanShard) and block r
+ * is computed on shards[r].device, on shards[r].hip_stream: an ordinary low-level call on that shard's slice of the
+ * input whose padding is the real neighbouring frames (clownresampler.h:725-733).  There is no exchange between the
+ * devices while they compute.  Optionally the blocks are then concatenated on one device, each transfer enqueued behind
+ * its shard's kernel on that shard's stream:
+ *   CLOWNRESAMPLER_AMD_GATHER_PEER_COPY  one hipMemcpyPeerAsync per shard (point-to-point over xGMI; exact sizes)
+ *   CLOWNRESAMPLER_AMD_GATHER_RCCL       ncclGather over a communicator set of the shards' devices (librccl.so is loaded on
+ *                                        first use; every ordinal may then appear only once; equal counts: every
+ *                                        device_output must have room for ceil(total / shard_count) frames, and root_output
+ *                                        for shard_count times that)
+ * Nothing is synchronised: use ClownResamplerAMD_ShardedSynchronize (or the streams) before reading.  Returns the total
+ * number of output frames and leaves *resampler as ONE ClownResampler_LowLevel_Resample over the whole input would
+ * (clownresampler.h:1065-1067); 0 after an error (reported through the handler).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ClownResamplerAMD_DeviceShard
+{
+	int device;                 /* HIP ordinal this shard runs on */
+	const void *device_input;   /* ON that device: the shard's own padded slice, i.e. frame `first_input_frame` (ClownResamplerAMD_PlanShard)
+	                               of the whole padded stream - its halo first; input_frames + 2 * halo_frames frames readable */
+	void *device_output;        /* ON that device: room for the shard's output_frames (int32, or int16 with output_is_s16) */
+	void *hip_stream;           /* a stream OF that device; NULL = its default stream */
+} ClownResamplerAMD_DeviceShard;
+
+enum
+{
+	CLOWNRESAMPLER_AMD_GATHER_NONE = 0,
+	CLOWNRESAMPLER_AMD_GATHER_PEER_COPY = 1,
+	CLOWNRESAMPLER_AMD_GATHER_RCCL = 2
+};
+
+size_t ClownResamplerAMD_ResampleShardedDevice(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed, size_t total_input_frames,
+                                               const ClownResamplerAMD_DeviceShard *shards, unsigned shard_count, int output_is_s16,
+                                               int gather_mode, unsigned root_shard, void *root_output);
+int ClownResamplerAMD_ShardedSynchronize(const ClownResamplerAMD_DeviceShard *shards, unsigned shard_count);
 
 #ifdef __cplusplus
 }

@@ -554,16 +554,37 @@ def test_highlevel_random_streams(products):
 
 
 def test_highlevel_reinit_reuses_window(products):
+    """The side window is registered under the state's ADDRESS: re-initialising a state (or a new state where a discarded one
+    lived) takes the window over, Release frees it, and a byte copy of a state elsewhere does not share it - like the
+    reference's state, whose input_buffer_start / _end point into itself (clownresampler.h:655-656)."""
     p = products[3]
-    hs = p.api.HighLevel_State()
-    import ctypes as C
-    keys = set()
+    api = p.api
+    hs = api.HighLevel_State()
+    before = api.StreamingWindowCount()
+    held = None
     for _ in range(5):
-        assert p.api.HighLevel_Init(hs, 2, 44100, 48000, 44100)
-        keys.add(bytes(C.string_at(C.addressof(hs.input_buffer), 16)))
+        assert api.HighLevel_Init(hs, 2, 44100, 48000, 44100)
         out = p.high_run_i32(_product.HighView(hs), ck.noise_pcm(2 * 5000, 8))
         assert out.size == 2 * 5443
-    assert len(keys) == 1
+        # one window for this address, however often it is initialised (it may be the window of a discarded state of an earlier
+        # test that lived at this very address: that is the point)
+        held = api.StreamingWindowCount() if held is None else held
+        assert api.StreamingWindowCount() == held and held in (before, before + 1)
+    # a byte copy at another address has no window of its own
+    clone = api.HighLevel_State.from_buffer_copy(hs)
+    with pytest.raises(cr.ClownResamplerError) as e:
+        api.HighLevel_Resample(clone, p.pre, lambda n: np.zeros(0, dtype=np.int16), lambda f: True)
+    assert e.value.code == cr.ERROR_ARGUMENT
+    api.HighLevel_Release(hs)
+    assert api.StreamingWindowCount() == held - 1
+    with pytest.raises(cr.ClownResamplerError):
+        api.HighLevel_Resample(hs, p.pre, lambda n: np.zeros(0, dtype=np.int16), lambda f: True)
+    # many short-lived resamplers do not accumulate windows when their owners release them
+    for k in range(40):
+        h = api.HighLevel_State()
+        assert api.HighLevel_Init(h, 1 + k % 4, 44100, 48000, 44100)
+        api.HighLevel_Release(h)
+    assert api.StreamingWindowCount() <= held - 1
 
 
 @pytest.mark.parametrize("variant", [13, 18, 3, 20, 21, 28, 29])

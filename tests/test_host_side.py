@@ -68,6 +68,105 @@ def test_header_compiles_as_c89_and_cxx(tmp_path):
     assert subprocess.run([str(exe)]).returncode == 0
 
 
+# a client that uses the helper macros a reference client may use: the 16.16 conversions (reference clownresampler.h:620-625)
+# and the printf conversions of the cc_* types (:503-543 / :562-602), with both integer-type choices
+_MACRO_CLIENT = r"""
+#include <stdio.h>
+#include <string.h>
+#include "clownresampler.h"
+int main(void)
+{
+	char text[256];
+	const cc_s32f one = CLOWNRESAMPLER_TO_FIXED_POINT_FROM_INTEGER(1);
+	const cc_s32f x = CLOWNRESAMPLER_TO_FIXED_POINT_FROM_INTEGER(5) / 2;        /* 2.5 */
+	const cc_s32l l32 = -123456789; const cc_u32l ul32 = 4000000000ul; const cc_s32f f32 = -7; const cc_u32f uf32 = 0xABCDEFul;
+	const cc_s16l l16 = -1234; const cc_u16f uf16 = 65535u; const cc_s8l l8 = -5; const cc_u8f uf8 = 200u;
+	if (one != 65536L || CLOWNRESAMPLER_FIXED_POINT_FRACTIONAL_SIZE != 65536L) return 1;
+	if (CLOWNRESAMPLER_TO_INTEGER_FROM_FIXED_POINT_FLOOR(x) != 2 || CLOWNRESAMPLER_TO_INTEGER_FROM_FIXED_POINT_ROUND(x) != 3
+	 || CLOWNRESAMPLER_TO_INTEGER_FROM_FIXED_POINT_CEILING(x) != 3 || CLOWNRESAMPLER_TO_INTEGER_FROM_FIXED_POINT_CEILING(one) != 1) return 2;
+	if (CLOWNRESAMPLER_FIXED_POINT_MULTIPLY(x, x) != 6 * 65536L + 16384L) return 3;                  /* 6.25 */
+	if (CLOWNRESAMPLER_FIXED_POINT_MULTIPLY(-x, one / 65536L * 3) != -7) return 4;                  /* truncation toward zero */
+	if (CLOWNRESAMPLER_CLAMP(-3, 3, 7) != 3 || CLOWNRESAMPLER_MIN(2, 1) != 1 || CLOWNRESAMPLER_MAX(2, 1) != 2) return 5;
+	sprintf(text, FMT(CC_PRIdLEAST32) " " FMT(CC_PRIuLEAST32) " " FMT(CC_PRIiFAST32) " " FMT(CC_PRIxFAST32) " " FMT(CC_PRIXFAST32) " " FMT(CC_PRIoFAST32),
+	        l32, ul32, f32, uf32, uf32, uf32);
+	if (strcmp(text, "-123456789 4000000000 -7 abcdef ABCDEF 52746757") != 0) return 6;
+	sprintf(text, FMT(CC_PRIdLEAST16) " " FMT(CC_PRIuFAST16) " " FMT(CC_PRIiLEAST8) " " FMT(CC_PRIuFAST8) " " FMT(CC_PRIxFAST8) " " FMT(CC_PRIXLEAST16) " " FMT(CC_PRIoLEAST8),
+	        l16, uf16, l8, uf8, uf8, (cc_u16l)0xBEEF, (cc_u8l)8);
+	if (strcmp(text, "-1234 65535 -5 200 c8 BEEF 10") != 0) return 7;
+	return 0;
+}
+"""
+
+
+@pytest.mark.parametrize("c99", [False, True])
+def test_header_has_the_references_helper_macros(tmp_path, c99):
+    src = tmp_path / "m.c"
+    # the C89 names are whole conversion specifications ("%ld"), the C99 ones are <inttypes.h>'s (no "%"): the reference's quirk
+    # (and a C99 client of the reference has to bring <inttypes.h> itself: the reference only includes <stdint.h>)
+    src.write_text(('#include <inttypes.h>\n#define FMT(x) "%" x\n' if c99 else '#define FMT(x) x\n') + _MACRO_CLIENT)
+    flags = ["-std=c99", "-DCC_USE_C99_INTEGERS", "-DCLOWNRESAMPLER_AMD_LINKS_C99_LIBRARY"] if c99 else ["-std=c89", "-Wno-long-long"]
+    exe = tmp_path / "m"
+    subprocess.run(["gcc"] + flags + ["-pedantic", "-Wall", "-Wno-format", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
+    if os.path.exists("/root/reference/clownresampler.h"):
+        # the same client against the real header, where it exists: same answers
+        ref = tmp_path / "r"
+        subprocess.run(["gcc"] + flags + ["-Wno-format", "-I", "/root/reference", str(src), "-o", str(ref)], check=True)
+        assert subprocess.run([str(ref)]).returncode == 0
+
+
+def test_c99_integer_abi_is_a_library_of_its_own(tmp_path):
+    """CC_USE_C99_INTEGERS (reference clownresampler.h:483-501) changes the widths of the cc_* types: the second build of the
+    same sources.  Layouts against the reference compiled the same way (where it exists), and the client-side guard."""
+    lib = os.path.join(os.path.dirname(cr.LIB_PATH), "libclownresampler_amd_c99.so")
+    assert os.path.exists(lib), "build() makes it (make c99)"
+    prog = ('#include <stdio.h>\n#include <stddef.h>\n#include "clownresampler.h"\n'
+            'int main(void){printf("%lu %lu %lu %lu %lu %lu %lu\\n", (unsigned long)sizeof(ClownResampler_Precomputed), (unsigned long)sizeof(ClownResampler_LowLevel_State),'
+            '(unsigned long)sizeof(ClownResampler_HighLevel_State), (unsigned long)offsetof(ClownResampler_LowLevel_State, position_integer),'
+            '(unsigned long)offsetof(ClownResampler_HighLevel_State, input_buffer), (unsigned long)sizeof(cc_s32f), (unsigned long)sizeof(cc_u8f)); return 0;}\n')
+    src = tmp_path / "s.c"
+    src.write_text(prog)
+    exe = tmp_path / "s"
+    subprocess.run(["gcc", "-std=c99", "-DCC_USE_C99_INTEGERS", "-DCLOWNRESAMPLER_AMD_LINKS_C99_LIBRARY", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    ours = subprocess.run([str(exe)], capture_output=True, text=True).stdout.split()
+    assert ours[0] == str(6144 * 4) and ours[5] == "8" and ours[6] == "1"     # int_least32_t table, long samples, uint_fast8_t channels (glibc x86-64)
+    if os.path.exists("/root/reference/clownresampler.h"):
+        ref = tmp_path / "sr"
+        subprocess.run(["gcc", "-std=c99", "-DCC_USE_C99_INTEGERS", "-I", "/root/reference", str(src), "-o", str(ref)], check=True)
+        assert subprocess.run([str(ref)], capture_output=True, text=True).stdout.split() == ours
+    # without the acknowledgement the header refuses: the default library has the other layouts
+    bad = subprocess.run(["gcc", "-std=c99", "-DCC_USE_C99_INTEGERS", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert bad.returncode != 0 and "libclownresampler_amd_c99" in bad.stderr
+    # same public symbols in both builds
+    def syms(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln)
+    assert syms(lib) == syms(cr.LIB_PATH)
+
+
+def test_cmake_target_has_the_references_name(tmp_path):
+    """`add_subdirectory(<this repo>)` + `target_link_libraries(app clownresampler)`: what a client of the reference's
+    CMakeLists.txt (:9, a library target named clownresampler) already has in its build."""
+    import shutil
+    if shutil.which("cmake") is None:
+        pytest.skip("no cmake here")
+    app = tmp_path / "app"
+    app.mkdir()
+    (app / "main.c").write_text('#define CLOWNRESAMPLER_IMPLEMENTATION\n#define CLOWNRESAMPLER_STATIC\n#include "clownresampler.h"\n#include <stdio.h>\n'
+                                'static ClownResampler_Precomputed p;\n'
+                                'int main(void){ClownResampler_LowLevel_State s; ClownResampler_Precompute(&p);\n'
+                                ' if(!ClownResampler_LowLevel_Init(&s, 2, 44100, 48000, 44100)) return 1;\n'
+                                ' printf("%lu %ld\\n", (unsigned long)s.increment, (long)p.lanczos_kernel_table[3072]); return 0;}\n')
+    (app / "CMakeLists.txt").write_text('cmake_minimum_required(VERSION 3.13)\nproject(app LANGUAGES C)\n'
+                                        'add_subdirectory("%s" clownresampler)\nadd_subdirectory("%s" clownresampler_again)\n'
+                                        'add_executable(app main.c)\ntarget_link_libraries(app clownresampler)\n' % (ROOT, ROOT))
+    build = tmp_path / "b"
+    subprocess.run(["cmake", "-S", str(app), "-B", str(build), "-DCMAKE_BUILD_TYPE=Release"], check=True, capture_output=True)
+    subprocess.run(["cmake", "--build", str(build)], check=True, capture_output=True)
+    out = subprocess.run([str(build / "app")], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.split() == ["60211", "65536"]
+
+
 @pytest.mark.parametrize("radius", [3, 8])
 def test_table_is_the_references(golden, radius):
     # host-side, reference clownresampler.h:955-961

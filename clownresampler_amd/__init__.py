@@ -38,7 +38,8 @@ class ClownResamplerError(RuntimeError):
 
 def build_native(verbose=False):
     """Compiles the HIP kernels (hipcc --offload-arch=gfx950) and the host C code into LIB_PATH, in-tree."""
-    cmd = ["make", "-C", os.path.join(_HERE, "csrc")] + ([] if verbose else ["-s"])
+    jobs = max(1, min(8, os.cpu_count() or 1))   # the kernel instances are spread over several units that compile side by side
+    cmd = ["make", "-j%d" % jobs, "-C", os.path.join(_HERE, "csrc")] + ([] if verbose else ["-s"])
     subprocess.run(cmd, check=True)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("build did not produce " + LIB_PATH)

@@ -1,0 +1,897 @@
+// cr_device.hpp - device-side building blocks shared by the kernels of libclownresampler_amd (gfx950 only): the fixed-point tap
+// arithmetic in its SDWA / 64-bit-chain forms, packed frames, the polyphase row index, one output frame from LDS, stores.
+// Included by every kernel header (cr_kpoly.hpp, cr_kwave.hpp, cr_kup.hpp); everything has internal linkage.
+#ifndef CR_DEVICE_HPP
+#define CR_DEVICE_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <string.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "crhip.h"
+
+namespace
+{
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------------------------
+// Fixed-point pieces
+// ---------------------------------------------------------------------------------------------------------
+
+// The per-tap term is (sample * weight) / 65536 with C semantics (truncation toward zero), clownresampler.h:1020 via
+// :625.  Both operands fit 24 bits and the host only selects the 32-bit kernels for -65536 < weight <= 65536 (cr_plan.c): with
+// |sample| <= 2^15 the product then fits int32 (-32768 * 65536 is exactly INT32_MIN), so the low 32 bits the full-rate 24-bit
+// multiplier delivers ARE the product; see accumulate_product below.  Larger weights (a caller's own table) go to k_generic.
+
+// (acc * reciprocal) / 32768 with C semantics, clownresampler.h:1033.  Host-proved: |acc| < 2^23,
+// 0 < reciprocal < 2^23 and either |acc * reciprocal| < 2^31 (NORM_S31) or < 2^32 (NORM_U32: the product of the
+// magnitudes is exact in the low 32 bits of the 24-bit multiplier; truncation toward zero is symmetric in sign).
+template <int NORM>
+__device__ __forceinline__ int normalise(int acc, int reciprocal)
+{
+	if constexpr (NORM == CRHIP_NORM_S31)
+	{
+		// truncation toward zero = + 0x7FFF before the shift when the product is negative; the reciprocal is positive, so
+		// that is when the ACCUMULATOR is negative: the bias does not wait for the product and the multiply becomes a
+		// multiply-add (4 instructions instead of 5: hipcc otherwise multiplies twice)
+		const int bias = (int)((unsigned)(acc >> 31) >> 17);
+		return (__mul24(acc, reciprocal) + bias) >> 15;
+	}
+	else
+	{
+		const int sign = acc >> 31;
+		const unsigned magnitude = (unsigned)((acc ^ sign) - sign);
+		const unsigned quotient = __umul24(magnitude, (unsigned)reciprocal) >> 15;
+		return ((int)quotient ^ sign) - sign;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Sub-dword (SDWA) forms of the tap arithmetic.  A stereo frame is one dword (left in the low word, right in the
+// high word); SDWA operand selects let the multiply read either word sign-extended, and let an add read the high
+// word of a register, which IS the shift by 16:
+//     x   = v_mul_i32_i24(sext(word k of frame), weight)            product, exact
+//     t   = x >> 31                                                  0 / -1
+//     x'  = x + (t >>> 16)                 add, src1 = WORD_1 of t   + 0xFFFF when negative (C truncation toward zero)
+//     acc = acc + (x' >> 16)               add, src1 = sext(WORD_1 of x')
+// 4 VALU per tap and channel instead of the 6-7 the compiler emits for the C expression (it unpacks the words
+// separately and redoes the multiply as a mad).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sdwa_add_word1_unsigned(int x, int t)
+{
+	int r;
+	asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(x), "v"(t));
+	return r;
+}
+
+__device__ __forceinline__ int sdwa_add_word1_signed(int acc, int x)
+{
+	int r;
+	asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(acc), "v"(x));
+	return r;
+}
+
+// One tap of a packed pair of channels as ONE statement (8 instructions): hipcc pads every asm statement whose outputs
+// the next instruction reads with an s_nop, so the four-statement form above costs three pads per tap and channel; here
+// the only values that leave the statement are the two accumulators.
+__device__ __forceinline__ void sdwa_tap_pair(int &acc_lo, int &acc_hi, int frame, int weight)
+{
+	int x0, x1, t0, t1;
+	asm("v_mul_i32_i24_sdwa %2, sext(%6), %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
+	    "v_mul_i32_i24_sdwa %3, sext(%6), %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+	    "v_ashrrev_i32_e32 %4, 31, %2\n\t"
+	    "v_ashrrev_i32_e32 %5, 31, %3\n\t"
+	    "v_add_u32_sdwa %2, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_add_u32_sdwa %3, %3, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_add_u32_sdwa %0, %0, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_add_u32_sdwa %1, %1, sext(%3) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+	    : "+v"(acc_lo), "+v"(acc_hi), "=&v"(x0), "=&v"(x1), "=&v"(t0), "=&v"(t1)
+	    : "v"(frame), "v"(weight));
+}
+
+// The same for the FIRST tap of an accumulator pair: the truncated terms are written, not added (no zeroing moves, and
+// the final shift is a plain v_ashrrev, which issues at twice the rate of an SDWA add on gfx950).
+__device__ __forceinline__ void sdwa_tap_pair_first(int &acc_lo, int &acc_hi, int frame, int weight)
+{
+	int t0, t1;
+	asm("v_mul_i32_i24_sdwa %0, sext(%4), %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
+	    "v_mul_i32_i24_sdwa %1, sext(%4), %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+	    "v_ashrrev_i32_e32 %2, 31, %0\n\t"
+	    "v_ashrrev_i32_e32 %3, 31, %1\n\t"
+	    "v_add_u32_sdwa %0, %0, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_add_u32_sdwa %1, %1, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_ashrrev_i32_e32 %0, 16, %0\n\t"
+	    "v_ashrrev_i32_e32 %1, 16, %1"
+	    : "=&v"(acc_lo), "=&v"(acc_hi), "=&v"(t0), "=&v"(t1)
+	    : "v"(frame), "v"(weight));
+}
+
+__device__ __forceinline__ void sdwa_tap_single_first(int &acc, int sample, int weight)
+{
+	int t;
+	asm("v_mul_i32_i24_e32 %0, %2, %3\n\t"
+	    "v_ashrrev_i32_e32 %1, 31, %0\n\t"
+	    "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_ashrrev_i32_e32 %0, 16, %0"
+	    : "=&v"(acc), "=&v"(t)
+	    : "v"(sample), "v"(weight));
+}
+
+// One tap of one (already sign-extended) sample as one statement (4 instructions).
+__device__ __forceinline__ void sdwa_tap_single(int &acc, int sample, int weight)
+{
+	int x, t;
+	asm("v_mul_i32_i24_e32 %1, %3, %4\n\t"
+	    "v_ashrrev_i32_e32 %2, 31, %1\n\t"
+	    "v_add_u32_sdwa %1, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_add_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+	    : "+v"(acc), "=&v"(x), "=&v"(t)
+	    : "v"(sample), "v"(weight));
+}
+
+// One tap of the sample in the LOW word of a dword (the odd channel that is left over when a frame is read as dwords).
+__device__ __forceinline__ void sdwa_tap_word0(int &acc, int frame, int weight)
+{
+	int x, t;
+	asm("v_mul_i32_i24_sdwa %1, sext(%3), %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
+	    "v_ashrrev_i32_e32 %2, 31, %1\n\t"
+	    "v_add_u32_sdwa %1, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_add_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+	    : "+v"(acc), "=&v"(x), "=&v"(t)
+	    : "v"(frame), "v"(weight));
+}
+
+__device__ __forceinline__ void sdwa_tap_word0_first(int &acc, int frame, int weight)
+{
+	int t;
+	asm("v_mul_i32_i24_sdwa %0, sext(%2), %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
+	    "v_ashrrev_i32_e32 %1, 31, %0\n\t"
+	    "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_ashrrev_i32_e32 %0, 16, %0"
+	    : "=&v"(acc), "=&v"(t)
+	    : "v"(frame), "v"(weight));
+}
+
+// ... and in the HIGH word (mono: two neighbouring frames of the window share a dword).
+__device__ __forceinline__ void sdwa_tap_word1(int &acc, int frame, int weight)
+{
+	int x, t;
+	asm("v_mul_i32_i24_sdwa %1, sext(%3), %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+	    "v_ashrrev_i32_e32 %2, 31, %1\n\t"
+	    "v_add_u32_sdwa %1, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_add_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+	    : "+v"(acc), "=&v"(x), "=&v"(t)
+	    : "v"(frame), "v"(weight));
+}
+
+__device__ __forceinline__ void sdwa_tap_word1_first(int &acc, int frame, int weight)
+{
+	int t;
+	asm("v_mul_i32_i24_sdwa %0, sext(%2), %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+	    "v_ashrrev_i32_e32 %1, 31, %0\n\t"
+	    "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+	    "v_ashrrev_i32_e32 %0, 16, %0"
+	    : "=&v"(acc), "=&v"(t)
+	    : "v"(frame), "v"(weight));
+}
+
+// acc += trunc(product / 65536)
+template <int ASM>
+__device__ __forceinline__ int accumulate_product(int acc, int product)
+{
+	if constexpr (ASM)
+		return sdwa_add_word1_signed(acc, sdwa_add_word1_unsigned(product, product >> 31));
+	else
+		return acc + ((product + (int)((unsigned)(product >> 31) >> 16)) >> 16);
+}
+
+// One input frame from LDS, kept PACKED (two int16 per dword) and multiplied straight out of the dwords by the SDWA
+// forms.  An odd channel count leaves one sample over: it sits in the low word of the last dword.
+// Frames of an odd channel count start on 2-byte boundaries, and LDS reads that are not naturally aligned are SLOW on
+// gfx950: hipcc merges neighbouring 16-bit reads into ds_read_b64 / b32 on 2-byte boundaries, and the mono and 3-channel
+// kernels measured 1.5-1.7x slower for it (profiles/).  So an odd frame is read as the ALIGNED dwords that cover it and
+// funnel-shifted into place (v_alignbit_b32 by 0 or 16): one instruction per dword, which also replaces the per-sample
+// sign extension the unpacked form needed.
+template <int CH>
+struct Frame
+{
+	static constexpr bool PACKED = (CH % 2) == 0;
+	static constexpr int WORDS = (CH + 1) / 2;
+	int v[WORDS];
+
+	__device__ __forceinline__ void load(const unsigned char *p)
+	{
+		if constexpr (CH == 2)
+		{
+			v[0] = *reinterpret_cast<const int *>(p);
+		}
+		else if constexpr (CH == 4)
+		{
+			const i32x2 d = *reinterpret_cast<const i32x2 *>(p);
+			v[0] = d.x;
+			v[1] = d.y;
+		}
+		else if constexpr (CH == 8)
+		{
+			const i32x4 d = *reinterpret_cast<const i32x4 *>(p);
+			v[0] = d.x;
+			v[1] = d.y;
+			v[2] = d.z;
+			v[3] = d.w;
+		}
+		else if constexpr (PACKED)
+		{
+#pragma unroll
+			for (int k = 0; k < WORDS; ++k)
+				v[k] = reinterpret_cast<const int *>(p)[k];
+		}
+		else
+		{
+			const unsigned odd = (unsigned)reinterpret_cast<uintptr_t>(p) & 2u;   // the frame starts in the high half of a dword
+			const unsigned *q = reinterpret_cast<const unsigned *>(p - odd);
+			unsigned d[WORDS];
+#pragma unroll
+			for (int k = 0; k < WORDS; ++k)
+				d[k] = q[k];
+#pragma unroll
+			for (int k = 0; k + 1 < WORDS; ++k)
+				v[k] = (int)__builtin_amdgcn_alignbit(d[k + 1], d[k], odd * 8u);
+			v[WORDS - 1] = (int)(d[WORDS - 1] >> (odd * 8u));
+		}
+	}
+
+	// the same for a frame that may start on ANY 2-byte boundary whatever its channel count (frames of an odd total channel
+	// count shared by two lanes): aligned dwords + funnel shift, as above
+	__device__ __forceinline__ void load_any(const unsigned char *p)
+	{
+		if constexpr (!PACKED)
+		{
+			load(p);
+		}
+		else
+		{
+			const unsigned odd = (unsigned)reinterpret_cast<uintptr_t>(p) & 2u;
+			const unsigned *q = reinterpret_cast<const unsigned *>(p - odd);
+			unsigned d[WORDS + 1];
+#pragma unroll
+			for (int k = 0; k < WORDS + 1; ++k)
+				d[k] = q[k];
+#pragma unroll
+			for (int k = 0; k < WORDS; ++k)
+				v[k] = (int)__builtin_amdgcn_alignbit(d[k + 1], d[k], odd * 8u);
+		}
+	}
+
+	// acc = first tap's terms (no previous contents)
+	template <int ASM>
+	__device__ __forceinline__ void mac_first(int (&acc)[CH], int weight) const
+	{
+		if constexpr (!ASM)
+		{
+#pragma unroll
+			for (int c = 0; c < CH; ++c)
+				acc[c] = 0;
+			mac<0>(acc, weight);
+		}
+		else
+		{
+#pragma unroll
+			for (int k = 0; k < CH / 2; ++k)
+				sdwa_tap_pair_first(acc[2 * k], acc[2 * k + 1], v[k], weight);
+			if constexpr (!PACKED)
+				sdwa_tap_word0_first(acc[CH - 1], v[WORDS - 1], weight);
+		}
+	}
+
+	template <int ASM>
+	__device__ __forceinline__ void mac(int (&acc)[CH], int weight) const
+	{
+#pragma unroll
+		for (int k = 0; k < CH / 2; ++k)
+		{
+			if constexpr (ASM)
+			{
+				sdwa_tap_pair(acc[2 * k], acc[2 * k + 1], v[k], weight);
+			}
+			else
+			{
+				acc[2 * k] = accumulate_product<0>(acc[2 * k], __mul24((int)(short)v[k], weight));
+				acc[2 * k + 1] = accumulate_product<0>(acc[2 * k + 1], __mul24(v[k] >> 16, weight));
+			}
+		}
+		if constexpr (!PACKED)
+		{
+			if constexpr (ASM)
+				sdwa_tap_word0(acc[CH - 1], v[WORDS - 1], weight);
+			else
+				acc[CH - 1] = accumulate_product<0>(acc[CH - 1], __mul24((int)(short)v[WORDS - 1], weight));
+		}
+	}
+};
+
+// N consecutive MONO frames (int16) starting at p, packed two per dword: pw[k] = frames 2k (low word) and 2k + 1 (high word).
+// Aligned dword reads + one funnel shift per dword (see Frame); pw must have (N + 1) / 2 elements.
+template <int N>
+__device__ __forceinline__ void load_mono_window(const unsigned char *p, int *pw)
+{
+	constexpr int NPW = (N + 1) / 2, NW = (N + 2) / 2;
+	const unsigned odd = (unsigned)reinterpret_cast<uintptr_t>(p) & 2u;
+	const unsigned *q = reinterpret_cast<const unsigned *>(p - odd);
+	unsigned d[NW];
+#pragma unroll
+	for (int k = 0; k < NW; ++k)
+		d[k] = q[k];
+#pragma unroll
+	for (int k = 0; k < NPW; ++k)
+		pw[k] = k + 1 < NW ? (int)__builtin_amdgcn_alignbit(d[k + 1], d[k], odd * 8u) : (int)(d[k] >> (odd * 8u));
+}
+
+// One mono tap out of a packed window: frame s of the window, weight w.
+template <int ASM, bool FIRST>
+__device__ __forceinline__ void mono_tap(int &acc, const int *pw, int s, int weight)
+{
+	if constexpr (!ASM)
+	{
+		const int sample = (s & 1) ? (pw[s / 2] >> 16) : (int)(short)pw[s / 2];
+		acc = accumulate_product<0>(FIRST ? 0 : acc, __mul24(sample, weight));
+	}
+	else if (s & 1)
+	{
+		if constexpr (FIRST)
+			sdwa_tap_word1_first(acc, pw[s / 2], weight);
+		else
+			sdwa_tap_word1(acc, pw[s / 2], weight);
+	}
+	else
+	{
+		if constexpr (FIRST)
+			sdwa_tap_word0_first(acc, pw[s / 2], weight);
+		else
+			sdwa_tap_word0(acc, pw[s / 2], weight);
+	}
+}
+
+// The frames of a tap window for an ODD channel count above one.  A frame is CH * 2 = 2 (mod 4) bytes, so consecutive frames
+// alternate between starting on a dword and in the middle of one; both aligned bases and both funnel shifts are formed once
+// per window, and every frame is then read at an immediate offset.
+template <int CH, int FB>
+struct OddWindow
+{
+	const unsigned char *even_base, *odd_base;   // aligned base of frame s is {even,odd}_base + s * FB for even / odd s
+	unsigned even_shift, odd_shift;
+
+	__device__ __forceinline__ explicit OddWindow(const unsigned char *p)
+	{
+		static_assert(CH % 2 == 1 && FB % 4 == 2, "frames of an odd channel count, one lane per frame");
+		const unsigned odd = (unsigned)reinterpret_cast<uintptr_t>(p) & 2u;
+		even_base = p - odd;
+		odd_base = p - 2u + odd;         // frame 1 starts FB = 2 (mod 4) bytes on: in the other half
+		even_shift = odd * 8u;
+		odd_shift = 16u - odd * 8u;
+	}
+
+	__device__ __forceinline__ void load(Frame<CH> &f, int slot) const
+	{
+		constexpr int WORDS = Frame<CH>::WORDS;
+		const unsigned *q = reinterpret_cast<const unsigned *>(((slot & 1) ? odd_base : even_base) + slot * FB);
+		const unsigned shift = (slot & 1) ? odd_shift : even_shift;
+		unsigned d[WORDS];
+#pragma unroll
+		for (int k = 0; k < WORDS; ++k)
+			d[k] = q[k];
+#pragma unroll
+		for (int k = 0; k + 1 < WORDS; ++k)
+			f.v[k] = (int)__builtin_amdgcn_alignbit(d[k + 1], d[k], shift);
+		f.v[WORDS - 1] = (int)(d[WORDS - 1] >> shift);
+	}
+};
+
+// NINT consecutive int32 to a destination that is only DWORD-aligned: 16-byte, then 8-byte, then 4-byte stores
+// (stores_of_ints_dword_aligned(NINT) instructions).
+typedef i32x4 i32x4_dword_aligned __attribute__((aligned(4)));
+typedef i32x2 i32x2_dword_aligned __attribute__((aligned(4)));
+
+template <int NINT, int NT>
+__device__ __forceinline__ void store_ints_dword_aligned(int *dst, const int *v)
+{
+	int c = 0;
+#pragma unroll
+	for (; c + 4 <= NINT; c += 4)
+	{
+		i32x4 q;
+		q.x = v[c];
+		q.y = v[c + 1];
+		q.z = v[c + 2];
+		q.w = v[c + 3];
+		if constexpr (NT)
+			__builtin_nontemporal_store(q, reinterpret_cast<i32x4_dword_aligned *>(dst + c));
+		else
+			*reinterpret_cast<i32x4_dword_aligned *>(dst + c) = q;
+	}
+	if constexpr (NINT % 4 >= 2)
+	{
+		i32x2 q;
+		q.x = v[c];
+		q.y = v[c + 1];
+		if constexpr (NT)
+			__builtin_nontemporal_store(q, reinterpret_cast<i32x2_dword_aligned *>(dst + c));
+		else
+			*reinterpret_cast<i32x2_dword_aligned *>(dst + c) = q;
+		c += 2;
+	}
+	if constexpr (NINT % 2 == 1)
+	{
+		if constexpr (NT)
+			__builtin_nontemporal_store(v[c], dst + c);
+		else
+			dst[c] = v[c];
+	}
+}
+
+constexpr int stores_of_ints_dword_aligned(int n)
+{
+	return n / 4 + (n % 4) / 2 + n % 2;
+}
+
+// NINT consecutive int32 -> global memory, widest stores the size allows.  NT = 1 marks them non-temporal: the output
+// is written once and never read by the kernel; on MI355X that is worth ~7 % of HBM throughput for the stereo stream
+// (8-byte stores) and costs a few % with 16-byte stores, so it is part of the per-instance tuning.
+template <int NINT, int NT>
+__device__ __forceinline__ void store_ints(int *dst, const int *v)
+{
+	if constexpr (NINT % 4 == 0)
+	{
+#pragma unroll
+		for (int c = 0; c < NINT; c += 4)
+		{
+			i32x4 q;
+			q.x = v[c];
+			q.y = v[c + 1];
+			q.z = v[c + 2];
+			q.w = v[c + 3];
+			if constexpr (NT)
+				__builtin_nontemporal_store(q, reinterpret_cast<i32x4 *>(dst + c));
+			else
+				*reinterpret_cast<i32x4 *>(dst + c) = q;
+		}
+	}
+	else if constexpr (NINT % 2 == 0)
+	{
+#pragma unroll
+		for (int c = 0; c < NINT; c += 2)
+		{
+			i32x2 q;
+			q.x = v[c];
+			q.y = v[c + 1];
+			if constexpr (NT)
+				__builtin_nontemporal_store(q, reinterpret_cast<i32x2 *>(dst + c));
+			else
+				*reinterpret_cast<i32x2 *>(dst + c) = q;
+		}
+	}
+	else
+	{
+		// an odd count: the frames are only dword-aligned; 16- and 8-byte stores need no more than that on gfx950
+		store_ints_dword_aligned<NINT, NT>(dst, v);
+	}
+}
+
+// The consumers of the reference clamp every sample to 16 bits in their output callback, to +-0x7FFF (note: -0x7FFF, not
+// -0x8000; examples/low-level.c:69-80, examples/high-level.c:74-85).  Opt-in fused form of that callback: clamp and
+// store int16, which also halves the write traffic.
+__device__ __forceinline__ int clamp_s16(int v)
+{
+	return v > 0x7FFF ? 0x7FFF : (v < -0x7FFF ? -0x7FFF : v);
+}
+
+template <int NSHORT, int NT>
+__device__ __forceinline__ void store_shorts(short *dst, const int *v)
+{
+	if constexpr (NSHORT % 2 == 0)
+	{
+		int packed[NSHORT / 2];
+#pragma unroll
+		for (int k = 0; k < NSHORT / 2; ++k)
+			packed[k] = (clamp_s16(v[2 * k]) & 0xFFFF) | (clamp_s16(v[2 * k + 1]) << 16);
+		store_ints<NSHORT / 2, NT>(reinterpret_cast<int *>(dst), packed);
+	}
+	else
+	{
+#pragma unroll
+		for (int c = 0; c < NSHORT; ++c)
+			dst[c] = (short)clamp_s16(v[c]);
+	}
+}
+
+constexpr int stores_of_ints(int n)
+{
+	return n % 4 == 0 ? n / 4 : (n % 2 == 0 ? n / 2 : stores_of_ints_dword_aligned(n));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Row index of a fractional position (host mirror: cr_plan.c cr_poly_row_of)
+// ---------------------------------------------------------------------------------------------------------
+// `shift` receives the number of frames this phase's window starts after the tile's first window frame: affine rows are laid
+// out from their own first tap (cr_plan.c, "SHIFTED windows"), and min_relative is computed here anyway.
+template <int MODE>
+__device__ __forceinline__ unsigned row_of(const crhip_poly_launch &a, unsigned frac, unsigned &shift)
+{
+	if constexpr (MODE == CRHIP_ROWMODE_UPSAMPLE)
+	{
+		shift = 0;
+		return (65536u - frac) >> 6;
+	}
+	else
+	{
+		// min_relative / max_relative of clownresampler.h:993-994, kernel_start of :1001
+		const unsigned mr = (frac + a.delta + 65535u) >> 16;
+		const unsigned xr = (frac + a.skr) >> 16;
+		const unsigned kstart = __umul24(a.step, (mr << 16) - frac) >> 16;
+		shift = mr - a.first_mr;
+		return (unsigned)((int)kstart + a.aff_a * (int)mr + a.aff_b * (int)xr + a.aff_c);
+	}
+}
+
+// Everything one output frame reads from LDS, held in registers: its row (weights + reciprocal) and its window of
+// input frames.  Splitting the frame into fetch_frame (LDS reads only) and compute_frame (VALU only) lets the kernel
+// issue the reads of frame i+1 before the arithmetic of frame i: hipcc does not software-pipeline across the asm tap
+// statements on its own, and with every wave of a workgroup released by the same barrier the waves otherwise alternate
+// in lockstep between an LDS phase and a VALU phase.
+template <int CH, int TT>
+struct FrameData
+{
+	static constexpr int RS = (TT + 1 + 3) & ~3;
+	int w[RS];
+	Frame<CH> f[TT];
+};
+
+// SPLIT > 1: a frame of CH * SPLIT channels is shared by SPLIT neighbouring lanes, each taking CH of them (`base` then
+// already points at the lane's share of the first frame); FS is the distance between consecutive frames.
+template <int CH, int TT, int MODE, int SWZ, int SPLIT = 1>
+__device__ __forceinline__ void fetch_frame(const crhip_poly_launch &a, const int *rows, const unsigned char *base, unsigned rel, FrameData<CH, TT> &d)
+{
+	constexpr unsigned FB = CH * 2 * SPLIT;
+	unsigned shift;
+	const unsigned row = row_of<MODE>(a, rel & 0xFFFFu, shift);
+	const unsigned phys = SWZ ? ((row & ~15u) | ((__umul24(row >> 4, a.swizzle) + row) & 15u)) : row;
+	const unsigned char *src = base + ((rel >> 16) + shift) * FB;
+	const i32x4 *plane0 = reinterpret_cast<const i32x4 *>(rows) + phys;
+
+#pragma unroll
+	for (int q = 0; q < FrameData<CH, TT>::RS / 4; ++q)
+	{
+		const i32x4 v = plane0[q * a.plane_rows];
+		d.w[4 * q] = v.x;
+		d.w[4 * q + 1] = v.y;
+		d.w[4 * q + 2] = v.z;
+		d.w[4 * q + 3] = v.w;
+	}
+	if constexpr (CH == 1 && SPLIT == 1)
+	{
+		// mono: the window as packed pairs in f[0 .. (TT + 1) / 2) (see compute_frame)
+		int pw[(TT + 1) / 2];
+		load_mono_window<TT>(src, pw);
+#pragma unroll
+		for (int k = 0; k < (TT + 1) / 2; ++k)
+			d.f[k].v[0] = pw[k];
+	}
+	else if constexpr (CH % 2 == 1 && SPLIT == 1)
+	{
+		const OddWindow<CH, (int)FB> window(src);
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+			window.load(d.f[s], s);
+	}
+	else
+	{
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+			d.f[s].load(src + s * FB);
+	}
+}
+
+// The tap arithmetic as a chain of full-rate 64-bit multiply-adds (ASM mode 2; pure upsampling only, where the sign of a
+// slot's weights is a compile-time property - NEGMASK in ASM >> 8, checked by the host against the plan's rows):
+//     P = (accumulator : bias)          high dword: the running sum; low dword: 0xFFFF0000 where sample * weight < 0, else 0
+//     P = v_mad_i64_i32(sample << 16, weight, P)
+// The product lands as (sample * weight) << 16, so with the bias beside it the carry into the high dword is exactly the
+// reference's (sample * weight) / 65536 with C truncation (clownresampler.h:1020 via :625) added to the running sum; what
+// is left in the low dword is overwritten by the next tap's bias.  Per packed pair of channels and tap: one v_pk_ashrrev_i16
+// (the sign masks of both samples; a zero sample may carry the bias too: (0 + 0xFFFF) >> 16 == 0), two shifts/masks for the
+// samples, two for the biases, two multiply-adds: ~22 cycles per wave against ~30 for the SDWA form.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// p = (sample << 16) * weight + p, 64 bits, one instruction.  Inline asm: left to itself hipcc re-associates the bias out of the
+// addend and adds it with a separate 64-bit add.
+__device__ __forceinline__ void mad64(i32x2 &p, int sample_shifted, int weight)
+{
+	long long carry;
+	asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(p), "=&s"(carry) : "v"(sample_shifted), "v"(weight));
+}
+
+template <bool NEGATIVE_SLOT, bool FIRST>
+__device__ __forceinline__ void mad64_tap_pair(i32x2 &p_lo, i32x2 &p_hi, int frame, int weight)
+{
+	const int seen = NEGATIVE_SLOT ? ~frame : frame;   // negative slot: the product is negative where the sample is positive
+	const s16x2 masks = __builtin_bit_cast(s16x2, seen) >> (short)15;
+	const unsigned pm = __builtin_bit_cast(unsigned, masks);
+	// the bias goes straight into the low dword of the accumulator pair (x); the high dword (y) is the running sum
+	p_lo.x = (int)(pm << 16);
+	p_hi.x = (int)(pm & 0xFFFF0000u);
+	if (FIRST)
+	{
+		p_lo.y = 0;
+		p_hi.y = 0;
+	}
+	mad64(p_lo, (int)((unsigned)frame << 16), weight);
+	mad64(p_hi, (int)((unsigned)frame & 0xFFFF0000u), weight);
+}
+
+template <unsigned NEGMASK, bool FIRST>
+__device__ __forceinline__ void mad64_tap_pair_dispatch(int slot, i32x2 &p_lo, i32x2 &p_hi, int frame, int weight)
+{
+	if ((NEGMASK >> slot) & 1u)
+		mad64_tap_pair<true, FIRST>(p_lo, p_hi, frame, weight);
+	else
+		mad64_tap_pair<false, FIRST>(p_lo, p_hi, frame, weight);
+}
+
+template <int CH, int TT, int NORM, int ASM>
+__device__ __forceinline__ void compute_frame(const FrameData<CH, TT> &d, int *out)
+{
+	if constexpr ((ASM & 0xFF) == 2)
+	{
+		static_assert(CH % 2 == 0, "the 64-bit chain works on packed pairs of channels");
+		constexpr unsigned NEGMASK = (unsigned)ASM >> 8;
+		i32x2 p[CH], p2[CH];   // two chains, taps alternating: consecutive multiply-adds are independent
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+		{
+#pragma unroll
+			for (int k = 0; k < CH / 2; ++k)
+			{
+				if (s == 0)
+					mad64_tap_pair_dispatch<NEGMASK, true>(s, p[2 * k], p[2 * k + 1], d.f[s].v[k], d.w[s]);
+				else if (s == 1)
+					mad64_tap_pair_dispatch<NEGMASK, true>(s, p2[2 * k], p2[2 * k + 1], d.f[s].v[k], d.w[s]);
+				else if (s & 1)
+					mad64_tap_pair_dispatch<NEGMASK, false>(s, p2[2 * k], p2[2 * k + 1], d.f[s].v[k], d.w[s]);
+				else
+					mad64_tap_pair_dispatch<NEGMASK, false>(s, p[2 * k], p[2 * k + 1], d.f[s].v[k], d.w[s]);
+			}
+		}
+#pragma unroll
+		for (int c = 0; c < CH; ++c)
+		{
+			const int acc = p[c].y + (TT > 1 ? p2[c].y : 0);
+			out[c] = normalise<NORM>(acc, d.w[TT]);
+		}
+		return;
+	}
+	if constexpr (CH == 1)
+	{
+		// mono: fetch_frame left the window packed, two frames per dword
+		int pw[(TT + 1) / 2];
+#pragma unroll
+		for (int k = 0; k < (TT + 1) / 2; ++k)
+			pw[k] = d.f[k].v[0];
+		int a0 = 0, a1 = 0;
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+		{
+			if (s == 0)
+				mono_tap<ASM, true>(a0, pw, s, d.w[s]);
+			else if (s == 1)
+				mono_tap<ASM, true>(a1, pw, s, d.w[s]);
+			else if (s & 1)
+				mono_tap<ASM, false>(a1, pw, s, d.w[s]);
+			else
+				mono_tap<ASM, false>(a0, pw, s, d.w[s]);
+		}
+		out[0] = normalise<NORM>(a0 + a1, d.w[TT]);
+		return;
+	}
+	// two accumulator sets, taps alternating between them: consecutive tap statements are independent (no asm boundary
+	// pad, more overlap); integer addition is associative, so the sum is the same
+	int acc[CH], acc2[CH];
+#pragma unroll
+	for (int s = 0; s < TT; ++s)
+	{
+		if (s == 0)
+			d.f[s].template mac_first<ASM>(acc, d.w[s]);
+		else if (s == 1)
+			d.f[s].template mac_first<ASM>(acc2, d.w[s]);
+		else if (s & 1)
+			d.f[s].template mac<ASM>(acc2, d.w[s]);
+		else
+			d.f[s].template mac<ASM>(acc, d.w[s]);
+	}
+	if constexpr (TT > 1)
+	{
+#pragma unroll
+		for (int c = 0; c < CH; ++c)
+			acc[c] += acc2[c];
+	}
+#pragma unroll
+	for (int c = 0; c < CH; ++c)
+		out[c] = normalise<NORM>(acc[c], d.w[TT]);
+}
+
+// One output frame: CH normalised int32 into out[0..CH).
+//   rel   16.16 position relative to the tile's first integer position
+//   base  LDS address of the tile's first window frame (tile + shift)
+template <int CH, int TT, int MODE, int NORM, int ASM, int SWZ, int SPLIT = 1, int PH = 0>
+__device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int *rows, const unsigned char *base, unsigned rel, int *out)
+{
+	static_assert(PH == 0 || (TT == 0 && SPLIT == 2), "the phantom channel exists for run-time-slot instances with two lanes per frame");
+	constexpr unsigned FB = (CH * SPLIT - PH) * 2;
+	constexpr int RS_CT = (TT + 1 + 3) & ~3;
+
+	const unsigned frac = rel & 0xFFFFu;
+	unsigned shift;
+	const unsigned row = row_of<MODE>(a, frac, shift);
+	// LDS image of the rows: PLANAR (plane q holds int32 [4q, 4q+4) of every row, 16 bytes per row) and SWIZZLED
+	// within each block of 16 rows by a host-chosen multiple of the block number, so that the 16 lanes a
+	// ds_read_b128 services together fall on 16 different 16-byte bank slots instead of the 5-8 the plain layout
+	// gives for a fixed increment (cr_plan.c cr_poly_pick_swizzle).
+	const unsigned phys = SWZ ? ((row & ~15u) | ((__umul24(row >> 4, a.swizzle) + row) & 15u)) : row;
+	const unsigned char *src = base + ((rel >> 16) + shift) * FB;
+	const i32x4 *plane0 = reinterpret_cast<const i32x4 *>(rows) + phys;
+
+	int acc[CH];
+#pragma unroll
+	for (int c = 0; c < CH; ++c)
+		acc[c] = 0;
+
+	int reciprocal = 0;
+
+	if constexpr (TT > 0)
+	{
+		int w[RS_CT];
+#pragma unroll
+		for (int q = 0; q < RS_CT / 4; ++q)
+		{
+			const i32x4 v = plane0[q * a.plane_rows];
+			w[4 * q] = v.x;
+			w[4 * q + 1] = v.y;
+			w[4 * q + 2] = v.z;
+			w[4 * q + 3] = v.w;
+		}
+		// two accumulator sets, taps alternating between them: consecutive tap statements are then independent (no asm
+		// boundary pad, more overlap); integer addition is associative, so the sum is the same
+		int acc2[CH];
+		int pw[CH == 1 && SPLIT == 1 ? (TT + 1) / 2 : 1];
+		if constexpr (CH == 1 && SPLIT == 1)
+			load_mono_window<TT>(src, pw);
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+		{
+			if constexpr (CH == 1 && SPLIT == 1)
+			{
+				if (s == 0)
+					mono_tap<ASM, true>(acc[0], pw, s, w[s]);
+				else if (s == 1)
+					mono_tap<ASM, true>(acc2[0], pw, s, w[s]);
+				else
+					mono_tap<ASM, false>((s & 1) ? acc2[0] : acc[0], pw, s, w[s]);
+				continue;
+			}
+			Frame<CH> f;
+			if constexpr (CH % 2 == 1 && SPLIT == 1)
+				OddWindow<CH, (int)FB>(src).load(f, s);
+			else
+				f.load(src + s * FB);
+			if (s == 0)
+				f.template mac_first<ASM>(acc, w[s]);
+			else if (s == 1)
+				f.template mac_first<ASM>(acc2, w[s]);
+			else if (s & 1)
+				f.template mac<ASM>(acc2, w[s]);
+			else
+				f.template mac<ASM>(acc, w[s]);
+		}
+		if constexpr (TT > 1)
+		{
+#pragma unroll
+			for (int c = 0; c < CH; ++c)
+				acc[c] += acc2[c];
+		}
+		reciprocal = w[TT];
+	}
+	else
+	{
+		// Run-time slot count.  The device image of the rows is laid out for this loop (cr_plan.c, SPLIT layout):
+		// ceil(slots / 4) planes of weights, zero-padded, then one plane that holds only the reciprocal.  Four taps
+		// per trip - one ds_read_b128 of weights, four frame reads, four independent multiply-accumulates - and, where it
+		// measured faster (TAIL below), a last SHORTER trip for slots % 4 taps (a wave-uniform switch): 5 slots - every pure
+		// upsampling with three lobes - are then 5 taps of arithmetic, not 8.
+		const unsigned weight_planes = a.row_stride / 4u - 1u;
+		auto trip = [&](unsigned q, auto count_tag) {
+			constexpr int N = decltype(count_tag)::value;   // taps of this trip, 1..4
+			const i32x4 v = plane0[q * a.plane_rows];
+			const int wv[4] = {v.x, v.y, v.z, v.w};
+			if constexpr (CH == 1 && SPLIT == 1)
+			{
+				// mono: the frames of this trip as packed dwords (the parity of the window's start is the same in every trip:
+				// four frames are 8 bytes)
+				int pw[2];
+				load_mono_window<N>(src + 4u * q * FB, pw);
+#pragma unroll
+				for (int k = 0; k < N; ++k)
+					mono_tap<ASM, false>(acc[0], pw, k, wv[k]);
+			}
+			else
+			{
+				Frame<CH> f[N];
+				if constexpr (CH % 2 == 1 && SPLIT == 1)
+				{
+					// four frames of an odd channel count are 4 * FB = 0 (mod 8) bytes: the window of every trip starts alike
+					const OddWindow<CH, (int)FB> window(src + 4u * q * FB);
+#pragma unroll
+					for (int k = 0; k < N; ++k)
+						window.load(f[k], k);
+				}
+				else
+				{
+#pragma unroll
+					for (int k = 0; k < N; ++k)
+					{
+						if constexpr (PH)
+							f[k].load_any(src + (4u * q + (unsigned)k) * FB);
+						else
+							f[k].load(src + (4u * q + (unsigned)k) * FB);
+					}
+				}
+#pragma unroll
+				for (int k = 0; k < N; ++k)
+					f[k].template mac<ASM>(acc, wv[k]);
+			}
+		};
+		// What to do with the slots % 4 taps of the last plane was MEASURED per lane shape (profiles/r01_channel_table.log;
+		// 44.1 -> 48 kHz, 5 slots): the shorter last trip gains 10-30 % up to 6 channels per lane; 7-8 channels per lane and
+		// most phantom shapes LOSE 10-30 % with it (three more unrolled trip bodies in every straight-line frame of a tile),
+		// so there the zero-padded full trip stays (a padded slot has weight 0 and contributes exactly 0 whatever the LDS
+		// read returns).
+		constexpr bool SHORT_TAIL = (CH <= 6 && !PH) || (CH == 5 && PH);
+		const unsigned full_trips = SHORT_TAIL ? a.slots / 4u : weight_planes;
+		for (unsigned q = 0; q < full_trips; ++q)
+			trip(q, std::integral_constant<int, 4>());
+		if constexpr (SHORT_TAIL)
+		{
+			switch (a.slots & 3u)
+			{
+				case 1: trip(full_trips, std::integral_constant<int, 1>()); break;
+				case 2: trip(full_trips, std::integral_constant<int, 2>()); break;
+				case 3: trip(full_trips, std::integral_constant<int, 3>()); break;
+				default: break;
+			}
+		}
+		reciprocal = reinterpret_cast<const int *>(plane0 + weight_planes * a.plane_rows)[0];
+	}
+
+#pragma unroll
+	for (int c = 0; c < CH; ++c)
+		out[c] = normalise<NORM>(acc[c], reciprocal);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SGPR budget.  Two 1024-thread workgroups per CU are 8 waves per SIMD, and on gfx950 a SIMD admits
+// min(8, 800 / (ceil(sgpr_count / 16) * 16 + 16)) waves (MI355X_MICROARCH.md, "Residency"): 8 only up to .sgpr_count 80,
+// 7 up to 96 - while the compiler's "Occupancy: 8" and hipOccupancyMaxActiveBlocksPerMultiprocessor still say 8 / two
+// workgroups.  Left alone hipcc gave most instances 82-106 SGPRs (wave-uniform 64-bit addresses, tile bookkeeping), so the
+// second workgroup of a CU only started when the first had finished - seen in the start ticks of the stamped diagnostic
+// instance.  80 includes VCC, FLAT_SCRATCH and XNACK_MASK; what does not fit is spilled to VGPR lanes, of which there are
+// plenty (38-63 of 64 used).
+// ---------------------------------------------------------------------------------------------------------
+#define CRHIP_SGPR_BUDGET 80
+
+} // namespace
+
+#endif // CR_DEVICE_HPP

@@ -1,0 +1,31 @@
+// cr_inst_long.hip - instance unit: the 8-lobe build: 15- and 17-slot windows (BASELINE configs[2]: stereo 8 -> 96 kHz through k_up)  (see cr_instances.hpp)
+#include "cr_instances.hpp"
+
+namespace crk
+{
+
+int specials_long(void *table, int capacity)
+{
+	static const special mine[] = {
+	    make_special<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 27, true, false, 0x2A55u>(),  // cfg 3: stereo 8 -> 96 kHz, 8 lobes (k_up, chain form, from 2x upsampling on; k_wave below)
+	    make_special_lite<1, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32>(),
+	    make_special_lite<1, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<2, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	};
+	const int n = (int)(sizeof(mine) / sizeof(mine[0]));
+	if (n > capacity)
+		return -1;
+	memcpy(table, mine, sizeof(mine));
+	return n;
+}
+
+void *ablation_instance_long(int abl)
+{
+	switch (abl)
+	{
+		case 8: return (void *)k_up<2, 15, CRHIP_NORM_U32, 0x2A55u, UP_WAVES, 0, 1, 6, 1>;   // k_up of the 8-lobe stereo instance (chain form, the default) + stamps
+		default: return nullptr;
+	}
+}
+
+} // namespace crk

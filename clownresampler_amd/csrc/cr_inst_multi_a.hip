@@ -1,0 +1,19 @@
+// cr_inst_multi_a.hip - instance unit: 8 channels 48 -> 44.1 kHz with every tuning variant (BASELINE configs[3])  (see cr_instances.hpp)
+#include "cr_instances.hpp"
+
+namespace crk
+{
+
+int specials_multi_a(void *table, int capacity)
+{
+	static const special mine[] = {
+	    make_special<8, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 2>(),     // cfg 4: 8 channels 48 -> 44.1 kHz (5-6 taps; 6 slots on shifted windows)
+	};
+	const int n = (int)(sizeof(mine) / sizeof(mine[0]));
+	if (n > capacity)
+		return -1;
+	memcpy(table, mine, sizeof(mine));
+	return n;
+}
+
+} // namespace crk

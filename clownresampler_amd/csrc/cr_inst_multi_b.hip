@@ -1,0 +1,31 @@
+// cr_inst_multi_b.hip - instance unit: 3 to 16 channels at 44.1 <-> 48 kHz, one instance each  (see cr_instances.hpp)
+#include "cr_instances.hpp"
+
+namespace crk
+{
+
+int specials_multi_b(void *table, int capacity)
+{
+	static const special mine[] = {
+	    make_special_lite<4, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),               // quad, 5.1 and 7.1 at 44.1 <-> 48 kHz
+	    make_special_lite<4, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<6, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),
+	    make_special_lite<6, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<8, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 2>(),            // (the geometry cfg 4's instance measured best with: 512 threads, plain stores)
+	    make_special_lite<3, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),               // and the odd layouts in between (2.1, 5.0, 6.1)
+	    make_special_lite<3, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<5, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),
+	    make_special_lite<7, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),
+	    make_special_lite<7, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite_split<12, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),        // 7.1.4 and 16 channels (the reference's maximum) at 44.1 <-> 48 kHz; (16,5) measured SLOWER than the run-time instance
+	    make_special_lite_split<12, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite_split<16, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	};
+	const int n = (int)(sizeof(mine) / sizeof(mine[0]));
+	if (n > capacity)
+		return -1;
+	memcpy(table, mine, sizeof(mine));
+	return n;
+}
+
+} // namespace crk

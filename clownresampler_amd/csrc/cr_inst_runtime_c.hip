@@ -1,0 +1,30 @@
+// cr_inst_runtime_c.hip - instance unit: run-time slot count, 9 to 16 channels (two lanes per frame)  (see cr_instances.hpp)
+#include "cr_instances.hpp"
+
+namespace
+{
+template <int OUT16>
+poly_fn pick(uint32_t channels, uint32_t mode, uint32_t norm)
+{
+	switch (channels)
+	{
+		case 9: return pick_runtime_split<5, OUT16, 1>(mode, norm);
+		case 10: return pick_runtime_split<5, OUT16>(mode, norm);
+		case 11: return pick_runtime_split<6, OUT16, 1>(mode, norm);
+		case 13: return pick_runtime_split<7, OUT16, 1>(mode, norm);
+		case 15: return pick_runtime_split<8, OUT16, 1>(mode, norm);
+		case 12: return pick_runtime_split<6, OUT16>(mode, norm);
+		case 14: return pick_runtime_split<7, OUT16>(mode, norm);
+		case 16: return pick_runtime_split<8, OUT16>(mode, norm);
+		default: return nullptr;
+	}
+}
+} // namespace
+
+namespace crk
+{
+void *runtime_instance_9_16(uint32_t channels, uint32_t mode, uint32_t norm, int out16)
+{
+	return out16 ? (void *)pick<1>(channels, mode, norm) : (void *)pick<0>(channels, mode, norm);
+}
+} // namespace crk

@@ -1,0 +1,207 @@
+// cr_instances.hpp - the instance tables of the polyphase kernels: which template instances exist, their tuning variants and
+// geometries.  The instances are spread over several translation units (cr_inst_*.hip) so that they compile side by side and a
+// change to one kernel rebuilds only the units that instantiate it; cr_kernels.hip (launch shim) merges what they provide.
+#ifndef CR_INSTANCES_HPP
+#define CR_INSTANCES_HPP
+
+#include "cr_kpoly.hpp"
+#include "cr_kwave.hpp"
+#include "cr_kup.hpp"
+
+namespace
+{
+
+// ---------------------------------------------------------------------------------------------------------
+// Instance table of k_poly
+// ---------------------------------------------------------------------------------------------------------
+typedef void (*poly_fn)(const crhip_poly_launch);
+
+// Tuning variants of the specialised instances: geometry x frames in flight x non-temporal stores.
+// (A swizzled LDS row image, SWZ = 1, measured no better than the plain one and is not instantiated.)
+//   variant = geo + 5 * ui + 10 * nt     geo: 0 (256 thr, 2 vec) 1 (512,1) 2 (512,2) 3 (1024,1) 4 (1024,2); ui: 0/1 -> U = 1/2
+// All k_poly instances use the SDWA arithmetic (ASM = 1); the plain-C form (ASM = 0) is kept in the source as its
+// readable definition, and k_generic is the independent 64-bit implementation the tests compare against the oracle too.
+struct geometry
+{
+	int threads, vecs;
+};
+constexpr geometry GEOMETRY[5] = {{256, 2}, {512, 1}, {512, 2}, {1024, 1}, {1024, 2}};
+constexpr int VARIANTS = 20;
+
+template <int CH, int TT, int MODE, int NORM, int GEO, int ASM, int UI, int NT, int OUT16 = 0>
+constexpr poly_fn instance()
+{
+	return (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[GEO].threads, GEOMETRY[GEO].vecs, ASM, (1 << UI), 0, 0, OUT16, NT>;
+}
+
+template <int CH, int TT, int MODE, int NORM, int V>
+struct variant_table
+{
+	static void fill(poly_fn *t)
+	{
+		t[V] = instance<CH, TT, MODE, NORM, V % 5, 1, (V / 5) % 2, (V / 10) % 2>();
+		variant_table<CH, TT, MODE, NORM, V + 1>::fill(t);
+	}
+};
+template <int CH, int TT, int MODE, int NORM>
+struct variant_table<CH, TT, MODE, NORM, VARIANTS>
+{
+	static void fill(poly_fn *) {}
+};
+
+// specialised (channels, slots, mode, norm) instances; the BASELINE.json configurations
+struct special
+{
+	uint32_t channels, slots, mode, norm;
+	uint32_t default_variant;   // from tools/sweep_variants.py on MI355X (profiles/)
+	poly_fn fn[VARIANTS];
+	poly_fn fn16;               // int16-output form, default variant only
+	poly_fn wave[2];            // k_wave (variants WAVE_VARIANT + {0: non-temporal stores, 1: plain}); nullptr if none
+	poly_fn wave16;             // k_wave, int16 output
+	bool dynamic_tiles;         // k_poly: draw tiles as tickets (measured per instance; see crhip_poly_launch.dynamic_tiles)
+	poly_fn split[4];           // k_poly with two lanes per frame (variants SPLIT_VARIANT + i: geometry {4, 2} x nt {1, 0}); nullptr if none
+	poly_fn up[2];              // k_up (variants UP_VARIANT + {0: 24-bit multiply-add + SDWA add per tap, 1: 64-bit multiply-add chain}); nullptr if none
+	poly_fn up16;               // k_up, int16 output
+	bool lite;                  // one k_poly instance only (the default variant, int32 and int16 forms): every variant id resolves to it
+	uint32_t lite_lanes;        // lite instances: lanes per frame (2: each lane takes half of the channels, as the run-time instances above 8 channels do)
+	uint32_t up_negmask;        // k_up / mad: bit s set = the weights of slot s are <= 0 in every row, clear = >= 0 (checked by the host per plan)
+	poly_fn mad[2];             // the 64-bit multiply-add chain (compute_frame, ASM mode 2): variant MAD_VARIANT = k_poly geometry 3 with non-temporal stores,
+	                            // MAD_VARIANT + 1 = k_wave where the instance has one, else k_poly geometry 3 with plain stores
+};
+
+constexpr uint32_t MAD_VARIANT = 28;    // variant ids 28, 29
+
+constexpr uint32_t UP_VARIANT = 26;     // variant ids 26, 27 select k_up where the instance has one and the plan qualifies
+constexpr int UP_WAVES = 12;
+constexpr uint32_t UP_MAX_WAVE_TILE = 1024;   // output frames per wave-tile (LDS staging)
+
+constexpr uint32_t SPLIT_VARIANT = 22;   // variant ids 22..25
+constexpr int SPLIT_GEO[4] = {4, 2, 4, 2};
+constexpr int SPLIT_NT[4] = {1, 1, 0, 0};
+
+constexpr uint32_t WAVE_VARIANT = 20;   // variant ids 20, 21 select k_wave where the instance has one
+constexpr int WAVE_WAVES = 16, WAVE_NVW = 1, WAVE_ITER = 4;
+
+template <int CH, int TT, int MODE, int NORM, int DV, bool WAVE = false, bool DYNAMIC = false, unsigned UPMASK = 0>
+special make_special()
+{
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, false, 1u, UPMASK, {nullptr, nullptr}};
+	if constexpr (UPMASK != 0 && CH % 2 == 0)
+	{
+		s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 1>;
+		s.mad[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 0>;
+		if constexpr (WAVE)
+			s.mad[1] = (poly_fn)k_wave<CH, TT, MODE, NORM, WAVE_WAVES, WAVE_NVW, WAVE_ITER, 0, 1, 0, (int)(2u | (UPMASK << 8))>;   // where the instance has a k_wave form, 29 is k_wave with the chain
+	}
+	if constexpr (UPMASK != 0)
+	{
+		static_assert(MODE == CRHIP_ROWMODE_UPSAMPLE, "k_up is for pure upsampling");
+		s.up[0] = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 0, 1>;
+		s.up[1] = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 0, 1, 0, 1>;   // the 64-bit chain form
+		s.up16 = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 1, 1, 0, 1>;
+	}
+	variant_table<CH, TT, MODE, NORM, 0>::fill(s.fn);
+	constexpr int KV = DV < 20 ? DV : 13;   // the k_poly variant behind a k_wave default (its fallback and int16 geometry)
+	s.fn16 = instance<CH, TT, MODE, NORM, KV % 5, 1, (KV / 5) % 2, (KV / 10) % 2, 1>();
+	if constexpr (CH % 2 == 0 && CH >= 8)
+	{
+		// two lanes per frame, each with CH / 2 channels
+		s.split[0] = (poly_fn)k_poly<CH / 2, TT, MODE, NORM, GEOMETRY[4].threads, GEOMETRY[4].vecs, 1, 1, 0, 0, 0, 1, 2>;
+		s.split[1] = (poly_fn)k_poly<CH / 2, TT, MODE, NORM, GEOMETRY[2].threads, GEOMETRY[2].vecs, 1, 1, 0, 0, 0, 1, 2>;
+		s.split[2] = (poly_fn)k_poly<CH / 2, TT, MODE, NORM, GEOMETRY[4].threads, GEOMETRY[4].vecs, 1, 1, 0, 0, 0, 0, 2>;
+		s.split[3] = (poly_fn)k_poly<CH / 2, TT, MODE, NORM, GEOMETRY[2].threads, GEOMETRY[2].vecs, 1, 1, 0, 0, 0, 0, 2>;
+	}
+	if constexpr (WAVE)
+	{
+		s.wave[0] = (poly_fn)k_wave<CH, TT, MODE, NORM, WAVE_WAVES, WAVE_NVW, WAVE_ITER, 0, 1>;
+		s.wave[1] = (poly_fn)k_wave<CH, TT, MODE, NORM, WAVE_WAVES, WAVE_NVW, WAVE_ITER, 0, 0>;
+		s.wave16 = (poly_fn)k_wave<CH, TT, MODE, NORM, WAVE_WAVES, WAVE_NVW, WAVE_ITER, 1, 1>;
+	}
+	return s;
+}
+
+// A specialised instance WITHOUT the tuning variants: one k_poly (compile-time slot count, pipelined LDS reads) at the
+// geometry the run-time-slot instance of that channel count uses, non-temporal stores, int32 and int16 forms.  For the common
+// surround layouts, where the run-time-slot loop leaves 10-20 % behind (profiles/r01_channel_table.log).
+template <int CH, int TT, int MODE, int NORM, int DV = (CH <= 4 ? 13 : 14)>   // default: (1024 threads, 1 or 2 vectors per thread), one frame in flight, non-temporal stores
+special make_special_lite()
+{
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 1u, 0u, {nullptr, nullptr}};
+	const poly_fn fn = instance<CH, TT, MODE, NORM, DV % 5, 1, (DV / 5) % 2, (DV / 10) % 2>();
+	for (int v = 0; v < VARIANTS; ++v)
+		s.fn[v] = fn;
+	s.fn16 = instance<CH, TT, MODE, NORM, DV % 5, 1, (DV / 5) % 2, (DV / 10) % 2, 1>();
+	return s;
+}
+
+// ... and with two lanes per frame (CHT channels in all, CHT / 2 per lane), at the geometry of the run-time instances above 8 channels
+template <int CHT, int TT, int MODE, int NORM>
+special make_special_lite_split()
+{
+	constexpr int DV = 14;   // (1024 threads, 2 vectors per thread), one frame in flight, non-temporal stores
+	constexpr int T = GEOMETRY[DV % 5].threads, V = GEOMETRY[DV % 5].vecs;
+	special s = {CHT, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 2u, 0u, {nullptr, nullptr}};
+	const poly_fn fn = (poly_fn)k_poly<CHT / 2, TT, MODE, NORM, T, V, 1, 1, 0, 0, 0, 1, 2>;
+	for (int v = 0; v < VARIANTS; ++v)
+		s.fn[v] = fn;
+	s.fn16 = (poly_fn)k_poly<CHT / 2, TT, MODE, NORM, T, V, 1, 1, 0, 0, 1, 1, 2>;
+	return s;
+}
+
+
+// run-time slot count: every channel count 1..8 and the even counts 10..16 (the reference's maximum,
+// CLOWNRESAMPLER_MAXIMUM_CHANNELS, clownresampler.h:462), both row modes, both normalisations, both output forms.  One
+// geometry per channel count - 1024 threads; 16 KiB tiles for up to 4 channels, 32 KiB above (an 8-channel frame is 16
+// bytes) - SDWA arithmetic, one frame in flight, non-temporal stores.  Above 8 channels a frame is shared by TWO neighbouring
+// lanes (k_poly's SPLIT), each taking half of its channels: the per-lane code is that of 5..8 channels.
+constexpr int runtime_geo(int channels)
+{
+	return channels <= 4 ? 3 : 4;   // (512 threads x 2 vectors, which the specialised 8-channel instances prefer, measured 10-20 % slower here)
+}
+constexpr int runtime_split(int channels)
+{
+	return channels > 8 ? 2 : 1;
+}
+
+template <int CH, int OUT16>
+poly_fn pick_runtime(uint32_t mode, uint32_t norm)
+{
+	constexpr int GEO = runtime_geo(CH);
+	if (norm == CRHIP_NORM_S31)
+		return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, GEO, 1, 0, 1, OUT16>()
+		                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, GEO, 1, 0, 1, OUT16>();
+	return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, GEO, 1, 0, 1, OUT16>()
+	                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, GEO, 1, 0, 1, OUT16>();
+}
+
+// two lanes per frame, HALF channels each (run-time slot count, geometry 4); PH = 1: 2 * HALF - 1 channels (see k_poly)
+template <int HALF, int OUT16, int PH = 0>
+poly_fn pick_runtime_split(uint32_t mode, uint32_t norm)
+{
+	constexpr int T = GEOMETRY[runtime_geo(16)].threads, V = GEOMETRY[runtime_geo(16)].vecs;
+	if (norm == CRHIP_NORM_S31)
+		return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, T, V, 1, 1, 0, 0, OUT16, 1, 2, PH>
+		                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, T, V, 1, 1, 0, 0, OUT16, 1, 2, PH>;
+	return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, T, V, 1, 1, 0, 0, OUT16, 1, 2, PH>
+	                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, T, V, 1, 1, 0, 0, OUT16, 1, 2, PH>;
+}
+
+
+} // namespace
+
+// what the instance units provide (external linkage; `special` is declared identically in every unit)
+namespace crk
+{
+int specials_headline(void *table, int capacity);   // cr_inst_headline.hip: stereo / mono 3-lobe instances of BASELINE configs[1] / [4] + ablations
+int specials_long(void *table, int capacity);       // cr_inst_long.hip: the 8-lobe (15- and 17-slot) instances, BASELINE configs[2]
+int specials_multi_a(void *table, int capacity);    // cr_inst_multi_a.hip: 8 channels 48 -> 44.1 kHz with every tuning variant, BASELINE configs[3]
+int specials_multi_b(void *table, int capacity);    // cr_inst_multi_b.hip: 3 to 16 channels at 44.1 <-> 48 kHz, one instance each
+int specials_down(void *table, int capacity);       // cr_inst_down.hip: mono / stereo at the usual downsampling ratios
+void *ablation_instance(int abl);                   // cr_inst_headline.hip / cr_inst_long.hip (abl 8)
+void *ablation_instance_long(int abl);
+void *runtime_instance_1_4(uint32_t channels, uint32_t mode, uint32_t norm, int out16);     // cr_inst_runtime_a.hip
+void *runtime_instance_5_8(uint32_t channels, uint32_t mode, uint32_t norm, int out16);     // cr_inst_runtime_b.hip
+void *runtime_instance_9_16(uint32_t channels, uint32_t mode, uint32_t norm, int out16);    // cr_inst_runtime_c.hip
+}
+
+#endif // CR_INSTANCES_HPP

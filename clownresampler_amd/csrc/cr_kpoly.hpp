@@ -1,0 +1,411 @@
+// cr_kpoly.hpp - k_poly: polyphase rows in LDS, workgroup tiles behind LDS-DMA (see cr_kernels.hip for the overview).
+#ifndef CR_KPOLY_HPP
+#define CR_KPOLY_HPP
+
+#include "cr_device.hpp"
+
+namespace
+{
+
+// ---------------------------------------------------------------------------------------------------------
+// k_poly
+// ---------------------------------------------------------------------------------------------------------
+// CH        channels (compile time)
+// TT        slots when > 0 (fully unrolled, weights in registers); 0 = run-time slot count
+// MODE      row-index formula
+// NORM      final normalisation form (CRHIP_NORM_*)
+// NTHREADS  workgroup size
+// NV        16-byte input vectors each thread moves per tile (LDS tile buffer = NV * 16 * NTHREADS bytes)
+// ASM       1 = SDWA tap arithmetic, 0 = what the compiler makes of the C expression
+// U         output frames a lane works on at once (independent instruction streams to cover LDS latency)
+// SWZ       1 = the LDS image of the rows is swizzled (a.swizzle), 0 = plain (a.swizzle must be 0)
+// ABL       0 in every shipped instance.  Timing-only ablations (WRONG results, reachable only through the debug
+//           launch flag of tools/): 1 = no output stores, 2 = no input DMA, 3 = neither, 4 = DMA + stores but no arithmetic
+// OUT16     1 = clamp to +-0x7FFF and store int16 (opt-in extension), 0 = the reference's unclamped int32
+// NT        1 = non-temporal output stores
+// SPLIT     lanes per frame: CH is then the channels of ONE lane and a frame has CH * SPLIT channels (8-channel
+//           frames as two lanes of 4: every store instruction of a wave is one contiguous 1 KiB)
+// PH        1 = the frame has CH * SPLIT - 1 channels (odd totals above 8, SPLIT == 2): the second lane's last channel is a
+//           PHANTOM - it multiplies whatever follows the frame in the window and its result is never stored
+template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0, int OUT16 = 0, int NT = 0, int SPLIT = 1, int PH = 0>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR_BUDGET))) void k_poly(const crhip_poly_launch a)
+{
+	constexpr unsigned CHT = CH * SPLIT - PH;             // channels of a frame
+	constexpr unsigned FB = CHT * 2;                      // bytes per input frame (all channels)
+	constexpr unsigned FBL = CH * 2;                      // bytes of one lane's share of a frame
+	constexpr unsigned TILE_BYTES = NV * 16u * NTHREADS;
+
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+	const unsigned tid = threadIdx.x;
+	unsigned stamp_cycles = 0;
+	if constexpr (ABL == 6)
+	{
+		// diagnostic build only: in-kernel clock = cycles / (ticks / 100 MHz)  (MI355X_MICROARCH.md, DVFS give-back item 6).
+		// 32 bits of the cycle counter, and the start tick goes out at once: the instance has to stay at or below 96 SGPRs
+		// to be the same kernel as the one it stands for (see the note at `phase` below).
+		stamp_cycles = (unsigned)__builtin_amdgcn_s_memtime();
+		if (tid == 0 && a.debug_stamps != nullptr)
+			a.debug_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+	}
+	const unsigned rows_bytes = a.plane_rows * a.row_stride * 4u;   // planes of plane_rows x 16 bytes
+	const int *rows = reinterpret_cast<const int *>(smem);
+	unsigned char *tiles = smem + rows_bytes;
+
+	// Tiles of tile_frames output frames are handed out in order: the first gridDim.x tiles by workgroup number, every
+	// further one by an atomic ticket (a.d_tickets[0]).  (1) At any moment the resident workgroups stream ONE compact
+	// window of the input and of the output, like a flat grid would, instead of gridDim.x far-apart streams: worth ~10 %
+	// of HBM throughput for this read:write mix (tools/microbench/streambench.hip).  (2) Workgroups do not run at the
+	// same speed - with equal shares the median workgroup finished at 49 us of a 64 us kernel - so whoever is free takes
+	// the next tile.  The ticket of the tile AFTER the next one is drawn while the current tile is computed and handed to
+	// the other waves through an LDS mailbox, so neither the atomic's latency nor the DMA of the next tile is exposed.
+	// The last workgroup to finish zeroes the two counters again: the slot is clean for the next launch (also for a
+	// hipGraph replay of this one).
+	const uint64_t NT64 = a.tile_frames;
+	const uint64_t n_tiles = (a.n_out + NT64 - 1) / NT64;
+	if (blockIdx.x >= n_tiles)
+		return;
+	volatile unsigned *mailbox = reinterpret_cast<volatile unsigned *>(smem + rows_bytes + 2u * TILE_BYTES);
+
+	const uint64_t in_base = reinterpret_cast<uint64_t>(a.d_in);
+	const uint64_t in_end = in_base + a.in_valid_bytes;
+	const unsigned T = (TT > 0 ? (unsigned)TT : a.slots) + a.window_extra;   // frames of a tap window, the largest shift included
+
+	// Starts the LDS-DMA of the input window of the tile that begins at output frame jt: 16-byte buffer loads that
+	// land directly in `tile` (no register staging, no ds_write), each wave filling a contiguous 1 KiB piece per
+	// instruction.  Returns the byte offset of the window's first frame inside the (16-byte aligned) tile image.
+	// The loads are NOT waited for here.
+	const unsigned wave_first = __builtin_amdgcn_readfirstlane(tid & ~63u);
+	auto fetch = [&](uint64_t jt, unsigned n, unsigned char *tile) -> unsigned {
+		const uint64_t pos = a.pos0 + jt * (uint64_t)a.increment;
+		const uint64_t first_byte = in_base + ((pos >> 16) + a.first_slot) * FB;
+		const uint64_t aligned = first_byte & ~(uint64_t)15;
+		const unsigned shift = (unsigned)(first_byte - aligned);
+		// bytes of the window: frames [0, last_rel + T) where last_rel is the last frame's integer advance
+		const unsigned last_rel = (unsigned)(((pos & 0xFFFFu) + (uint64_t)(n - 1) * a.increment) >> 16);
+		uint64_t want = (uint64_t)shift + (uint64_t)(last_rel + T) * FB;
+		uint64_t avail = in_end > aligned ? in_end - aligned : 0;
+		if (want > avail)
+			want = avail;
+		// The descriptor's range check works on whole dwords: a window that ends on a 2-byte boundary (odd channel
+		// counts, mono) would lose its last sample.  Rounding up stays inside the same aligned dword, hence inside the
+		// same page as the last valid sample; the extra half-dword only ever meets a zero weight.
+		want = (want + 3u) & ~(uint64_t)3u;
+		// wave-uniform descriptor: base = aligned window start, num_records = bytes we may touch (loads beyond it
+		// deliver zeros, which only ever meet zero weights)
+		const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)aligned);
+		const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(aligned >> 32));
+		const unsigned rec = __builtin_amdgcn_readfirstlane((unsigned)want);
+		const __amdgpu_buffer_rsrc_t rsrc =
+		    __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)rec, 0x00020000);
+#pragma unroll
+		for (int v = 0; v < NV; ++v)
+			if (!(ABL == 2 || ABL == 3) || a.n_out == 1)
+			__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(tile + (v * NTHREADS + wave_first) * 16u), 16,
+			                                         (int)((v * NTHREADS + tid) * 16u), 0, 0, 0);
+		return shift;
+	};
+
+	// vmcnt counts loads, LDS-DMA and stores together, in issue order.  The DMA of the NEXT tile is issued before
+	// this tile's stores, so waiting until only this tile's stores are outstanding means the DMA has landed, while
+	// the stores stay in flight across the barrier.  The count must be a literal: full tiles of 4, 2 or 1 groups run
+	// as straight-line code for that reason; a ragged tile drains everything.
+	constexpr unsigned GROUP = NTHREADS * U;
+	constexpr int ADJ = 0;   // a lane's U frames are NTHREADS apart: every store instruction is coalesced across the wave
+	constexpr int STORES_PER_GROUP = PH ? U * (OUT16 ? CH : stores_of_ints_dword_aligned(CH - 1) + 1)
+	                                    : U * (OUT16 ? (CH % 2 == 0 ? stores_of_ints(CH / 2) : CH) : stores_of_ints(CH));
+
+	// Tickets.  One global counter would serialise: a single word sustains ~88 atomic draws per microsecond on this
+	// chip (MI355X_MICROARCH.md, "dequeue") and a 10-minute stereo launch draws 7,000 of them - measured 92 us instead
+	// of 64.  So there are LANES counters (each on its own 128-byte line); the tiles are dealt round-robin to LANES
+	// sequences, workgroup b belongs to sequence b % LANES (workgroups b and b + 8 are observed to share an XCD, so with
+	// 8 lanes a sequence is mostly one XCD's - a speed matter only), starts with the tile of its own number and then
+	// draws from its sequence's counter.  Every sequence has at least one workgroup (LANES <= gridDim.x), so every tile
+	// is computed wherever the workgroups land.  Only thread 0 of the workgroup draws.
+	const unsigned LANES = gridDim.x < 8u ? gridDim.x : 8u;
+	const unsigned lane_id = blockIdx.x % LANES;
+	const uint64_t lane_tiles = (n_tiles - lane_id + LANES - 1u) / LANES;            // tiles of this sequence
+	const unsigned lane_groups = (gridDim.x - lane_id + LANES - 1u) / LANES;          // its workgroups = its pre-assigned tiles
+	unsigned *lane_counter = a.d_tickets + lane_id * 32u;
+	// (Helping other sequences out once the own one is exhausted was tried: deciding where to draw needs the counter's
+	// value NOW, and a dependent load at the top of every tile stalls wave 0 - and with it the workgroup - for a memory
+	// round trip per tile: 148 us instead of 64.  The draw below has no consumer until the end of the tile.)
+	auto draw = [&]() -> unsigned {
+		const uint64_t k = (uint64_t)lane_groups + __hip_atomic_fetch_add(lane_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return k < lane_tiles ? (unsigned)(lane_id + LANES * k) : 0xFFFFFFFFu;
+	};
+	// a workgroup that has drawn a ticket beyond its sequence is done drawing; the last such workgroup zeroes the slot
+	auto retire = [&]() {
+		if (tid == 0)
+		{
+			unsigned *finished = a.d_tickets + 8u * 32u;
+			if (__hip_atomic_fetch_add(finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u)
+			{
+				for (unsigned c = 0; c < 8u; ++c)
+					__hip_atomic_store(a.d_tickets + c * 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	};
+
+	uint64_t tile_index = blockIdx.x;
+	uint64_t jt = tile_index * NT64;
+	unsigned n = (unsigned)((a.n_out - jt < NT64) ? (a.n_out - jt) : NT64);
+	unsigned shift = fetch(jt, n, tiles);
+	// a.dynamic_tiles == 0: plain round-robin (tile + gridDim.x), no tickets - for configurations whose tiles are so
+	// small that a ticket and a mailbox hand-over per tile cost more than the imbalance they remove (8-channel frames)
+	const bool dynamic = a.dynamic_tiles != 0;
+	if (dynamic && tid == 0)
+		mailbox[0] = draw();
+	// stage the polyphase rows once per workgroup (L2-resident after the first workgroups) - AFTER the first tile's DMA and
+	// the first ticket are on their way, so that the three round trips of a workgroup's start overlap
+	{
+		const unsigned nvec = rows_bytes / 16u;
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.d_rows);
+		u32x4 *dst = reinterpret_cast<u32x4 *>(smem);
+		for (unsigned i = tid; i < nvec; i += NTHREADS)
+			dst[i] = src[i];
+	}
+	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+	__syncthreads();   // rows staged (plain stores to LDS), first tile landed and first ticket posted, for every wave
+	uint64_t next_index = dynamic ? __builtin_amdgcn_readfirstlane(mailbox[0]) : tile_index + gridDim.x;   // wave-uniform
+
+	// diagnostic instance (ABL == 6) only: where a tile's cycles go, summed over the tiles of this workgroup as seen by
+	// wave 0 - [0] issuing the next tile's DMA + ticket, [1] arithmetic + stores, [2] waiting for the DMA (vmcnt),
+	// [3] waiting at the barrier (+ mailbox)
+	// The sums live in VGPRs on purpose: as wave-uniform 64-bit values they took the instance from 80 to 106 SGPRs, and above
+	// 96 SGPRs a SIMD holds 7 waves instead of 8 - one 1024-thread workgroup per CU instead of two, i.e. a different kernel.
+	unsigned phase[4] = {0, 0, 0, 0};
+	unsigned t_mark = 0;
+	auto mark = [&](int which) {
+		if constexpr (ABL == 6)
+		{
+			__builtin_amdgcn_sched_barrier(0);
+			const unsigned now = (unsigned)__builtin_amdgcn_s_memtime();
+			__builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): s_memtime returns through the scalar data path
+			if (which >= 0)
+				asm volatile("v_add_u32 %0, %0, %1" : "+v"(phase[which]) : "s"(now - t_mark));
+			t_mark = now;
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	};
+	mark(-1);
+
+	for (unsigned it = 0;; ++it)
+	{
+		const unsigned char *tile = tiles + (it & 1u) * TILE_BYTES;
+		const bool more = next_index < n_tiles;
+		const uint64_t jn = next_index * NT64;
+		unsigned n_next = 0, shift_next = 0;
+		unsigned ticket = 0;
+
+		if (more)
+		{
+			// the other buffer was last read in the previous iteration, which every wave has left (barrier below)
+			n_next = (unsigned)((a.n_out - jn < NT64) ? (a.n_out - jn) : NT64);
+			shift_next = fetch(jn, n_next, tiles + ((it + 1u) & 1u) * TILE_BYTES);
+			if (dynamic && tid == 0)
+				ticket = draw();   // for the tile after the next one; posted below, just before the barrier
+		}
+		mark(0);
+
+		const uint64_t pos = a.pos0 + jt * (uint64_t)a.increment;
+		const unsigned frac0 = (unsigned)(pos & 0xFFFFu);
+		// lane-frames: a frame shared by SPLIT lanes counts SPLIT times; lane-frame L is lane share L % SPLIT of frame L / SPLIT
+		const unsigned nl = n * SPLIT;
+		int *out_tile = reinterpret_cast<int *>(a.d_out) + jt * CHT;             // OUT16 == 0
+		short *out_tile16 = reinterpret_cast<short *>(a.d_out) + jt * CHT;       // OUT16 == 1
+		// phantom instances: lane-frame L is share L % 2 of frame L / 2; the shares are CH and CH - 1 channels, stored sample by
+		// sample (an odd channel count leaves nothing wider aligned), the last one only by the first lane of a pair - one store
+		// instruction per wave either way, so the counted vmcnt below holds
+		auto store_phantom = [&](unsigned L, const int *v) {
+			const size_t at = (size_t)(L >> 1) * CHT + (L & 1u) * CH;
+			if constexpr (OUT16)
+			{
+#pragma unroll
+				for (int c = 0; c < CH; ++c)
+				{
+					if (c == CH - 1 && (L & 1u))
+						break;
+					out_tile16[at + c] = (short)clamp_s16(v[c]);
+				}
+			}
+			else
+			{
+				store_ints_dword_aligned<CH - 1, NT>(out_tile + at, v);
+				if (!(L & 1u))
+				{
+					if constexpr (NT)
+						__builtin_nontemporal_store(v[CH - 1], out_tile + at + CH - 1);
+					else
+						out_tile[at + CH - 1] = v[CH - 1];
+				}
+			}
+		};
+		const unsigned char *base = tile + shift + (tid % SPLIT) * FBL;
+
+		// One group = NTHREADS * U frames: U independent frames per lane, no bounds checks.
+		// Positions are formed as (lane part, once per tile) + (group part, wave-uniform, scalar unit): one VALU add per
+		// frame instead of a 24-bit multiply-add; same for the output address, which goes out as SGPR base + lane offset.
+		const unsigned lane_rel = __umul24(tid / SPLIT, a.increment) + frac0;
+		auto group = [&](unsigned g) {
+			int outv[U * CH];
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+			{
+				const unsigned first = g + u * NTHREADS;   // wave-uniform: frame of lane 0 of the workgroup
+				if constexpr (ABL == 4)
+				{
+#pragma unroll
+					for (int c = 0; c < CH; ++c)
+						outv[u * CH + c] = (int)(first + tid);
+				}
+				else
+					one_frame<CH, TT, MODE, NORM, ASM, SWZ, SPLIT, PH>(a, rows, base, lane_rel + (first / SPLIT) * a.increment, outv + u * CH);
+			}
+			if constexpr (ABL == 1 || ABL == 3)
+			{
+				// keep the arithmetic alive without the stores (cdna_hip_programming.md rule 17)
+#pragma unroll
+				for (int c = 0; c < U * CH; ++c)
+					asm volatile("" ::"v"(outv[c]));
+				return;
+			}
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+			{
+				if constexpr (PH)
+				{
+					store_phantom(g + u * NTHREADS + tid, outv + u * CH);
+				}
+				else if constexpr (OUT16)
+				{
+					short *group_out = out_tile16 + (size_t)(g + u * NTHREADS) * CH;   // uniform
+					store_shorts<CH, NT>(group_out + tid * CH, outv + u * CH);
+				}
+				else
+				{
+					int *group_out = out_tile + (size_t)(g + u * NTHREADS) * CH;   // uniform
+					store_ints<CH, NT>(group_out + tid * CH, outv + u * CH);
+				}
+			}
+		};
+
+		// Full tiles of 4, 2 or 1 groups as straight-line code (see the vmcnt note above).  Specialised instances
+		// (TT > 0) run the frames of a tile as a software pipeline: the LDS reads of frame i+1 are issued before the
+		// arithmetic of frame i.
+		auto run_groups = [&](auto groups_tag) {
+			constexpr int G = decltype(groups_tag)::value;
+			constexpr int N = G * U;   // frames per lane in this tile
+
+			if constexpr (TT > 0 && (ABL == 0 || ABL == 6))
+			{
+				FrameData<CH, TT> d[2];
+				fetch_frame<CH, TT, MODE, SWZ, SPLIT>(a, rows, base, lane_rel, d[0]);
+#pragma unroll
+				for (int i = 0; i < N; ++i)
+				{
+					const unsigned first = (unsigned)(i / U) * GROUP + (unsigned)(i % U) * NTHREADS;   // uniform
+					int outv[CH];
+
+					if (i + 1 < N)
+					{
+						const unsigned next_first = (unsigned)((i + 1) / U) * GROUP + (unsigned)((i + 1) % U) * NTHREADS;
+						fetch_frame<CH, TT, MODE, SWZ, SPLIT>(a, rows, base, lane_rel + (next_first / SPLIT) * a.increment, d[(i + 1) & 1]);
+					}
+					__builtin_amdgcn_sched_barrier(0);   // keep the reads above the arithmetic below
+					compute_frame<CH, TT, NORM, ASM>(d[i & 1], outv);
+
+					if constexpr (OUT16)
+						store_shorts<CH, NT>(out_tile16 + (size_t)first * CH + tid * CH, outv);
+					else
+						store_ints<CH, NT>(out_tile + (size_t)first * CH + tid * CH, outv);
+					__builtin_amdgcn_sched_barrier(0);
+				}
+			}
+			else
+			{
+#pragma unroll
+				for (int gi = 0; gi < G; ++gi)
+					group((unsigned)gi * GROUP);
+			}
+
+			mark(1);
+			if constexpr (G * STORES_PER_GROUP <= 63)
+				asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G * STORES_PER_GROUP) : "memory");
+			else
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			mark(2);
+		};
+
+		if (nl == 4u * GROUP)
+			run_groups(std::integral_constant<int, 4>());
+		else if (nl == 2u * GROUP)
+			run_groups(std::integral_constant<int, 2>());
+		else if (nl == GROUP)
+			run_groups(std::integral_constant<int, 1>());
+		else
+		{
+			// ragged tile (only the stream's last tile can be one)
+			const unsigned n_full = nl - nl % GROUP;
+			unsigned g = 0;
+			for (; g < n_full; g += GROUP)
+				group(g);
+			for (unsigned jl = g + tid; jl < nl; jl += NTHREADS)
+			{
+				int outv[CH];
+				one_frame<CH, TT, MODE, NORM, ASM, SWZ, SPLIT, PH>(a, rows, base, __umul24(jl / SPLIT, a.increment) + frac0, outv);
+				if constexpr (PH)
+					store_phantom(jl, outv);
+				else if constexpr (OUT16)
+					store_shorts<CH, NT>(out_tile16 + (size_t)jl * CH, outv);
+				else
+					store_ints<CH, NT>(out_tile + (size_t)jl * CH, outv);
+			}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+
+		if constexpr (ABL == 6)
+		{
+			// per tile of every workgroup (first 32): tile index << 48 | tick at which wave 0 had issued the tile's last store
+			if (tid == 0 && a.debug_stamps != nullptr && it < 32u)
+				a.debug_stamps[4 * 4096 + 4 * 64 + 32 * blockIdx.x + it] = (tile_index << 48) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFFFFFull);
+		}
+		if (!more)
+		{
+			if constexpr (ABL == 6)
+			{
+				if (tid == 0 && a.debug_stamps != nullptr)
+				{
+					// per workgroup: {shader cycles of its lifetime, start tick, end tick, XCC id}
+					a.debug_stamps[4 * blockIdx.x + 0] = (unsigned)__builtin_amdgcn_s_memtime() - stamp_cycles;
+					a.debug_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+					a.debug_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(63508 /* HW_REG_XCC_ID, bits 0..3 */) & 0xF;
+					if (blockIdx.x < 64u)
+						for (int k = 0; k < 4; ++k)
+							a.debug_stamps[4 * 4096 + 4 * blockIdx.x + k] = phase[k];
+				}
+			}
+			if (dynamic)
+				retire();
+			break;
+		}
+
+		// every wave's share of the next tile has landed once every wave is past its wait; the mailbox has two slots,
+		// used alternately, so that a slot is never rewritten before every wave has read it
+		if (dynamic && tid == 0)
+			mailbox[(it + 1u) & 1u] = ticket;
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		mark(3);
+		tile_index = next_index;
+		jt = jn;
+		n = n_next;
+		shift = shift_next;
+		next_index = dynamic ? __builtin_amdgcn_readfirstlane(mailbox[(it + 1u) & 1u]) : tile_index + gridDim.x;
+	}
+}
+
+} // namespace
+
+#endif // CR_KPOLY_HPP

@@ -644,7 +644,7 @@ static uint32_t current_variant(void)
 	{
 		const char *e = getenv("CLOWNRESAMPLER_AMD_VARIANT");
 		g_variant = (e != NULL && *e != '\0') ? atoi(e) : CR_DEFAULT_VARIANT;
-		if (g_variant < 0 || (g_variant >= crhip_poly_variants() && !(g_variant >= 1000 && g_variant < 1010)))
+		if (g_variant < 0 || (g_variant >= crhip_poly_variants() && !(g_variant >= 1000 && g_variant <= 1010)))
 			g_variant = CR_DEFAULT_VARIANT;
 	}
 	return (uint32_t)g_variant;
@@ -1644,7 +1644,7 @@ uint32_t ClownResamplerAMD_PlanRowOf(const ClownResamplerAMD_Plan *plan, uint32_
 
 void ClownResamplerAMD_DebugSetVariant(int variant)
 {
-	g_variant = ((variant >= 0 && variant < crhip_poly_variants()) || (variant >= 1000 && variant < 1010)) ? variant : CR_DEFAULT_VARIANT;
+	g_variant = ((variant >= 0 && variant < crhip_poly_variants()) || (variant >= 1000 && variant <= 1010)) ? variant : CR_DEFAULT_VARIANT;
 }
 
 void ClownResamplerAMD_DebugForceGenericKernel(int on)

@@ -96,9 +96,17 @@ special make_special()
 	if constexpr (UPMASK != 0)
 	{
 		static_assert(MODE == CRHIP_ROWMODE_UPSAMPLE, "k_up is for pure upsampling");
-		s.up[0] = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 0, 1>;
-		s.up[1] = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 0, 1, 0, 1>;   // the 64-bit chain form
-		s.up16 = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 1, 1, 0, 1>;
+		s.up[0] = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 0, 1, 0, 1>;   // round 1's form (64-bit chain, bias registers): kept for comparison
+		if constexpr (CH == 2)
+		{
+			s.up[1] = (poly_fn)k_up2<CH, TT, NORM, UPMASK, UP_WAVES, 0, 1>;
+			s.up16 = (poly_fn)k_up2<CH, TT, NORM, UPMASK, UP_WAVES, 1, 1>;
+		}
+		else
+		{
+			s.up[1] = s.up[0];
+			s.up16 = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 1, 1, 0, 1>;
+		}
 	}
 	variant_table<CH, TT, MODE, NORM, 0>::fill(s.fn);
 	constexpr int KV = DV < 20 ? DV : 13;   // the k_poly variant behind a k_wave default (its fallback and int16 geometry)

@@ -338,11 +338,11 @@ static uint32_t resolve_variant(const special *sp, uint32_t variant, uint32_t ou
 		return 0u;
 	if (sp->lite)
 		return sp->default_variant;
-	if (variant == 1008u)
+	if (variant >= 1008u && variant <= 1010u)
 		return sp->up[0] != nullptr ? UP_VARIANT : (sp->wave[0] != nullptr ? WAVE_VARIANT : 13u);   // diagnostic k_up instance
 	if (variant == 1007u && sp->wave[0] != nullptr)
 		return WAVE_VARIANT;                                  // diagnostic k_wave instance: k_wave geometry
-	if (variant >= 1000u && variant < 1010u)
+	if (variant >= 1000u && variant < 1008u)
 		return 3u;                                            // diagnostic k_poly instances: headline geometry
 	if (variant >= MAD_VARIANT + 2u)
 		variant = sp->default_variant;
@@ -489,8 +489,8 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 	if (sp != nullptr && v >= UP_VARIANT)
 	{
 		*geo = 200u;
-		if (launch->variant == 1008u && !launch->out_s16 && launch->channels == 2 && launch->slots == 15)
-			return ablation_instance(8);
+		if (launch->variant >= 1008u && launch->variant <= 1010u && !launch->out_s16 && launch->channels == 2 && launch->slots == 15)
+			return ablation_instance((int)(launch->variant - 1000u));
 		return launch->out_s16 ? sp->up16 : sp->up[v - UP_VARIANT];
 	}
 
@@ -515,7 +515,7 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 		fn = sp != nullptr ? sp->fn[v] : pick_runtime_channels<0>(launch->channels, launch->row_mode, launch->norm_mode);
 
 	// debug: variant 1000 + k selects timing-only ablation k of the headline instance (results are wrong by design)
-	if (sp != nullptr && launch->variant >= 1000u && launch->variant < 1010u && launch->channels == 2 && launch->slots == 5)
+	if (sp != nullptr && launch->variant >= 1000u && launch->variant < 1008u && launch->channels == 2 && launch->slots == 5)
 		fn = ablation_instance((int)(launch->variant - 1000u));
 
 	*geo = sp != nullptr ? v % 5 : (uint32_t)runtime_geo((int)launch->channels);

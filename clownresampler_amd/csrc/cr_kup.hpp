@@ -416,6 +416,413 @@ __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 	finish();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_up2 - the input-stationary kernel, second form.  Same ownership as k_up (a lane owns one INPUT position of a wave-tile
+// and produces all of its output frames; results staged through LDS, coalesced stores; wave-autonomous), different arithmetic
+// and bookkeeping:
+//
+//   * The tap is  P = v_mad_i64_i32(S, W, P)  on a 64-bit accumulator pair P = {lo, hi} with
+//         S  = sample * 32768, negated for the slots whose weights are <= 0      (once per window, one multiply)
+//         W  = 2 * |weight|                                                      (once per workgroup, while the rows are staged)
+//         lo = S >> 31  (all ones where S < 0)                                   (once per window; one plain move per tap re-arms it)
+//     S * W = sample * weight * 65536 exactly (the two sign flips cancel), so the product's integer part lands in `hi` and its
+//     16 fraction bits in the top of `lo`.  With every W >= 0 the product is negative exactly where S is, and there the all-ones
+//     `lo` makes the carry into `hi` round the quotient up: hi += trunc(sample * weight / 65536), C's division
+//     (clownresampler.h:1020 via :625), for negative and positive products alike ((p << 16) + 0xFFFFFFFF carries iff the
+//     fraction bits of p are not all zero).  No per-sample sign work in the frame loop: a move and a multiply-add per tap and
+//     channel, against 4 VALU of the per-output-frame kernels.
+//   * The final (acc * reciprocal) / 32768 (clownresampler.h:1033) is one more 64-bit multiply-add and a funnel shift.
+//   * The frames of a lane run under a WAVE-UNIFORM trip count (floor(65536 / increment), plus one only for waves in which
+//     some position has the extra frame), with one predicate for the staging store - no per-lane loop control - and the
+//     lane's first frame is found once per wave-tile (its end is the next lane's start).
+//   * The copy-out of the staged frames runs on a wave-uniform base with one lane offset: no address arithmetic per vector.
+// ---------------------------------------------------------------------------------------------------------
+template <int CH, int TT, int NORM, unsigned NEGMASK, int WAVES, int OUT16, int NT, int ABL = 0>
+__global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
+{
+	static_assert(CH == 2, "k_up2 is written for stereo (one packed dword per input frame, two accumulator pairs)");
+	constexpr unsigned NTHREADS = WAVES * 64u;
+	constexpr unsigned FB = CH * 2;                // bytes per input frame
+	constexpr unsigned BUF = 1024u;                // bytes per window buffer: one 16-byte DMA per lane
+	constexpr unsigned UNIT = OUT16 ? CH * 2 : CH * 4;   // bytes per output frame
+	constexpr int RS = (TT + 1 + 3) & ~3;
+	static_assert((63 + TT) * FB + 16 <= BUF, "the window of 64 input positions must fit one DMA piece");
+	static_assert(UNIT % 4 == 0, "output frames are moved as dwords");
+	constexpr unsigned VEC = UNIT % 8 == 0 ? 8 : 4;   // bytes per lane per store
+
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+	const unsigned tid = threadIdx.x;
+	const unsigned lane = tid & 63u;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+	// diagnostic instances only (ABL: 6 = clock stamps and where wave 0's cycles go - [0] tile setup + window unpack, [1] the
+	// frames, [2] staged results to global memory, [3] waiting for the next window; timing-only, WRONG results: 1 = no global
+	// stores, 2 = no frames)
+	unsigned long long stamp_cycles = 0, stamp_ticks = 0, phase[4] = {0, 0, 0, 0}, t_mark = 0;
+	if constexpr (ABL == 6)
+	{
+		stamp_cycles = __builtin_amdgcn_s_memtime();
+		stamp_ticks = __builtin_amdgcn_s_memrealtime();
+	}
+	auto mark = [&](int which) {
+		if constexpr (ABL == 6)
+		{
+			__builtin_amdgcn_sched_barrier(0);
+			const unsigned long long now = __builtin_amdgcn_s_memtime();
+			__builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): s_memtime returns through the scalar data path
+			if (which >= 0)
+				phase[which] += now - t_mark;
+			t_mark = now;
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	};
+	auto finish = [&]() {
+		if constexpr (ABL == 6)
+		{
+			if (lane == 0 && wave == 0 && a.debug_stamps != nullptr)
+			{
+				a.debug_stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - stamp_cycles;
+				a.debug_stamps[4 * blockIdx.x + 1] = stamp_ticks;
+				a.debug_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+				a.debug_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(63508) & 0xF;
+				if (blockIdx.x < 64u)
+					for (int q = 0; q < 4; ++q)
+						a.debug_stamps[4 * 4096 + 4 * blockIdx.x + q] = phase[q];
+			}
+		}
+	};
+
+	const unsigned WT = a.tile_frames / 4u;        // output frames per wave-tile: at most 64 input positions
+	const unsigned stage_bytes = (WT * UNIT + 15u) & ~15u;
+
+	const unsigned rows_bytes = a.plane_rows * a.row_stride * 4u;
+	unsigned char *my_buf = smem + rows_bytes + wave * (2u * BUF + stage_bytes);
+	unsigned char *my_stage = my_buf + 2u * BUF;
+	unsigned *waves_done = reinterpret_cast<unsigned *>(smem + rows_bytes + WAVES * (2u * BUF + stage_bytes));
+
+	if (tid == 0)
+		*waves_done = 0;
+
+	// Stage the polyphase rows once per workgroup - as W = 2 * |weight|: plane q of the image holds int32 [4q, 4q + 4) of every
+	// row, i.e. slots 4q .. 4q + 3 (the reciprocal sits in slot TT and stays as it is).  The only barrier of the kernel.
+	{
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.d_rows);
+		u32x4 *dst = reinterpret_cast<u32x4 *>(smem);
+#pragma unroll
+		for (int q = 0; q < RS / 4; ++q)
+		{
+			for (unsigned r = tid; r < UP_PLANE_ROWS; r += NTHREADS)
+			{
+				const u32x4 v = src[q * UP_PLANE_ROWS + r];
+				int e[4] = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+#pragma unroll
+				for (int k = 0; k < 4; ++k)
+				{
+					const int slot = 4 * q + k;
+					if (slot < TT)
+						e[k] = ((NEGMASK >> slot) & 1u) ? -2 * e[k] : 2 * e[k];
+				}
+				u32x4 w;
+				w.x = (unsigned)e[0];
+				w.y = (unsigned)e[1];
+				w.z = (unsigned)e[2];
+				w.w = (unsigned)e[3];
+				dst[q * UP_PLANE_ROWS + r] = w;
+			}
+		}
+	}
+	__syncthreads();
+
+	// Wave-tiles are TICKETS, as in k_wave: the first by global wave number, every further one from 32 global counter lanes.
+	// The XCDs of one chip do not run this kernel at one speed - under sustained load their clocks sit between 1.9 and 2.1 GHz,
+	// and with equal static shares the launch lasted as long as the slowest XCD (end times 143 .. 159 us,
+	// profiles/r02_kup2_sweep.log) - so whoever is free takes the next tile.  A ticket's atomic returns through vmcnt like the
+	// stores do, in issue order: it is issued BEFORE a wave-tile's stores, two tiles ahead of its use, so the wait that the
+	// next window's DMA needs anyway (everything but this tile's stores) covers it - no drain of its own.
+	const uint64_t n_tiles = (a.n_out + WT - 1) / WT;
+	const uint64_t global_wave = (uint64_t)blockIdx.x * WAVES + wave;
+	const uint64_t global_waves = (uint64_t)gridDim.x * WAVES;
+	const unsigned LANES = global_waves < 32u ? (unsigned)global_waves : 32u;
+	const unsigned lane_id = (unsigned)(global_wave % LANES);
+	const uint64_t lane_tiles = n_tiles > lane_id ? (n_tiles - lane_id + LANES - 1u) / LANES : 0;   // tiles of this counter's sequence
+	const unsigned lane_waves = (unsigned)((global_waves - lane_id + LANES - 1u) / LANES);          // its waves = its pre-assigned tiles
+	unsigned *lane_counter = a.d_tickets + lane_id * 32u;
+	auto draw_issue = [&]() -> unsigned {
+		unsigned got = 0;
+		if (lane == 0)
+			got = __hip_atomic_fetch_add(lane_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return got;
+	};
+	auto draw_resolve = [&](unsigned got) -> uint64_t {
+		const uint64_t k = (uint64_t)lane_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+		return k < lane_tiles ? lane_id + (uint64_t)LANES * k : ~0ull;
+	};
+	// a wave that has run out of tickets retires; the last wave of a workgroup reports to the global finished counter and the
+	// last workgroup zeroes the ticket block for the next launch (see k_wave)
+	auto retire = [&]() {
+		if (lane == 0 && __hip_atomic_fetch_add(waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == WAVES - 1u)
+		{
+			unsigned *finished = a.d_tickets + 32u * 32u;
+			if (__hip_atomic_fetch_add(finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u)
+			{
+				for (unsigned c = 0; c < 32u; ++c)
+					__hip_atomic_store(a.d_tickets + c * 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	};
+
+	const uint64_t in_base = reinterpret_cast<uint64_t>(a.d_in);
+	const uint64_t in_end = in_base + a.in_valid_bytes;
+	const float inv_increment = __builtin_amdgcn_rcpf((float)a.increment);
+	// frames every input position is sure to have: floor(65536 / increment) (wave-uniform; 2 .. 16)
+	unsigned n_min = (unsigned)(65536.0f * inv_increment);
+	n_min += (n_min + 1u) * a.increment <= 65536u ? 1u : 0u;
+	n_min -= n_min * a.increment > 65536u ? 1u : 0u;
+	n_min = __builtin_amdgcn_readfirstlane(n_min);
+
+	auto fetch = [&](uint64_t first, unsigned n, unsigned char *buf) -> unsigned {
+		const uint64_t pos = a.pos0 + first * (uint64_t)a.increment;
+		const uint64_t first_byte = in_base + ((pos >> 16) + a.first_slot) * FB;
+		const uint64_t aligned = first_byte & ~(uint64_t)15;
+		const unsigned shift = (unsigned)(first_byte - aligned);
+		const unsigned last_rel = (unsigned)(((pos & 0xFFFFu) + (uint64_t)(n - 1) * a.increment) >> 16);
+		uint64_t want = (uint64_t)shift + (uint64_t)(last_rel + TT + a.window_extra) * FB;
+		uint64_t avail = in_end > aligned ? in_end - aligned : 0;
+		if (want > avail)
+			want = avail;
+		want = (want + 3u) & ~(uint64_t)3u;   // whole dwords: see k_poly
+		const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)aligned);
+		const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(aligned >> 32));
+		const unsigned rec = __builtin_amdgcn_readfirstlane((unsigned)want);
+		const __amdgpu_buffer_rsrc_t rsrc =
+		    __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)rec, 0x00020000);
+		__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)buf, 16, (int)(lane * 16u), 0, 0, 0);
+		return shift;
+	};
+
+	// smallest k with frac0 + k * increment >= l * 65536: the first frame (relative to the wave-tile) of input position l >= 1
+	auto first_frame_of = [&](unsigned l, unsigned frac0) -> unsigned {
+		const unsigned x = (l << 16) - frac0;                     // 1 .. 2^22
+		unsigned k = (unsigned)((float)x * inv_increment);        // within one of the quotient; made exact below
+		k += (__umul24(k, a.increment) < x) ? 1u : 0u;
+		k += (__umul24(k, a.increment) < x) ? 1u : 0u;
+		k -= (k != 0 && __umul24(k - 1u, a.increment) >= x) ? 1u : 0u;
+		k -= (k != 0 && __umul24(k - 1u, a.increment) >= x) ? 1u : 0u;
+		return k;
+	};
+
+	// one wave-tile: n output frames from `first`, window at `base`; returns the number of store instructions issued
+	auto wave_tile = [&](uint64_t first, unsigned n, const unsigned char *base) -> unsigned {
+		const uint64_t pos = a.pos0 + first * (uint64_t)a.increment;
+		const unsigned frac0 = (unsigned)(pos & 0xFFFFu);
+
+		// this lane's frames: [k0, k1) = [first frame of position `lane`, first frame of position `lane + 1`), clipped to the tile
+		unsigned k1 = first_frame_of(lane + 1u, frac0);
+		k1 = k1 < n ? k1 : n;
+		unsigned k0 = (unsigned)__shfl_up((int)k1, 1);
+		k0 = lane == 0 ? 0u : k0;
+		const unsigned count = k1 - k0;
+		// wave-uniform trip count: n_min, or one more where some lane has its position's extra frame
+		const unsigned trips = ABL == 2 ? 0u : __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(count > n_min) != 0 ? n_min + 1u : n_min);
+
+		// the window of this lane's input position: S = sample * +-32768, once
+		int f[TT];
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+			f[s] = *reinterpret_cast<const int *>(base + (lane + (unsigned)s) * FB);
+		int S[TT][CH], B[TT][CH];   // B = all ones where S < 0: the low dword a tap's accumulator pair starts from
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+		{
+			const int k = ((NEGMASK >> s) & 1u) ? -32768 : 32768;
+			S[s][0] = __mul24((int)(short)f[s], k);
+			S[s][1] = __mul24(f[s] >> 16, k);
+			B[s][0] = S[s][0] >> 31;
+			B[s][1] = S[s][1] >> 31;
+			asm volatile("" : "+v"(B[s][0]), "+v"(B[s][1]));   // keep them in registers: hipcc otherwise re-forms the shift in every frame
+		}
+
+		// g = 65536 - fraction of the lane's current frame: the row is g >> 6 (pure-upsampling row index), 16 bytes per row and plane
+		unsigned g = 65536u - ((frac0 + __umul24(k0, a.increment)) & 0xFFFFu);
+		unsigned stage_at = k0 * UNIT;   // byte offset of the lane's current frame in the staging buffer
+
+		auto read_row = [&](unsigned gg, int (&w)[RS]) {
+			const unsigned at = (gg >> 2) & 0x7FF0u;   // (a prefetch past the lane's last frame stays inside the image)
+			const i32x4 *plane0 = reinterpret_cast<const i32x4 *>(smem + at);
+#pragma unroll
+			for (int q = 0; q < RS / 4; ++q)
+			{
+				const i32x4 v = plane0[q * UP_PLANE_ROWS];   // compile-time stride: the further planes are immediate offsets
+				w[4 * q] = v.x;
+				w[4 * q + 1] = v.y;
+				w[4 * q + 2] = v.z;
+				w[4 * q + 3] = v.w;
+			}
+		};
+
+		auto one = [&](const int (&w)[RS], bool mine) {
+			// accumulator pairs pinned to physical registers; the low dword is re-armed by a plain move of the slot's bias register
+			// (a v_ashrrev from S instead would save the bias registers but measured 30 % slower per frame at this occupancy:
+			// tools/microbench/chainbench.hip, profiles/r02_chainbench.log)
+			int lo0, hi0 = 0, lo1, hi1 = 0;
+#define CRHIP_UP2_TAP(LO, HI, VLO, VHI, SAMPLE, WEIGHT, BIAS)                                                                       \
+	VLO = (BIAS);                                                                                                                  \
+	asm("v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]" : "+{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(SAMPLE), "v"(WEIGHT) : "vcc")
+#pragma unroll
+			for (int s = 0; s < TT; ++s)
+			{
+				CRHIP_UP2_TAP(120, 121, lo0, hi0, S[s][0], w[s], B[s][0]);
+				CRHIP_UP2_TAP(124, 125, lo1, hi1, S[s][1], w[s], B[s][1]);
+			}
+#undef CRHIP_UP2_TAP
+			(void)lo0;
+			(void)lo1;
+
+			int out0, out1;
+			if constexpr (NORM == CRHIP_NORM_U32)
+			{
+				// (acc * reciprocal) / 32768 with C truncation: 64-bit product + 0x7FFF where negative, arithmetic shift by 15
+				const long long v0 = (long long)hi0 * (long long)w[TT] + (long long)((unsigned)(hi0 >> 31) >> 17);
+				const long long v1 = (long long)hi1 * (long long)w[TT] + (long long)((unsigned)(hi1 >> 31) >> 17);
+				out0 = (int)(v0 >> 15);
+				out1 = (int)(v1 >> 15);
+			}
+			else
+			{
+				out0 = normalise<NORM>(hi0, w[TT]);
+				out1 = normalise<NORM>(hi1, w[TT]);
+			}
+
+			if (mine)
+			{
+				if constexpr (OUT16)
+					*reinterpret_cast<int *>(my_stage + stage_at) = (clamp_s16(out0) & 0xFFFF) | (clamp_s16(out1) << 16);
+				else
+				{
+					i32x2 q;
+					q.x = out0;
+					q.y = out1;
+					*reinterpret_cast<i32x2 *>(my_stage + stage_at) = q;
+				}
+			}
+		};
+
+		mark(0);
+		// the row of frame j + 1 is read before the arithmetic of frame j (two register sets, loop unrolled by two)
+		int wa[RS], wb[RS];
+		read_row(g, wa);
+		for (unsigned j = 0; j < trips; j += 2u)
+		{
+			read_row(g - a.increment, wb);
+			__builtin_amdgcn_sched_barrier(0);
+			one(wa, j < count);
+			stage_at += UNIT;
+			if (j + 1u >= trips)
+				break;
+			read_row(g - 2u * a.increment, wa);
+			__builtin_amdgcn_sched_barrier(0);
+			one(wb, j + 1u < count);
+			stage_at += UNIT;
+			g -= 2u * a.increment;
+		}
+
+		mark(1);
+		// the staged frames of the other lanes: same wave, LDS operations of a wave complete in order
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+		// copy-out: wave-uniform base, one lane offset; four LDS reads in flight per trip
+		typedef typename std::conditional<VEC == 8, i32x2, int>::type vec_t;
+		const unsigned vectors = n * UNIT / VEC;
+		const vec_t *staged = reinterpret_cast<const vec_t *>(my_stage) + lane;
+		const uint64_t out_first = reinterpret_cast<uint64_t>(a.d_out) + first * UNIT;
+		const unsigned out_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)out_first);
+		const unsigned out_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(out_first >> 32));
+		vec_t *dst = reinterpret_cast<vec_t *>(((uint64_t)out_hi << 32) | out_lo);
+		auto put = [&](vec_t *to, vec_t v) {
+			if constexpr (ABL == 1)
+			{
+				asm volatile("" ::"v"(v));
+				return;
+			}
+			if constexpr (NT)
+				__builtin_nontemporal_store(v, to);
+			else
+				*to = v;
+		};
+		unsigned done = 0;   // wave-uniform
+		for (; done + 256u <= vectors; done += 256u)
+		{
+			const vec_t v0 = staged[done], v1 = staged[done + 64u], v2 = staged[done + 128u], v3 = staged[done + 192u];
+			put(dst + done + lane, v0);
+			put(dst + done + 64u + lane, v1);
+			put(dst + done + 128u + lane, v2);
+			put(dst + done + 192u + lane, v3);
+		}
+		for (; done < vectors; done += 64u)
+			if (done + lane < vectors)
+				put(dst + done + lane, staged[done]);
+		__builtin_amdgcn_wave_barrier();
+		mark(2);
+		return ABL == 1 ? 0u : __builtin_amdgcn_readfirstlane((vectors + 63u) / 64u);
+	};
+
+	uint64_t tile = global_wave;
+	if (tile >= n_tiles)
+	{
+		retire();
+		finish();
+		return;
+	}
+
+	unsigned cur = 0, shift = 0;
+	uint64_t next;
+	{
+		const unsigned ticket = draw_issue();
+		const uint64_t first = tile * WT;
+		const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
+		shift = fetch(first, n, my_buf);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		next = draw_resolve(ticket);
+	}
+	mark(-1);
+
+	for (;;)
+	{
+		const uint64_t first = tile * WT;
+		const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
+		const bool have_next = next != ~0ull;
+		unsigned shift_next = 0, ticket = 0;
+
+		// the ticket for the tile after the next one, then the DMA of the next one (its buffer was consumed one step ago): both
+		// ahead of this tile's stores in vmcnt's order
+		if (have_next)
+		{
+			const uint64_t nf = next * WT;
+			const unsigned nn = (unsigned)((a.n_out - nf < WT) ? (a.n_out - nf) : WT);
+			ticket = draw_issue();
+			shift_next = fetch(nf, nn, my_buf + (cur ^ 1u) * BUF);
+		}
+
+		const unsigned stores = wave_tile(first, n, my_buf + cur * BUF + shift);
+
+		if (!have_next)
+			break;
+		wait_vmcnt_at_most(stores);
+		mark(3);
+		cur ^= 1u;
+		shift = shift_next;
+		tile = next;
+		next = draw_resolve(ticket);
+	}
+
+	retire();
+	finish();
+}
+
 } // namespace
 
 #endif // CR_KUP_HPP

@@ -60,6 +60,11 @@ WORKLOADS = {
     "dn2": (3, 2, (48000, 44100, 44100), 28800000),    # stereo 48 -> 44.1 kHz, 10 min
     "dn1": (3, 1, (48000, 44100, 44100), 57600000),    # mono 48 -> 44.1 kHz, 20 min
     "hq44": (8, 2, (48000, 44100, 44100), 28800000),   # 8 lobes, 48 -> 44.1 kHz (17-tap windows)
+    "dn21": (3, 2, (96000, 48000, 48000), 57600000),   # stereo 2:1, 12-slot windows
+    "dn32": (3, 2, (48000, 32000, 32000), 28800000),   # stereo 3:2, 9-slot windows
+    "dn31": (3, 2, (96000, 32000, 32000), 57600000),   # stereo 3:1, 18-slot windows
+    "dn96": (3, 2, (96000, 44100, 44100), 57600000),   # stereo 96 -> 44.1 kHz, 13-slot windows
+    "dn4432": (3, 2, (44100, 32000, 32000), 26460000), # stereo 44.1 -> 32 kHz, 8-slot windows
 }
 CONFIG_NAMES = {"cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2]", "cfg4": "BASELINE configs[3]", "cfg5": "BASELINE configs[4]"}
 
@@ -343,7 +348,7 @@ def main():
     # the dominant (only) kernel: algorithmic bytes of THIS rank's launch / its launch duration
     launch_bytes = shard.input_frames * ch * 2 + shard.output_frames * ch * (2 if args.s16 else 4)
     achieved = launch_bytes / (mean_ms * 1e-3) / 1e9
-    kernel_name = {1: "k_poly<%d,%d>", 2: "k_wave<%d,%d>", 3: "k_up<%d,%d>"}[info.kernel] % (ch, info.slots) if info.kernel else "k_generic"
+    kernel_name = {1: "k_poly<%d,%d>", 2: "k_wave<%d,%d>", 3: "k_up<%d,%d>", 4: "k_wave2<%d,%d>"}[info.kernel] % (ch, info.slots) if info.kernel else "k_generic"
     traffic, traffic_note = None, "no PMC summary for this workload under profiles/"
     pmc, pmc_file = pmc_summary(workload) if (world == 1 and not args.s16) else (None, None)
     if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:

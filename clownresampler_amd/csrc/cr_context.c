@@ -757,18 +757,40 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 		crhip_poly_geometry(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
 	}
 
+	if (plan->vecs >= 150u)
+	{
+		/* k_wave2 needs its slot signs, where it is built for fixed ones (checked like k_up's); geometry below with k_wave's */
+		uint32_t negmask = 0, pos_bits = 0, neg_bits = 0;
+		const int fixed = crhip_poly_wave2_negmask(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, &negmask);
+		int ok = fixed >= 0;
+
+		if (fixed == 1)
+		{
+			cr_poly_slot_signs(&plan->poly, &pos_bits, &neg_bits);
+			ok = (neg_bits & ~negmask) == 0 && (pos_bits & negmask) == 0;
+		}
+		if (!ok)
+		{
+			plan->variant = crhip_poly_wave2_fallback_variant(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
+			crhip_poly_geometry(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
+		}
+	}
+
 	if (plan->vecs >= 100u)
 	{
-		/* k_wave: every wave streams wave-tiles of 64 * 4 frames through a private, double-buffered (vecs - 100) KiB
-		   slice of LDS; work is handed out in chunks of 4 wave-tiles (frames_multiple) */
-		const uint32_t piece_bytes = (plan->vecs - 100u) * 1024u;
+		/* k_wave: every wave streams wave-tiles of 64 * ITER frames through a private, double-buffered (vecs - 100) KiB
+		   slice of LDS; work is handed out in chunks of 4 wave-tiles (frames_multiple).  k_wave2 (vecs - 150 KiB pieces) keeps a
+		   third buffer of twice the size beside them: the window expanded to one dword per sample. */
+		const int wave2 = plan->vecs >= 150u;
+		const uint32_t piece_bytes = (plan->vecs - (wave2 ? 150u : 100u)) * 1024u;
+		const uint32_t per_wave = wave2 ? 4u * piece_bytes : 2u * piece_bytes;
 		const uint32_t wave_tile = frames_multiple / 4u;
 		const uint64_t last_rel = (65535u + (uint64_t)(wave_tile - 1u) * plan->increment) >> 16;
 		const uint64_t window = 12u + (last_rel + window_slots) * frame_bytes;
 
 		if (window <= piece_bytes && (uint64_t)wave_tile * plan->increment < (1ull << 32) - 65536u)
 		{
-			plan->lds_bytes = rows_bytes + (plan->threads / 64u) * 2u * piece_bytes + 16u; /* + the retired-waves counter */
+			plan->lds_bytes = rows_bytes + (plan->threads / 64u) * per_wave + 16u; /* + the retired-waves counter */
 			plan->tile_frames = frames_multiple;
 			per_cu = (160u * 1024u) / plan->lds_bytes;
 			if (per_cu > 2048u / plan->threads)
@@ -781,7 +803,9 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 		}
 
 		/* the window of this configuration does not fit a wave's slice: use a k_poly variant instead */
-		plan->variant = crhip_poly_fallback_variant();
+		plan->variant = wave2 ? crhip_poly_wave2_fallback_variant(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode) : crhip_poly_fallback_variant();
+		if (plan->variant >= 20u && plan->variant < 22u)
+			plan->variant = crhip_poly_fallback_variant();
 		crhip_poly_geometry(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
 	}
 
@@ -1051,6 +1075,9 @@ ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t t
 	if (plan->use_poly)
 		plan_geometry(plan);
 
+	if (plan->use_poly && plan->vecs >= 150u && plan->vecs < 200u)
+		plan->lds_swizzle = cr_poly_pick_swizzle(&plan->poly, increment, &plan->conflict_plain, &plan->conflict_best);
+
 	if (plan->use_poly)
 	{
 		const int layout = plan->specialised ? CR_IMAGE_COMPACT : CR_IMAGE_SPLIT;
@@ -1187,7 +1214,7 @@ static void fill_poly_launch(const ClownResamplerAMD_Plan *plan, crhip_poly_laun
 	l->specialised = plan->specialised;
 	l->variant = plan->variant;
 	l->plane_rows = plan->plane_rows;
-	l->swizzle = plan->swizzle;
+	l->swizzle = (plan->vecs >= 150u && plan->vecs < 200u) ? plan->lds_swizzle : plan->swizzle;
 	l->debug_stamps = g_debug_stamps;
 }
 
@@ -1616,7 +1643,7 @@ int cr_run_single_frame(const ClownResamplerAMD_Plan *plan, const int16_t *host_
 void ClownResamplerAMD_PlanGetInfo(const ClownResamplerAMD_Plan *plan, ClownResamplerAMD_PlanInfo *info)
 {
 	memset(info, 0, sizeof(*info));
-	info->kernel = plan->use_poly ? (plan->vecs >= 200u ? 3u : plan->vecs >= 100u ? 2u : 1u) : 0u;
+	info->kernel = plan->use_poly ? (plan->vecs >= 200u ? 3u : plan->vecs >= 150u ? 4u : plan->vecs >= 100u ? 2u : 1u) : 0u;
 	info->variant = plan->variant;
 	info->channels = plan->channels;
 	info->norm_mode = plan->poly.norm_mode;

@@ -7,6 +7,7 @@
 #include "cr_kpoly.hpp"
 #include "cr_kwave.hpp"
 #include "cr_kup.hpp"
+#include "cr_kwave2.hpp"
 
 namespace
 {
@@ -67,9 +68,43 @@ struct special
 	uint32_t up_negmask;        // k_up / mad: bit s set = the weights of slot s are <= 0 in every row, clear = >= 0 (checked by the host per plan)
 	poly_fn mad[2];             // the 64-bit multiply-add chain (compute_frame, ASM mode 2): variant MAD_VARIANT = k_poly geometry 3 with non-temporal stores,
 	                            // MAD_VARIANT + 1 = k_wave where the instance has one, else k_poly geometry 3 with plain stores
+	poly_fn wave2, wave2_16;    // k_wave2 (variant WAVE2_VARIANT): expanded window + 64-bit multiply-add taps; nullptr if none
+	uint32_t wave2_waves, wave2_nvw, wave2_iter;   // its geometry (template WAVES, NVW, ITER)
+	uint32_t wave2_fallback;    // the variant used instead when k_wave2 is the default and a plan does not qualify for it
+	uint32_t wave2_fixed_signs; // 1: built for the slot signs in up_negmask (the host checks the plan's rows), 0: any rows
 };
 
 constexpr uint32_t MAD_VARIANT = 28;    // variant ids 28, 29
+constexpr uint32_t WAVE2_VARIANT = 30;  // variant id 30: k_wave2 where the instance has one
+
+// k_wave2 of a stereo instance: fixed slot signs (NEGMASK != 0: pure upsampling, 2 VALU per tap and channel) or any rows (3)
+template <int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, unsigned NEGMASK>
+void add_wave2(special &s)
+{
+	constexpr int SIGNED = NEGMASK == 0 ? 1 : 0;
+	s.wave2 = (poly_fn)k_wave2<TT, MODE, NORM, WAVES, NVW, ITER, 0, 1, NEGMASK, SIGNED>;
+	s.wave2_16 = (poly_fn)k_wave2<TT, MODE, NORM, WAVES, NVW, ITER, 1, 1, NEGMASK, SIGNED>;
+	s.wave2_waves = WAVES;
+	s.wave2_nvw = NVW;
+	s.wave2_iter = ITER;
+	s.wave2_fixed_signs = SIGNED ? 0u : 1u;
+	if (!SIGNED)
+		s.up_negmask = NEGMASK;
+}
+
+// DEFAULT: k_wave2 becomes the instance's default variant (where it measured faster than the k_poly / k_wave forms); the
+// previous default stays the fallback for plans whose window does not fit a wave's slice
+template <int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, unsigned NEGMASK, bool DEFAULT = false>
+special with_wave2(special s)
+{
+	add_wave2<TT, MODE, NORM, WAVES, NVW, ITER, NEGMASK>(s);
+	if (DEFAULT)
+	{
+		s.wave2_fallback = s.default_variant;
+		s.default_variant = WAVE2_VARIANT;
+	}
+	return s;
+}
 
 constexpr uint32_t UP_VARIANT = 26;     // variant ids 26, 27 select k_up where the instance has one and the plan qualifies
 constexpr int UP_WAVES = 12;
@@ -85,7 +120,7 @@ constexpr int WAVE_WAVES = 16, WAVE_NVW = 1, WAVE_ITER = 4;
 template <int CH, int TT, int MODE, int NORM, int DV, bool WAVE = false, bool DYNAMIC = false, unsigned UPMASK = 0>
 special make_special()
 {
-	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, false, 1u, UPMASK, {nullptr, nullptr}};
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, false, 1u, UPMASK, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u};
 	if constexpr (UPMASK != 0 && CH % 2 == 0)
 	{
 		s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 1>;
@@ -134,7 +169,7 @@ special make_special()
 template <int CH, int TT, int MODE, int NORM, int DV = (CH <= 4 ? 13 : 14)>   // default: (1024 threads, 1 or 2 vectors per thread), one frame in flight, non-temporal stores
 special make_special_lite()
 {
-	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 1u, 0u, {nullptr, nullptr}};
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 1u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u};
 	const poly_fn fn = instance<CH, TT, MODE, NORM, DV % 5, 1, (DV / 5) % 2, (DV / 10) % 2>();
 	for (int v = 0; v < VARIANTS; ++v)
 		s.fn[v] = fn;
@@ -148,7 +183,7 @@ special make_special_lite_split()
 {
 	constexpr int DV = 14;   // (1024 threads, 2 vectors per thread), one frame in flight, non-temporal stores
 	constexpr int T = GEOMETRY[DV % 5].threads, V = GEOMETRY[DV % 5].vecs;
-	special s = {CHT, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 2u, 0u, {nullptr, nullptr}};
+	special s = {CHT, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 2u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u};
 	const poly_fn fn = (poly_fn)k_poly<CHT / 2, TT, MODE, NORM, T, V, 1, 1, 0, 0, 0, 1, 2>;
 	for (int v = 0; v < VARIANTS; ++v)
 		s.fn[v] = fn;

@@ -336,8 +336,14 @@ static uint32_t resolve_variant(const special *sp, uint32_t variant, uint32_t ou
 {
 	if (sp == nullptr)
 		return 0u;
+	if (variant == WAVE2_VARIANT || (variant == CRHIP_VARIANT_DEFAULT && sp->default_variant == WAVE2_VARIANT))
+	{
+		if (sp->wave2 != nullptr)
+			return WAVE2_VARIANT;
+		variant = sp->default_variant != WAVE2_VARIANT ? sp->default_variant : sp->wave2_fallback;
+	}
 	if (sp->lite)
-		return sp->default_variant;
+		return sp->default_variant != WAVE2_VARIANT ? sp->default_variant : sp->wave2_fallback;
 	if (variant >= 1008u && variant <= 1010u)
 		return sp->up[0] != nullptr ? UP_VARIANT : (sp->wave[0] != nullptr ? WAVE_VARIANT : 13u);   // diagnostic k_up instance
 	if (variant == 1007u && sp->wave[0] != nullptr)
@@ -379,7 +385,7 @@ int crhip_poly_swizzled(uint32_t channels, uint32_t slots, uint32_t row_mode, ui
 
 int crhip_poly_variants(void)
 {
-	return VARIANTS + 10;   // + the two k_wave variants, the four two-lanes-per-frame variants, the two k_up variants and the two 64-bit-chain variants
+	return VARIANTS + 11;   // + the two k_wave variants, the four two-lanes-per-frame variants, the two k_up variants and the two 64-bit-chain variants
 }
 
 int crhip_poly_up_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t *negmask)
@@ -399,7 +405,11 @@ int crhip_poly_default_is_mad(uint32_t channels, uint32_t slots, uint32_t row_mo
 
 uint32_t crhip_poly_up_fallback_variant(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
 {
+	// below 2x upsampling k_up does not apply: k_wave2 where the instance has one (8-lobe stereo 44.1 -> 48 kHz: 106 us against
+	// k_wave's 127), else k_wave, else k_poly
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
+	if (sp != nullptr && sp->wave2 != nullptr)
+		return WAVE2_VARIANT;
 	return sp != nullptr && sp->wave[0] != nullptr ? WAVE_VARIANT : 13u;
 }
 
@@ -407,6 +417,25 @@ int crhip_poly_dynamic_default(uint32_t channels, uint32_t slots, uint32_t row_m
 {
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
 	return sp != nullptr && sp->dynamic_tiles ? 1 : 0;
+}
+
+int crhip_poly_wave2_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t *negmask)
+{
+	const special *sp = find_special(channels, slots, row_mode, norm_mode);
+	if (sp == nullptr || sp->wave2 == nullptr)
+		return -1;                      // no k_wave2 form
+	*negmask = sp->up_negmask;
+	return sp->wave2_fixed_signs ? 1 : 0;   // 1: the plan's slot signs must match *negmask
+}
+
+uint32_t crhip_poly_wave2_fallback_variant(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
+{
+	const special *sp = find_special(channels, slots, row_mode, norm_mode);
+	if (sp == nullptr)
+		return 13u;
+	if (sp->default_variant != WAVE2_VARIANT)
+		return sp->default_variant >= UP_VARIANT && sp->default_variant < MAD_VARIANT ? (sp->wave[0] != nullptr ? WAVE_VARIANT : 13u) : sp->default_variant;
+	return sp->wave2_fallback;
 }
 
 uint32_t crhip_poly_fallback_variant(void)
@@ -419,6 +448,15 @@ void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, u
 {
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
 	const uint32_t v = sp != nullptr ? resolve_variant(sp, variant) : (uint32_t)runtime_geo((int)channels);
+
+	if (sp != nullptr && v == WAVE2_VARIANT)
+	{
+		// k_wave2: vecs = 150 + (1 KiB DMA pieces per wave-tile); frames_multiple = frames per ticket
+		*threads = sp->wave2_waves * 64u;
+		*vecs = 150u + sp->wave2_nvw;
+		*frames_multiple = 64u * sp->wave2_iter * 4u;
+		return;
+	}
 
 	if (sp != nullptr && v == MAD_VARIANT + 1u && sp->wave[0] != nullptr)
 	{
@@ -479,6 +517,12 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 	const special *sp = launch->specialised ? find_special(launch->channels, launch->slots, launch->row_mode, launch->norm_mode) : nullptr;
 	const uint32_t v = resolve_variant(sp, launch->variant, launch->out_s16);
 	poly_fn fn;
+
+	if (sp != nullptr && v == WAVE2_VARIANT)
+	{
+		*geo = 150u;
+		return launch->out_s16 ? sp->wave2_16 : sp->wave2;
+	}
 
 	if (sp != nullptr && v >= MAD_VARIANT)
 	{
@@ -578,7 +622,12 @@ int crhip_launch_poly(const crhip_poly_launch *launch, void *stream)
 
 	if (fn == nullptr)
 		return (int)hipErrorInvalidValue;
-	if (geo == 200u ? (launch->threads != UP_WAVES * 64u || launch->vecs != 200u || launch->tile_frames % 4u != 0 || launch->tile_frames / 4u > UP_MAX_WAVE_TILE || launch->plane_rows != UP_PLANE_ROWS)
+	if (geo == 150u)
+	{
+		if (launch->threads % 64u != 0 || launch->vecs < 150u || launch->vecs >= 200u)
+			return (int)hipErrorInvalidValue;
+	}
+	else if (geo == 200u ? (launch->threads != UP_WAVES * 64u || launch->vecs != 200u || launch->tile_frames % 4u != 0 || launch->tile_frames / 4u > UP_MAX_WAVE_TILE || launch->plane_rows != UP_PLANE_ROWS)
 	  : geo == 100u ? (launch->threads != WAVE_WAVES * 64u || launch->vecs != 100u + WAVE_NVW)
 	                : (launch->threads != (uint32_t)GEOMETRY[geo].threads || launch->vecs != (uint32_t)GEOMETRY[geo].vecs))
 		return (int)hipErrorInvalidValue;

@@ -1,0 +1,398 @@
+// cr_kwave2.hpp - k_wave2: k_wave's streaming with the tap arithmetic of k_up2, for STEREO streams.
+#ifndef CR_KWAVE2_HPP
+#define CR_KWAVE2_HPP
+
+#include "cr_device.hpp"
+
+namespace
+{
+
+// ---------------------------------------------------------------------------------------------------------
+// k_wave2 - one lane per output frame (as k_poly / k_wave), 2-3 VALU per tap and channel instead of 4
+// ---------------------------------------------------------------------------------------------------------
+// k_poly and k_wave keep the input window packed (two int16 per dword) and spend four SDWA instructions per tap and channel:
+// multiply, sign, +0xFFFF where negative, add the high word.  Here the wave first EXPANDS its window once per wave-tile into a
+// second LDS buffer of X = sample << 16 (one dword per sample: a shift or a mask per sample, amortised over the ~15 output
+// frames that read it), and the tap is the 64-bit multiply-add of k_up2 on an accumulator pair {lo, hi}:
+//     lo = X >> 31                       all ones where the product can be negative
+//     {lo, hi} = X * W + {lo, hi}        X * W = sample * weight << 16: integer part into hi, fraction bits in the top of lo;
+//                                        the all-ones lo carries exactly when a negative product has a fraction: C's truncation
+//                                        (clownresampler.h:1020 via :625)
+// which needs W >= 0 - otherwise the product's sign is not the sample's:
+//   SIGNED == 0 (pure upsampling: the sign of a slot's weights is a compile-time property, NEGMASK, checked by the host per
+//                plan as for k_up): the rows are staged as W = |weight|, the slots with negative weights accumulate into a
+//                second pair and the two sums are subtracted at the end (truncation toward zero is odd-symmetric).  2 VALU.
+//   SIGNED == 1 (any rows): W = weight as it is, lo = (X ^ W) >> 31.  3 VALU.
+// Everything else - tickets over 32 counter lanes, a private double-buffered LDS-DMA window per wave, counted vmcnt, coalesced
+// non-temporal stores - is k_wave's.  LDS per wave: two packed windows (NVW KiB each) and one expanded window (2 x NVW KiB).
+//   WAVES  waves per workgroup     NVW  1 KiB DMA pieces per wave-tile     ITER  frames per lane per wave-tile
+// ---------------------------------------------------------------------------------------------------------
+template <int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, int OUT16, int NT, unsigned NEGMASK, int SIGNED>
+__global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
+{
+	constexpr int CH = 2;
+	constexpr unsigned FB = CH * 2;
+	constexpr unsigned NTHREADS = WAVES * 64;
+	constexpr unsigned WT = 64u * ITER;            // frames per wave-tile
+	constexpr unsigned CW = 4;                     // wave-tiles per chunk (ticket)
+	constexpr unsigned CHUNK = WT * CW;
+	constexpr unsigned BUF = NVW * 1024u;          // bytes per packed window
+	constexpr unsigned XBUF = 2u * BUF;            // bytes of the expanded window (8 per stereo frame)
+	constexpr unsigned PER_WAVE = 2u * BUF + XBUF;
+	constexpr int RS = (TT + 1 + 3) & ~3;
+	constexpr int STORES_PER_FRAME = 1;            // one 8-byte (int32 x 2) or 4-byte (int16 x 2) store
+
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+	const unsigned tid = threadIdx.x;
+	const unsigned lane = tid & 63u;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+	const unsigned rows_bytes = a.plane_rows * a.row_stride * 4u;
+	unsigned char *my_buf = smem + rows_bytes + wave * PER_WAVE;
+	unsigned char *my_x = my_buf + 2u * BUF;
+
+	unsigned *waves_done = reinterpret_cast<unsigned *>(smem + rows_bytes + WAVES * PER_WAVE);
+	if (tid == 0)
+		*waves_done = 0;
+
+	// stage the polyphase rows once per workgroup (as magnitudes where the slot signs are fixed): the only barrier of the kernel
+	{
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.d_rows);
+		u32x4 *dst = reinterpret_cast<u32x4 *>(smem);
+#pragma unroll
+		for (int q = 0; q < RS / 4; ++q)
+		{
+			for (unsigned r = tid; r < a.plane_rows; r += NTHREADS)
+			{
+				const u32x4 v = src[q * a.plane_rows + r];
+				int e[4] = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+				if constexpr (!SIGNED)
+				{
+#pragma unroll
+					for (int k = 0; k < 4; ++k)
+					{
+						const int slot = 4 * q + k;
+						if (slot < TT && ((NEGMASK >> slot) & 1u))
+							e[k] = -e[k];
+					}
+				}
+				u32x4 w;
+				w.x = (unsigned)e[0];
+				w.y = (unsigned)e[1];
+				w.z = (unsigned)e[2];
+				w.w = (unsigned)e[3];
+				// rows land SWIZZLED within their block of 16 (see one_frame2): the global image is the plain one, shared by plans of
+				// every increment; the multiplier that suits THIS increment is the plan's (host: cr_poly_pick_swizzle)
+				dst[q * a.plane_rows + ((r & ~15u) | ((__umul24(r >> 4, a.swizzle) + r) & 15u))] = w;
+			}
+		}
+	}
+	__syncthreads();
+
+	const uint64_t n_chunks = (a.n_out + CHUNK - 1) / CHUNK;
+	const uint64_t global_wave = (uint64_t)blockIdx.x * WAVES + wave;
+	const uint64_t global_waves = (uint64_t)gridDim.x * WAVES;
+
+	// tickets: as in k_wave
+	const unsigned LANES = global_waves < 32u ? (unsigned)global_waves : 32u;
+	const unsigned lane_id = (unsigned)(global_wave % LANES);
+	const uint64_t lane_chunks = n_chunks > lane_id ? (n_chunks - lane_id + LANES - 1u) / LANES : 0;
+	const unsigned lane_waves = (unsigned)((global_waves - lane_id + LANES - 1u) / LANES);
+	unsigned *lane_counter = a.d_tickets + lane_id * 32u;
+	auto draw_issue = [&]() -> unsigned {
+		unsigned got = 0;
+		if (lane == 0)
+			got = __hip_atomic_fetch_add(lane_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return got;
+	};
+	auto draw_resolve = [&](unsigned got) -> uint64_t {
+		const uint64_t k = (uint64_t)lane_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+		return k < lane_chunks ? lane_id + (uint64_t)LANES * k : ~0ull;
+	};
+	auto retire = [&]() {
+		if (lane == 0 && __hip_atomic_fetch_add(waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == WAVES - 1u)
+		{
+			unsigned *finished = a.d_tickets + 32u * 32u;
+			if (__hip_atomic_fetch_add(finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u)
+			{
+				for (unsigned c = 0; c < 32u; ++c)
+					__hip_atomic_store(a.d_tickets + c * 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	};
+
+	const uint64_t in_base = reinterpret_cast<uint64_t>(a.d_in);
+	const uint64_t in_end = in_base + a.in_valid_bytes;
+
+	// LDS-DMA of the packed window of the wave-tile of `n` frames starting at output frame `first` into `buf`.  Returns the byte
+	// offset of the window's first frame inside the buffer in the low 16 bits and the window's frame count above them.  Not waited for.
+	auto fetch = [&](uint64_t first, unsigned n, unsigned char *buf) -> unsigned {
+		const uint64_t pos = a.pos0 + first * (uint64_t)a.increment;
+		const uint64_t first_byte = in_base + ((pos >> 16) + a.first_slot) * FB;
+		const uint64_t aligned = first_byte & ~(uint64_t)15;
+		const unsigned shift = (unsigned)(first_byte - aligned);
+		const unsigned last_rel = (unsigned)(((pos & 0xFFFFu) + (uint64_t)(n - 1) * a.increment) >> 16);
+		const unsigned frames = last_rel + TT + a.window_extra;
+		uint64_t want = (uint64_t)shift + (uint64_t)frames * FB;
+		uint64_t avail = in_end > aligned ? in_end - aligned : 0;
+		if (want > avail)
+			want = avail;
+		want = (want + 3u) & ~(uint64_t)3u;   // whole dwords: see k_poly
+		const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)aligned);
+		const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(aligned >> 32));
+		const unsigned rec = __builtin_amdgcn_readfirstlane((unsigned)want);
+		const __amdgpu_buffer_rsrc_t rsrc =
+		    __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)rec, 0x00020000);
+#pragma unroll
+		for (int v = 0; v < NVW; ++v)
+			__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + v * 1024u), 16,
+			                                         (int)(v * 1024u + lane * 16u), 0, 0, 0);
+		return (unsigned)__builtin_amdgcn_readfirstlane((int)(shift | (frames << 16)));
+	};
+
+	// packed window -> X = sample << 16, one dword per sample (the frames beyond the caller's buffer were delivered as zeros)
+	auto expand = [&](const unsigned char *buf, unsigned shift_frames) {
+		const unsigned shift = shift_frames & 0xFFFFu, frames = shift_frames >> 16;
+		for (unsigned i = lane; i < frames; i += 64u)
+		{
+			const int f = *reinterpret_cast<const int *>(buf + shift + i * FB);
+			i32x2 x;
+			x.x = (int)((unsigned)f << 16);
+			x.y = (int)((unsigned)f & 0xFFFF0000u);
+			*reinterpret_cast<i32x2 *>(my_x + i * 8u) = x;
+		}
+		// same wave: its LDS operations complete in order
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	};
+
+	// one output frame from the expanded window
+	auto one_frame2 = [&](unsigned rel, int &out0, int &out1) {
+		unsigned shift;
+		const unsigned row = row_of<MODE>(a, rel & 0xFFFFu, shift);
+		// The lanes of a wave hold consecutive output frames, so their rows step by a fixed amount (83.2 rows per lane at
+		// 44.1 -> 48 kHz) and the 16 lanes a ds_read_b128 services together fall on 5-8 of the 16 bank slots: the row reads were
+		// half of this kernel's LDS cycles as conflicts (profiles/r02_hq48_pmc.txt).  Within each block of 16 rows the rows are
+		// rotated by a host-chosen multiple of the block number, which spreads them over all 16 slots.
+		const unsigned phys = (row & ~15u) | ((__umul24(row >> 4, a.swizzle) + row) & 15u);
+		const i32x4 *plane0 = reinterpret_cast<const i32x4 *>(smem) + phys;
+		const i32x2 *win = reinterpret_cast<const i32x2 *>(my_x) + (rel >> 16) + shift;
+		int w[RS];
+#pragma unroll
+		for (int q = 0; q < RS / 4; ++q)
+		{
+			const i32x4 v = plane0[q * a.plane_rows];
+			w[4 * q] = v.x;
+			w[4 * q + 1] = v.y;
+			w[4 * q + 2] = v.z;
+			w[4 * q + 3] = v.w;
+		}
+		// the window as TT separate 8-byte reads: left to itself hipcc pairs them into ds_read2_b64, which moves 128 B per clock
+		// where ds_read_b64 moves 256 (MI355X_MICROARCH.md, LDS) - and this kernel is as much LDS- as VALU-bound
+		i32x2 x[TT];
+		{
+			const unsigned win_at = (unsigned)(uintptr_t)win;   // LDS byte address (the low 32 bits of a __shared__ pointer)
+#pragma unroll
+			for (int s = 0; s < TT; ++s)
+				asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(x[s]) : "v"(win_at), "n"(s * 8));
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+			for (int s = 0; s < TT; ++s)
+				asm volatile("" : "+v"(x[s]));   // (uses stay below the wait)
+		}
+
+		// accumulator pairs pinned to physical registers (see k_up2): L+ v[120:121], R+ v[122:123], L- v[124:125], R- v[126:127]
+		int lo0, hi0 = 0, lo1, hi1 = 0, lo2, hi2 = 0, lo3, hi3 = 0;
+#define CRHIP_W2_TAP(LO, HI, VLO, VHI, X, W)                                                                                       \
+	asm("v_ashrrev_i32_e32 v" #LO ", 31, %2\n\t"                                                                                  \
+	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
+	    : "=&{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc")
+#define CRHIP_W2_TAP_SIGNED(LO, HI, VLO, VHI, X, W)                                                                                \
+	asm("v_xor_b32_e32 v" #LO ", %2, %3\n\t"                                                                                      \
+	    "v_ashrrev_i32_e32 v" #LO ", 31, v" #LO "\n\t"                                                                            \
+	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
+	    : "=&{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc")
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+		{
+			if constexpr (SIGNED)
+			{
+				CRHIP_W2_TAP_SIGNED(120, 121, lo0, hi0, x[s].x, w[s]);
+				CRHIP_W2_TAP_SIGNED(122, 123, lo1, hi1, x[s].y, w[s]);
+			}
+			else if ((NEGMASK >> s) & 1u)
+			{
+				CRHIP_W2_TAP(124, 125, lo2, hi2, x[s].x, w[s]);
+				CRHIP_W2_TAP(126, 127, lo3, hi3, x[s].y, w[s]);
+			}
+			else
+			{
+				CRHIP_W2_TAP(120, 121, lo0, hi0, x[s].x, w[s]);
+				CRHIP_W2_TAP(122, 123, lo1, hi1, x[s].y, w[s]);
+			}
+		}
+#undef CRHIP_W2_TAP
+#undef CRHIP_W2_TAP_SIGNED
+		(void)lo0;
+		(void)lo1;
+		(void)lo2;
+		(void)lo3;
+		const int acc0 = SIGNED ? hi0 : hi0 - hi2;
+		const int acc1 = SIGNED ? hi1 : hi1 - hi3;
+		if constexpr (NORM == CRHIP_NORM_U32)
+		{
+			const long long v0 = (long long)acc0 * (long long)w[TT] + (long long)((unsigned)(acc0 >> 31) >> 17);
+			const long long v1 = (long long)acc1 * (long long)w[TT] + (long long)((unsigned)(acc1 >> 31) >> 17);
+			out0 = (int)(v0 >> 15);
+			out1 = (int)(v1 >> 15);
+		}
+		else
+		{
+			out0 = normalise<NORM>(acc0, w[TT]);
+			out1 = normalise<NORM>(acc1, w[TT]);
+		}
+	};
+
+	auto store_frame = [&](uint64_t frame, int out0, int out1) {
+		if constexpr (OUT16)
+		{
+			const int packed = (clamp_s16(out0) & 0xFFFF) | (clamp_s16(out1) << 16);
+			int *dst = reinterpret_cast<int *>(a.d_out) + frame;
+			if constexpr (NT)
+				__builtin_nontemporal_store(packed, dst);
+			else
+				*dst = packed;
+		}
+		else
+		{
+			i32x2 q;
+			q.x = out0;
+			q.y = out1;
+			i32x2 *dst = reinterpret_cast<i32x2 *>(a.d_out) + frame;
+			if constexpr (NT)
+				__builtin_nontemporal_store(q, dst);
+			else
+				*dst = q;
+		}
+	};
+
+	if (global_wave >= n_chunks)
+	{
+		retire();
+		return;
+	}
+
+	uint64_t chunk = global_wave;
+	unsigned cur = 0, packed_info = 0;
+	{
+		const uint64_t first = chunk * CHUNK;
+		const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
+		packed_info = fetch(first, n, my_buf);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+
+	for (;;)
+	{
+		const unsigned ticket = draw_issue();          // one chunk ahead; resolved at the end of this chunk
+		uint64_t next_chunk = ~0ull;
+		const uint64_t chunk_first = chunk * CHUNK;
+		bool done = false;
+
+		for (unsigned j = 0; j < CW && !done; ++j)
+		{
+			const uint64_t first = chunk_first + (uint64_t)j * WT;
+			const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
+			const bool last_of_stream = first + n >= a.n_out;
+			unsigned next_info = 0;
+			bool have_next = false;
+
+			// this wave-tile's window becomes X (the previous tile's frames have all been read: same wave, in order) ...
+			expand(my_buf + cur * BUF, packed_info);
+
+			// ... and the DMA of the wave-tile after it starts (the other packed buffer was expanded one step ago)
+			if (!last_of_stream)
+			{
+				if (j + 1 < CW)
+				{
+					const uint64_t nf = first + WT;
+					const unsigned nn = (unsigned)((a.n_out - nf < WT) ? (a.n_out - nf) : WT);
+					next_info = fetch(nf, nn, my_buf + (cur ^ 1u) * BUF);
+					have_next = true;
+				}
+				else
+				{
+					next_chunk = draw_resolve(ticket);
+					if (next_chunk != ~0ull)
+					{
+						const uint64_t nf = next_chunk * CHUNK;
+						const unsigned nn = (unsigned)((a.n_out - nf < WT) ? (a.n_out - nf) : WT);
+						next_info = fetch(nf, nn, my_buf + (cur ^ 1u) * BUF);
+						have_next = true;
+					}
+				}
+			}
+			else if (j + 1 == CW)
+				next_chunk = draw_resolve(ticket);
+
+			const uint64_t pos = a.pos0 + first * (uint64_t)a.increment;
+			const unsigned lane_rel = __umul24(lane, a.increment) + (unsigned)(pos & 0xFFFFu);
+			if (n == WT)
+			{
+#pragma unroll
+				for (int i = 0; i < ITER; ++i)
+				{
+					int out0, out1;
+					one_frame2(lane_rel + (unsigned)i * 64u * a.increment, out0, out1);
+					store_frame(first + (unsigned)i * 64u + lane, out0, out1);
+				}
+			}
+			else
+			{
+				for (unsigned jl = lane; jl < n; jl += 64u)
+				{
+					int out0, out1;
+					one_frame2(__umul24(jl, a.increment) + (unsigned)(pos & 0xFFFFu), out0, out1);
+					store_frame(first + jl, out0, out1);
+				}
+			}
+
+			if (last_of_stream)
+			{
+				done = true;
+				break;
+			}
+			if (!have_next)
+				break;
+			// own DMA landed once only this wave-tile's stores are outstanding (vmcnt is in order)
+			if (n == WT)
+			{
+				if constexpr (ITER * STORES_PER_FRAME <= 63)
+					asm volatile("s_waitcnt vmcnt(%0)" ::"i"(ITER * STORES_PER_FRAME) : "memory");
+				else
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			}
+			else
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			cur ^= 1u;
+			packed_info = next_info;
+		}
+
+		if (done)
+		{
+			(void)draw_resolve(ticket);   // the stream's last chunk is the last of its sequence: nothing follows
+			break;
+		}
+		if (next_chunk == ~0ull)
+			break;
+		chunk = next_chunk;
+	}
+
+	retire();
+}
+
+} // namespace
+
+#endif // CR_KWAVE2_HPP

@@ -451,7 +451,7 @@ static double swizzle_cost(const cr_poly *poly, uint64_t increment, uint32_t swi
 	double extra = 0.0;
 	unsigned trial;
 
-	for (trial = 0; trial < 128; ++trial)
+	for (trial = 0; trial < 32; ++trial)
 	{
 		const uint32_t frac0 = (trial * 40503u + 977u) & 0xFFFFu;
 		unsigned g;
@@ -484,7 +484,7 @@ static double swizzle_cost(const cr_poly *poly, uint64_t increment, uint32_t swi
 		}
 	}
 
-	return extra / 128.0;
+	return extra / 32.0;
 }
 
 void cr_poly_slot_signs(const cr_poly *poly, uint32_t *positive, uint32_t *negative)

@@ -50,7 +50,7 @@ typedef struct crhip_poly_launch
 	uint32_t step;              /* kernel_step_size */
 	int32_t aff_a, aff_b, aff_c;
 	uint32_t threads;           /* workgroup size the instance was compiled for */
-	uint32_t vecs;              /* k_poly: 16-byte input vectors per thread per tile (template NV); k_wave: 100 + NVW */
+	uint32_t vecs;              /* k_poly: 16-byte input vectors per thread per tile (template NV); k_wave: 100 + NVW; k_wave2: 150 + NVW; k_up: 200 */
 	uint32_t tile_frames;       /* output frames per tile */
 	uint32_t lds_bytes;         /* polyphase rows + two tiles + 16 bytes of mailbox */
 	uint32_t blocks;            /* grid size */
@@ -150,6 +150,11 @@ int crhip_poly_up_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, 
 /* 1 when the instance's default variant is one of the 64-bit-chain variants (whose sign precondition the host must check) */
 int crhip_poly_default_is_mad(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
 uint32_t crhip_poly_up_fallback_variant(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
+/* k_wave2 (expanded window, 64-bit multiply-add taps; variant 30): -1 when the instance has none, 1 when it is built for the slot
+   signs in *negmask (the host checks the plan's rows against them, as for k_up), 0 when it takes any rows */
+int crhip_poly_wave2_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t *negmask);
+/* the variant to use when a plan does not qualify for k_wave2 */
+uint32_t crhip_poly_wave2_fallback_variant(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
 /* Number of tuning variants of the specialised instances (crhip_poly_launch.variant). */
 int crhip_poly_variants(void);
 /* Geometry the instance that a launch with these parameters selects is compiled for: workgroup size, 16-byte input

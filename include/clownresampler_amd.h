@@ -144,7 +144,7 @@ typedef struct ClownResamplerAMD_Plan ClownResamplerAMD_Plan;
 
 typedef struct ClownResamplerAMD_PlanInfo
 {
-	uint32_t kernel;            /* 1 = k_poly (polyphase rows in LDS, workgroup tiles), 2 = k_wave (same, wave-autonomous), 3 = k_up (input-stationary, strong upsampling), 0 = generic 64-bit kernel */
+	uint32_t kernel;            /* 1 = k_poly (polyphase rows in LDS, workgroup tiles), 2 = k_wave (same, wave-autonomous), 3 = k_up / k_up2 (input-stationary, strong upsampling), 4 = k_wave2 (wave-autonomous, expanded window, 64-bit multiply-add taps), 0 = generic 64-bit kernel */
 	uint32_t channels;
 	uint32_t slots;             /* taps evaluated per output frame (zero-weight slots included) */
 	uint32_t first_slot;        /* frame offset of slot 0 relative to position_integer, in padded-buffer frames (row_mode 0: of the

@@ -115,8 +115,8 @@ def main():
         if v >= 22 and v < 26:
             print("%3d  2 lanes/frame geo %s nt=%d %5d %6d %4d | %7.1f %7.1f | %7.0f  %.3f %s" % (v, [(1024, 2), (512, 2)][(v - 22) % 2], 1 - (v - 22) // 2, i.tile_frames, i.lds_bytes, i.max_blocks, med, mn, nbytes / med / 1e3, nbytes / med / 1e3 / 8000, "MISMATCH" if v in bad else ""))
             continue
-        if v in (26, 27, 28, 29):
-            kind = {26: "k_up nt=1", 27: "k_up 64-bit chain", 28: "k_poly 64-bit chain", 29: "k_wave/k_poly 64-bit chain"}[v]
+        if v in (26, 27, 28, 29, 30):
+            kind = {26: "k_up (round 1)", 27: "k_up2", 28: "k_poly 64-bit chain", 29: "k_wave/k_poly 64-bit chain", 30: "k_wave2"}[v]
             print("%3d  %-26s kernel %d %5d %6d %4d | %7.1f %7.1f | %7.0f  %.3f %s" % (v, kind, i.kernel, i.tile_frames, i.lds_bytes, i.max_blocks, med, mn, nbytes / med / 1e3, nbytes / med / 1e3 / 8000, "MISMATCH" if v in bad else ""))
             continue
         if v in (20, 21):

@@ -1075,18 +1075,17 @@ ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t t
 	if (plan->use_poly)
 		plan_geometry(plan);
 
-	if (plan->use_poly && plan->vecs >= 150u && plan->vecs < 200u)
+	/* instances that rotate the rows while staging them into LDS get the rotation that suits THIS plan's increment (the image
+	   in global memory stays the plain one, shared by the plans of every increment) */
+	plan->lds_swizzle = 0;
+	if (plan->use_poly && crhip_poly_swizzled(plan->channels, plan->specialised ? plan->poly.slots : 0xFFFFu, plan->poly.row_mode, plan->poly.norm_mode, plan->variant))
 		plan->lds_swizzle = cr_poly_pick_swizzle(&plan->poly, increment, &plan->conflict_plain, &plan->conflict_best);
 
 	if (plan->use_poly)
 	{
 		const int layout = plan->specialised ? CR_IMAGE_COMPACT : CR_IMAGE_SPLIT;
 
-		/* the bank-conflict model walks a few thousand wave footprints (~0.4 ms): only worth running for an instance that
-		   can read a swizzled image, and none is built at present */
-		plan->swizzle = 0;
-		if (crhip_poly_swizzled(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant))
-			plan->swizzle = cr_poly_pick_swizzle(&plan->poly, increment, &plan->conflict_plain, &plan->conflict_best);
+		plan->swizzle = 0;   /* (the image in global memory is never swizzled: see lds_swizzle) */
 
 		if (store->d_rows != NULL && (store->rows_layout != layout || store->swizzle != plan->swizzle))
 		{
@@ -1214,7 +1213,7 @@ static void fill_poly_launch(const ClownResamplerAMD_Plan *plan, crhip_poly_laun
 	l->specialised = plan->specialised;
 	l->variant = plan->variant;
 	l->plane_rows = plan->plane_rows;
-	l->swizzle = (plan->vecs >= 150u && plan->vecs < 200u) ? plan->lds_swizzle : plan->swizzle;
+	l->swizzle = plan->lds_swizzle;
 	l->debug_stamps = g_debug_stamps;
 }
 

@@ -29,10 +29,10 @@ struct geometry
 constexpr geometry GEOMETRY[5] = {{256, 2}, {512, 1}, {512, 2}, {1024, 1}, {1024, 2}};
 constexpr int VARIANTS = 20;
 
-template <int CH, int TT, int MODE, int NORM, int GEO, int ASM, int UI, int NT, int OUT16 = 0>
+template <int CH, int TT, int MODE, int NORM, int GEO, int ASM, int UI, int NT, int OUT16 = 0, int SWZ = 0>
 constexpr poly_fn instance()
 {
-	return (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[GEO].threads, GEOMETRY[GEO].vecs, ASM, (1 << UI), 0, 0, OUT16, NT>;
+	return (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[GEO].threads, GEOMETRY[GEO].vecs, ASM, (1 << UI), SWZ, 0, OUT16, NT>;
 }
 
 template <int CH, int TT, int MODE, int NORM, int V>
@@ -201,6 +201,11 @@ constexpr int runtime_geo(int channels)
 {
 	return channels <= 4 ? 3 : 4;   // (512 threads x 2 vectors, which the specialised 8-channel instances prefer, measured 10-20 % slower here)
 }
+// 1 = the run-time-slot instances stage their rows rotated (the plan picks the rotation for its increment).  Measured with 1 on
+// every channel count and ratio of tools/channel_table.py: no gain anywhere, 0-5 % slower (profiles/
+// r02_channel_table_runtime_rows_swizzled.log against r02_channel_table.log) - bank conflicts are half of these kernels' LDS
+// cycles, but the LDS is not what binds them - so it stays 0; k_wave2, which IS LDS-bound, rotates its rows.
+constexpr int RUNTIME_SWZ = 0;
 constexpr int runtime_split(int channels)
 {
 	return channels > 8 ? 2 : 1;
@@ -211,10 +216,10 @@ poly_fn pick_runtime(uint32_t mode, uint32_t norm)
 {
 	constexpr int GEO = runtime_geo(CH);
 	if (norm == CRHIP_NORM_S31)
-		return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, GEO, 1, 0, 1, OUT16>()
-		                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, GEO, 1, 0, 1, OUT16>();
-	return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, GEO, 1, 0, 1, OUT16>()
-	                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, GEO, 1, 0, 1, OUT16>();
+		return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, GEO, 1, 0, 1, OUT16, RUNTIME_SWZ>()
+		                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, GEO, 1, 0, 1, OUT16, RUNTIME_SWZ>();
+	return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, GEO, 1, 0, 1, OUT16, RUNTIME_SWZ>()
+	                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, GEO, 1, 0, 1, OUT16, RUNTIME_SWZ>();
 }
 
 // two lanes per frame, HALF channels each (run-time slot count, geometry 4); PH = 1: 2 * HALF - 1 channels (see k_poly)
@@ -223,10 +228,10 @@ poly_fn pick_runtime_split(uint32_t mode, uint32_t norm)
 {
 	constexpr int T = GEOMETRY[runtime_geo(16)].threads, V = GEOMETRY[runtime_geo(16)].vecs;
 	if (norm == CRHIP_NORM_S31)
-		return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, T, V, 1, 1, 0, 0, OUT16, 1, 2, PH>
-		                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, T, V, 1, 1, 0, 0, OUT16, 1, 2, PH>;
-	return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, T, V, 1, 1, 0, 0, OUT16, 1, 2, PH>
-	                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, T, V, 1, 1, 0, 0, OUT16, 1, 2, PH>;
+		return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, T, V, 1, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>
+		                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, T, V, 1, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>;
+	return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, T, V, 1, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>
+	                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, T, V, 1, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>;
 }
 
 

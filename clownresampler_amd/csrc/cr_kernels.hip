@@ -377,10 +377,12 @@ static uint32_t resolve_variant(const special *sp, uint32_t variant, uint32_t ou
 
 int crhip_poly_swizzled(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t variant)
 {
+	// instances that stage their rows rotated for the plan's increment (crhip_poly_launch.swizzle): k_wave2, and k_poly with a
+	// run-time slot count
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
-	(void)sp;
-	(void)variant;
-	return 0;   // no swizzled instance is built
+	if (sp == nullptr)
+		return RUNTIME_SWZ;
+	return resolve_variant(sp, variant) == WAVE2_VARIANT ? 1 : 0;
 }
 
 int crhip_poly_variants(void)

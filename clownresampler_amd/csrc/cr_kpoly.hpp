@@ -163,8 +163,21 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 		const unsigned nvec = rows_bytes / 16u;
 		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.d_rows);
 		u32x4 *dst = reinterpret_cast<u32x4 *>(smem);
-		for (unsigned i = tid; i < nvec; i += NTHREADS)
-			dst[i] = src[i];
+		if constexpr (SWZ)
+		{
+			// the rows land rotated within their block of 16 (one_frame / fetch_frame read them back the same way): the image in
+			// global memory is the plain one, shared by plans of every increment; the rotation that suits THIS increment is the
+			// plan's (cr_poly_pick_swizzle)
+			const unsigned planes = a.row_stride / 4u;
+			for (unsigned q = 0; q < planes; ++q)
+				for (unsigned r = tid; r < a.plane_rows; r += NTHREADS)
+					dst[q * a.plane_rows + ((r & ~15u) | ((__umul24(r >> 4, a.swizzle) + r) & 15u))] = src[q * a.plane_rows + r];
+		}
+		else
+		{
+			for (unsigned i = tid; i < nvec; i += NTHREADS)
+				dst[i] = src[i];
+		}
 	}
 	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 	__syncthreads();   // rows staged (plain stores to LDS), first tile landed and first ticket posted, for every wave

@@ -38,10 +38,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-# integer VALU: 256 CUs x 4 SIMDs; a wave64 multiply / multiply-add / SDWA form issues every 4.2 cycles, a plain add / shift
-# every 2.3 (profiles/r01_valubench.log), at the ~2.25 GHz the chip sustains under this load (profiles/r01_sweeps_final.log)
-SIMDS = 1024
-VALU_CLOCK_GHZ = 2.25
+SIMDS = 1024           # 256 CUs x 4 SIMDs
 
 WORKLOADS = {
     # name: (radius, channels, (in, out, lowpass), input frames)
@@ -361,18 +358,20 @@ def main():
                 "algorithmic_bytes_per_launch": launch_bytes, "launch_ms": mean_ms, "launch_ms_is": "mean of the %d timed launches (one HIP event pair on the launch stream)" % args.steps,
                 "read_only_GBs": shard.input_frames * ch * 2 / (mean_ms * 1e-3) / 1e9}
     roofline_valu = None
-    if pmc and "SQ_INSTS_VALU" in pmc:
-        # Which ceiling binds?  The launch's VALU wave-instructions (PMC) at the SIMDs' measured issue rate, against the launch
-        # time.  Instruction mix of the tap arithmetic: multiplies / multiply-adds / SDWA adds at 4.2 cycles; taken as the rate
-        # of every instruction this is a LOWER bound of the VALU time (plain adds and shifts issue in 2.3).
-        insts = pmc["SQ_INSTS_VALU"]
-        peak = SIMDS * VALU_CLOCK_GHZ * 1e9 / 4.2
-        ach = insts / (mean_ms * 1e-3)
-        roofline_valu = {"bound": "valu", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s", "frac": ach / peak,
-                         "valu_wave_instructions_per_launch": insts, "per_tap_channel": insts * 64.0 / (shard.output_frames * ch * max(1, info.slots)),
-                         "note": "SQ_INSTS_VALU per launch from profiles/%s (not measured in this run); peak = %d SIMDs x %.2f GHz / 4.2 cycles per wave64 multiply-class instruction (profiles/r01_valubench.log)" % (pmc_file, SIMDS, VALU_CLOCK_GHZ)}
+    if pmc and "SQ_ACTIVE_INST_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
+        # Which ceiling binds?  VALU busy = the cycles the SIMDs spent issuing VALU instructions over the cycles the launch
+        # lasted, both from PMC counters of a profiled run of this same command (rocprofv3's VALUBusy: SQ_ACTIVE_INST_VALU counts
+        # in units of 4 cycles and is summed over the 1,024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs).
+        busy = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / SIMDS
+        available = pmc["GRBM_GUI_ACTIVE"] / 8.0
+        insts = pmc.get("SQ_INSTS_VALU", 0.0)
+        roofline_valu = {"bound": "valu", "achieved": busy, "peak": available, "unit": "cycles per SIMD per launch (VALU issuing / elapsed)", "frac": busy / available,
+                         "valu_wave_instructions_per_launch": insts,
+                         "valu_per_tap_channel": insts * 64.0 / (shard.output_frames * ch * max(1, info.slots)) if insts else None,
+                         "lds_bank_conflict_share": (pmc["SQ_LDS_BANK_CONFLICT"] / pmc["SQ_LDS_IDX_ACTIVE"]) if pmc.get("SQ_LDS_IDX_ACTIVE") else None,
+                         "note": "NOT measured in this run: SQ_ACTIVE_INST_VALU x 4 / %d SIMDs against GRBM_GUI_ACTIVE / 8 XCDs, per-dispatch means of profiles/%s" % (SIMDS, pmc_file)}
         if roofline_valu["frac"] > roofline["frac"]:
-            roofline["binding"] = "valu (see roofline_valu): the integer VALU ceiling is below the HBM ceiling for this workload"
+            roofline["binding"] = "valu (see roofline_valu): the SIMDs issue VALU instructions for %.0f %% of the launch; the HBM figure above is what that leaves" % (100 * roofline_valu["frac"])
 
     def oracle_window(first_out, n_chk, salt):
         """Frames [first_out, first_out + n_chk) of the WHOLE stream's output from the oracle: closed-form state at first_out

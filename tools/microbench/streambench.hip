@@ -34,6 +34,8 @@ __global__ __launch_bounds__(256) void k_flat(const u32x4 *in, size_t in_vecs, u
 		if (i < out_vecs)
 			out[i] = acc + (unsigned)w;
 	}
+	if constexpr (WV == 0)
+		asm volatile("" ::"v"(acc.x), "v"(acc.y), "v"(acc.z), "v"(acc.w));   // the loads stay (cdna_hip_programming.md rule 17)
 }
 
 // A2: flat grid, every thread writes one 32-byte output record as two 16-byte stores (lane stride 32 B: the shape of an
@@ -120,7 +122,9 @@ int main()
 {
 	const size_t in_bytes = 26460006ull * 4, out_bytes = 28800096ull * 8;
 	const size_t in_vecs = in_bytes / 16, out_vecs = out_bytes / 16;
-	const int SETS = 3;
+	// Rotating buffers whose TOTAL exceeds 1 GB for each direction on its own: the 256 MiB Infinity Cache must not be able to
+	// serve (or absorb) a launch that follows another - with 3 x 230 MB the write-only case of round 1 "ran" at 9.4 TB/s.
+	const int SETS = 12;   // 12 x 105.8 MB = 1.27 GB of input, 12 x 230.4 MB = 2.76 GB of output
 	u32x4 *in[SETS];
 	u32x4 *out[SETS];
 	for (int s = 0; s < SETS; ++s)
@@ -129,8 +133,9 @@ int main()
 		CHECK(hipMalloc(&out[s], out_bytes + 4096));
 		CHECK(hipMemset(in[s], s + 1, in_bytes));
 	}
-	const double total = (double)in_bytes + (double)out_bytes;
-	printf("traffic per launch: read %.2f MB + write %.2f MB; 3 rotating buffer sets\n", in_bytes / 1e6, out_bytes / 1e6);
+	double total = (double)in_bytes + (double)out_bytes;
+	printf("traffic per launch: read %.2f MB + write %.2f MB; %d rotating buffer sets (%.2f GB read side, %.2f GB write side)\n", in_bytes / 1e6, out_bytes / 1e6, SETS,
+	       SETS * in_bytes / 1e9, SETS * out_bytes / 1e9);
 	auto report = [&](const char *name, double us) { printf("%-58s %8.1f us  %7.0f GB/s  (%.3f of 8 TB/s)\n", name, us, total / us / 1e3, total / us / 1e3 / 8000); };
 
 	{
@@ -142,9 +147,12 @@ int main()
 		report("flat, 2 read vecs + 4 write vecs per thread", time_us([&](int i) { hipLaunchKernelGGL((k_flat<2, 4>), dim3(grid4), dim3(256), 0, 0, in[i % SETS], in_vecs, out[i % SETS], out_vecs); }));
 		const unsigned grid8 = (unsigned)(((out_vecs + 7) / 8 + 255) / 256);
 		report("flat, 4 read vecs + 8 write vecs per thread", time_us([&](int i) { hipLaunchKernelGGL((k_flat<4, 8>), dim3(grid8), dim3(256), 0, 0, in[i % SETS], in_vecs, out[i % SETS], out_vecs); }));
-		report("flat, write only (2 vecs per thread)", time_us([&](int i) { hipLaunchKernelGGL((k_flat<0, 2>), dim3(grid), dim3(256), 0, 0, in[i % SETS], in_vecs, out[i % SETS], out_vecs); }));
+		total = (double)out_bytes;   // bytes this case really moves
+		report("flat, write only (2 vecs per thread), 230.4 MB", time_us([&](int i) { hipLaunchKernelGGL((k_flat<0, 2>), dim3(grid), dim3(256), 0, 0, in[i % SETS], in_vecs, out[i % SETS], out_vecs); }));
 		const unsigned gridr = (unsigned)((in_vecs + 255) / 256);
-		report("flat, read only (1 vec per thread; bytes counted as all)", time_us([&](int i) { hipLaunchKernelGGL((k_flat<1, 0>), dim3(gridr), dim3(256), 0, 0, in[i % SETS], in_vecs, out[i % SETS], (size_t)0); }));
+		total = (double)in_bytes;
+		report("flat, read only (1 vec per thread), 105.8 MB", time_us([&](int i) { hipLaunchKernelGGL((k_flat<1, 0>), dim3(gridr), dim3(256), 0, 0, in[i % SETS], in_vecs, out[i % SETS], (size_t)0); }));
+		total = (double)in_bytes + (double)out_bytes;
 	}
 	{
 		// 8-channel shape (cfg 4): 28.8 M frames of 16 B in, 26.46 M frames of 32 B out

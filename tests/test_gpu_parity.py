@@ -682,12 +682,14 @@ def test_input_stationary_variants_on_golden_cases(golden, products, name, varia
 
 @pytest.mark.parametrize("radius,rates", [(8, (8000, 96000, 8000)), (8, (22050, 44100, 22050)), (8, (8000, 127999, 8000)), (3, (11025, 44100, 11025)),
                                          (3, (8000, 24000, 8000)), (3, (12000, 191999, 12000)), (3, (16000, 32001, 16000)), (3, (8000, 44100, 8000))])
-def test_input_stationary_kernel_bit_exact(products, radius, rates):
-    """k_up (one lane per INPUT position, truncation bias from the sample's sign and the slot's compile-time weight sign) against the
-    oracle: ratios 2x-16x, both radii, ragged lengths, a carried start position, a capacity stop, and the clamped int16 output."""
+@pytest.mark.parametrize("variant", [26, 27])
+def test_input_stationary_kernel_bit_exact(products, radius, rates, variant):
+    """k_up (26: round 1's form) and k_up2 (27) - one lane per INPUT position, truncation bias from the sample's sign and the slot's
+    compile-time weight sign - against the oracle: ratios 2x-16x, both radii, ragged lengths, a carried start position, a capacity
+    stop, and the clamped int16 output."""
     p, o = products[radius], ck.oracle(radius)
     ch = 2
-    p.api.DebugSetVariant(26)
+    p.api.DebugSetVariant(variant)
     try:
         for frames, first_call in [(1, 0), (63, 0), (4099, 0), (30011, 777)]:
             pcm = ck.noise_pcm(frames * ch, 31 + frames)
@@ -720,11 +722,12 @@ def test_input_stationary_kernel_bit_exact(products, radius, rates):
         p.api.DebugSetVariant(0xFFFF)
 
 
-def test_input_stationary_kernel_random_ratios(products):
-    """k_up over 80 random pure-upsampling ratios between 2x and 16x (random rates, so the increments are arbitrary), random lengths,
-    and a random split into two calls (the second starts at a fractional position): every stream equals the oracle's."""
+@pytest.mark.parametrize("variant", [26, 27])
+def test_input_stationary_kernel_random_ratios(products, variant):
+    """k_up / k_up2 over 80 random pure-upsampling ratios between 2x and 16x (random rates, so the increments are arbitrary), random
+    lengths, and a random split into two calls (the second starts at a fractional position): every stream equals the oracle's."""
     import random
-    rng = random.Random(4711)
+    rng = random.Random(4711 + variant)
     used = 0
     for draw in range(80):
         radius = rng.choice([3, 8])
@@ -735,7 +738,7 @@ def test_input_stationary_kernel_random_ratios(products):
         ok, a = p.low_init(2, i, out, i)
         ok2, b = o.low_init(2, i, out, i)
         assert ok == ok2 and a.astuple() == b.astuple()
-        p.api.DebugSetVariant(26)
+        p.api.DebugSetVariant(variant)
         try:
             info = p.api.PlanGetInfo(p.api.PlanCreate(a.raw, p.pre))
             used += info.kernel == 3
@@ -754,6 +757,54 @@ def test_input_stationary_kernel_random_ratios(products):
         finally:
             p.api.DebugSetVariant(0xFFFF)
     assert used >= 70, used       # nearly all draws qualify (increment within 4096..32768)
+
+
+def test_expanded_window_kernel_random_ratios(products):
+    """k_wave2 (window expanded to sample << 16 per wave-tile, 64-bit multiply-add taps; the 8-lobe stereo instances) over random
+    ratios: pure upsampling below 2x (15 slots, slot signs fixed: magnitudes + a second accumulator pair) and mild downsampling
+    (17 slots, any-sign rows), random lengths incl. shorter than a wave-tile, a random split into two calls, int32 and clamped
+    int16 output, full-scale square input among the noise."""
+    import random
+    rng = random.Random(90125)
+    p, o = products[8], ck.oracle(8)
+    used = {15: 0, 17: 0}
+    for draw in range(60):
+        if draw % 2 == 0:
+            i = rng.randrange(8000, 96000)
+            out = int(i * rng.uniform(1.0, 1.99))
+            lp = i
+        else:
+            out = rng.randrange(8000, 96000)
+            i = int(out * rng.uniform(1.02, 1.12))
+            lp = out
+        frames = rng.choice([rng.randrange(1, 300), rng.randrange(300, 6000), rng.randrange(6000, 60000)])
+        ok, a = p.low_init(2, i, out, lp)
+        ok2, b = o.low_init(2, i, out, lp)
+        assert ok == ok2 and a.astuple() == b.astuple()
+        info = p.api.PlanGetInfo(p.api.PlanCreate(a.raw, p.pre))
+        if info.kernel == 4:
+            used[info.slots] = used.get(info.slots, 0) + 1
+        pcm = ck.noise_pcm(frames * 2, 2000 + draw)
+        if draw % 5 == 0:
+            pcm[: min(pcm.size, 4000)] = np.where(np.arange(min(pcm.size, 4000)) % 14 < 7, 32767, -32768)
+        padded = ck.pad_frames(pcm, 2, int(b.cfg.radius_frames))
+        total = ck.count_output_frames(b, frames)
+        if draw % 3 == 0:
+            want, _, _ = o.low_resample_i32(b, padded, frames)
+            got, left, ran_out = p.api.LowLevel_ResampleBulkS16(a.raw, p.pre, padded, frames)
+            assert np.array_equal(got, np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16)), (i, out, frames)
+            continue
+        cut = rng.randrange(1, total) if total > 1 else None
+        if cut is not None:
+            xa, la, ra = p.low_resample_i32(a, padded, frames, capacity=cut)
+            xb, lb, rb = o.low_resample_i32(b, padded, frames, capacity=cut)
+            assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple(), (i, out, frames, cut)
+            padded = padded[(frames - la) * 2:]
+            frames = la
+        xa, la, ra = p.low_resample_i32(a, padded, frames)
+        xb, lb, rb = o.low_resample_i32(b, padded, frames)
+        assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple(), (i, out, frames)
+    assert used[15] >= 20 and used[17] >= 5, used
 
 
 @pytest.mark.parametrize("variant", [2, 4, 14, 22, 23, 24, 25])

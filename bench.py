@@ -57,6 +57,14 @@ WORKLOADS = {
     "dn2": (3, 2, (48000, 44100, 44100), 28800000),    # stereo 48 -> 44.1 kHz, 10 min
     "dn1": (3, 1, (48000, 44100, 44100), 57600000),    # mono 48 -> 44.1 kHz, 20 min
     "hq44": (8, 2, (48000, 44100, 44100), 28800000),   # 8 lobes, 48 -> 44.1 kHz (17-tap windows)
+    "hq48m": (8, 1, (44100, 48000, 44100), 52920000),  # 8 lobes, mono
+    "hq44m": (8, 1, (48000, 44100, 44100), 57600000),
+    "hq48c4": (8, 4, (44100, 48000, 44100), 13230000), # 8 lobes, 4 / 6 / 8 channels
+    "hq48c6": (8, 6, (44100, 48000, 44100), 8820000),
+    "hq48c8": (8, 8, (44100, 48000, 44100), 6615000),
+    "hq44c6": (8, 6, (48000, 44100, 44100), 9600000),
+    "hq48c3": (8, 3, (44100, 48000, 44100), 17640000),
+    "hq48c5": (8, 5, (44100, 48000, 44100), 10584000),
     "dn21": (3, 2, (96000, 48000, 48000), 57600000),   # stereo 2:1, 12-slot windows
     "dn32": (3, 2, (48000, 32000, 32000), 28800000),   # stereo 3:2, 9-slot windows
     "dn31": (3, 2, (96000, 32000, 32000), 57600000),   # stereo 3:1, 18-slot windows

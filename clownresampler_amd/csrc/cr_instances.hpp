@@ -77,13 +77,13 @@ struct special
 constexpr uint32_t MAD_VARIANT = 28;    // variant ids 28, 29
 constexpr uint32_t WAVE2_VARIANT = 30;  // variant id 30: k_wave2 where the instance has one
 
-// k_wave2 of a stereo instance: fixed slot signs (NEGMASK != 0: pure upsampling, 2 VALU per tap and channel) or any rows (3)
-template <int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, unsigned NEGMASK>
+// k_wave2 of an instance: fixed slot signs (NEGMASK != 0: pure upsampling, 2 VALU per tap and channel) or any rows (3)
+template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, unsigned NEGMASK>
 void add_wave2(special &s)
 {
 	constexpr int SIGNED = NEGMASK == 0 ? 1 : 0;
-	s.wave2 = (poly_fn)k_wave2<TT, MODE, NORM, WAVES, NVW, ITER, 0, 1, NEGMASK, SIGNED>;
-	s.wave2_16 = (poly_fn)k_wave2<TT, MODE, NORM, WAVES, NVW, ITER, 1, 1, NEGMASK, SIGNED>;
+	s.wave2 = (poly_fn)k_wave2<CH, TT, MODE, NORM, WAVES, NVW, ITER, 0, 1, NEGMASK, SIGNED>;
+	s.wave2_16 = (poly_fn)k_wave2<CH, TT, MODE, NORM, WAVES, NVW, ITER, 1, 1, NEGMASK, SIGNED>;
 	s.wave2_waves = WAVES;
 	s.wave2_nvw = NVW;
 	s.wave2_iter = ITER;
@@ -94,10 +94,10 @@ void add_wave2(special &s)
 
 // DEFAULT: k_wave2 becomes the instance's default variant (where it measured faster than the k_poly / k_wave forms); the
 // previous default stays the fallback for plans whose window does not fit a wave's slice
-template <int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, unsigned NEGMASK, bool DEFAULT = false>
+template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, unsigned NEGMASK, bool DEFAULT = false>
 special with_wave2(special s)
 {
-	add_wave2<TT, MODE, NORM, WAVES, NVW, ITER, NEGMASK>(s);
+	add_wave2<CH, TT, MODE, NORM, WAVES, NVW, ITER, NEGMASK>(s);
 	if (DEFAULT)
 	{
 		s.wave2_fallback = s.default_variant;

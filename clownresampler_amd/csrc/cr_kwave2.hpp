@@ -1,4 +1,4 @@
-// cr_kwave2.hpp - k_wave2: k_wave's streaming with the tap arithmetic of k_up2, for STEREO streams.
+// cr_kwave2.hpp - k_wave2: k_wave's streaming with the tap arithmetic of k_up2, 1 to 8 channels.
 #ifndef CR_KWAVE2_HPP
 #define CR_KWAVE2_HPP
 
@@ -25,22 +25,26 @@ namespace
 //   SIGNED == 1 (any rows): W = weight as it is, lo = (X ^ W) >> 31.  3 VALU.
 // Everything else - tickets over 32 counter lanes, a private double-buffered LDS-DMA window per wave, counted vmcnt, coalesced
 // non-temporal stores - is k_wave's.  LDS per wave: two packed windows (NVW KiB each) and one expanded window (2 x NVW KiB).
+// (Loading the packed window into registers instead of LDS - coalesced buffer loads a wave-tile ahead, the expansion straight
+// from registers, half the LDS footprint - was tried and is not kept: with hipcc's own loads it protects the registers with
+// vmcnt(0), draining the tile's stores every time (117 against 105 us on the 8-lobe 44.1 -> 48 kHz workload), and inline-assembly
+// loads cannot be made safe: hipcc copies their destination registers before the data has landed.)
 //   WAVES  waves per workgroup     NVW  1 KiB DMA pieces per wave-tile     ITER  frames per lane per wave-tile
 // ---------------------------------------------------------------------------------------------------------
-template <int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, int OUT16, int NT, unsigned NEGMASK, int SIGNED>
+template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, int OUT16, int NT, unsigned NEGMASK, int SIGNED>
 __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 {
-	constexpr int CH = 2;
+	static_assert(CH >= 1 && CH <= 8, "one lane per frame");
 	constexpr unsigned FB = CH * 2;
 	constexpr unsigned NTHREADS = WAVES * 64;
 	constexpr unsigned WT = 64u * ITER;            // frames per wave-tile
 	constexpr unsigned CW = 4;                     // wave-tiles per chunk (ticket)
 	constexpr unsigned CHUNK = WT * CW;
 	constexpr unsigned BUF = NVW * 1024u;          // bytes per packed window
-	constexpr unsigned XBUF = 2u * BUF;            // bytes of the expanded window (8 per stereo frame)
+	constexpr unsigned XBUF = 2u * BUF;            // bytes of the expanded window (4 per sample)
 	constexpr unsigned PER_WAVE = 2u * BUF + XBUF;
 	constexpr int RS = (TT + 1 + 3) & ~3;
-	constexpr int STORES_PER_FRAME = 1;            // one 8-byte (int32 x 2) or 4-byte (int16 x 2) store
+	constexpr int STORES_PER_FRAME = OUT16 ? (CH % 2 == 0 ? stores_of_ints(CH / 2) : CH) : stores_of_ints(CH);
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -152,12 +156,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 		return (unsigned)__builtin_amdgcn_readfirstlane((int)(shift | (frames << 16)));
 	};
 
-	// packed window -> X = sample << 16, one dword per sample (the frames beyond the caller's buffer were delivered as zeros)
-	auto expand = [&](const unsigned char *buf, unsigned shift_frames) {
+	// packed window -> X = sample << 16, one dword per sample, in window order (the frames beyond the caller's buffer were delivered
+	// as zeros).  The window is converted dword by dword from the aligned dword its first sample sits in: for an odd channel
+	// count that sample may be the dword's HIGH half, and sample j of the window is then X[1 + j] (returned: 0 or 1).
+	auto expand = [&](const unsigned char *buf, unsigned shift_frames) -> unsigned {
 		const unsigned shift = shift_frames & 0xFFFFu, frames = shift_frames >> 16;
-		for (unsigned i = lane; i < frames; i += 64u)
+		const unsigned odd = (shift >> 1) & 1u;
+		const unsigned dwords = (odd + frames * CH + 1u) / 2u;
+		const unsigned char *from = buf + (shift & ~3u);
+		for (unsigned i = lane; i < dwords; i += 64u)
 		{
-			const int f = *reinterpret_cast<const int *>(buf + shift + i * FB);
+			const int f = *reinterpret_cast<const int *>(from + i * 4u);
 			i32x2 x;
 			x.x = (int)((unsigned)f << 16);
 			x.y = (int)((unsigned)f & 0xFFFF0000u);
@@ -167,19 +176,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		return odd;
 	};
 
-	// one output frame from the expanded window
-	auto one_frame2 = [&](unsigned rel, int &out0, int &out1) {
+	// one output frame from the expanded window: CH normalised results into out[]
+	auto one_frame2 = [&](unsigned rel, unsigned x_odd, int *out) {
 		unsigned shift;
 		const unsigned row = row_of<MODE>(a, rel & 0xFFFFu, shift);
 		// The lanes of a wave hold consecutive output frames, so their rows step by a fixed amount (83.2 rows per lane at
 		// 44.1 -> 48 kHz) and the 16 lanes a ds_read_b128 services together fall on 5-8 of the 16 bank slots: the row reads were
-		// half of this kernel's LDS cycles as conflicts (profiles/r02_hq48_pmc.txt).  Within each block of 16 rows the rows are
-		// rotated by a host-chosen multiple of the block number, which spreads them over all 16 slots.
+		// half of this kernel's LDS cycles as conflicts (profiles/r02_kwave2_trials.log).  Within each block of 16 rows the rows
+		// are rotated by a host-chosen multiple of the block number, which spreads them over all 16 slots.
 		const unsigned phys = (row & ~15u) | ((__umul24(row >> 4, a.swizzle) + row) & 15u);
 		const i32x4 *plane0 = reinterpret_cast<const i32x4 *>(smem) + phys;
-		const i32x2 *win = reinterpret_cast<const i32x2 *>(my_x) + (rel >> 16) + shift;
+		// LDS byte address of sample 0 of slot 0 (the low 32 bits of a __shared__ pointer are the LDS address)
+		const unsigned win_at = (unsigned)(uintptr_t)my_x + (x_odd + ((rel >> 16) + shift) * CH) * 4u;
 		int w[RS];
 #pragma unroll
 		for (int q = 0; q < RS / 4; ++q)
@@ -190,22 +201,52 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 			w[4 * q + 2] = v.z;
 			w[4 * q + 3] = v.w;
 		}
-		// the window as TT separate 8-byte reads: left to itself hipcc pairs them into ds_read2_b64, which moves 128 B per clock
-		// where ds_read_b64 moves 256 (MI355X_MICROARCH.md, LDS) - and this kernel is as much LDS- as VALU-bound
-		i32x2 x[TT];
+
+		// channels two at a time (the last one alone when CH is odd): the TT samples of each, then the taps
+#pragma unroll
+		for (int c0 = 0; c0 < CH; c0 += 2)
 		{
-			const unsigned win_at = (unsigned)(uintptr_t)win;   // LDS byte address (the low 32 bits of a __shared__ pointer)
+			constexpr bool EVEN = CH % 2 == 0;
+			const bool pair = c0 + 1 < CH;
+			// The window as separate reads: left to itself hipcc pairs them into ds_read2_b64, which moves 128 B per clock where
+			// ds_read_b64 moves 256 (MI355X_MICROARCH.md, LDS) - and this kernel is as much LDS- as VALU-bound.  8-byte reads need
+			// 8-byte alignment: even channel counts only.
+			int xa[TT], xb[TT];
+			i32x2 xv[TT];   // (the 8-byte reads land here; nothing may touch them before the wait below)
 #pragma unroll
 			for (int s = 0; s < TT; ++s)
-				asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(x[s]) : "v"(win_at), "n"(s * 8));
+			{
+				if (pair && EVEN)
+					asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xv[s]) : "v"(win_at), "n"((s * CH + c0) * 4));
+				else
+				{
+					asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(xa[s]) : "v"(win_at), "n"((s * CH + c0) * 4));
+					if (pair)
+						asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(xb[s]) : "v"(win_at), "n"((s * CH + c0 + 1) * 4));
+				}
+			}
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
 			for (int s = 0; s < TT; ++s)
-				asm volatile("" : "+v"(x[s]));   // (uses stay below the wait)
-		}
+			{
+				// (uses stay below the wait)
+				if (pair && EVEN)
+				{
+					asm volatile("" : "+v"(xv[s]));
+					xa[s] = xv[s].x;
+					xb[s] = xv[s].y;
+				}
+				else if (pair)
+					asm volatile("" : "+v"(xa[s]), "+v"(xb[s]));
+				else
+				{
+					asm volatile("" : "+v"(xa[s]));
+					xb[s] = 0;
+				}
+			}
 
-		// accumulator pairs pinned to physical registers (see k_up2): L+ v[120:121], R+ v[122:123], L- v[124:125], R- v[126:127]
-		int lo0, hi0 = 0, lo1, hi1 = 0, lo2, hi2 = 0, lo3, hi3 = 0;
+			// accumulator pairs pinned to physical registers (see k_up2): A+ v[120:121], B+ v[122:123], A- v[124:125], B- v[126:127]
+			int lo0, hi0 = 0, lo1, hi1 = 0, lo2, hi2 = 0, lo3, hi3 = 0;
 #define CRHIP_W2_TAP(LO, HI, VLO, VHI, X, W)                                                                                       \
 	asm("v_ashrrev_i32_e32 v" #LO ", 31, %2\n\t"                                                                                  \
 	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
@@ -216,67 +257,59 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
 	    : "=&{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc")
 #pragma unroll
-		for (int s = 0; s < TT; ++s)
-		{
-			if constexpr (SIGNED)
+			for (int s = 0; s < TT; ++s)
 			{
-				CRHIP_W2_TAP_SIGNED(120, 121, lo0, hi0, x[s].x, w[s]);
-				CRHIP_W2_TAP_SIGNED(122, 123, lo1, hi1, x[s].y, w[s]);
+				if constexpr (SIGNED)
+				{
+					CRHIP_W2_TAP_SIGNED(120, 121, lo0, hi0, xa[s], w[s]);
+					if (pair)
+						CRHIP_W2_TAP_SIGNED(122, 123, lo1, hi1, xb[s], w[s]);
+				}
+				else if ((NEGMASK >> s) & 1u)
+				{
+					CRHIP_W2_TAP(124, 125, lo2, hi2, xa[s], w[s]);
+					if (pair)
+						CRHIP_W2_TAP(126, 127, lo3, hi3, xb[s], w[s]);
+				}
+				else
+				{
+					CRHIP_W2_TAP(120, 121, lo0, hi0, xa[s], w[s]);
+					if (pair)
+						CRHIP_W2_TAP(122, 123, lo1, hi1, xb[s], w[s]);
+				}
 			}
-			else if ((NEGMASK >> s) & 1u)
+#undef CRHIP_W2_TAP
+#undef CRHIP_W2_TAP_SIGNED
+			(void)lo0;
+			(void)lo1;
+			(void)lo2;
+			(void)lo3;
+			const int acc0 = SIGNED ? hi0 : hi0 - hi2;
+			const int acc1 = SIGNED ? hi1 : hi1 - hi3;
+			if constexpr (NORM == CRHIP_NORM_U32)
 			{
-				CRHIP_W2_TAP(124, 125, lo2, hi2, x[s].x, w[s]);
-				CRHIP_W2_TAP(126, 127, lo3, hi3, x[s].y, w[s]);
+				const long long v0 = (long long)acc0 * (long long)w[TT] + (long long)((unsigned)(acc0 >> 31) >> 17);
+				out[c0] = (int)(v0 >> 15);
+				if (pair)
+				{
+					const long long v1 = (long long)acc1 * (long long)w[TT] + (long long)((unsigned)(acc1 >> 31) >> 17);
+					out[c0 + 1] = (int)(v1 >> 15);
+				}
 			}
 			else
 			{
-				CRHIP_W2_TAP(120, 121, lo0, hi0, x[s].x, w[s]);
-				CRHIP_W2_TAP(122, 123, lo1, hi1, x[s].y, w[s]);
+				out[c0] = normalise<NORM>(acc0, w[TT]);
+				if (pair)
+					out[c0 + 1] = normalise<NORM>(acc1, w[TT]);
 			}
-		}
-#undef CRHIP_W2_TAP
-#undef CRHIP_W2_TAP_SIGNED
-		(void)lo0;
-		(void)lo1;
-		(void)lo2;
-		(void)lo3;
-		const int acc0 = SIGNED ? hi0 : hi0 - hi2;
-		const int acc1 = SIGNED ? hi1 : hi1 - hi3;
-		if constexpr (NORM == CRHIP_NORM_U32)
-		{
-			const long long v0 = (long long)acc0 * (long long)w[TT] + (long long)((unsigned)(acc0 >> 31) >> 17);
-			const long long v1 = (long long)acc1 * (long long)w[TT] + (long long)((unsigned)(acc1 >> 31) >> 17);
-			out0 = (int)(v0 >> 15);
-			out1 = (int)(v1 >> 15);
-		}
-		else
-		{
-			out0 = normalise<NORM>(acc0, w[TT]);
-			out1 = normalise<NORM>(acc1, w[TT]);
 		}
 	};
 
-	auto store_frame = [&](uint64_t frame, int out0, int out1) {
+	auto store_frame = [&](uint64_t frame, const int *out) {
 		if constexpr (OUT16)
-		{
-			const int packed = (clamp_s16(out0) & 0xFFFF) | (clamp_s16(out1) << 16);
-			int *dst = reinterpret_cast<int *>(a.d_out) + frame;
-			if constexpr (NT)
-				__builtin_nontemporal_store(packed, dst);
-			else
-				*dst = packed;
-		}
+			store_shorts<CH, NT>(reinterpret_cast<short *>(a.d_out) + frame * CH, out);
 		else
-		{
-			i32x2 q;
-			q.x = out0;
-			q.y = out1;
-			i32x2 *dst = reinterpret_cast<i32x2 *>(a.d_out) + frame;
-			if constexpr (NT)
-				__builtin_nontemporal_store(q, dst);
-			else
-				*dst = q;
-		}
+			store_ints<CH, NT>(reinterpret_cast<int *>(a.d_out) + frame * CH, out);
 	};
 
 	if (global_wave >= n_chunks)
@@ -310,7 +343,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 			bool have_next = false;
 
 			// this wave-tile's window becomes X (the previous tile's frames have all been read: same wave, in order) ...
-			expand(my_buf + cur * BUF, packed_info);
+			const unsigned x_odd = expand(my_buf + cur * BUF, packed_info);
 
 			// ... and the DMA of the wave-tile after it starts (the other packed buffer was expanded one step ago)
 			if (!last_of_stream)
@@ -344,18 +377,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 #pragma unroll
 				for (int i = 0; i < ITER; ++i)
 				{
-					int out0, out1;
-					one_frame2(lane_rel + (unsigned)i * 64u * a.increment, out0, out1);
-					store_frame(first + (unsigned)i * 64u + lane, out0, out1);
+					int out[CH];
+					one_frame2(lane_rel + (unsigned)i * 64u * a.increment, x_odd, out);
+					store_frame(first + (unsigned)i * 64u + lane, out);
 				}
 			}
 			else
 			{
 				for (unsigned jl = lane; jl < n; jl += 64u)
 				{
-					int out0, out1;
-					one_frame2(__umul24(jl, a.increment) + (unsigned)(pos & 0xFFFFu), out0, out1);
-					store_frame(first + jl, out0, out1);
+					int out[CH];
+					one_frame2(__umul24(jl, a.increment) + (unsigned)(pos & 0xFFFFu), x_odd, out);
+					store_frame(first + jl, out);
 				}
 			}
 

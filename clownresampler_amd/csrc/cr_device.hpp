@@ -510,6 +510,17 @@ __device__ __forceinline__ void store_shorts(short *dst, const int *v)
 	}
 }
 
+// The FEWEST store instructions a lane's `bytes` contiguous output bytes can leave as: 16 per instruction.  This, not the number
+// of store statements in the source, is what a counted s_waitcnt vmcnt(N) behind a tile's stores may assume: hipcc merges
+// neighbouring stores (the 8 + 4 bytes of a 3-channel frame leave as ONE global_store_dwordx3), and a count larger than the
+// stores really outstanding no longer covers the LDS-DMA issued before them.  (Round 1 counted statements: with 3, 6 and 7
+// channels the wait was too weak - never seen with k_poly's long tiles, caught by k_wave2's short ones.)  A count that is too
+// small only waits for some of the tile's own stores as well.
+constexpr int min_stores_of_bytes(int bytes)
+{
+	return (bytes + 15) / 16;
+}
+
 constexpr int stores_of_ints(int n)
 {
 	return n % 4 == 0 ? n / 4 : (n % 2 == 0 ? n / 2 : stores_of_ints_dword_aligned(n));

@@ -8,8 +8,8 @@ int specials_long(void *table, int capacity)
 {
 	static const special mine[] = {
 	    with_wave2<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 16, 1, 4, 0x2A55u>(make_special<2, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 27, true, false, 0x2A55u>()),  // cfg 3: stereo 8 -> 96 kHz, 8 lobes (k_up, chain form, from 2x upsampling on; k_wave below)
-	    with_wave2<1, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 16, 1, 4, 0x2A55u>(make_special_lite<1, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32>()),
-	    with_wave2<1, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 1, 4, 0u>(make_special_lite<1, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
+	    with_wave2<1, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 16, 1, 4, 0x2A55u, true>(make_special_lite<1, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32>()),
+	    with_wave2<1, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 1, 4, 0u, true>(make_special_lite<1, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_wave2<2, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 1, 2, 0u, true>(make_special_lite<2, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),   // 8 lobes, stereo 48 -> 44.1 kHz: k_wave2 by default (144 against 171 us)
 	};
 	const int n = (int)(sizeof(mine) / sizeof(mine[0]));

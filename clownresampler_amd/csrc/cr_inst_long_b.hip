@@ -1,0 +1,28 @@
+// cr_inst_long_b.hip - instance unit: the 8-lobe build at 44.1 <-> 48 kHz for 3 to 6 channels (15- and 17-slot windows): a
+// specialised k_poly (the fallback) and k_wave2 (the default) each  (see cr_instances.hpp)
+#include "cr_instances.hpp"
+
+namespace crk
+{
+
+int specials_long_b(void *table, int capacity)
+{
+	// k_wave2 geometry: 16 waves, one 1 KiB window piece per wave-tile; 64 frames per wave-tile from 4 channels on (a frame of 4+
+	// channels is 8+ bytes: 128 frames of window would not fit the piece), 128 below
+	static const special mine[] = {
+	    with_wave2<3, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 16, 1, 2, 0x2A55u, true>(make_special_lite<3, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32>()),
+	    with_wave2<4, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 16, 1, 1, 0x2A55u, true>(make_special_lite<4, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32>()),
+	    with_wave2<5, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 16, 1, 1, 0x2A55u, true>(make_special_lite<5, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32>()),
+	    with_wave2<6, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 16, 1, 1, 0x2A55u, true>(make_special_lite<6, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32>()),
+	    with_wave2<3, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 1, 2, 0u, true>(make_special_lite<3, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
+	    with_wave2<4, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 1, 1, 0u, true>(make_special_lite<4, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
+	    with_wave2<5, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 1, 1, 0u, true>(make_special_lite<5, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
+	};
+	const int n = (int)(sizeof(mine) / sizeof(mine[0]));
+	if (n > capacity)
+		return -1;
+	memcpy(table, mine, sizeof(mine));
+	return n;
+}
+
+} // namespace crk

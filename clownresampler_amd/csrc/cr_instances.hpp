@@ -241,7 +241,8 @@ poly_fn pick_runtime_split(uint32_t mode, uint32_t norm)
 namespace crk
 {
 int specials_headline(void *table, int capacity);   // cr_inst_headline.hip: stereo / mono 3-lobe instances of BASELINE configs[1] / [4] + ablations
-int specials_long(void *table, int capacity);       // cr_inst_long.hip: the 8-lobe (15- and 17-slot) instances, BASELINE configs[2]
+int specials_long(void *table, int capacity);       // cr_inst_long.hip: the 8-lobe (15- and 17-slot) instances for mono and stereo, BASELINE configs[2]
+int specials_long_b(void *table, int capacity);     // cr_inst_long_b.hip: the same for 3 to 6 channels
 int specials_multi_a(void *table, int capacity);    // cr_inst_multi_a.hip: 8 channels 48 -> 44.1 kHz with every tuning variant, BASELINE configs[3]
 int specials_multi_b(void *table, int capacity);    // cr_inst_multi_b.hip: 3 to 16 channels at 44.1 <-> 48 kHz, one instance each
 int specials_down(void *table, int capacity);       // cr_inst_down.hip: mono / stereo at the usual downsampling ratios

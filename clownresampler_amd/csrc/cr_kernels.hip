@@ -110,7 +110,7 @@ const special *specials(int *count)
 	static std::once_flag once;
 	std::call_once(once, [] {
 		int total = 0;
-		int (*const providers[])(void *, int) = {crk::specials_headline, crk::specials_long, crk::specials_multi_a, crk::specials_multi_b, crk::specials_down};
+		int (*const providers[])(void *, int) = {crk::specials_headline, crk::specials_long, crk::specials_long_b, crk::specials_multi_a, crk::specials_multi_b, crk::specials_down};
 		for (auto provider : providers)
 		{
 			const int got = provider(table + total, 64 - total);

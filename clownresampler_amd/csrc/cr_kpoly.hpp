@@ -112,8 +112,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 	// as straight-line code for that reason; a ragged tile drains everything.
 	constexpr unsigned GROUP = NTHREADS * U;
 	constexpr int ADJ = 0;   // a lane's U frames are NTHREADS apart: every store instruction is coalesced across the wave
-	constexpr int STORES_PER_GROUP = PH ? U * (OUT16 ? CH : stores_of_ints_dword_aligned(CH - 1) + 1)
-	                                    : U * (OUT16 ? (CH % 2 == 0 ? stores_of_ints(CH / 2) : CH) : stores_of_ints(CH));
+	// (a LOWER bound of the store instructions per group: see min_stores_of_bytes; a phantom lane-frame leaves as at least one)
+	constexpr int STORES_PER_GROUP = PH ? U : U * min_stores_of_bytes(CH * (OUT16 ? 2 : 4));
 
 	// Tickets.  One global counter would serialise: a single word sustains ~88 atomic draws per microsecond on this
 	// chip (MI355X_MICROARCH.md, "dequeue") and a 10-minute stereo launch draws 7,000 of them - measured 92 us instead

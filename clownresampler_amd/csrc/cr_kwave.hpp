@@ -28,7 +28,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(CRHIP_SG
 	constexpr unsigned CW = 4;                     // wave-tiles per chunk (ticket)
 	constexpr unsigned CHUNK = WT * CW;
 	constexpr unsigned BUF = NVW * 1024u;          // bytes per wave-tile buffer
-	constexpr int STORES_PER_FRAME = OUT16 ? (CH % 2 == 0 ? stores_of_ints(CH / 2) : CH) : stores_of_ints(CH);
+	constexpr int STORES_PER_FRAME = min_stores_of_bytes(CH * (OUT16 ? 2 : 4));   // a lower bound: see cr_device.hpp
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 

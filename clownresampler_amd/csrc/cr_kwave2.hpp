@@ -44,7 +44,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	constexpr unsigned XBUF = 2u * BUF;            // bytes of the expanded window (4 per sample)
 	constexpr unsigned PER_WAVE = 2u * BUF + XBUF;
 	constexpr int RS = (TT + 1 + 3) & ~3;
-	constexpr int STORES_PER_FRAME = OUT16 ? (CH % 2 == 0 ? stores_of_ints(CH / 2) : CH) : stores_of_ints(CH);
+	constexpr int STORES_PER_FRAME = min_stores_of_bytes(CH * (OUT16 ? 2 : 4));   // a lower bound: see cr_device.hpp
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 

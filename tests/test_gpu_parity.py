@@ -759,6 +759,33 @@ def test_input_stationary_kernel_random_ratios(products, variant):
     assert used >= 70, used       # nearly all draws qualify (increment within 4096..32768)
 
 
+@pytest.mark.parametrize("radius,ch,rates", [(8, 3, (8000, 72747, 8000)), (8, 5, (44100, 48000, 44100)), (8, 3, (48000, 44100, 44100)), (8, 6, (44100, 48000, 44100)),
+                                             (3, 3, (44100, 48000, 44100)), (3, 7, (48000, 44100, 44100)), (8, 1, (44100, 48000, 44100))])
+def test_many_short_launches_odd_frame_sizes(products, radius, ch, rates):
+    """A stream taken in hundreds of capacity-stopped calls of 333 and 1,024 frames - launches of a few wave-tiles whose stores and
+    next-window DMA are in flight together.  Regression test for the counted vmcnt wait behind a tile's stores: it must assume the
+    FEWEST store instructions the compiler can make of a frame (a 3-channel frame leaves as one global_store_dwordx3, not as an
+    8-byte and a 4-byte store), or the wait no longer covers the DMA and a short tile reads a window that has not landed."""
+    p, o = products[radius], ck.oracle(radius)
+    frames = 9000
+    for cap in (333, 1024):
+        ok, a = p.low_init(ch, *rates)
+        ok, b = o.low_init(ch, *rates)
+        R = int(b.cfg.radius_frames)
+        padded = ck.pad_frames(ck.noise_pcm(frames * ch, 5 + cap), ch, R)
+        left, off, calls = frames, 0, 0
+        while left > 0:
+            xa, la, ra = p.low_resample_i32(a, padded[off * ch:], left, capacity=cap)
+            xb, lb, rb = o.low_resample_i32(b, padded[off * ch:], left, capacity=cap)
+            assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple(), (cap, calls, off)
+            off += left - lb
+            left = lb
+            calls += 1
+            if xb.size == 0 and rb:
+                break
+        assert calls > frames // (2 * cap)
+
+
 def test_expanded_window_kernel_random_ratios(products):
     """k_wave2 (window expanded to sample << 16 per wave-tile, 64-bit multiply-add taps; the 8-lobe stereo instances) over random
     ratios: pure upsampling below 2x (15 slots, slot signs fixed: magnitudes + a second accumulator pair) and mild downsampling

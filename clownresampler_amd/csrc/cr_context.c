@@ -1236,8 +1236,19 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		l.n_out = n_out;
 		l.out_s16 = out_s16 ? 1u : 0u;
 
+		if (plan->vecs >= 150u && plan->vecs < 200u)
+		{
+			/* k_wave2 draws chunks of 4 wave-tiles; a launch that leaves a wave only two or three of those ends with a third of
+			   the waves idle, so short launches get chunks of 2 or 1 (the kernel takes the chunk size from the launch) */
+			const uint32_t wave_tile = plan->tile_frames / 4u;
+			const uint64_t waves = (uint64_t)(out_s16 ? plan->max_blocks_s16 : plan->max_blocks) * (plan->threads / 64u);
+
+			while (l.tile_frames > wave_tile && n_out / l.tile_frames < 8u * waves)
+				l.tile_frames /= 2u;
+		}
+
 		/* tiles are dealt round-robin to a persistent grid (see k_poly) */
-		blocks = (n_out + plan->tile_frames - 1) / plan->tile_frames;
+		blocks = (n_out + l.tile_frames - 1) / l.tile_frames;
 		if (plan->vecs >= 100u)
 			blocks = (blocks + plan->threads / 64u - 1) / (plan->threads / 64u); /* k_wave hands chunks to WAVES */
 		if (blocks > (out_s16 ? plan->max_blocks_s16 : plan->max_blocks))

@@ -626,7 +626,8 @@ int crhip_launch_poly(const crhip_poly_launch *launch, void *stream)
 		return (int)hipErrorInvalidValue;
 	if (geo == 150u)
 	{
-		if (launch->threads % 64u != 0 || launch->vecs < 150u || launch->vecs >= 200u)
+		if (launch->threads % 64u != 0 || launch->vecs < 150u || launch->vecs >= 200u || launch->tile_frames < 64u
+		    || (launch->tile_frames & (launch->tile_frames - 1u)) != 0)
 			return (int)hipErrorInvalidValue;
 	}
 	else if (geo == 200u ? (launch->threads != UP_WAVES * 64u || launch->vecs != 200u || launch->tile_frames % 4u != 0 || launch->tile_frames / 4u > UP_MAX_WAVE_TILE || launch->plane_rows != UP_PLANE_ROWS)

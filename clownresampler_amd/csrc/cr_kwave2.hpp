@@ -22,7 +22,10 @@ namespace
 //   SIGNED == 0 (pure upsampling: the sign of a slot's weights is a compile-time property, NEGMASK, checked by the host per
 //                plan as for k_up): the rows are staged as W = |weight|, the slots with negative weights accumulate into a
 //                second pair and the two sums are subtracted at the end (truncation toward zero is odd-symmetric).  2 VALU.
-//   SIGNED == 1 (any rows): W = weight as it is, lo = (X ^ W) >> 31.  3 VALU.
+//   SIGNED == 1 (any rows): W = weight as it is, lo = sext(top byte of X) ^ sext(top byte of W) in ONE SDWA instruction: its
+//                bits 31..7 are the product's sign, its low 7 bits are noise - which the carry does not see: X * W is a multiple
+//                of 65536, so a lo in [2^32 - 128, 2^32) carries exactly when the fraction is not zero and a lo in [0, 128)
+//                never does.  2 VALU.  (The first form, (X ^ W) >> 31 in two instructions, was 3.)
 // Everything else - tickets over 32 counter lanes, a private double-buffered LDS-DMA window per wave, counted vmcnt, coalesced
 // non-temporal stores - is k_wave's.  LDS per wave: two packed windows (NVW KiB each) and one expanded window (2 x NVW KiB).
 // (Loading the packed window into registers instead of LDS - coalesced buffer loads a wave-tile ahead, the expansion straight
@@ -38,8 +41,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	constexpr unsigned FB = CH * 2;
 	constexpr unsigned NTHREADS = WAVES * 64;
 	constexpr unsigned WT = 64u * ITER;            // frames per wave-tile
-	constexpr unsigned CW = 4;                     // wave-tiles per chunk (ticket)
-	constexpr unsigned CHUNK = WT * CW;
+	// wave-tiles per chunk (ticket): 4 for long launches, fewer where a launch would otherwise leave a wave only a handful of
+	// chunks (the host halves tile_frames until every wave has ~8: cr_plan_launch); always a power of two
+	const unsigned CHUNK = a.tile_frames;
+	const unsigned CW = CHUNK / WT;
+	const unsigned chunk_shift = (unsigned)__builtin_ctz(CHUNK);
 	constexpr unsigned BUF = NVW * 1024u;          // bytes per packed window
 	constexpr unsigned XBUF = 2u * BUF;            // bytes of the expanded window (4 per sample)
 	constexpr unsigned PER_WAVE = 2u * BUF + XBUF;
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	}
 	__syncthreads();
 
-	const uint64_t n_chunks = (a.n_out + CHUNK - 1) / CHUNK;
+	const uint64_t n_chunks = (a.n_out + CHUNK - 1) >> chunk_shift;
 	const uint64_t global_wave = (uint64_t)blockIdx.x * WAVES + wave;
 	const uint64_t global_waves = (uint64_t)gridDim.x * WAVES;
 
@@ -162,15 +168,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	auto expand = [&](const unsigned char *buf, unsigned shift_frames) -> unsigned {
 		const unsigned shift = shift_frames & 0xFFFFu, frames = shift_frames >> 16;
 		const unsigned odd = (shift >> 1) & 1u;
-		const unsigned dwords = (odd + frames * CH + 1u) / 2u;
-		const unsigned char *from = buf + (shift & ~3u);
-		for (unsigned i = lane; i < dwords; i += 64u)
+		const unsigned dwords = (odd + frames * CH + 1u) / 2u;   // wave-uniform
+		// straight-line over the whole buffer, left early on a scalar compare: two VALU per 64 dwords (the lanes beyond the window
+		// convert whatever the buffer holds - at most 12 bytes of it the neighbouring buffer's - into X entries nobody reads)
+		const int *from = reinterpret_cast<const int *>(buf + (shift & ~3u)) + lane;
+		i32x2 *to = reinterpret_cast<i32x2 *>(my_x) + lane;
+#pragma unroll
+		for (unsigned k = 0; k < BUF / 256u; ++k)
 		{
-			const int f = *reinterpret_cast<const int *>(from + i * 4u);
+			if (k * 64u >= dwords)
+				break;
+			const int f = from[k * 64u];
 			i32x2 x;
 			x.x = (int)((unsigned)f << 16);
 			x.y = (int)((unsigned)f & 0xFFFF0000u);
-			*reinterpret_cast<i32x2 *>(my_x + i * 8u) = x;
+			to[k * 64u] = x;
 		}
 		// same wave: its LDS operations complete in order
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -252,8 +264,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
 	    : "=&{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc")
 #define CRHIP_W2_TAP_SIGNED(LO, HI, VLO, VHI, X, W)                                                                                \
-	asm("v_xor_b32_e32 v" #LO ", %2, %3\n\t"                                                                                      \
-	    "v_ashrrev_i32_e32 v" #LO ", 31, v" #LO "\n\t"                                                                            \
+	asm("v_xor_b32_sdwa v" #LO ", sext(%2), sext(%3) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"   \
 	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
 	    : "=&{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc")
 #pragma unroll
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	uint64_t chunk = global_wave;
 	unsigned cur = 0, packed_info = 0;
 	{
-		const uint64_t first = chunk * CHUNK;
+		const uint64_t first = chunk << chunk_shift;
 		const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
 		packed_info = fetch(first, n, my_buf);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	{
 		const unsigned ticket = draw_issue();          // one chunk ahead; resolved at the end of this chunk
 		uint64_t next_chunk = ~0ull;
-		const uint64_t chunk_first = chunk * CHUNK;
+		const uint64_t chunk_first = chunk << chunk_shift;
 		bool done = false;
 
 		for (unsigned j = 0; j < CW && !done; ++j)
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 					next_chunk = draw_resolve(ticket);
 					if (next_chunk != ~0ull)
 					{
-						const uint64_t nf = next_chunk * CHUNK;
+						const uint64_t nf = next_chunk << chunk_shift;
 						const unsigned nn = (unsigned)((a.n_out - nf < WT) ? (a.n_out - nf) : WT);
 						next_info = fetch(nf, nn, my_buf + (cur ^ 1u) * BUF);
 						have_next = true;

@@ -19,7 +19,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libclownresampler_amd.so")
+# (CLOWNRESAMPLER_AMD_LIBRARY: development hook - A/B timing of two builds on one box, tools/ab.sh)
+LIB_PATH = os.environ.get("CLOWNRESAMPLER_AMD_LIBRARY") or os.path.join(_HERE, "libclownresampler_amd.so")
 SUPPORTED_RADII = (3, 8)
 
 KERNEL_RESOLUTION = 0x400      # CLOWNRESAMPLER_KERNEL_RESOLUTION, reference clownresampler.h:452-454

@@ -104,10 +104,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	const uint64_t global_wave = (uint64_t)blockIdx.x * WAVES + wave;
 	const uint64_t global_waves = (uint64_t)gridDim.x * WAVES;
 
-	// tickets: as in k_wave
+	// Who takes which chunk.  Chunks go round-robin over the waves (wave w: chunks w, w + waves, ...) for all but the last two
+	// rounds - no atomics, nothing to wait for - and the chunks of those last rounds are drawn as tickets, as in k_wave (32 counter
+	// lanes; a wave's first chunk of the ticketed region is implicit), so that the waves that got ahead (the XCDs differ by 10 %
+	// in clock under load) take more of the tail.  Why not tickets throughout: a returning atomic is a VMEM load into a VGPR,
+	// and hipcc waits for such a register at the head of any loop that uses it - vmcnt(0), every store of the previous chunk
+	// included - however far apart issue and use are put.  (Worth 1-4 %: profiles/r02_kwave2_trials.log.)
+	const uint64_t rounds = n_chunks / global_waves;
+	const uint64_t static_limit = rounds > 3u ? (rounds - 2u) * global_waves : 0u;   // chunks [0, static_limit) are dealt statically
+	const uint64_t region_chunks = n_chunks - static_limit;                         // the ticketed region, numbered from 0
+
 	const unsigned LANES = global_waves < 32u ? (unsigned)global_waves : 32u;
 	const unsigned lane_id = (unsigned)(global_wave % LANES);
-	const uint64_t lane_chunks = n_chunks > lane_id ? (n_chunks - lane_id + LANES - 1u) / LANES : 0;
+	const uint64_t lane_chunks = region_chunks > lane_id ? (region_chunks - lane_id + LANES - 1u) / LANES : 0;
 	const unsigned lane_waves = (unsigned)((global_waves - lane_id + LANES - 1u) / LANES);
 	unsigned *lane_counter = a.d_tickets + lane_id * 32u;
 	auto draw_issue = [&]() -> unsigned {
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	};
 	auto draw_resolve = [&](unsigned got) -> uint64_t {
 		const uint64_t k = (uint64_t)lane_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)got);
-		return k < lane_chunks ? lane_id + (uint64_t)LANES * k : ~0ull;
+		return k < lane_chunks ? static_limit + lane_id + (uint64_t)LANES * k : ~0ull;
 	};
 	auto retire = [&]() {
 		if (lane == 0 && __hip_atomic_fetch_add(waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == WAVES - 1u)
@@ -357,14 +366,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	}
 
-	for (;;)
-	{
-		const unsigned ticket = draw_issue();          // one chunk ahead; resolved at the end of this chunk
+	// One chunk: its wave-tiles, the window of the following chunk's first tile fetched under the last one.  `next_of` names that
+	// chunk (or ~0) when asked, in the chunk's last tile.  Returns the chunk to go on with, ~0 when the wave is done.
+	auto run_chunk = [&](uint64_t this_chunk, auto next_of) -> uint64_t {
 		uint64_t next_chunk = ~0ull;
-		const uint64_t chunk_first = chunk << chunk_shift;
-		bool done = false;
+		const uint64_t chunk_first = this_chunk << chunk_shift;
 
-		for (unsigned j = 0; j < CW && !done; ++j)
+		for (unsigned j = 0; j < CW; ++j)
 		{
 			const uint64_t first = chunk_first + (uint64_t)j * WT;
 			const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
@@ -376,29 +384,26 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 			const unsigned x_odd = expand(my_buf + cur * BUF, packed_info);
 
 			// ... and the DMA of the wave-tile after it starts (the other packed buffer was expanded one step ago)
-			if (!last_of_stream)
+			if (!last_of_stream && j + 1 < CW)
 			{
-				if (j + 1 < CW)
+				const uint64_t nf = first + WT;
+				const unsigned nn = (unsigned)((a.n_out - nf < WT) ? (a.n_out - nf) : WT);
+				next_info = fetch(nf, nn, my_buf + (cur ^ 1u) * BUF);
+				have_next = true;
+			}
+			else
+			{
+				// (the stream's last chunk is the last of its wave's sequence, but the question is asked all the same: a ticket
+				// drawn for it must have returned before the counters are reset)
+				next_chunk = next_of();
+				if (next_chunk != ~0ull && !last_of_stream)
 				{
-					const uint64_t nf = first + WT;
+					const uint64_t nf = next_chunk << chunk_shift;
 					const unsigned nn = (unsigned)((a.n_out - nf < WT) ? (a.n_out - nf) : WT);
 					next_info = fetch(nf, nn, my_buf + (cur ^ 1u) * BUF);
 					have_next = true;
 				}
-				else
-				{
-					next_chunk = draw_resolve(ticket);
-					if (next_chunk != ~0ull)
-					{
-						const uint64_t nf = next_chunk << chunk_shift;
-						const unsigned nn = (unsigned)((a.n_out - nf < WT) ? (a.n_out - nf) : WT);
-						next_info = fetch(nf, nn, my_buf + (cur ^ 1u) * BUF);
-						have_next = true;
-					}
-				}
 			}
-			else if (j + 1 == CW)
-				next_chunk = draw_resolve(ticket);
 
 			const uint64_t pos = a.pos0 + first * (uint64_t)a.increment;
 			const unsigned lane_rel = __umul24(lane, a.increment) + (unsigned)(pos & 0xFFFFu);
@@ -422,13 +427,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 				}
 			}
 
-			if (last_of_stream)
-			{
-				done = true;
-				break;
-			}
-			if (!have_next)
-				break;
+			if (last_of_stream || !have_next)
+				return ~0ull;
 			// own DMA landed once only this wave-tile's stores are outstanding (vmcnt is in order)
 			if (n == WT)
 			{
@@ -442,15 +442,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 			cur ^= 1u;
 			packed_info = next_info;
 		}
+		return next_chunk;
+	};
 
-		if (done)
-		{
-			(void)draw_resolve(ticket);   // the stream's last chunk is the last of its sequence: nothing follows
-			break;
-		}
-		if (next_chunk == ~0ull)
-			break;
-		chunk = next_chunk;
+	// the statically dealt rounds ...
+	while (chunk != ~0ull && chunk < static_limit)
+	{
+		const uint64_t this_chunk = chunk;
+		chunk = run_chunk(this_chunk, [&]() -> uint64_t {
+			const uint64_t next = this_chunk + global_waves;
+			return next < n_chunks ? next : ~0ull;
+		});
+	}
+	// ... and the ticketed ones (a ticket is drawn when a chunk is entered and resolved in its last tile)
+	while (chunk != ~0ull)
+	{
+		const unsigned ticket = draw_issue();
+		chunk = run_chunk(chunk, [&]() -> uint64_t { return draw_resolve(ticket); });
 	}
 
 	retire();

@@ -130,10 +130,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 	// (Helping other sequences out once the own one is exhausted was tried: deciding where to draw needs the counter's
 	// value NOW, and a dependent load at the top of every tile stalls wave 0 - and with it the workgroup - for a memory
 	// round trip per tile: 148 us instead of 64.  The draw below has no consumer until the end of the tile.)
+	// The draw is a scalar atomic (draw_ticket, cr_device.hpp), made by wave 0 alone (wave-uniform branch).  As a vector atomic
+	// of thread 0 it cost wave 0 a vmcnt(0) per tile - every store of the previous tile and the DMA just issued - which was the
+	// "issuing the next tile's DMA" share of a tile in the stamped diagnostic instance (42-44 % of wave 0's cycles, the other
+	// waves waiting for it at the barrier).
 	auto draw = [&]() -> unsigned {
-		const uint64_t k = (uint64_t)lane_groups + __hip_atomic_fetch_add(lane_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint64_t k = (uint64_t)lane_groups + draw_ticket(lane_counter);
 		return k < lane_tiles ? (unsigned)(lane_id + LANES * k) : 0xFFFFFFFFu;
 	};
+	const bool wave0 = __builtin_amdgcn_readfirstlane((int)(tid >> 6)) == 0;
 	// a workgroup that has drawn a ticket beyond its sequence is done drawing; the last such workgroup zeroes the slot
 	auto retire = [&]() {
 		if (tid == 0)
@@ -155,8 +160,12 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 	// a.dynamic_tiles == 0: plain round-robin (tile + gridDim.x), no tickets - for configurations whose tiles are so
 	// small that a ticket and a mailbox hand-over per tile cost more than the imbalance they remove (8-channel frames)
 	const bool dynamic = a.dynamic_tiles != 0;
-	if (dynamic && tid == 0)
-		mailbox[0] = draw();
+	if (dynamic && wave0)
+	{
+		const unsigned first_ticket = draw();
+		if (tid == 0)
+			mailbox[0] = first_ticket;
+	}
 	// stage the polyphase rows once per workgroup (L2-resident after the first workgroups) - AFTER the first tile's DMA and
 	// the first ticket are on their way, so that the three round trips of a workgroup's start overlap
 	{
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 			// the other buffer was last read in the previous iteration, which every wave has left (barrier below)
 			n_next = (unsigned)((a.n_out - jn < NT64) ? (a.n_out - jn) : NT64);
 			shift_next = fetch(jn, n_next, tiles + ((it + 1u) & 1u) * TILE_BYTES);
-			if (dynamic && tid == 0)
+			if (dynamic && wave0)
 				ticket = draw();   // for the tile after the next one; posted below, just before the barrier
 		}
 		mark(0);

@@ -72,12 +72,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(CRHIP_SG
 	unsigned *lane_counter = a.d_tickets + lane_id * 32u;
 	// the draw is split: the atomic is issued at the start of a chunk, its result is first looked at when the last
 	// wave-tile of the chunk needs it - by then the per-wave-tile vmcnt waits have long covered it
-	auto draw_issue = [&]() -> unsigned {
-		unsigned got = 0;
-		if (lane == 0)
-			got = __hip_atomic_fetch_add(lane_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		return got;
-	};
+	auto draw_issue = [&]() -> unsigned { return draw_ticket(lane_counter); };   // (scalar, the whole wave: cr_device.hpp)
 	auto draw_resolve = [&](unsigned got) -> uint64_t {
 		const uint64_t k = (uint64_t)lane_waves + __builtin_amdgcn_readfirstlane(got);
 		return k < lane_chunks ? lane_id + (uint64_t)LANES * k : ~0ull;

@@ -119,12 +119,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	const uint64_t lane_chunks = region_chunks > lane_id ? (region_chunks - lane_id + LANES - 1u) / LANES : 0;
 	const unsigned lane_waves = (unsigned)((global_waves - lane_id + LANES - 1u) / LANES);
 	unsigned *lane_counter = a.d_tickets + lane_id * 32u;
-	auto draw_issue = [&]() -> unsigned {
-		unsigned got = 0;
-		if (lane == 0)
-			got = __hip_atomic_fetch_add(lane_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		return got;
-	};
+	auto draw_issue = [&]() -> unsigned { return draw_ticket(lane_counter); };   // (scalar, the whole wave: cr_device.hpp)
 	auto draw_resolve = [&](unsigned got) -> uint64_t {
 		const uint64_t k = (uint64_t)lane_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)got);
 		return k < lane_chunks ? static_limit + lane_id + (uint64_t)LANES * k : ~0ull;

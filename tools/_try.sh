@@ -1,4 +1,5 @@
 #!/bin/bash
-O=gpurun_out/try7; mkdir -p $O
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu > $O/tests.log 2>&1; echo "rc=$?"; tail -3 $O/tests.log
-bash tools/ab.sh 30 "A ST" hq48 dn8 dn31 dn21 hq44 hq48c6
+CLOWNRESAMPLER_AMD_LIBRARY=$PWD/tools/ab/libSA.so python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
+bash tools/ab.sh 27 "A SA" cfg3
+bash tools/ab.sh 30 "A SA" hq48 dn31
+bash tools/ab.sh 13 "A SA" cfg2

@@ -65,7 +65,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 	const uint64_t n_tiles = (a.n_out + NT64 - 1) / NT64;
 	if (blockIdx.x >= n_tiles)
 		return;
-	volatile unsigned *mailbox = reinterpret_cast<volatile unsigned *>(smem + rows_bytes + 2u * TILE_BYTES);
+	// (an LDS pointer by TYPE: through a generic pointer the mailbox was written and read with flat instructions, which count in
+	// vmcnt as well - and a volatile flat access is followed by vmcnt(0): every wave drained its tile's stores behind the
+	// barrier of every tile before it read the next tile's number)
+	typedef __attribute__((address_space(3))) volatile unsigned lds_word;
+	lds_word *mailbox = (lds_word *)(smem + rows_bytes + 2u * TILE_BYTES);
 
 	const uint64_t in_base = reinterpret_cast<uint64_t>(a.d_in);
 	const uint64_t in_end = in_base + a.in_valid_bytes;

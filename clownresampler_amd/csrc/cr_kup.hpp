@@ -736,8 +736,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 		const uint64_t out_first = reinterpret_cast<uint64_t>(a.d_out) + first * UNIT;
 		const unsigned out_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)out_first);
 		const unsigned out_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(out_first >> 32));
-		vec_t *dst = reinterpret_cast<vec_t *>(((uint64_t)out_hi << 32) | out_lo);
-		auto put = [&](vec_t *to, vec_t v) {
+		// (a GLOBAL pointer by type: through a generic one these were flat stores, which go down the LDS path as well)
+		typedef __attribute__((address_space(1))) vec_t global_vec;
+		global_vec *dst = (global_vec *)(((uint64_t)out_hi << 32) | out_lo);
+		auto put = [&](global_vec *to, vec_t v) {
 			if constexpr (ABL == 1)
 			{
 				asm volatile("" ::"v"(v));

@@ -909,6 +909,21 @@ __device__ __forceinline__ unsigned draw_ticket(unsigned *counter)
 	return got;
 }
 
+// The same in two halves, for a caller that has a wait of its own to put in between (the round trip then runs under it).  The
+// SGPR is in flight between the two: NOTHING but the caller's own inline-assembly waits may stand between them - hipcc knows
+// nothing of the pending write and would read the register early if it had a reason to touch it.
+__device__ __forceinline__ unsigned draw_ticket_begin(unsigned *counter)
+{
+	unsigned got = 1u;
+	asm volatile("s_atomic_add %0, %1, 0x0 glc" : "+s"(got) : "s"(counter) : "memory");
+	return got;
+}
+__device__ __forceinline__ unsigned draw_ticket_end(unsigned got)
+{
+	asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(got) : : "memory");
+	return got;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // SGPR budget.  Two 1024-thread workgroups per CU are 8 waves per SIMD, and on gfx950 a SIMD admits
 // min(8, 800 / (ceil(sgpr_count / 16) * 16 + 16)) waves (MI355X_MICROARCH.md, "Residency"): 8 only up to .sgpr_count 80,

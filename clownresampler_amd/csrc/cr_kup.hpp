@@ -537,9 +537,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 	// Wave-tiles are TICKETS, as in k_wave: the first by global wave number, every further one from 32 global counter lanes.
 	// The XCDs of one chip do not run this kernel at one speed - under sustained load their clocks sit between 1.9 and 2.1 GHz,
 	// and with equal static shares the launch lasted as long as the slowest XCD (end times 143 .. 159 us,
-	// profiles/r02_kup2_sweep.log) - so whoever is free takes the next tile.  A ticket's atomic returns through vmcnt like the
-	// stores do, in issue order: it is issued BEFORE a wave-tile's stores, two tiles ahead of its use, so the wait that the
-	// next window's DMA needs anyway (everything but this tile's stores) covers it - no drain of its own.
+	// profiles/r02_kup2_sweep.log) - so whoever is free takes the next tile.  A ticket is a scalar atomic (draw_ticket, cr_device.hpp:
+	// through lgkmcnt, not through the vmcnt the stores and the DMA share), drawn a tile ahead of its use, its round trip under the
+	// wait for the next window.
 	const uint64_t n_tiles = (a.n_out + WT - 1) / WT;
 	const uint64_t global_wave = (uint64_t)blockIdx.x * WAVES + wave;
 	const uint64_t global_waves = (uint64_t)gridDim.x * WAVES;
@@ -792,15 +792,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 		const uint64_t first = tile * WT;
 		const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
 		const bool have_next = next != ~0ull;
-		unsigned shift_next = 0, ticket = 0;
+		unsigned shift_next = 0;
 
-		// the ticket for the tile after the next one, then the DMA of the next one (its buffer was consumed one step ago): both
-		// ahead of this tile's stores in vmcnt's order
+		// the DMA of the next tile (its buffer was consumed one step ago): ahead of this tile's stores in vmcnt's order
 		if (have_next)
 		{
 			const uint64_t nf = next * WT;
 			const unsigned nn = (unsigned)((a.n_out - nf < WT) ? (a.n_out - nf) : WT);
-			ticket = draw_issue();
 			shift_next = fetch(nf, nn, my_buf + (cur ^ 1u) * BUF);
 		}
 
@@ -808,7 +806,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 
 		if (!have_next)
 			break;
+		// the ticket for the tile after the next one: its round trip runs under the wait for the next tile's window
+		unsigned ticket = draw_ticket_begin(lane_counter);
 		wait_vmcnt_at_most(stores);
+		ticket = draw_ticket_end(ticket);
 		mark(3);
 		cur ^= 1u;
 		shift = shift_next;

@@ -353,7 +353,8 @@ def main():
     # the dominant (only) kernel: algorithmic bytes of THIS rank's launch / its launch duration
     launch_bytes = shard.input_frames * ch * 2 + shard.output_frames * ch * (2 if args.s16 else 4)
     achieved = launch_bytes / (mean_ms * 1e-3) / 1e9
-    kernel_name = {1: "k_poly<%d,%d>", 2: "k_wave<%d,%d>", 3: "k_up<%d,%d>", 4: "k_wave2<%d,%d>"}[info.kernel] % (ch, info.slots) if info.kernel else "k_generic"
+    kernel_name = {1: "k_poly<%d,%d>", 2: "k_wave<%d,%d>", 3: "k_up2<%d,%d>" if (info.variant == 27 and ch == 2) else "k_up<%d,%d>",
+                   4: "k_wave2<%d,%d>"}[info.kernel] % (ch, info.slots) if info.kernel else "k_generic"
     traffic, traffic_note = None, "no PMC summary for this workload under profiles/"
     pmc, pmc_file = pmc_summary(workload) if (world == 1 and not args.s16) else (None, None)
     if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:

@@ -1,4 +1,4 @@
-// cr_inst_long_b.hip - instance unit: the 8-lobe build at 44.1 <-> 48 kHz for 3 to 6 channels (15- and 17-slot windows): a
+// cr_inst_long_b.hip - instance unit: the 8-lobe build at 44.1 <-> 48 kHz for 3 to 8 channels (15- and 17-slot windows): a
 // specialised k_poly (the fallback) and k_wave2 (the default) each  (see cr_instances.hpp)
 #include "cr_instances.hpp"
 
@@ -17,6 +17,15 @@ int specials_long_b(void *table, int capacity)
 	    with_wave2<3, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 1, 2, 0u, true>(make_special_lite<3, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_wave2<4, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 1, 1, 0u, true>(make_special_lite<4, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_wave2<5, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 1, 1, 0u, true>(make_special_lite<5, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
+	    // windows of more than 1 KiB: two pieces per wave-tile, and as many waves as then fit beside the 66 KB of rows (pure
+	    // upsampling: one configuration whatever the ratio, so the fit does not depend on it)
+	    with_wave2<7, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 11, 2, 1, 0x2A55u, true>(make_special_lite<7, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32>()),
+	    with_wave2<8, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, 11, 2, 1, 0x2A55u, true>(make_special_lite<8, 15, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32>()),
+	    // 48 -> 44.1 kHz with 6 to 8 channels: k_wave2 with 10 waves measured 0.35 / 0.30 / 0.27 of the roofline against 0.29 / 0.24 / 0.27
+	    // for the run-time-slot k_poly - but the specialised k_poly these entries would fall back to where a ratio's rows do not
+	    // fit is far slower for 6 and 7 channels (0.19, 0.10: spills), so those two stay on the run-time-slot instance; for 8
+	    // channels the specialised k_poly itself is the best of the three (0.32)
+	    make_special_lite<8, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
 	};
 	const int n = (int)(sizeof(mine) / sizeof(mine[0]));
 	if (n > capacity)

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_generic(const crhip_generic_launch a)
 // ---------------------------------------------------------------------------------------------------------
 const special *specials(int *count)
 {
-	static special table[64];
+	static special table[96];
 	static int n = -1;
 	static std::once_flag once;
 	std::call_once(once, [] {
@@ -113,7 +113,7 @@ const special *specials(int *count)
 		int (*const providers[])(void *, int) = {crk::specials_headline, crk::specials_long, crk::specials_long_b, crk::specials_multi_a, crk::specials_multi_b, crk::specials_down};
 		for (auto provider : providers)
 		{
-			const int got = provider(table + total, 64 - total);
+			const int got = provider(table + total, 96 - total);
 			if (got < 0)
 				abort();
 			total += got;

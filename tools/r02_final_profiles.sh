@@ -18,13 +18,15 @@ for w in cfg2 cfg3 cfg4 hq48; do
 done
 cd $R
 python3 bench.py --workload cfg5 --no-cpu-baseline > $O/bench_cfg5.json 2>/dev/null
-python3 bench.py --workload hq44 --no-cpu-baseline > $O/bench_hq44.json 2>/dev/null
+for w in hq44 dn8 dn21 dn96 dn31; do python3 bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null; done
 python3 bench.py --workload cfg2 --s16 --no-cpu-baseline > $O/bench_cfg2_s16.json 2>/dev/null
 for n in 2 8; do python3 bench.py --gpus $n > $O/bench_n${n}_sharedgpu_gloo.json 2> $O/bench_n$n.err; done
-(python3 tools/channel_table.py 3; python3 tools/channel_table.py 8 44100:48000 48000:44100) > $O/channel_table.log 2>&1
+(python3 tools/channel_table.py 3; python3 tools/channel_table.py 8 44100:48000 48000:44100; python3 tools/channel_table.py 3 96000:48000 96000:44100 96000:32000 channels=1,2) > $O/channel_table.log 2>&1
+# the specialised k_poly the 17-slot k_wave2 entries fall back to where a ratio's rows do not fit, against the run-time-slot instance
+(CLOWNRESAMPLER_AMD_VARIANT=13 python3 tools/channel_table.py 8 48000:44100 channels=1,2,3,4,5; CLOWNRESAMPLER_AMD_NO_SPECIAL=1 python3 tools/channel_table.py 8 48000:44100 channels=1,2,3,4,5) > $O/fallback_17slot.log 2>&1
 python3 tools/size_sweep.py > $O/size_sweep.log 2>&1
 ls -la $O
-for w in cfg2 cfg3 cfg4 hq48 cfg5 hq44; do python3 - <<PY
+for w in cfg2 cfg3 cfg4 hq48 cfg5 hq44 dn8 dn21 dn96 dn31; do python3 - <<PY
 import json
 l=json.loads([x for x in open("$O/bench_$w.json") if x.startswith("{")][0])
 print("$w", l["roofline"]["kernel"], "%.1f us" % (l["ms_per_step"]*1e3), "frac %.3f" % l["roofline"]["frac"], "valu", (l.get("roofline_valu") or {}).get("frac"))

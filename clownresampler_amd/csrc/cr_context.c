@@ -155,12 +155,25 @@ static int g_force_generic = 0;
 static unsigned long long *g_debug_stamps = NULL;
 static int g_variant = -1; /* -1: CLOWNRESAMPLER_AMD_VARIANT from the environment, else the default */
 
+/* Where a plan WITHOUT a specialised instance runs the run-time-slot k_wave2 instead of the run-time-slot k_poly.  Measured on
+   one box per pair, tools/channel_table.py with CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS=999 as the "off" leg
+   (profiles/r02_rt_wave2.log): the 8-lobe build at 1.4:1 ... 3:1 (22-48 slots) gains +5 ... +52 % for 2-7 channels (two
+   odd-channel cells lose 3-11 %); exact 3:1 with 3 lobes (18 slots, a handful of rows) +12 ... +42 %; but 3 lobes at 3.2:1
+   (19 slots) -16 ... -25 %, at 4:1 -16 ... -36 %, 48 -> 11.025 and 44.1 -> 8 kHz mixed; mono and 8 channels lose at any length
+   (too little arithmetic per frame for the per-tile work / too few waves beside the rows).  Hence: 2-7 channels, at most 3.25
+   input frames per output frame, and 20 slots - or 18 where the rows are a few KB (exact ratios). */
+#define CR_RT_WAVE2_MIN_SLOTS 20
+#define CR_RT_WAVE2_MIN_SLOTS_FEW_ROWS 18
+#define CR_RT_WAVE2_FEW_ROWS_BYTES 8192u
+#define CR_RT_WAVE2_MAX_INCREMENT ((13u << 16) / 4u)
+
 /* Environment switches are read ONCE (tuning hooks; none of them changes results). */
 static struct
 {
 	int loaded;
 	int dynamic_tiles;          /* CLOWNRESAMPLER_AMD_DYNAMIC_TILES: -1 unset, else 0 / 1 */
 	int no_special, debug, no_occupancy_clamp, tile_groups, no_host_pipeline, no_small_call_path;
+	int rt_wave2_min_slots;     /* CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS: windows from this many slots on take the run-time-slot k_wave2 */
 } g_env;
 static pthread_once_t g_env_once = PTHREAD_ONCE_INIT;
 
@@ -177,6 +190,8 @@ static void load_env(void)
 	g_env.tile_groups = (e != NULL && atoi(e) > 0) ? atoi(e) : 0;
 	g_env.no_host_pipeline = getenv("CLOWNRESAMPLER_AMD_NO_HOST_PIPELINE") != NULL;
 	g_env.no_small_call_path = getenv("CLOWNRESAMPLER_AMD_NO_SMALL_CALL_PATH") != NULL;
+	e = getenv("CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS");
+	g_env.rt_wave2_min_slots = (e != NULL && atoi(e) > 0) ? atoi(e) : CR_RT_WAVE2_MIN_SLOTS;
 	g_env.loaded = 1;
 }
 
@@ -700,6 +715,39 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 			crhip_poly_geometry(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
 		}
 	}
+
+	if (!plan->specialised && crhip_poly_runtime_wave2(plan->channels, plan->poly.row_mode)
+	 && (plan->variant == CRHIP_VARIANT_RT_WAVE2
+	     || (plan->variant == 0xFFFFu && plan->channels >= 2u && plan->channels <= 7u && plan->increment <= CR_RT_WAVE2_MAX_INCREMENT
+	         && (plan->poly.slots >= (uint32_t)g_env.rt_wave2_min_slots
+	             || (rows_bytes <= CR_RT_WAVE2_FEW_ROWS_BYTES && plan->poly.slots >= CR_RT_WAVE2_MIN_SLOTS_FEW_ROWS
+	                 && g_env.rt_wave2_min_slots == CR_RT_WAVE2_MIN_SLOTS)))))
+	{
+		/* The run-time-slot k_wave2 (2 VALU per tap and channel instead of the ~5.6 of the run-time-slot k_poly loop), for
+		   long windows: one frame per lane and wave-tile, as many 1 KiB window pieces as that takes, as many waves as then
+		   fit beside the rows - at least 8 (two per SIMD), or the shape stays with k_poly. */
+		const uint64_t last_rel = (65535u + 63ull * plan->increment) >> 16;
+		const uint64_t window = 12u + (last_rel + window_slots) * frame_bytes;
+		const uint32_t pieces = (uint32_t)((window + 1023u) / 1024u);
+		const uint32_t lds = (uint32_t)di->max_lds_per_block < 160u * 1024u ? (uint32_t)di->max_lds_per_block : 160u * 1024u;
+		const uint32_t room = lds > rows_bytes + 16u ? lds - rows_bytes - 16u : 0u;
+		uint32_t waves = pieces > 0 ? room / (4u * 1024u * pieces) : 0u;
+
+		if (waves > 16u)
+			waves = 16u;
+		if (pieces <= 8u && waves >= 8u && 64ull * plan->increment < (1ull << 32) - 65536u)
+		{
+			plan->variant = CRHIP_VARIANT_RT_WAVE2;
+			plan->threads = waves * 64u;
+			plan->vecs = 150u + pieces;
+			plan->tile_frames = 256u;
+			plan->lds_bytes = rows_bytes + waves * 4u * 1024u * pieces + 16u;
+			plan->max_blocks = (uint32_t)(di->compute_units > 0 ? di->compute_units : 256);
+			return;
+		}
+	}
+	if (plan->variant == CRHIP_VARIANT_RT_WAVE2)
+		plan->variant = 0xFFFFu;   /* asked for, not applicable: the instance's (or the run-time-slot k_poly's) default */
 
 	if (plan->vecs >= 200u)
 	{

@@ -1,0 +1,29 @@
+// cr_inst_runtime_w.hip - instance unit: k_wave2 with a run-time slot count (any downsampling configuration, 1 to 8 channels, both
+// output forms): what plans WITHOUT a specialised instance run when their windows are long enough for the 2-instruction tap
+// to pay and fit a wave's slice of the LDS (cr_context.c plan_geometry)  (see cr_instances.hpp)
+#include "cr_instances.hpp"
+
+namespace
+{
+template <int OUT16>
+poly_fn pick(uint32_t channels)
+{
+	switch (channels)
+	{
+#define CRK_CASE(CH) case CH: return (poly_fn)k_wave2<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 1, 1, OUT16, 1, 0u, 1>;
+		CRK_CASE(1) CRK_CASE(2) CRK_CASE(3) CRK_CASE(4) CRK_CASE(5) CRK_CASE(6) CRK_CASE(7) CRK_CASE(8)
+#undef CRK_CASE
+		default: return nullptr;
+	}
+}
+} // namespace
+
+namespace crk
+{
+void *runtime_wave2_instance(uint32_t channels, uint32_t mode, int out16)
+{
+	if (mode != CRHIP_ROWMODE_AFFINE)
+		return nullptr;
+	return out16 ? (void *)pick<1>(channels) : (void *)pick<0>(channels);
+}
+} // namespace crk

@@ -76,6 +76,7 @@ struct special
 
 constexpr uint32_t MAD_VARIANT = 28;    // variant ids 28, 29
 constexpr uint32_t WAVE2_VARIANT = 30;  // variant id 30: k_wave2 where the instance has one
+constexpr uint32_t RT_WAVE2_VARIANT = 31;   // variant id 31: the run-time-slot k_wave2 (plans without a specialised instance; chosen by the host)
 
 // k_wave2 of an instance: fixed slot signs (NEGMASK != 0: pure upsampling, 2 VALU per tap and channel) or any rows (3)
 template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, unsigned NEGMASK>
@@ -251,6 +252,7 @@ void *ablation_instance_long(int abl);
 void *runtime_instance_1_4(uint32_t channels, uint32_t mode, uint32_t norm, int out16);     // cr_inst_runtime_a.hip
 void *runtime_instance_5_8(uint32_t channels, uint32_t mode, uint32_t norm, int out16);     // cr_inst_runtime_b.hip
 void *runtime_instance_9_16(uint32_t channels, uint32_t mode, uint32_t norm, int out16);    // cr_inst_runtime_c.hip
+void *runtime_wave2_instance(uint32_t channels, uint32_t mode, int out16);                  // cr_inst_runtime_w.hip: k_wave2, run-time slot count
 }
 
 #endif // CR_INSTANCES_HPP

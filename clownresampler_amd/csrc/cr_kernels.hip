@@ -381,13 +381,18 @@ int crhip_poly_swizzled(uint32_t channels, uint32_t slots, uint32_t row_mode, ui
 	// run-time slot count
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
 	if (sp == nullptr)
-		return RUNTIME_SWZ;
+		return variant == RT_WAVE2_VARIANT ? 1 : RUNTIME_SWZ;
 	return resolve_variant(sp, variant) == WAVE2_VARIANT ? 1 : 0;
+}
+
+int crhip_poly_runtime_wave2(uint32_t channels, uint32_t row_mode)
+{
+	return crk::runtime_wave2_instance(channels, row_mode, 0) != nullptr ? 1 : 0;
 }
 
 int crhip_poly_variants(void)
 {
-	return VARIANTS + 11;   // + the two k_wave variants, the four two-lanes-per-frame variants, the two k_up variants and the two 64-bit-chain variants
+	return VARIANTS + 12;   // + the two k_wave variants, the four two-lanes-per-frame variants, the two k_up variants and the two 64-bit-chain variants
 }
 
 int crhip_poly_up_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t *negmask)
@@ -524,6 +529,12 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 	{
 		*geo = 150u;
 		return launch->out_s16 ? sp->wave2_16 : sp->wave2;
+	}
+
+	if (sp == nullptr && launch->variant == RT_WAVE2_VARIANT && launch->vecs >= 150u)
+	{
+		*geo = 150u;
+		return (poly_fn)crk::runtime_wave2_instance(launch->channels, launch->row_mode, launch->out_s16 ? 1 : 0);
 	}
 
 	if (sp != nullptr && v >= MAD_VARIANT)

@@ -155,6 +155,11 @@ uint32_t crhip_poly_up_fallback_variant(uint32_t channels, uint32_t slots, uint3
 int crhip_poly_wave2_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t *negmask);
 /* the variant to use when a plan does not qualify for k_wave2 */
 uint32_t crhip_poly_wave2_fallback_variant(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
+/* 1 when there is a k_wave2 instance with a run-time slot count for this channel count and row mode (downsampling rows, 1-8
+   channels): the host may then give a plan WITHOUT a specialised instance the geometry threads = 64 * waves, vecs = 150 + (1 KiB
+   window pieces per wave-tile), tile_frames = 256 and variant CRHIP_VARIANT_RT_WAVE2 */
+int crhip_poly_runtime_wave2(uint32_t channels, uint32_t row_mode);
+#define CRHIP_VARIANT_RT_WAVE2 31u
 /* Number of tuning variants of the specialised instances (crhip_poly_launch.variant). */
 int crhip_poly_variants(void);
 /* Geometry the instance that a launch with these parameters selects is compiled for: workgroup size, 16-byte input

@@ -696,6 +696,9 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	plan->specialised = (uint32_t)crhip_poly_has_instance(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
 	if (g_env.no_special) /* tuning hook (CLOWNRESAMPLER_AMD_NO_SPECIAL): time the run-time-slot instance instead */
 		plan->specialised = 0;
+	/* (variant 31 - the run-time-slot k_wave2, a testing hook as an explicit choice - means nothing to a specialised instance) */
+	if (plan->variant == CRHIP_VARIANT_RT_WAVE2 && (plan->specialised || !crhip_poly_runtime_wave2(plan->channels, plan->poly.row_mode)))
+		plan->variant = 0xFFFFu;
 	crhip_poly_geometry(plan->channels, plan->specialised ? plan->poly.slots : 0xFFFFu, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
 	if (plan->variant == 28u || plan->variant == 29u || (plan->variant == 0xFFFFu && crhip_poly_default_is_mad(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode)))
 	{
@@ -747,7 +750,11 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 		}
 	}
 	if (plan->variant == CRHIP_VARIANT_RT_WAVE2)
-		plan->variant = 0xFFFFu;   /* asked for, not applicable: the instance's (or the run-time-slot k_poly's) default */
+	{
+		/* asked for, but the window does not fit: the run-time-slot k_poly */
+		plan->variant = 0xFFFFu;
+		crhip_poly_geometry(plan->channels, 0xFFFFu, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
+	}
 
 	if (plan->vecs >= 200u)
 	{

@@ -847,3 +847,55 @@ def test_eight_channel_variants_bit_exact(golden, products, name, variant):
     finally:
         p.api.DebugSetVariant(0xFFFF)
     assert res == golden["cases"][name]
+
+
+def test_run_time_slot_expanded_window_kernel(products):
+    """k_wave2 with a run-time slot count (cr_inst_runtime_w.hip): what plans WITHOUT a specialised instance run for long windows.
+    The 8-lobe build at random downsampling ratios 1.3:1 ... 3.2:1 for 2-7 channels (the host's own rule picks it), and - forced
+    through variant 31 - shapes the rule leaves to k_poly: mono, 8 channels, 3 lobes, windows of a few slots; random lengths incl.
+    shorter than a wave-tile, a split into two calls, int32 and clamped int16 output, full-scale squares among the noise."""
+    import random
+    rng = random.Random(271828)
+    used = 0
+    for draw in range(72):
+        forced = draw % 3 == 2
+        radius = 8 if not forced else rng.choice([3, 8])
+        p, o = products[radius], ck.oracle(radius)
+        ch = rng.randrange(2, 8) if not forced else rng.choice([1, 2, 3, 5, 8])
+        out = rng.randrange(8000, 48000)
+        i = int(out * (rng.uniform(1.3, 3.2) if not forced else rng.uniform(1.15, 3.2)))
+        frames = rng.choice([rng.randrange(1, 200), rng.randrange(200, 5000), rng.randrange(5000, 40000)])
+        ok, a = p.low_init(ch, i, out, out)
+        ok2, b = o.low_init(ch, i, out, out)
+        assert ok == ok2 and a.astuple() == b.astuple()
+        if forced:
+            p.api.DebugSetVariant(31)
+        try:
+            info = p.api.PlanGetInfo(p.api.PlanCreate(a.raw, p.pre))
+            if info.kernel == 4 and not info.specialised:
+                used += 1
+            pcm = ck.noise_pcm(frames * ch, 3000 + draw)
+            if draw % 4 == 0:
+                n = min(pcm.size, 6000)
+                pcm[:n] = np.where(np.arange(n) % 22 < 11, 32767, -32768)
+            padded = ck.pad_frames(pcm, ch, int(b.cfg.radius_frames))
+            total = ck.count_output_frames(b, frames)
+            if draw % 5 == 0:
+                want, _, _ = o.low_resample_i32(b, padded, frames)
+                got, left, ran_out = p.api.LowLevel_ResampleBulkS16(a.raw, p.pre, padded, frames)
+                assert np.array_equal(got, np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16)), (radius, ch, i, out, frames)
+                continue
+            cut = rng.randrange(1, total) if total > 1 else None
+            if cut is not None:
+                xa, la, ra = p.low_resample_i32(a, padded, frames, capacity=cut)
+                xb, lb, rb = o.low_resample_i32(b, padded, frames, capacity=cut)
+                assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple(), (radius, ch, i, out, frames, cut)
+                padded = padded[(frames - la) * ch:]
+                frames = la
+            xa, la, ra = p.low_resample_i32(a, padded, frames)
+            xb, lb, rb = o.low_resample_i32(b, padded, frames)
+            assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple(), (radius, ch, i, out, frames)
+        finally:
+            if forced:
+                p.api.DebugSetVariant(0xFFFF)
+    assert used >= 40, used

@@ -358,3 +358,49 @@ def test_default_error_handler_aborts(tmp_path):
     if r.returncode == 77:
         pytest.skip("a GPU is present")
     assert r.returncode < 0 and "clownresampler_amd: no usable HIP device" in r.stderr
+
+
+def test_device_code_keeps_its_promises(tmp_path):
+    """Reads the gfx950 code objects out of the built library and checks two things the kernels' comments rely on and hipcc is
+    free to break behind the source's back ("Tickets"):
+    (1) no flat_ memory instruction anywhere: LDS words are addressed as LDS, global memory as global (a flat access counts in
+        vmcnt AND lgkmcnt, and a volatile one is followed by vmcnt(0));
+    (2) the SGPR of a ticket drawn with draw_ticket_begin (s_atomic_add, result in flight) is not touched by ANY instruction
+        before the s_waitcnt lgkmcnt(0) of draw_ticket_end."""
+    import shutil
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    lib = tmp_path / "lib.so"
+    shutil.copy(cr.LIB_PATH, lib)
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, capture_output=True)
+    bundles = sorted(p for p in tmp_path.iterdir() if "gfx950" in p.name)
+    assert len(bundles) >= 10, [p.name for p in tmp_path.iterdir()]
+    draws = pending_checked = 0
+    for bundle in bundles:
+        text = subprocess.run([objdump, "-d", str(bundle)], check=True, capture_output=True, text=True).stdout
+        lines = [l.split("//")[0].strip() for l in text.splitlines()]
+        lines = [l for l in lines if l and not l.endswith(":") and not l.startswith(("Disassembly", "/"))]
+        flat = [l for l in lines if l.startswith("flat_")]
+        assert not flat, (bundle.name, flat[:3])
+        i = 0
+        while i < len(lines):
+            m = re.match(r"s_atomic_add s(\d+),", lines[i])
+            if not m:
+                i += 1
+                continue
+            draws += 1
+            reg = int(m.group(1))
+            j = i + 1
+            while j < len(lines) and not re.match(r"s_waitcnt .*lgkmcnt\(0\)", lines[j]):
+                ops = lines[j]
+                singles = {int(x) for x in re.findall(r"\bs(\d+)\b", ops)}
+                ranges = [(int(a), int(b)) for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", ops)]
+                assert reg not in singles and not any(a <= reg <= b for a, b in ranges), (bundle.name, lines[i], ops)
+                assert not ops.startswith(("s_endpgm", "s_atomic_add")), (bundle.name, lines[i], "no wait before", ops)
+                j += 1
+            assert j < len(lines), (bundle.name, lines[i], "never waited for")
+            if j > i + 1:
+                pending_checked += 1
+            i = j
+    assert draws >= 50 and pending_checked >= 2, (draws, pending_checked)   # every ticketed kernel; k_up2's two output forms

@@ -821,8 +821,13 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 
 		if (fixed == 1)
 		{
+			const uint32_t safemask = crhip_poly_wave2_safemask(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
+
 			cr_poly_slot_signs(&plan->poly, &pos_bits, &neg_bits);
 			ok = (neg_bits & ~negmask) == 0 && (pos_bits & negmask) == 0;
+			/* the mov-armed form stages every other slot's weights as |weight| << 15 */
+			if (ok && safemask != 0 && (cr_poly_slots_reaching(&plan->poly, 65536) & ~safemask) != 0)
+				ok = 0;
 		}
 		if (!ok)
 		{

@@ -72,6 +72,7 @@ struct special
 	uint32_t wave2_waves, wave2_nvw, wave2_iter;   // its geometry (template WAVES, NVW, ITER)
 	uint32_t wave2_fallback;    // the variant used instead when k_wave2 is the default and a plan does not qualify for it
 	uint32_t wave2_fixed_signs; // 1: built for the slot signs in up_negmask (the host checks the plan's rows), 0: any rows
+	uint32_t wave2_safemask;    // fixed signs: != 0 = the mov-armed form; these slots take weights up to 65536, the others only below it
 };
 
 constexpr uint32_t MAD_VARIANT = 28;    // variant ids 28, 29
@@ -79,12 +80,15 @@ constexpr uint32_t WAVE2_VARIANT = 30;  // variant id 30: k_wave2 where the inst
 constexpr uint32_t RT_WAVE2_VARIANT = 31;   // variant id 31: the run-time-slot k_wave2 (plans without a specialised instance; chosen by the host)
 
 // k_wave2 of an instance: fixed slot signs (NEGMASK != 0: pure upsampling, 2 VALU per tap and channel) or any rows (3)
+// SAFEMASK (fixed signs only): see k_wave2 - 15 slots of the 8-lobe table: slots 7 and 8 are the ones that reach 65536
 template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, unsigned NEGMASK>
 void add_wave2(special &s)
 {
 	constexpr int SIGNED = NEGMASK == 0 ? 1 : 0;
-	s.wave2 = (poly_fn)k_wave2<CH, TT, MODE, NORM, WAVES, NVW, ITER, 0, 1, NEGMASK, SIGNED>;
-	s.wave2_16 = (poly_fn)k_wave2<CH, TT, MODE, NORM, WAVES, NVW, ITER, 1, 1, NEGMASK, SIGNED>;
+	constexpr unsigned SAFEMASK = (!SIGNED && TT == 15) ? 0x180u : 0u;
+	s.wave2 = (poly_fn)k_wave2<CH, TT, MODE, NORM, WAVES, NVW, ITER, 0, 1, NEGMASK, SIGNED, SAFEMASK>;
+	s.wave2_16 = (poly_fn)k_wave2<CH, TT, MODE, NORM, WAVES, NVW, ITER, 1, 1, NEGMASK, SIGNED, SAFEMASK>;
+	s.wave2_safemask = SAFEMASK;
 	s.wave2_waves = WAVES;
 	s.wave2_nvw = NVW;
 	s.wave2_iter = ITER;
@@ -121,7 +125,7 @@ constexpr int WAVE_WAVES = 16, WAVE_NVW = 1, WAVE_ITER = 4;
 template <int CH, int TT, int MODE, int NORM, int DV, bool WAVE = false, bool DYNAMIC = false, unsigned UPMASK = 0>
 special make_special()
 {
-	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, false, 1u, UPMASK, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u};
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, false, 1u, UPMASK, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u};
 	if constexpr (UPMASK != 0 && CH % 2 == 0)
 	{
 		s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 1>;
@@ -170,7 +174,7 @@ special make_special()
 template <int CH, int TT, int MODE, int NORM, int DV = (CH <= 4 ? 13 : 14)>   // default: (1024 threads, 1 or 2 vectors per thread), one frame in flight, non-temporal stores
 special make_special_lite()
 {
-	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 1u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u};
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 1u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u};
 	const poly_fn fn = instance<CH, TT, MODE, NORM, DV % 5, 1, (DV / 5) % 2, (DV / 10) % 2>();
 	for (int v = 0; v < VARIANTS; ++v)
 		s.fn[v] = fn;
@@ -184,7 +188,7 @@ special make_special_lite_split()
 {
 	constexpr int DV = 14;   // (1024 threads, 2 vectors per thread), one frame in flight, non-temporal stores
 	constexpr int T = GEOMETRY[DV % 5].threads, V = GEOMETRY[DV % 5].vecs;
-	special s = {CHT, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 2u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u};
+	special s = {CHT, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 2u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u};
 	const poly_fn fn = (poly_fn)k_poly<CHT / 2, TT, MODE, NORM, T, V, 1, 1, 0, 0, 0, 1, 2>;
 	for (int v = 0; v < VARIANTS; ++v)
 		s.fn[v] = fn;

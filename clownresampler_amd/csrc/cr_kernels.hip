@@ -435,6 +435,12 @@ int crhip_poly_wave2_negmask(uint32_t channels, uint32_t slots, uint32_t row_mod
 	return sp->wave2_fixed_signs ? 1 : 0;   // 1: the plan's slot signs must match *negmask
 }
 
+uint32_t crhip_poly_wave2_safemask(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
+{
+	const special *sp = find_special(channels, slots, row_mode, norm_mode);
+	return sp != nullptr && sp->wave2 != nullptr ? sp->wave2_safemask : 0u;
+}
+
 uint32_t crhip_poly_wave2_fallback_variant(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
 {
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
@@ -638,7 +644,8 @@ int crhip_launch_poly(const crhip_poly_launch *launch, void *stream)
 	if (geo == 150u)
 	{
 		if (launch->threads % 64u != 0 || launch->vecs < 150u || launch->vecs >= 200u || launch->tile_frames < 64u
-		    || (launch->tile_frames & (launch->tile_frames - 1u)) != 0)
+		    || (launch->tile_frames & (launch->tile_frames - 1u)) != 0
+		    || (launch->row_mode == CRHIP_ROWMODE_UPSAMPLE && launch->plane_rows != UP_PLANE_ROWS))   // (k_wave2 reads the planes of pure-upsampling rows at immediate offsets)
 			return (int)hipErrorInvalidValue;
 	}
 	else if (geo == 200u ? (launch->threads != UP_WAVES * 64u || launch->vecs != 200u || launch->tile_frames % 4u != 0 || launch->tile_frames / 4u > UP_MAX_WAVE_TILE || launch->plane_rows != UP_PLANE_ROWS)

@@ -34,10 +34,21 @@ namespace
 // loads cannot be made safe: hipcc copies their destination registers before the data has landed.)
 //   WAVES  waves per workgroup     NVW  1 KiB DMA pieces per wave-tile     ITER  frames per lane per wave-tile
 // ---------------------------------------------------------------------------------------------------------
-template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, int OUT16, int NT, unsigned NEGMASK, int SIGNED>
+template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, int OUT16, int NT, unsigned NEGMASK, int SIGNED, unsigned SAFEMASK = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 {
 	static_assert(CH >= 1 && CH <= 8, "one lane per frame");
+	// SAFEMASK != 0 (fixed signs only): the MOV-ARMED form.  Of all the one-instruction ways to arm `lo`, a plain v_mov_b32 is the
+	// only one that costs next to nothing beside the multiply-add (tools/microbench/chainbench.hip: 231 cycles per wave-frame for
+	// the multiply-adds alone, 258 with a v_mov_b32 each, 313-348 with v_and / v_ashrrev / v_not / v_mov_sdwa / v_xor_sdwa / v_bfe).
+	// So the window is expanded to X = 2 * sample (sign-extended) instead of sample << 16 and the rows are staged as
+	// |weight| << 15: X * W is the same sample * |weight| * 65536, and X ITSELF is a valid `lo` - in [2^32 - 65536, 2^32) where
+	// the sample is negative, in [0, 65536) where it is not, which is all the carry needs (the product is a multiple of 65536).
+	// |weight| << 15 needs |weight| < 65536; the slots in SAFEMASK - the two around the kernel's centre, whose weights reach
+	// 65536 in one row each - keep the plain |weight| and take X << 15 = sample << 16 (one more shift); the host checks the
+	// plan's rows against the mask.
+	constexpr bool MOVARM = SAFEMASK != 0;
+	static_assert(!MOVARM || (!SIGNED && NEGMASK != 0 && TT > 0), "the mov-armed form is for fixed slot signs");
 	// TT == 0: the run-time-slot form - slot count, window pieces and waves per workgroup come with the launch (a.slots,
 	// a.vecs - 150, blockDim.x / 64), the rows in the run-time-slot image (ceil(slots / 4) zero-padded planes of weights, then
 	// one plane with the reciprocal: cr_plan.c), any rows (SIGNED), one frame per lane and wave-tile
@@ -66,6 +77,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	const unsigned tid = threadIdx.x;
 	const unsigned lane = tid & 63u;
 	const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	int zero119 = 0;   // lives in v119 wherever the taps want it (see one_frame2)
+	asm volatile("" : "+v"(zero119));   // (a value, not a constant hipcc would re-materialise in front of every use)
 
 	const unsigned rows_bytes = a.plane_rows * a.row_stride * 4u;
 	unsigned char *my_buf = smem + rows_bytes + wave * PER_WAVE;
@@ -93,6 +106,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 						const int slot = 4 * (int)q + k;
 						if (slot < TT && ((NEGMASK >> slot) & 1u))
 							e[k] = -e[k];
+						if (MOVARM && slot < TT && !((SAFEMASK >> slot) & 1u))
+							e[k] = (int)((unsigned)e[k] << 15);
 					}
 				}
 				u32x4 w;
@@ -197,8 +212,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 		auto convert = [&](unsigned k) {
 			const int f = from[k * 64u];
 			i32x2 x;
-			x.x = (int)((unsigned)f << 16);
-			x.y = (int)((unsigned)f & 0xFFFF0000u);
+			if constexpr (MOVARM)
+			{
+				x.x = (int)((unsigned)f << 16) >> 15;   // 2 * sample
+				x.y = (f >> 16) * 2;
+			}
+			else
+			{
+				x.x = (int)((unsigned)f << 16);
+				x.y = (int)((unsigned)f & 0xFFFF0000u);
+			}
 			to[k * 64u] = x;
 		};
 		if constexpr (RT)
@@ -368,8 +391,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 			{
 				if (c0 == 0)
 				{
-					const unsigned at = row_at + (unsigned)q * plane_bytes;
-					asm volatile("ds_read_b128 %0, %1" : "=v"(wv[q]) : "v"(at));
+					if constexpr (MODE == CRHIP_ROWMODE_UPSAMPLE)
+					{
+						// pure upsampling has ONE row image whatever the ratio (UP_PLANE_ROWS rows per plane, checked at launch): the
+						// further planes are immediate offsets
+						asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wv[q]) : "v"(row_at), "n"(q * (int)UP_PLANE_ROWS * 16));
+					}
+					else
+					{
+						const unsigned at = row_at + (unsigned)q * plane_bytes;
+						asm volatile("ds_read_b128 %0, %1" : "=v"(wv[q]) : "v"(at));
+					}
 				}
 #pragma unroll
 				for (int s = 4 * q; s < 4 * q + 4 && s < TT; ++s)
@@ -386,7 +418,31 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 			}
 
 			// accumulator pairs pinned to physical registers (see k_up2): A+ v[120:121], B+ v[122:123], A- v[124:125], B- v[126:127]
+			// (an accumulator's FIRST tap adds to {arm, 0} - a scratch register paired with a register that holds 0 for the whole
+			// kernel, v[118:119] - instead of to itself: no v_mov to clear it)
 			int lo0, hi0 = 0, lo1, hi1 = 0, lo2, hi2 = 0, lo3, hi3 = 0;
+			constexpr int FIRST_POS = SIGNED ? 0 : __builtin_ctz(~NEGMASK), FIRST_NEG = SIGNED ? -1 : (NEGMASK ? __builtin_ctz(NEGMASK) : -1);
+#define CRHIP_W2_TAP_FIRST(LO, HI, VLO, VHI, X, W)                                                                                 \
+	asm("v_ashrrev_i32_e32 v118, 31, %2\n\t"                                                                                     \
+	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[118:119]"                                                               \
+	    : "=&{v" #LO "}"(VLO), "=&{v" #HI "}"(VHI) : "v"(X), "v"(W), "{v119}"(zero119) : "vcc", "v118")
+#define CRHIP_W2_TAP_MOV(LO, HI, VLO, VHI, X, W)                                                                                   \
+	asm("v_mov_b32_e32 v" #LO ", %2\n\t"                                                                                         \
+	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
+	    : "=&{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc")
+#define CRHIP_W2_TAP_MOV_SAFE(LO, HI, VLO, VHI, X, W)                                                                              \
+	asm("v_lshlrev_b32_e32 v118, 15, %2\n\t"                                                                                     \
+	    "v_mov_b32_e32 v" #LO ", %2\n\t"                                                                                         \
+	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, v118, %3, v[" #LO ":" #HI "]"                                                    \
+	    : "=&{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc", "v118")
+#define CRHIP_W2_TAP_MOV_FIRST(LO, HI, VLO, VHI, X, W)                                                                             \
+	asm("v_mov_b32_e32 v118, %2\n\t"                                                                                             \
+	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[118:119]"                                                               \
+	    : "=&{v" #LO "}"(VLO), "=&{v" #HI "}"(VHI) : "v"(X), "v"(W), "{v119}"(zero119) : "vcc", "v118")
+#define CRHIP_W2_TAP_SIGNED_FIRST(LO, HI, VLO, VHI, X, W)                                                                          \
+	asm("v_xor_b32_sdwa v118, sext(%2), sext(%3) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"      \
+	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[118:119]"                                                               \
+	    : "=&{v" #LO "}"(VLO), "=&{v" #HI "}"(VHI) : "v"(X), "v"(W), "{v119}"(zero119) : "vcc", "v118")
 #define CRHIP_W2_TAP(LO, HI, VLO, VHI, X, W)                                                                                       \
 	asm("v_ashrrev_i32_e32 v" #LO ", 31, %2\n\t"                                                                                  \
 	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
@@ -428,26 +484,96 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 					}
 					if constexpr (SIGNED)
 					{
-						CRHIP_W2_TAP_SIGNED(120, 121, lo0, hi0, xa[s], w[s]);
-						if (pair)
-							CRHIP_W2_TAP_SIGNED(122, 123, lo1, hi1, xb[s], w[s]);
+						if (s == FIRST_POS)
+						{
+							CRHIP_W2_TAP_SIGNED_FIRST(120, 121, lo0, hi0, xa[s], w[s]);
+							if (pair)
+								CRHIP_W2_TAP_SIGNED_FIRST(122, 123, lo1, hi1, xb[s], w[s]);
+						}
+						else
+						{
+							CRHIP_W2_TAP_SIGNED(120, 121, lo0, hi0, xa[s], w[s]);
+							if (pair)
+								CRHIP_W2_TAP_SIGNED(122, 123, lo1, hi1, xb[s], w[s]);
+						}
+					}
+					else if constexpr (MOVARM)
+					{
+						static_assert(!MOVARM || (!((SAFEMASK >> (FIRST_POS < 0 ? 0 : FIRST_POS)) & 1u) && !((SAFEMASK >> (FIRST_NEG < 0 ? 0 : FIRST_NEG)) & 1u) && !(SAFEMASK & NEGMASK)),
+						              "an accumulator's first tap is an ordinary slot, and the unrestricted slots are positive ones");
+						if ((NEGMASK >> s) & 1u)
+						{
+							if (s == FIRST_NEG)
+							{
+								CRHIP_W2_TAP_MOV_FIRST(124, 125, lo2, hi2, xa[s], w[s]);
+								if (pair)
+									CRHIP_W2_TAP_MOV_FIRST(126, 127, lo3, hi3, xb[s], w[s]);
+							}
+							else
+							{
+								CRHIP_W2_TAP_MOV(124, 125, lo2, hi2, xa[s], w[s]);
+								if (pair)
+									CRHIP_W2_TAP_MOV(126, 127, lo3, hi3, xb[s], w[s]);
+							}
+						}
+						else if (s == FIRST_POS)
+						{
+							CRHIP_W2_TAP_MOV_FIRST(120, 121, lo0, hi0, xa[s], w[s]);
+							if (pair)
+								CRHIP_W2_TAP_MOV_FIRST(122, 123, lo1, hi1, xb[s], w[s]);
+						}
+						else if ((SAFEMASK >> s) & 1u)
+						{
+							CRHIP_W2_TAP_MOV_SAFE(120, 121, lo0, hi0, xa[s], w[s]);
+							if (pair)
+								CRHIP_W2_TAP_MOV_SAFE(122, 123, lo1, hi1, xb[s], w[s]);
+						}
+						else
+						{
+							CRHIP_W2_TAP_MOV(120, 121, lo0, hi0, xa[s], w[s]);
+							if (pair)
+								CRHIP_W2_TAP_MOV(122, 123, lo1, hi1, xb[s], w[s]);
+						}
 					}
 					else if ((NEGMASK >> s) & 1u)
 					{
-						CRHIP_W2_TAP(124, 125, lo2, hi2, xa[s], w[s]);
-						if (pair)
-							CRHIP_W2_TAP(126, 127, lo3, hi3, xb[s], w[s]);
+						if (s == FIRST_NEG)
+						{
+							CRHIP_W2_TAP_FIRST(124, 125, lo2, hi2, xa[s], w[s]);
+							if (pair)
+								CRHIP_W2_TAP_FIRST(126, 127, lo3, hi3, xb[s], w[s]);
+						}
+						else
+						{
+							CRHIP_W2_TAP(124, 125, lo2, hi2, xa[s], w[s]);
+							if (pair)
+								CRHIP_W2_TAP(126, 127, lo3, hi3, xb[s], w[s]);
+						}
 					}
 					else
 					{
-						CRHIP_W2_TAP(120, 121, lo0, hi0, xa[s], w[s]);
-						if (pair)
-							CRHIP_W2_TAP(122, 123, lo1, hi1, xb[s], w[s]);
+						if (s == FIRST_POS)
+						{
+							CRHIP_W2_TAP_FIRST(120, 121, lo0, hi0, xa[s], w[s]);
+							if (pair)
+								CRHIP_W2_TAP_FIRST(122, 123, lo1, hi1, xb[s], w[s]);
+						}
+						else
+						{
+							CRHIP_W2_TAP(120, 121, lo0, hi0, xa[s], w[s]);
+							if (pair)
+								CRHIP_W2_TAP(122, 123, lo1, hi1, xb[s], w[s]);
+						}
 					}
 				}
 			}
 #undef CRHIP_W2_TAP
 #undef CRHIP_W2_TAP_SIGNED
+#undef CRHIP_W2_TAP_FIRST
+#undef CRHIP_W2_TAP_MOV
+#undef CRHIP_W2_TAP_MOV_SAFE
+#undef CRHIP_W2_TAP_MOV_FIRST
+#undef CRHIP_W2_TAP_SIGNED_FIRST
 			(void)lo0;
 			(void)lo1;
 			(void)lo2;

@@ -508,6 +508,24 @@ void cr_poly_slot_signs(const cr_poly *poly, uint32_t *positive, uint32_t *negat
 	}
 }
 
+uint32_t cr_poly_slots_reaching(const cr_poly *poly, int32_t magnitude)
+{
+	uint32_t row, slot, mask = 0;
+
+	for (row = 0; row < poly->rows; ++row)
+	{
+		for (slot = 0; slot < poly->slots && slot < 32u; ++slot)
+		{
+			const int32_t w = poly->weights[(size_t)row * poly->row_stride + slot];
+
+			if (w >= magnitude || w <= -magnitude)
+				mask |= 1u << slot;
+		}
+	}
+
+	return mask;
+}
+
 uint32_t cr_poly_pick_swizzle(const cr_poly *poly, uint64_t increment, double *conflict_plain, double *conflict_best)
 {
 	uint32_t best = 0, k;

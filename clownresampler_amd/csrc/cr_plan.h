@@ -69,6 +69,8 @@ uint32_t cr_poly_phys_row(uint32_t row, uint32_t swizzle);
 /* Signs of the weights per slot over all rows: bit s of *positive / *negative is set when slot s holds a weight > 0 / < 0
    in some row. */
 void cr_poly_slot_signs(const cr_poly *poly, uint32_t *positive, uint32_t *negative);
+/* bit s set: some row has a weight of at least this magnitude in slot s */
+uint32_t cr_poly_slots_reaching(const cr_poly *poly, int32_t magnitude);
 /* Chooses the swizzle (0..15) that minimises ds_read_b128 bank conflicts for lanes that hold consecutive output frames
    `increment` apart; *conflict_cycles_plain / _best receive the modelled extra LDS cycles per wave read. */
 uint32_t cr_poly_pick_swizzle(const cr_poly *poly, uint64_t increment, double *conflict_plain, double *conflict_best);

@@ -153,6 +153,9 @@ uint32_t crhip_poly_up_fallback_variant(uint32_t channels, uint32_t slots, uint3
 /* k_wave2 (expanded window, 64-bit multiply-add taps; variant 30): -1 when the instance has none, 1 when it is built for the slot
    signs in *negmask (the host checks the plan's rows against them, as for k_up), 0 when it takes any rows */
 int crhip_poly_wave2_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t *negmask);
+/* the slots whose weights that k_wave2 instance takes at ANY magnitude up to 65536; every other slot's weights must stay below
+   65536 in every row (they are staged as |weight| << 15).  0: no such restriction */
+uint32_t crhip_poly_wave2_safemask(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
 /* the variant to use when a plan does not qualify for k_wave2 */
 uint32_t crhip_poly_wave2_fallback_variant(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
 /* 1 when there is a k_wave2 instance with a run-time slot count for this channel count and row mode (downsampling rows, 1-8

@@ -199,6 +199,50 @@ __global__ __launch_bounds__(WAVES * 64) void k(int *out, int frames, unsigned i
 			acc0 = h0;
 			acc1 = h1;
 		}
+		else if constexpr (FORM >= 14 && FORM <= 19)
+		{
+			// 2 pairs, one statement per frame (as form 2 / 12), the low dword armed by ...: which single instructions are as cheap
+			// as form 12's v_mov_b32?  (14, 17: right arithmetic - bits 31..7 the sign, low bits noise the carry does not see;
+			// 15, 18: right; 16, 19: timing only)
+			int h0 = 0, h1 = 0, l0, l1;
+#define ARM14(r, x) "v_mov_b32_sdwa v" #r ", sext(%[" #x "]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3\n\t"
+#define ARM15(r, x) "v_bfe_i32 v" #r ", %[" #x "], 31, 1\n\t"
+#define ARM16(r, x) "v_not_b32_e32 v" #r ", %[" #x "]\n\t"
+#define ARM17(r, x, w) "v_xor_b32_sdwa v" #r ", sext(%[" #x "]), sext(%[" #w "]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
+#define ARM18(r, x) "v_ashrrev_i32_e64 v" #r ", 31, %[" #x "]\n\t"
+#define ARM19(r, x) "v_and_b32_e32 v" #r ", 0x7f, %[" #x "]\n\t"
+#define MADS(s) "v_mad_i64_i32 v[120:121], vcc, %[a" #s "], %[w" #s "], v[120:121]\n\t"
+#define MADT(s) "v_mad_i64_i32 v[124:125], vcc, %[b" #s "], %[w" #s "], v[124:125]\n\t"
+#define FRAME(A, B) A(0) B(0) A(1) B(1) A(2) B(2) A(3) B(3) A(4) B(4) A(5) B(5) A(6) B(6) A(7) B(7) A(8) B(8) A(9) B(9) A(10) B(10) A(11) B(11) A(12) B(12) A(13) B(13) A(14) B(14)
+#define OUTS : "=&{v120}"(l0), "+{v121}"(h0), "=&{v124}"(l1), "+{v125}"(h1)
+#define INS : OPS(0), OPS(1), OPS(2), OPS(3), OPS(4), OPS(5), OPS(6), OPS(7), OPS(8), OPS(9), OPS(10), OPS(11), OPS(12), OPS(13), OPS(14) : "vcc"
+#define L14(s) ARM14(120, a##s) MADS(s)
+#define R14(s) ARM14(124, b##s) MADT(s)
+#define L15(s) ARM15(120, a##s) MADS(s)
+#define R15(s) ARM15(124, b##s) MADT(s)
+#define L16(s) ARM16(120, a##s) MADS(s)
+#define R16(s) ARM16(124, b##s) MADT(s)
+#define L17(s) ARM17(120, a##s, w##s) MADS(s)
+#define R17(s) ARM17(124, b##s, w##s) MADT(s)
+#define L18(s) ARM18(120, a##s) MADS(s)
+#define R18(s) ARM18(124, b##s) MADT(s)
+#define L19(s) ARM19(120, a##s) MADS(s)
+#define R19(s) ARM19(124, b##s) MADT(s)
+			if constexpr (FORM == 14)
+				asm(FRAME(L14, R14) "s_nop 0" OUTS INS);
+			else if constexpr (FORM == 15)
+				asm(FRAME(L15, R15) "s_nop 0" OUTS INS);
+			else if constexpr (FORM == 16)
+				asm(FRAME(L16, R16) "s_nop 0" OUTS INS);
+			else if constexpr (FORM == 17)
+				asm(FRAME(L17, R17) "s_nop 0" OUTS INS);
+			else if constexpr (FORM == 18)
+				asm(FRAME(L18, R18) "s_nop 0" OUTS INS);
+			else
+				asm(FRAME(L19, R19) "s_nop 0" OUTS INS);
+			acc0 = h0;
+			acc1 = h1;
+		}
 		else if constexpr (FORM == 12 || FORM == 13)
 		{
 			// 2 pairs (one per channel), low dword armed by a MOVE from a bias register (B = S >> 31, formed once per window)
@@ -323,6 +367,16 @@ int main()
 	run<11, 12>("4 pairs, multiply-adds only (timing only)", d);
 	run<12, 12>("mov bias + mad64, 2 pairs, one statement per frame", d);
 	run<13, 12>("mov bias + mad64, 2 pairs, statement per tap", d);
+	run<2, 12>("ashr + mad64, 2 pairs, one statement per frame (again)", d);
+	run<12, 12>("mov bias + mad64, 2 pairs, one statement per frame (again)", d);
+	run<14, 12>("v_mov_b32_sdwa sext(byte 3) + mad64", d);
+	run<15, 12>("v_bfe_i32 + mad64", d);
+	run<16, 12>("v_not_b32 + mad64 (timing only)", d);
+	run<17, 12>("v_xor_b32_sdwa sext(byte 3), sext(byte 3) + mad64", d);
+	run<18, 12>("v_ashrrev_i32_e64 + mad64", d);
+	run<19, 12>("v_and_b32 + mad64 (timing only)", d);
+	run<14, 16>("v_mov_b32_sdwa sext(byte 3) + mad64", d);
+	run<2, 16>("ashr + mad64, 2 pairs, one statement per frame", d);
 	run<13, 16>("mov bias + mad64, 2 pairs, statement per tap", d);
 	run<8, 16>("4 pairs, armed one slot ahead, one statement", d);
 	run<4, 16>("mov bias + mad64, 4 pairs, statement per tap (round 1)", d);

@@ -899,3 +899,33 @@ def test_run_time_slot_expanded_window_kernel(products):
             if forced:
                 p.api.DebugSetVariant(0xFFFF)
     assert used >= 40, used
+
+
+def test_mov_armed_taps_at_the_sample_range_limits(products):
+    """k_wave2's mov-armed form (8 lobes, pure upsampling below 2x, 1-8 channels): X = 2 * sample serves as the low dword of the
+    64-bit accumulator itself, which is valid at the very ends of the sample range too (-32768: lo = 0xFFFF0000, the lowest value
+    that still carries; 32767: lo = 65534, the highest that never does), for weights up to 65536 in the two centre slots (the
+    rows around fraction 0) and |weight| << 15 elsewhere.  Inputs made of -32768, 32767, -1, 0, 1 runs and noise."""
+    import random
+    rng = random.Random(4242)
+    p, o = products[8], ck.oracle(8)
+    for draw in range(32):
+        ch = draw % 8 + 1
+        i = rng.choice([44100, 48000, 32000, rng.randrange(8000, 96000)])
+        out = i if draw % 7 == 0 else int(i * rng.uniform(1.0, 1.99))      # (1:1 -> every frame sits on fraction 0: the 65536 weights)
+        frames = rng.randrange(200, 9000)
+        ok, a = p.low_init(ch, i, out, i)
+        ok2, b = o.low_init(ch, i, out, i)
+        assert ok == ok2 and a.astuple() == b.astuple()
+        info = p.api.PlanGetInfo(p.api.PlanCreate(a.raw, p.pre))
+        assert info.kernel == 4 and info.slots == 15, (ch, i, out, info.kernel, info.slots)
+        pcm = ck.noise_pcm(frames * ch, 5000 + draw)
+        edge = np.array([-32768, 32767, -1, 0, 1, -32768, -32768, 32767], dtype=np.int16)
+        runs = rng.randrange(1, 40)
+        pattern = np.repeat(edge[np.array([rng.randrange(len(edge)) for _ in range(pcm.size // runs + 1)])], runs)[: pcm.size]
+        mask = (np.arange(pcm.size) // (runs * 16)) % 2 == 0
+        pcm = np.where(mask, pattern, pcm).astype(np.int16)
+        padded = ck.pad_frames(pcm, ch, int(b.cfg.radius_frames))
+        xa, la, ra = p.low_resample_i32(a, padded, frames)
+        xb, lb, rb = o.low_resample_i32(b, padded, frames)
+        assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple(), (ch, i, out, frames)

@@ -70,6 +70,12 @@ WORKLOADS = {
     "dn31": (3, 2, (96000, 32000, 32000), 57600000),   # stereo 3:1, 18-slot windows
     "dn96": (3, 2, (96000, 44100, 44100), 57600000),   # stereo 96 -> 44.1 kHz, 13-slot windows
     "dn4432": (3, 2, (44100, 32000, 32000), 26460000), # stereo 44.1 -> 32 kHz, 8-slot windows
+    "up4": (3, 4, (44100, 48000, 44100), 26460000),    # 10 minutes of 4 / 6 / 8 channels, 3 lobes, both directions (tuning only)
+    "up6": (3, 6, (44100, 48000, 44100), 26460000),
+    "up8": (3, 8, (44100, 48000, 44100), 26460000),
+    "dn4": (3, 4, (48000, 44100, 44100), 28800000),
+    "dn6": (3, 6, (48000, 44100, 44100), 28800000),
+    "up12": (3, 12, (44100, 48000, 44100), 26460000),
 }
 CONFIG_NAMES = {"cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2]", "cfg4": "BASELINE configs[3]", "cfg5": "BASELINE configs[4]"}
 

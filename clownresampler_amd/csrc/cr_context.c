@@ -1319,6 +1319,13 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			   stereo 3-lobe upsampling gains ~4 %, 8-channel and 8-lobe instances lose 1-8 %: a per-instance default */
 			l.dynamic_tiles = g_env.dynamic_tiles >= 0 ? (uint32_t)g_env.dynamic_tiles
 			                                           : (uint32_t)crhip_poly_dynamic_default(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
+			/* ... and, whatever the instance, LONG launches of wide frames: with 8 channels and more a tile is 512-1024 frames, a
+			   10-minute stream is a few hundred tiles per workgroup, and the workgroups drift apart (bench.py --workload up8 /
+			   up12, 10 minutes: 253 -> 239 us, 505 -> 460 us with tickets; the channel table's launches of ~40 tiles per
+			   workgroup: within +-2 % either way) */
+			if (g_env.dynamic_tiles < 0 && plan->channels >= 8u && plan->vecs < 100u
+			 && (n_out + l.tile_frames - 1) / l.tile_frames >= 48ull * (out_s16 ? plan->max_blocks_s16 : plan->max_blocks))
+				l.dynamic_tiles = 1u;
 		}
 		l.d_tickets = ticket_block_for(g_ctx[plan->device], stream);
 		if (l.d_tickets == NULL)

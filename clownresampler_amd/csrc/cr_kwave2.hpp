@@ -1,4 +1,4 @@
-// cr_kwave2.hpp - k_wave2: k_wave's streaming with the tap arithmetic of k_up2, 1 to 8 channels.
+// cr_kwave2.hpp - k_wave2: k_wave's streaming with the tap arithmetic of k_up2, 1 to 8 channels, compile-time or run-time slot count.
 #ifndef CR_KWAVE2_HPP
 #define CR_KWAVE2_HPP
 
@@ -8,26 +8,27 @@ namespace
 {
 
 // ---------------------------------------------------------------------------------------------------------
-// k_wave2 - one lane per output frame (as k_poly / k_wave), 2-3 VALU per tap and channel instead of 4
+// k_wave2 - one lane per output frame (as k_poly / k_wave), 2 VALU per tap and channel instead of 4
 // ---------------------------------------------------------------------------------------------------------
 // k_poly and k_wave keep the input window packed (two int16 per dword) and spend four SDWA instructions per tap and channel:
 // multiply, sign, +0xFFFF where negative, add the high word.  Here the wave first EXPANDS its window once per wave-tile into a
-// second LDS buffer of X = sample << 16 (one dword per sample: a shift or a mask per sample, amortised over the ~15 output
-// frames that read it), and the tap is the 64-bit multiply-add of k_up2 on an accumulator pair {lo, hi}:
-//     lo = X >> 31                       all ones where the product can be negative
+// second LDS buffer of one dword per sample (a shift or a mask per sample, amortised over the output frames that read it),
+// and the tap is the 64-bit multiply-add of k_up2 on an accumulator pair {lo, hi}:
+//     lo = arm                           anything in [2^32 - 65536, 2^32) where the product can be negative, in [0, 65536) where not
 //     {lo, hi} = X * W + {lo, hi}        X * W = sample * weight << 16: integer part into hi, fraction bits in the top of lo;
-//                                        the all-ones lo carries exactly when a negative product has a fraction: C's truncation
+//                                        such a lo carries exactly when a negative product has a fraction: C's truncation
 //                                        (clownresampler.h:1020 via :625)
-// which needs W >= 0 - otherwise the product's sign is not the sample's:
+// Three ways to arm, by what is known about the rows:
+//   SIGNED == 1 (any rows): X = sample << 16, W = weight as it is, lo = sext(top byte of X) ^ sext(top byte of W) in ONE SDWA
+//                instruction - bits 31..7 the product's sign, the low 7 bits noise the carry does not see.  (The first form,
+//                (X ^ W) >> 31 in two instructions, made the tap 3.)  Also the run-time-slot form (TT == 0, below).
 //   SIGNED == 0 (pure upsampling: the sign of a slot's weights is a compile-time property, NEGMASK, checked by the host per
-//                plan as for k_up): the rows are staged as W = |weight|, the slots with negative weights accumulate into a
-//                second pair and the two sums are subtracted at the end (truncation toward zero is odd-symmetric).  2 VALU.
-//   SIGNED == 1 (any rows): W = weight as it is, lo = sext(top byte of X) ^ sext(top byte of W) in ONE SDWA instruction: its
-//                bits 31..7 are the product's sign, its low 7 bits are noise - which the carry does not see: X * W is a multiple
-//                of 65536, so a lo in [2^32 - 128, 2^32) carries exactly when the fraction is not zero and a lo in [0, 128)
-//                never does.  2 VALU.  (The first form, (X ^ W) >> 31 in two instructions, was 3.)
-// Everything else - tickets over 32 counter lanes, a private double-buffered LDS-DMA window per wave, counted vmcnt, coalesced
-// non-temporal stores - is k_wave's.  LDS per wave: two packed windows (NVW KiB each) and one expanded window (2 x NVW KiB).
+//                plan as for k_up): rows staged as magnitudes, the slots with negative weights accumulate into a second pair,
+//                the two sums subtracted at the end (truncation toward zero is odd-symmetric); lo = X >> 31 - or, with
+//   SAFEMASK != 0, the mov-armed form (below): X = 2 * sample is its own lo.
+// The streaming - a private double-buffered LDS-DMA window per wave, counted vmcnt, coalesced non-temporal stores, tickets over
+// 32 counter lanes (for the tail of a launch only) - is k_wave's.  LDS per wave: two packed windows (NVW KiB each) and one
+// expanded window (2 x NVW KiB).
 // (Loading the packed window into registers instead of LDS - coalesced buffer loads a wave-tile ahead, the expansion straight
 // from registers, half the LDS footprint - was tried and is not kept: with hipcc's own loads it protects the registers with
 // vmcnt(0), draining the tile's stores every time (117 against 105 us on the 8-lobe 44.1 -> 48 kHz workload), and inline-assembly

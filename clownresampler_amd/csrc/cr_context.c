@@ -161,8 +161,8 @@ static int g_variant = -1; /* -1: CLOWNRESAMPLER_AMD_VARIANT from the environmen
    odd-channel cells lose 3-11 %); exact 3:1 with 3 lobes (18 slots, a handful of rows) +12 ... +42 %; but 3 lobes at 3.2:1
    (19 slots) -16 ... -25 %, at 4:1 -16 ... -36 %, 48 -> 11.025 and 44.1 -> 8 kHz mixed; mono and 8 channels lose at any length
    (too little arithmetic per frame for the per-tile work / too few waves beside the rows).  Hence: 2-7 channels, at most 3.25
-   input frames per output frame, and 20 slots - or 18 where the rows are a few KB (exact ratios). */
-#define CR_RT_WAVE2_MIN_SLOTS 20
+   input frames per output frame, and 22 slots - or 18 where the rows are a few KB (exact ratios). */
+#define CR_RT_WAVE2_MIN_SLOTS 22   /* (20-21 slots within the increment limit would be 3 lobes at 3.2:1: the losing case) */
 #define CR_RT_WAVE2_MIN_SLOTS_FEW_ROWS 18
 #define CR_RT_WAVE2_FEW_ROWS_BYTES 8192u
 #define CR_RT_WAVE2_MAX_INCREMENT ((13u << 16) / 4u)

@@ -89,40 +89,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	if (tid == 0)
 		*waves_done = 0;
 
-	// stage the polyphase rows once per workgroup (as magnitudes where the slot signs are fixed): the only barrier of the kernel
-	{
-		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.d_rows);
-		u32x4 *dst = reinterpret_cast<u32x4 *>(smem);
-		for (unsigned q = 0; q < planes_total; ++q)
-		{
-			for (unsigned r = tid; r < a.plane_rows; r += NTHREADS)
-			{
-				const u32x4 v = src[q * a.plane_rows + r];
-				int e[4] = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-				if constexpr (!SIGNED)
-				{
-#pragma unroll
-					for (int k = 0; k < 4; ++k)
-					{
-						const int slot = 4 * (int)q + k;
-						if (slot < TT && ((NEGMASK >> slot) & 1u))
-							e[k] = -e[k];
-						if (MOVARM && slot < TT && !((SAFEMASK >> slot) & 1u))
-							e[k] = (int)((unsigned)e[k] << 15);
-					}
-				}
-				u32x4 w;
-				w.x = (unsigned)e[0];
-				w.y = (unsigned)e[1];
-				w.z = (unsigned)e[2];
-				w.w = (unsigned)e[3];
-				// rows land SWIZZLED within their block of 16 (see one_frame2): the global image is the plain one, shared by plans of
-				// every increment; the multiplier that suits THIS increment is the plan's (host: cr_poly_pick_swizzle)
-				dst[q * a.plane_rows + ((r & ~15u) | ((__umul24(r >> 4, a.swizzle) + r) & 15u))] = w;
-			}
-		}
-	}
-	__syncthreads();
 
 	const uint64_t n_chunks = (a.n_out + CHUNK - 1) >> chunk_shift;
 	const uint64_t global_wave = (uint64_t)blockIdx.x * n_waves + wave;
@@ -198,6 +164,51 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 		}
 		return (unsigned)__builtin_amdgcn_readfirstlane((int)(shift | (frames << 16)));
 	};
+
+	// the first wave-tile's window is fetched BEFORE the rows are staged: its round trip runs under theirs
+	unsigned first_info = 0;
+	if (global_wave < n_chunks)
+	{
+		const uint64_t first = global_wave << chunk_shift;
+		const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
+		first_info = fetch(first, n, my_buf);
+	}
+
+	// stage the polyphase rows once per workgroup (as magnitudes where the slot signs are fixed): the only barrier of the kernel
+	{
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.d_rows);
+		u32x4 *dst = reinterpret_cast<u32x4 *>(smem);
+		for (unsigned q = 0; q < planes_total; ++q)
+		{
+			for (unsigned r = tid; r < a.plane_rows; r += NTHREADS)
+			{
+				const u32x4 v = src[q * a.plane_rows + r];
+				int e[4] = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+				if constexpr (!SIGNED)
+				{
+#pragma unroll
+					for (int k = 0; k < 4; ++k)
+					{
+						const int slot = 4 * (int)q + k;
+						if (slot < TT && ((NEGMASK >> slot) & 1u))
+							e[k] = -e[k];
+						if (MOVARM && slot < TT && !((SAFEMASK >> slot) & 1u))
+							e[k] = (int)((unsigned)e[k] << 15);
+					}
+				}
+				u32x4 w;
+				w.x = (unsigned)e[0];
+				w.y = (unsigned)e[1];
+				w.z = (unsigned)e[2];
+				w.w = (unsigned)e[3];
+				// rows land SWIZZLED within their block of 16 (see one_frame2): the global image is the plain one, shared by plans of
+				// every increment; the multiplier that suits THIS increment is the plan's (host: cr_poly_pick_swizzle)
+				dst[q * a.plane_rows + ((r & ~15u) | ((__umul24(r >> 4, a.swizzle) + r) & 15u))] = w;
+			}
+		}
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the rows' loads are hipcc's; this is for the window in flight)
+	__syncthreads();
 
 	// packed window -> X = sample << 16, one dword per sample, in window order (the frames beyond the caller's buffer were delivered
 	// as zeros).  The window is converted dword by dword from the aligned dword its first sample sits in: for an odd channel
@@ -614,13 +625,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	}
 
 	uint64_t chunk = global_wave;
-	unsigned cur = 0, packed_info = 0;
-	{
-		const uint64_t first = chunk << chunk_shift;
-		const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
-		packed_info = fetch(first, n, my_buf);
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	}
+	unsigned cur = 0, packed_info = first_info;   // (fetched before the rows were staged, landed before the barrier)
 
 	// One chunk: its wave-tiles, the window of the following chunk's first tile fetched under the last one.  `next_of` names that
 	// chunk (or ~0) when asked, in the chunk's last tile.  Returns the chunk to go on with, ~0 when the wave is done.

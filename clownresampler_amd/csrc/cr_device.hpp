@@ -398,9 +398,21 @@ struct OddWindow
 typedef i32x4 i32x4_dword_aligned __attribute__((aligned(4)));
 typedef i32x2 i32x2_dword_aligned __attribute__((aligned(4)));
 
-template <int NINT, int NT>
+// Non-temporal stores are for lanes whose bytes leave GAPLESS: one instruction whose lanes tile a contiguous stretch (4, 8, 12 or
+// 16 bytes per lane), or whole aligned 16-byte granules (32 bytes per lane as two).  A 24-byte frame leaves as 16 + 8 bytes at a
+// stride of 24: each instruction writes part of every 16-byte granule, and marked non-temporal such partial lines may be written
+// out before the other instruction has completed them - measured as a slow MODE some boxes / runs fall into and others do not
+// (10 minutes of 6 channels at 44.1 -> 48 kHz: 186 us with plain stores on every box, 186 or 245 us with non-temporal ones;
+// 12 channels 375 against 375 / 456 us; profiles/r02_nt_partial_lines.log), while 4 and 8 channels gain 2 % from the hint.
+constexpr bool nt_suits_ints(int n, bool dword_aligned_only)
+{
+	return dword_aligned_only ? (n == 1 || n == 3) : (n <= 4 || n % 4 == 0);
+}
+
+template <int NINT, int NT_ASKED>
 __device__ __forceinline__ void store_ints_dword_aligned(int *dst, const int *v)
 {
+	constexpr int NT = NT_ASKED && nt_suits_ints(NINT, true);
 	int c = 0;
 #pragma unroll
 	for (; c + 4 <= NINT; c += 4)
@@ -443,9 +455,10 @@ constexpr int stores_of_ints_dword_aligned(int n)
 // NINT consecutive int32 -> global memory, widest stores the size allows.  NT = 1 marks them non-temporal: the output
 // is written once and never read by the kernel; on MI355X that is worth ~7 % of HBM throughput for the stereo stream
 // (8-byte stores) and costs a few % with 16-byte stores, so it is part of the per-instance tuning.
-template <int NINT, int NT>
+template <int NINT, int NT_ASKED>
 __device__ __forceinline__ void store_ints(int *dst, const int *v)
 {
+	constexpr int NT = NT_ASKED && nt_suits_ints(NINT, false);
 	if constexpr (NINT % 4 == 0)
 	{
 #pragma unroll
@@ -479,7 +492,7 @@ __device__ __forceinline__ void store_ints(int *dst, const int *v)
 	else
 	{
 		// an odd count: the frames are only dword-aligned; 16- and 8-byte stores need no more than that on gfx950
-		store_ints_dword_aligned<NINT, NT>(dst, v);
+		store_ints_dword_aligned<NINT, NT_ASKED>(dst, v);
 	}
 }
 

@@ -258,14 +258,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 			}
 			else
 			{
-				store_ints_dword_aligned<CH - 1, NT>(out_tile + at, v);
+				// (plain stores whatever NT says: the two shares of a frame leave in pieces that do not tile 16-byte granules -
+				// see nt_suits_ints, cr_device.hpp)
+				store_ints_dword_aligned<CH - 1, 0>(out_tile + at, v);
 				if (!(L & 1u))
-				{
-					if constexpr (NT)
-						__builtin_nontemporal_store(v[CH - 1], out_tile + at + CH - 1);
-					else
-						out_tile[at + CH - 1] = v[CH - 1];
-				}
+					out_tile[at + CH - 1] = v[CH - 1];
 			}
 		};
 		const unsigned char *base = tile + shift + (tid % SPLIT) * FBL;

@@ -70,6 +70,9 @@ WORKLOADS = {
     "dn31": (3, 2, (96000, 32000, 32000), 57600000),   # stereo 3:1, 18-slot windows
     "dn96": (3, 2, (96000, 44100, 44100), 57600000),   # stereo 96 -> 44.1 kHz, 13-slot windows
     "dn4432": (3, 2, (44100, 32000, 32000), 26460000), # stereo 44.1 -> 32 kHz, 8-slot windows
+    "up2x": (3, 2, (48000, 96000, 48000), 14400000),   # stereo 3 lobes 2x / 4x / 3x upsampling, 5 minutes in
+    "up4x": (3, 2, (48000, 192000, 48000), 7200000),
+    "up3x": (3, 2, (16000, 48000, 16000), 9600000),
     "up4": (3, 4, (44100, 48000, 44100), 26460000),    # 10 minutes of 4 / 6 / 8 channels, 3 lobes, both directions (tuning only)
     "up6": (3, 6, (44100, 48000, 44100), 26460000),
     "up8": (3, 8, (44100, 48000, 44100), 26460000),

@@ -243,6 +243,31 @@ def test_baseline_configs_full_size_bit_exact(products, name, radius, ch, rates,
     assert np.array_equal(a, want[: a.size]) and np.array_equal(b, want[a.size:])
 
 
+@pytest.mark.parametrize("name,radius,ch,rates,frames,kernel", [
+    ("hq48", 8, 2, (44100, 48000, 44100), 26460000, 4),     # 8 lobes 44.1 -> 48 kHz: k_wave2, mov-armed taps
+    ("hq44", 8, 2, (48000, 44100, 44100), 28800000, 4),     # 8 lobes 48 -> 44.1 kHz: k_wave2, any-sign taps
+    ("dn8", 3, 2, (44100, 8000, 8000), 26460000, 4),        # 33-slot windows
+    ("dn21", 3, 2, (96000, 48000, 48000), 57600000, 4),     # exact 2:1 (12 waves, 2 KiB windows)
+    ("hq48c7", 8, 7, (44100, 48000, 44100), 7560000, 4),    # 7 channels: 11 waves, odd channel count
+    ("rt4", 8, 4, (48000, 19200, 19200), 24000000, 4),      # no specialised instance: the run-time-slot k_wave2 (40 slots)
+    ("up12", 3, 12, (44100, 48000, 44100), 6615000, 1),     # two lanes per frame, ticketed tiles by the wide-frame rule
+])
+def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch, rates, frames, kernel):
+    """10-minute streams (5 for the widest) through the kernels the BASELINE configurations do not reach, against the
+    multi-threaded oracle: a whole launch's worth of chunks, static rounds AND ticketed tail."""
+    p, o = products[radius], ck.oracle(radius)
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    info = p.api.PlanGetInfo(p.api.PlanCreate(st.raw, p.pre))
+    assert info.kernel == kernel, (name, info.kernel)
+    R = int(ost.cfg.radius_frames)
+    padded = ck.pad_frames(ck.noise_pcm(frames * ch, 99), ch, R)
+    want = o.low_resample_i32_mt(ost, padded, frames, threads=min(32, os.cpu_count() or 1))
+    got, left, ran_out = p.low_resample_i32(st, padded, frames)
+    assert got.size == want.size == ck.count_output_frames(ost, frames) * ch and ran_out == 1 and left == 0
+    assert np.array_equal(got, want)
+
+
 def test_c_harness_reproduces_reference_harness_outputs(golden, tmp_path):
     """tools/cr_resample.c - a plain C client of include/clownresampler.h, shaped like tests/test-low-level.c and
     tests/test-high-level.c - on the reference's own fixture and ctest triples: byte-identical files (sha256 of the real

@@ -709,7 +709,8 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 		if (ok)
 		{
 			cr_poly_slot_signs(&plan->poly, &pos_bits, &neg_bits);
-			ok = (neg_bits & ~negmask) == 0 && (pos_bits & negmask) == 0;
+			ok = (neg_bits & ~negmask) == 0 && (pos_bits & negmask) == 0
+			  && (cr_poly_slots_reaching(&plan->poly, 65536) & ~crhip_poly_mad_safemask(plan->poly.slots)) == 0;
 		}
 
 		if (!ok)

@@ -621,50 +621,71 @@ __device__ __forceinline__ void fetch_frame(const crhip_poly_launch &a, const in
 	}
 }
 
-// The tap arithmetic as a chain of full-rate 64-bit multiply-adds (ASM mode 2; pure upsampling only, where the sign of a
-// slot's weights is a compile-time property - NEGMASK in ASM >> 8, checked by the host against the plan's rows):
-//     P = (accumulator : bias)          high dword: the running sum; low dword: 0xFFFF0000 where sample * weight < 0, else 0
-//     P = v_mad_i64_i32(sample << 16, weight, P)
-// The product lands as (sample * weight) << 16, so with the bias beside it the carry into the high dword is exactly the
-// reference's (sample * weight) / 65536 with C truncation (clownresampler.h:1020 via :625) added to the running sum; what
-// is left in the low dword is overwritten by the next tap's bias.  Per packed pair of channels and tap: one v_pk_ashrrev_i16
-// (the sign masks of both samples; a zero sample may carry the bias too: (0 + 0xFFFF) >> 16 == 0), two shifts/masks for the
-// samples, two for the biases, two multiply-adds: ~22 cycles per wave against ~30 for the SDWA form.
+// The tap arithmetic as a chain of 64-bit multiply-adds (ASM mode 2; pure upsampling only, where the sign of a slot's weights is
+// a compile-time property - NEGMASK in ASM >> 8, checked by the host against the plan's rows), in k_wave2's mov-armed form:
+//     X = 2 * sample                    one SDWA shift straight from the packed frame (left: low word, right: high word)
+//     P = (accumulator : X)             high dword: the running sum; low dword: X itself - in [2^32 - 65536, 2^32) where the sample
+//                                       is negative, in [0, 65536) where it is not, which is all the carry needs (a v_mov_b32, the
+//                                       one arming instruction that is nearly free beside the multiply-add: chainbench forms 12-19)
+//     P = v_mad_i64_i32(X, W, P)        W = |weight| << 15 as the kernel staged it: X * W = sample * |weight| * 65536, the integer part
+//                                       of sample * |weight| / 65536 lands in the high dword, truncated toward zero
+// (clownresampler.h:1020 via :625).  Slots with negative weights run on a second chain whose sum is subtracted at the end
+// (truncation toward zero is odd-symmetric) - which also keeps consecutive multiply-adds independent.  |weight| << 15 needs
+// |weight| < 65536: the slots in mad_safemask<TT>() - the two around the kernel's centre, whose weights reach 65536 in one row each -
+// are staged as plain |weight| and take X << 15 = sample << 16 with the sign-shift arm.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
-// p = (sample << 16) * weight + p, 64 bits, one instruction.  Inline asm: left to itself hipcc re-associates the bias out of the
-// addend and adds it with a separate 64-bit add.
-__device__ __forceinline__ void mad64(i32x2 &p, int sample_shifted, int weight)
+template <int TT>
+constexpr unsigned mad_safemask()
 {
-	long long carry;
-	asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(p), "=&s"(carry) : "v"(sample_shifted), "v"(weight));
+	return TT == 5 ? 0xCu : (TT == 15 ? 0x180u : 0u);
 }
 
-template <bool NEGATIVE_SLOT, bool FIRST>
+// what a kernel does to weight `e` of slot `slot` while it stages the rows for this arithmetic
+template <int TT, unsigned NEGMASK>
+__device__ __forceinline__ int mad_staged_weight(int e, int slot)
+{
+	if (slot < TT && ((NEGMASK >> slot) & 1u))
+		e = -e;
+	if (slot < TT && !((mad_safemask<TT>() >> slot) & 1u))
+		e = (int)((unsigned)e << 15);
+	return e;
+}
+
+// p = x * weight + p, 64 bits, one instruction.  Inline asm: left to itself hipcc re-associates the low dword out of the addend and
+// adds it with a separate 64-bit add.
+__device__ __forceinline__ void mad64(i32x2 &p, int x, int weight)
+{
+	long long carry;
+	asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(p), "=&s"(carry) : "v"(x), "v"(weight));
+}
+
+template <bool SAFE, bool FIRST>
 __device__ __forceinline__ void mad64_tap_pair(i32x2 &p_lo, i32x2 &p_hi, int frame, int weight)
 {
-	const int seen = NEGATIVE_SLOT ? ~frame : frame;   // negative slot: the product is negative where the sample is positive
-	const s16x2 masks = __builtin_bit_cast(s16x2, seen) >> (short)15;
-	const unsigned pm = __builtin_bit_cast(unsigned, masks);
-	// the bias goes straight into the low dword of the accumulator pair (x); the high dword (y) is the running sum
-	p_lo.x = (int)(pm << 16);
-	p_hi.x = (int)(pm & 0xFFFF0000u);
 	if (FIRST)
 	{
 		p_lo.y = 0;
 		p_hi.y = 0;
 	}
-	mad64(p_lo, (int)((unsigned)frame << 16), weight);
-	mad64(p_hi, (int)((unsigned)frame & 0xFFFF0000u), weight);
-}
-
-template <unsigned NEGMASK, bool FIRST>
-__device__ __forceinline__ void mad64_tap_pair_dispatch(int slot, i32x2 &p_lo, i32x2 &p_hi, int frame, int weight)
-{
-	if ((NEGMASK >> slot) & 1u)
-		mad64_tap_pair<true, FIRST>(p_lo, p_hi, frame, weight);
+	if constexpr (SAFE)
+	{
+		const int xl = (int)((unsigned)frame << 16), xr = (int)((unsigned)frame & 0xFFFF0000u);
+		p_lo.x = xl >> 31;
+		p_hi.x = xr >> 31;
+		mad64(p_lo, xl, weight);
+		mad64(p_hi, xr, weight);
+	}
 	else
-		mad64_tap_pair<false, FIRST>(p_lo, p_hi, frame, weight);
+	{
+		int xl, xr;   // 2 * sample, sign-extended
+		asm("v_lshlrev_b32_sdwa %0, %2, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(xl) : "v"(frame), "v"(1));
+		asm("v_lshlrev_b32_sdwa %0, %2, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(xr) : "v"(frame), "v"(1));
+		p_lo.x = xl;
+		p_hi.x = xr;
+		mad64(p_lo, xl, weight);
+		mad64(p_hi, xr, weight);
+	}
 }
 
 template <int CH, int TT, int NORM, int ASM>
@@ -674,27 +695,36 @@ __device__ __forceinline__ void compute_frame(const FrameData<CH, TT> &d, int *o
 	{
 		static_assert(CH % 2 == 0, "the 64-bit chain works on packed pairs of channels");
 		constexpr unsigned NEGMASK = (unsigned)ASM >> 8;
-		i32x2 p[CH], p2[CH];   // two chains, taps alternating: consecutive multiply-adds are independent
+		constexpr unsigned SAFEMASK = mad_safemask<TT>();
+		static_assert(SAFEMASK != 0 && (SAFEMASK & NEGMASK) == 0 && NEGMASK != 0 && (~NEGMASK & ((1u << TT) - 1u)) != 0, "slot classes of the instance");
+		constexpr int FIRST_POS = __builtin_ctz(~NEGMASK), FIRST_NEG = __builtin_ctz(NEGMASK);
+		static_assert(!((SAFEMASK >> FIRST_POS) & 1u), "a chain's first tap is an ordinary slot");
+		i32x2 p[CH], p2[CH];   // the chain of the positive slots and the chain of the negative ones
 #pragma unroll
 		for (int s = 0; s < TT; ++s)
 		{
 #pragma unroll
 			for (int k = 0; k < CH / 2; ++k)
 			{
-				if (s == 0)
-					mad64_tap_pair_dispatch<NEGMASK, true>(s, p[2 * k], p[2 * k + 1], d.f[s].v[k], d.w[s]);
-				else if (s == 1)
-					mad64_tap_pair_dispatch<NEGMASK, true>(s, p2[2 * k], p2[2 * k + 1], d.f[s].v[k], d.w[s]);
-				else if (s & 1)
-					mad64_tap_pair_dispatch<NEGMASK, false>(s, p2[2 * k], p2[2 * k + 1], d.f[s].v[k], d.w[s]);
+				if ((NEGMASK >> s) & 1u)
+				{
+					if (s == FIRST_NEG)
+						mad64_tap_pair<false, true>(p2[2 * k], p2[2 * k + 1], d.f[s].v[k], d.w[s]);
+					else
+						mad64_tap_pair<false, false>(p2[2 * k], p2[2 * k + 1], d.f[s].v[k], d.w[s]);
+				}
+				else if (s == FIRST_POS)
+					mad64_tap_pair<false, true>(p[2 * k], p[2 * k + 1], d.f[s].v[k], d.w[s]);
+				else if ((SAFEMASK >> s) & 1u)
+					mad64_tap_pair<true, false>(p[2 * k], p[2 * k + 1], d.f[s].v[k], d.w[s]);
 				else
-					mad64_tap_pair_dispatch<NEGMASK, false>(s, p[2 * k], p[2 * k + 1], d.f[s].v[k], d.w[s]);
+					mad64_tap_pair<false, false>(p[2 * k], p[2 * k + 1], d.f[s].v[k], d.w[s]);
 			}
 		}
 #pragma unroll
 		for (int c = 0; c < CH; ++c)
 		{
-			const int acc = p[c].y + (TT > 1 ? p2[c].y : 0);
+			const int acc = p[c].y - p2[c].y;
 			out[c] = normalise<NORM>(acc, d.w[TT]);
 		}
 		return;
@@ -755,6 +785,14 @@ template <int CH, int TT, int MODE, int NORM, int ASM, int SWZ, int SPLIT = 1, i
 __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int *rows, const unsigned char *base, unsigned rel, int *out)
 {
 	static_assert(PH == 0 || (TT == 0 && SPLIT == 2), "the phantom channel exists for run-time-slot instances with two lanes per frame");
+	if constexpr ((ASM & 0xFF) == 2)
+	{
+		// (the rows are staged for the 64-bit chain: every path of such an instance goes through it)
+		FrameData<CH, TT> d;
+		fetch_frame<CH, TT, MODE, SWZ, SPLIT>(a, rows, base, rel, d);
+		compute_frame<CH, TT, NORM, ASM>(d, out);
+		return;
+	}
 	constexpr unsigned FB = (CH * SPLIT - PH) * 2;
 	constexpr int RS_CT = (TT + 1 + 3) & ~3;
 

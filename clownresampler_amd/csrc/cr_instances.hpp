@@ -130,8 +130,6 @@ special make_special()
 	{
 		s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 1>;
 		s.mad[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 0>;
-		if constexpr (WAVE)
-			s.mad[1] = (poly_fn)k_wave<CH, TT, MODE, NORM, WAVE_WAVES, WAVE_NVW, WAVE_ITER, 0, 1, 0, (int)(2u | (UPMASK << 8))>;   // where the instance has a k_wave form, 29 is k_wave with the chain
 	}
 	if constexpr (UPMASK != 0)
 	{

@@ -404,6 +404,12 @@ int crhip_poly_up_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, 
 	return 1;
 }
 
+uint32_t crhip_poly_mad_safemask(uint32_t slots)
+{
+	// the slots the 64-bit chain of k_poly (variants 28 / 29) takes at any magnitude up to 65536 (mad_safemask, cr_device.hpp)
+	return slots == 5u ? mad_safemask<5>() : (slots == 15u ? mad_safemask<15>() : 0u);
+}
+
 int crhip_poly_default_is_mad(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
 {
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
@@ -468,14 +474,6 @@ void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, u
 		*threads = sp->wave2_waves * 64u;
 		*vecs = 150u + sp->wave2_nvw;
 		*frames_multiple = 64u * sp->wave2_iter * 4u;
-		return;
-	}
-
-	if (sp != nullptr && v == MAD_VARIANT + 1u && sp->wave[0] != nullptr)
-	{
-		*threads = WAVE_WAVES * 64u;
-		*vecs = 100u + WAVE_NVW;
-		*frames_multiple = 64u * WAVE_ITER * 4u;
 		return;
 	}
 
@@ -545,7 +543,7 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 
 	if (sp != nullptr && v >= MAD_VARIANT)
 	{
-		*geo = (v == MAD_VARIANT + 1u && sp->wave[0] != nullptr) ? 100u : 3u;
+		*geo = 3u;
 		return sp->mad[v - MAD_VARIANT];
 	}
 

@@ -186,6 +186,21 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 				for (unsigned r = tid; r < a.plane_rows; r += NTHREADS)
 					dst[q * a.plane_rows + ((r & ~15u) | ((__umul24(r >> 4, a.swizzle) + r) & 15u))] = src[q * a.plane_rows + r];
 		}
+		else if constexpr ((ASM & 0xFF) == 2)
+		{
+			// the 64-bit chain takes its weights as magnitudes, << 15 outside the two centre slots (mad_staged_weight, cr_device.hpp)
+			const unsigned planes = a.row_stride / 4u;
+			for (unsigned q = 0; q < planes; ++q)
+				for (unsigned r = tid; r < a.plane_rows; r += NTHREADS)
+				{
+					u32x4 v = src[q * a.plane_rows + r];
+					v.x = (unsigned)mad_staged_weight<TT, ((unsigned)ASM >> 8)>((int)v.x, (int)(4 * q));
+					v.y = (unsigned)mad_staged_weight<TT, ((unsigned)ASM >> 8)>((int)v.y, (int)(4 * q + 1));
+					v.z = (unsigned)mad_staged_weight<TT, ((unsigned)ASM >> 8)>((int)v.z, (int)(4 * q + 2));
+					v.w = (unsigned)mad_staged_weight<TT, ((unsigned)ASM >> 8)>((int)v.w, (int)(4 * q + 3));
+					dst[q * a.plane_rows + r] = v;
+				}
+		}
 		else
 		{
 			for (unsigned i = tid; i < nvec; i += NTHREADS)

@@ -152,6 +152,8 @@ int crhip_poly_default_is_mad(uint32_t channels, uint32_t slots, uint32_t row_mo
 uint32_t crhip_poly_up_fallback_variant(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
 /* k_wave2 (expanded window, 64-bit multiply-add taps; variant 30): -1 when the instance has none, 1 when it is built for the slot
    signs in *negmask (the host checks the plan's rows against them, as for k_up), 0 when it takes any rows */
+/* k_poly's 64-bit chain (variants 28 / 29) stages every weight outside these slots as |weight| << 15: they must stay below 65536 */
+uint32_t crhip_poly_mad_safemask(uint32_t slots);
 int crhip_poly_wave2_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t *negmask);
 /* the slots whose weights that k_wave2 instance takes at ANY magnitude up to 65536; every other slot's weights must stay below
    65536 in every row (they are staged as |weight| << 15).  0: no such restriction */

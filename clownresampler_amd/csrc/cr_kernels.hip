@@ -354,7 +354,7 @@ static uint32_t resolve_variant(const special *sp, uint32_t variant, uint32_t ou
 		variant = sp->default_variant;
 	if (variant >= MAD_VARIANT)
 	{
-		if (sp->mad[0] != nullptr && !out_s16)
+		if (sp->mad[0] != nullptr && (!out_s16 || sp->mad16 != nullptr))
 			return variant;
 		variant = 13u;
 	}
@@ -544,7 +544,7 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 	if (sp != nullptr && v >= MAD_VARIANT)
 	{
 		*geo = 3u;
-		return sp->mad[v - MAD_VARIANT];
+		return launch->out_s16 ? sp->mad16 : sp->mad[v - MAD_VARIANT];
 	}
 
 	if (sp != nullptr && v >= UP_VARIANT)

@@ -74,6 +74,7 @@ struct special
 	uint32_t wave2_fixed_signs; // 1: built for the slot signs in up_negmask (the host checks the plan's rows), 0: any rows
 	uint32_t wave2_safemask;    // fixed signs: != 0 = the mov-armed form; these slots take weights up to 65536, the others only below it
 	poly_fn mad16;              // the 64-bit chain with int16 output (non-temporal stores); nullptr: int16 output takes the SDWA form
+	uint32_t lite_variant;      // lite instances with a chain: the variant id (geometry) of their SDWA form, which explicit k_poly variants resolve to
 };
 
 constexpr uint32_t MAD_VARIANT = 28;    // variant ids 28, 29
@@ -126,7 +127,7 @@ constexpr int WAVE_WAVES = 16, WAVE_NVW = 1, WAVE_ITER = 4;
 template <int CH, int TT, int MODE, int NORM, int DV, bool WAVE = false, bool DYNAMIC = false, unsigned UPMASK = 0>
 special make_special()
 {
-	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, false, 1u, UPMASK, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u, nullptr};
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, false, 1u, UPMASK, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u, nullptr, 13u};
 	if constexpr (UPMASK != 0 && CH % 2 == 0)
 	{
 		s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 1>;
@@ -174,11 +175,28 @@ special make_special()
 template <int CH, int TT, int MODE, int NORM, int DV = (CH <= 4 ? 13 : 14)>   // default: (1024 threads, 1 or 2 vectors per thread), one frame in flight, non-temporal stores
 special make_special_lite()
 {
-	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 1u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u, nullptr};
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 1u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u, nullptr, 13u};
 	const poly_fn fn = instance<CH, TT, MODE, NORM, DV % 5, 1, (DV / 5) % 2, (DV / 10) % 2>();
 	for (int v = 0; v < VARIANTS; ++v)
 		s.fn[v] = fn;
 	s.fn16 = instance<CH, TT, MODE, NORM, DV % 5, 1, (DV / 5) % 2, (DV / 10) % 2, 1>();
+	return s;
+}
+
+// ... whose default is the 64-bit chain (pure upsampling, even channel counts: UPMASK = the slots with negative weights), at the same
+// geometry; the SDWA form stays behind every explicit k_poly variant id - the fallback for plans whose rows do not match the masks
+template <int CH, int TT, int NORM, unsigned UPMASK, int DV = (CH <= 4 ? 13 : 14)>
+special make_special_lite_chain()
+{
+	static_assert(CH % 2 == 0 && UPMASK != 0, "the chain works on packed pairs of channels, with fixed slot signs");
+	special s = make_special_lite<CH, TT, CRHIP_ROWMODE_UPSAMPLE, NORM, DV>();
+	constexpr int T = GEOMETRY[DV % 5].threads, V = GEOMETRY[DV % 5].vecs;
+	s.mad[0] = (poly_fn)k_poly<CH, TT, CRHIP_ROWMODE_UPSAMPLE, NORM, T, V, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 1>;
+	s.mad[1] = (poly_fn)k_poly<CH, TT, CRHIP_ROWMODE_UPSAMPLE, NORM, T, V, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 0>;
+	s.mad16 = (poly_fn)k_poly<CH, TT, CRHIP_ROWMODE_UPSAMPLE, NORM, T, V, (int)(2u | (UPMASK << 8)), 1, 0, 0, 1, 1>;
+	s.up_negmask = UPMASK;
+	s.lite_variant = DV;
+	s.default_variant = MAD_VARIANT;
 	return s;
 }
 
@@ -188,7 +206,7 @@ special make_special_lite_split()
 {
 	constexpr int DV = 14;   // (1024 threads, 2 vectors per thread), one frame in flight, non-temporal stores
 	constexpr int T = GEOMETRY[DV % 5].threads, V = GEOMETRY[DV % 5].vecs;
-	special s = {CHT, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 2u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u, nullptr};
+	special s = {CHT, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 2u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u, nullptr, 13u};
 	const poly_fn fn = (poly_fn)k_poly<CHT / 2, TT, MODE, NORM, T, V, 1, 1, 0, 0, 0, 1, 2>;
 	for (int v = 0; v < VARIANTS; ++v)
 		s.fn[v] = fn;

@@ -342,6 +342,13 @@ static uint32_t resolve_variant(const special *sp, uint32_t variant, uint32_t ou
 			return WAVE2_VARIANT;
 		variant = sp->default_variant != WAVE2_VARIANT ? sp->default_variant : sp->wave2_fallback;
 	}
+	if (sp->lite && sp->mad[0] != nullptr)
+	{
+		// a lite instance with a chain: the default and the chain's ids are the chain, every k_poly variant id its SDWA form
+		if (variant == CRHIP_VARIANT_DEFAULT || variant == MAD_VARIANT || variant == MAD_VARIANT + 1u)
+			return (!out_s16 || sp->mad16 != nullptr) ? (variant == MAD_VARIANT + 1u ? MAD_VARIANT + 1u : MAD_VARIANT) : sp->lite_variant;
+		return sp->lite_variant;
+	}
 	if (sp->lite)
 		return sp->default_variant != WAVE2_VARIANT ? sp->default_variant : sp->wave2_fallback;
 	if (variant >= 1008u && variant <= 1010u)
@@ -479,8 +486,9 @@ void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, u
 
 	if (sp != nullptr && v >= MAD_VARIANT)
 	{
-		*threads = (uint32_t)GEOMETRY[3].threads;
-		*vecs = (uint32_t)GEOMETRY[3].vecs;
+		const int g = sp->lite ? (int)(sp->lite_variant % 5u) : 3;   // (a lite instance's chain has the geometry of its SDWA form)
+		*threads = (uint32_t)GEOMETRY[g].threads;
+		*vecs = (uint32_t)GEOMETRY[g].vecs;
 		*frames_multiple = *threads;
 		return;
 	}
@@ -543,7 +551,7 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 
 	if (sp != nullptr && v >= MAD_VARIANT)
 	{
-		*geo = 3u;
+		*geo = sp->lite ? sp->lite_variant % 5u : 3u;
 		return launch->out_s16 ? sp->mad16 : sp->mad[v - MAD_VARIANT];
 	}
 

@@ -688,12 +688,65 @@ __device__ __forceinline__ void mad64_tap_pair(i32x2 &p_lo, i32x2 &p_hi, int fra
 	}
 }
 
+// ... and for mono, where a packed dword holds two FRAMES (two slots, each with its own weight and slot class): word WORD of `packed`
+template <bool SAFE, bool FIRST, int WORD>
+__device__ __forceinline__ void mad64_tap_mono(i32x2 &p, int packed, int weight)
+{
+	if (FIRST)
+		p.y = 0;
+	if constexpr (SAFE)
+	{
+		const int x = WORD ? (int)((unsigned)packed & 0xFFFF0000u) : (int)((unsigned)packed << 16);
+		p.x = x >> 31;
+		mad64(p, x, weight);
+	}
+	else
+	{
+		int x;   // 2 * sample, sign-extended
+		if constexpr (WORD)
+			asm("v_lshlrev_b32_sdwa %0, %2, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(x) : "v"(packed), "v"(1));
+		else
+			asm("v_lshlrev_b32_sdwa %0, %2, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(x) : "v"(packed), "v"(1));
+		p.x = x;
+		mad64(p, x, weight);
+	}
+}
+
 template <int CH, int TT, int NORM, int ASM>
 __device__ __forceinline__ void compute_frame(const FrameData<CH, TT> &d, int *out)
 {
-	if constexpr ((ASM & 0xFF) == 2)
+	if constexpr ((ASM & 0xFF) == 2 && CH == 1)
 	{
-		static_assert(CH % 2 == 0, "the 64-bit chain works on packed pairs of channels");
+		constexpr unsigned NEGMASK = (unsigned)ASM >> 8;
+		constexpr unsigned SAFEMASK = mad_safemask<TT>();
+		static_assert(SAFEMASK != 0 && (SAFEMASK & NEGMASK) == 0 && NEGMASK != 0, "slot classes of the instance");
+		constexpr int FIRST_POS = __builtin_ctz(~NEGMASK), FIRST_NEG = __builtin_ctz(NEGMASK);
+		static_assert(!((SAFEMASK >> FIRST_POS) & 1u), "a chain's first tap is an ordinary slot");
+		i32x2 p, p2;   // the chain of the positive slots and the chain of the negative ones
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+		{
+			const int packed = d.f[s / 2].v[0];   // fetch_frame left the window packed, two frames per dword
+			if ((NEGMASK >> s) & 1u)
+			{
+				if (s == FIRST_NEG)
+					(s & 1) ? mad64_tap_mono<false, true, 1>(p2, packed, d.w[s]) : mad64_tap_mono<false, true, 0>(p2, packed, d.w[s]);
+				else
+					(s & 1) ? mad64_tap_mono<false, false, 1>(p2, packed, d.w[s]) : mad64_tap_mono<false, false, 0>(p2, packed, d.w[s]);
+			}
+			else if (s == FIRST_POS)
+				(s & 1) ? mad64_tap_mono<false, true, 1>(p, packed, d.w[s]) : mad64_tap_mono<false, true, 0>(p, packed, d.w[s]);
+			else if ((SAFEMASK >> s) & 1u)
+				(s & 1) ? mad64_tap_mono<true, false, 1>(p, packed, d.w[s]) : mad64_tap_mono<true, false, 0>(p, packed, d.w[s]);
+			else
+				(s & 1) ? mad64_tap_mono<false, false, 1>(p, packed, d.w[s]) : mad64_tap_mono<false, false, 0>(p, packed, d.w[s]);
+		}
+		out[0] = normalise<NORM>(p.y - p2.y, d.w[TT]);
+		return;
+	}
+	else if constexpr ((ASM & 0xFF) == 2)
+	{
+		static_assert(CH % 2 == 0, "the 64-bit chain works on packed pairs of channels (or on mono: above)");
 		constexpr unsigned NEGMASK = (unsigned)ASM >> 8;
 		constexpr unsigned SAFEMASK = mad_safemask<TT>();
 		static_assert(SAFEMASK != 0 && (SAFEMASK & NEGMASK) == 0 && NEGMASK != 0 && (~NEGMASK & ((1u << TT) - 1u)) != 0, "slot classes of the instance");

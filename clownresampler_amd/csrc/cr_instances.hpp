@@ -75,6 +75,7 @@ struct special
 	uint32_t wave2_safemask;    // fixed signs: != 0 = the mov-armed form; these slots take weights up to 65536, the others only below it
 	poly_fn mad16;              // the 64-bit chain with int16 output (non-temporal stores); nullptr: int16 output takes the SDWA form
 	uint32_t lite_variant;      // lite instances with a chain: the variant id (geometry) of their SDWA form, which explicit k_poly variants resolve to
+	uint32_t mad_frames;        // frames in flight per lane of the chain kernels (k_poly's U): 1 or 2
 };
 
 constexpr uint32_t MAD_VARIANT = 28;    // variant ids 28, 29
@@ -97,6 +98,18 @@ void add_wave2(special &s)
 	s.wave2_fixed_signs = SIGNED ? 0u : 1u;
 	if (!SIGNED)
 		s.up_negmask = NEGMASK;
+}
+
+// The 64-bit chain (variants 28 / 29, + int16 form) added to a full instance that has no k_up form - mono - and made its default
+template <int CH, int TT, int MODE, int NORM, unsigned UPMASK, int U = 1>
+special with_chain(special s)
+{
+	s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), U, 0, 0, 0, 1>;
+	s.mad[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), U, 0, 0, 0, 0>;
+	s.mad16 = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), U, 0, 0, 1, 1>;
+	s.up_negmask = UPMASK;
+	s.mad_frames = U;
+	return s;
 }
 
 // DEFAULT: k_wave2 becomes the instance's default variant (where it measured faster than the k_poly / k_wave forms); the
@@ -127,7 +140,7 @@ constexpr int WAVE_WAVES = 16, WAVE_NVW = 1, WAVE_ITER = 4;
 template <int CH, int TT, int MODE, int NORM, int DV, bool WAVE = false, bool DYNAMIC = false, unsigned UPMASK = 0>
 special make_special()
 {
-	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, false, 1u, UPMASK, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u, nullptr, 13u};
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, DYNAMIC, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, false, 1u, UPMASK, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u, nullptr, 13u, 1u};
 	if constexpr (UPMASK != 0 && CH % 2 == 0)
 	{
 		s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 1>;
@@ -175,7 +188,7 @@ special make_special()
 template <int CH, int TT, int MODE, int NORM, int DV = (CH <= 4 ? 13 : 14)>   // default: (1024 threads, 1 or 2 vectors per thread), one frame in flight, non-temporal stores
 special make_special_lite()
 {
-	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 1u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u, nullptr, 13u};
+	special s = {CH, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 1u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u, nullptr, 13u, 1u};
 	const poly_fn fn = instance<CH, TT, MODE, NORM, DV % 5, 1, (DV / 5) % 2, (DV / 10) % 2>();
 	for (int v = 0; v < VARIANTS; ++v)
 		s.fn[v] = fn;
@@ -206,7 +219,7 @@ special make_special_lite_split()
 {
 	constexpr int DV = 14;   // (1024 threads, 2 vectors per thread), one frame in flight, non-temporal stores
 	constexpr int T = GEOMETRY[DV % 5].threads, V = GEOMETRY[DV % 5].vecs;
-	special s = {CHT, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 2u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u, nullptr, 13u};
+	special s = {CHT, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 2u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u, nullptr, 13u, 1u};
 	const poly_fn fn = (poly_fn)k_poly<CHT / 2, TT, MODE, NORM, T, V, 1, 1, 0, 0, 0, 1, 2>;
 	for (int v = 0; v < VARIANTS; ++v)
 		s.fn[v] = fn;

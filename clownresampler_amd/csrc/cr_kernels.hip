@@ -489,7 +489,7 @@ void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, u
 		const int g = sp->lite ? (int)(sp->lite_variant % 5u) : 3;   // (a lite instance's chain has the geometry of its SDWA form)
 		*threads = (uint32_t)GEOMETRY[g].threads;
 		*vecs = (uint32_t)GEOMETRY[g].vecs;
-		*frames_multiple = *threads;
+		*frames_multiple = *threads * sp->mad_frames;
 		return;
 	}
 

@@ -954,3 +954,41 @@ def test_mov_armed_taps_at_the_sample_range_limits(products):
         xa, la, ra = p.low_resample_i32(a, padded, frames)
         xb, lb, rb = o.low_resample_i32(b, padded, frames)
         assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple(), (ch, i, out, frames)
+
+
+def test_chain_taps_at_the_sample_range_limits(products):
+    """k_poly's 64-bit chain (the default of the mono, stereo, 4- and 6-channel 3-lobe upsampling instances): as above - X = 2 * sample
+    as its own low dword at -32768 / 32767 / -1 / 0 / 1, the 65536 weights of the two centre slots (1:1: every frame), int32 and
+    clamped int16 output, and an input split across two calls."""
+    import random
+    rng = random.Random(777)
+    p, o = products[3], ck.oracle(3)
+    for draw in range(40):
+        ch = [1, 2, 4, 6][draw % 4]
+        i = rng.choice([44100, 48000, 8000, rng.randrange(8000, 96000)])
+        out = i if draw % 9 == 0 else int(i * rng.uniform(1.0, 6.0))
+        frames = rng.randrange(300, 12000)
+        ok, a = p.low_init(ch, i, out, i)
+        ok2, b = o.low_init(ch, i, out, i)
+        assert ok == ok2 and a.astuple() == b.astuple()
+        info = p.api.PlanGetInfo(p.api.PlanCreate(a.raw, p.pre))
+        assert info.kernel == 1 and info.slots == 5 and info.specialised, (ch, i, out, info.kernel, info.slots)
+        pcm = ck.noise_pcm(frames * ch, 7000 + draw)
+        edge = np.array([-32768, 32767, -1, 0, 1, -32768, 32767, 32767], dtype=np.int16)
+        runs = rng.randrange(1, 30)
+        pattern = np.repeat(edge[np.array([rng.randrange(len(edge)) for _ in range(pcm.size // runs + 1)])], runs)[: pcm.size]
+        mask = (np.arange(pcm.size) // (runs * 16)) % 2 == 0
+        pcm = np.where(mask, pattern, pcm).astype(np.int16)
+        padded = ck.pad_frames(pcm, ch, int(b.cfg.radius_frames))
+        if draw % 5 == 1:
+            want, _, _ = o.low_resample_i32(b, padded, frames)
+            got, left, ran_out = p.api.LowLevel_ResampleBulkS16(a.raw, p.pre, padded, frames)
+            assert np.array_equal(got, np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16)), (ch, i, out, frames)
+            continue
+        cut = rng.randrange(1, frames)
+        xa, la, ra = p.low_resample_i32(a, padded, cut)
+        xb, lb, rb = o.low_resample_i32(b, padded, cut)
+        assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple(), (ch, i, out, frames, cut)
+        xa, la, ra = p.low_resample_i32(a, padded[cut * ch:], frames - cut)
+        xb, lb, rb = o.low_resample_i32(b, padded[cut * ch:], frames - cut)
+        assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple(), (ch, i, out, frames)

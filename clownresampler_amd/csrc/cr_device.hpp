@@ -398,15 +398,16 @@ struct OddWindow
 typedef i32x4 i32x4_dword_aligned __attribute__((aligned(4)));
 typedef i32x2 i32x2_dword_aligned __attribute__((aligned(4)));
 
-// Non-temporal stores are for lanes whose bytes leave GAPLESS: one instruction whose lanes tile a contiguous stretch (4, 8, 12 or
-// 16 bytes per lane), or whole aligned 16-byte granules (32 bytes per lane as two).  A 24-byte frame leaves as 16 + 8 bytes at a
+// Non-temporal stores are for lanes whose bytes leave GAPLESS in ONE instruction whose lanes tile a contiguous stretch (4, 8, 12 or
+// 16 bytes per lane).  (32 bytes per lane - two instructions, each writing every other 16-byte granule - gain 3-4 % from the hint
+// on some boxes and lose 3-50 % on others: cfg 4's geometry sweep, the 8-channel chain trial; plain there too.)  A 24-byte frame leaves as 16 + 8 bytes at a
 // stride of 24: each instruction writes part of every 16-byte granule, and marked non-temporal such partial lines may be written
 // out before the other instruction has completed them - measured as a slow MODE some boxes / runs fall into and others do not
 // (10 minutes of 6 channels at 44.1 -> 48 kHz: 186 us with plain stores on every box, 186 or 245 us with non-temporal ones;
 // 12 channels 375 against 375 / 456 us; profiles/r02_nt_partial_lines.log), while 4 and 8 channels gain 2 % from the hint.
 constexpr bool nt_suits_ints(int n, bool dword_aligned_only)
 {
-	return dword_aligned_only ? (n == 1 || n == 3) : (n <= 4 || n % 4 == 0);
+	return dword_aligned_only ? (n == 1 || n == 3) : n <= 4;
 }
 
 template <int NINT, int NT_ASKED>

@@ -189,17 +189,45 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 		else if constexpr ((ASM & 0xFF) == 2)
 		{
 			// the 64-bit chain takes its weights as magnitudes, << 15 outside the two centre slots (mad_staged_weight, cr_device.hpp)
-			const unsigned planes = a.row_stride / 4u;
-			for (unsigned q = 0; q < planes; ++q)
-				for (unsigned r = tid; r < a.plane_rows; r += NTHREADS)
-				{
-					u32x4 v = src[q * a.plane_rows + r];
-					v.x = (unsigned)mad_staged_weight<TT, ((unsigned)ASM >> 8)>((int)v.x, (int)(4 * q));
-					v.y = (unsigned)mad_staged_weight<TT, ((unsigned)ASM >> 8)>((int)v.y, (int)(4 * q + 1));
-					v.z = (unsigned)mad_staged_weight<TT, ((unsigned)ASM >> 8)>((int)v.z, (int)(4 * q + 2));
-					v.w = (unsigned)mad_staged_weight<TT, ((unsigned)ASM >> 8)>((int)v.w, (int)(4 * q + 3));
-					dst[q * a.plane_rows + r] = v;
-				}
+			// (every load first, then the stores: a row image of 1,025 rows is two rows per thread and plane, and one round trip
+			// instead of four is 0.4 us of every launch)
+			constexpr int PL = (TT + 1 + 3) / 4;
+			auto staged = [&](u32x4 v, int q) {
+				v.x = (unsigned)mad_staged_weight<TT, ((unsigned)ASM >> 8)>((int)v.x, 4 * q);
+				v.y = (unsigned)mad_staged_weight<TT, ((unsigned)ASM >> 8)>((int)v.y, 4 * q + 1);
+				v.z = (unsigned)mad_staged_weight<TT, ((unsigned)ASM >> 8)>((int)v.z, 4 * q + 2);
+				v.w = (unsigned)mad_staged_weight<TT, ((unsigned)ASM >> 8)>((int)v.w, 4 * q + 3);
+				return v;
+			};
+			if (a.plane_rows <= 2u * NTHREADS && a.row_stride == 4u * PL)
+			{
+				u32x4 v[PL][2];
+#pragma unroll
+				for (int q = 0; q < PL; ++q)
+#pragma unroll
+					for (int k = 0; k < 2; ++k)
+					{
+						const unsigned r = tid + (unsigned)k * NTHREADS;
+						if (r < a.plane_rows)
+							v[q][k] = src[(unsigned)q * a.plane_rows + r];
+					}
+#pragma unroll
+				for (int q = 0; q < PL; ++q)
+#pragma unroll
+					for (int k = 0; k < 2; ++k)
+					{
+						const unsigned r = tid + (unsigned)k * NTHREADS;
+						if (r < a.plane_rows)
+							dst[(unsigned)q * a.plane_rows + r] = staged(v[q][k], q);
+					}
+			}
+			else
+			{
+				const unsigned planes = a.row_stride / 4u;
+				for (unsigned q = 0; q < planes; ++q)
+					for (unsigned r = tid; r < a.plane_rows; r += NTHREADS)
+						dst[q * a.plane_rows + r] = staged(src[q * a.plane_rows + r], (int)q);
+			}
 		}
 		else
 		{

@@ -1324,6 +1324,13 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			   10-minute stream is a few hundred tiles per workgroup, and the workgroups drift apart (bench.py --workload up8 /
 			   up12, 10 minutes: 253 -> 239 us, 505 -> 460 us with tickets; the channel table's launches of ~40 tiles per
 			   workgroup: within +-2 % either way) */
+			/* ... and never for SHORT launches: a draw is a memory round trip in wave 0 (the other waves wait for it at the tile's
+			   barrier), one in the prologue, one per tile, and a count-down at the end.  With a dozen tiles per workgroup the
+			   second workgroup of a CU hides that and the balance is worth 1 %; with one or two it is most of what the launch
+			   spends outside its tiles (tools/size_sweep.py, stereo 44.1 -> 48 kHz: 30 s 9.5 -> 7.6 us, one minute 12.3 -> 9.0 us,
+			   two minutes 16.1 -> 14.5 us, five minutes 29.5 -> 29.3 us, ten minutes 61.3 against 62.0 us the other way) */
+			if (g_env.dynamic_tiles < 0 && plan->vecs < 100u && (n_out + l.tile_frames - 1) / l.tile_frames < 8ull * blocks)
+				l.dynamic_tiles = 0u;
 			if (g_env.dynamic_tiles < 0 && plan->channels >= 8u && plan->vecs < 100u
 			 && (n_out + l.tile_frames - 1) / l.tile_frames >= 48ull * (out_s16 ? plan->max_blocks_s16 : plan->max_blocks))
 				l.dynamic_tiles = 1u;

@@ -101,7 +101,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	// and hipcc waits for such a register at the head of any loop that uses it - vmcnt(0), every store of the previous chunk
 	// included - however far apart issue and use are put.  (Worth 1-4 %: profiles/r02_kwave2_trials.log.)
 	const uint64_t rounds = n_chunks / global_waves;
-	const uint64_t static_limit = rounds > 3u ? (rounds - 2u) * global_waves : 0u;   // chunks [0, static_limit) are dealt statically
+	// (a launch of three rounds or fewer is dealt statically altogether: a draw is a memory round trip per chunk, more than the
+	// balance of so few chunks is worth)
+	const uint64_t static_limit = rounds > 3u ? (rounds - 2u) * global_waves : n_chunks;   // chunks [0, static_limit) are dealt statically
 	const uint64_t region_chunks = n_chunks - static_limit;                         // the ticketed region, numbered from 0
 
 	const unsigned LANES = global_waves < 32u ? (unsigned)global_waves : 32u;

@@ -70,6 +70,8 @@ WORKLOADS = {
     "dn31": (3, 2, (96000, 32000, 32000), 57600000),   # stereo 3:1, 18-slot windows
     "dn96": (3, 2, (96000, 44100, 44100), 57600000),   # stereo 96 -> 44.1 kHz, 13-slot windows
     "dn4432": (3, 2, (44100, 32000, 32000), 26460000), # stereo 44.1 -> 32 kHz, 8-slot windows
+    "cfg3s": (8, 2, (8000, 96000, 8000), 80000),       # cfg 3's conversion, 10 s and 1 min of it (launch floor of k_up2)
+    "cfg3m": (8, 2, (8000, 96000, 8000), 480000),
     "up2x": (3, 2, (48000, 96000, 48000), 14400000),   # stereo 3 lobes 2x / 4x / 3x upsampling, 5 minutes in
     "up4x": (3, 2, (48000, 192000, 48000), 7200000),
     "up3x": (3, 2, (16000, 48000, 16000), 9600000),
@@ -362,8 +364,10 @@ def main():
     # the dominant (only) kernel: algorithmic bytes of THIS rank's launch / its launch duration
     launch_bytes = shard.input_frames * ch * 2 + shard.output_frames * ch * (2 if args.s16 else 4)
     achieved = launch_bytes / (mean_ms * 1e-3) / 1e9
+    # (a k_up plan sends launches of fewer than brief_below output frames to its other kernel)
+    ran = info.brief_kernel if (info.kernel == 3 and shard.output_frames < info.brief_below) else info.kernel
     kernel_name = {1: "k_poly<%d,%d>", 2: "k_wave<%d,%d>", 3: "k_up2<%d,%d>" if (info.variant == 27 and ch == 2) else "k_up<%d,%d>",
-                   4: "k_wave2<%d,%d>"}[info.kernel] % (ch, info.slots) if info.kernel else "k_generic"
+                   4: "k_wave2<%d,%d>"}[ran] % (ch, info.slots) if ran else "k_generic"
     traffic, traffic_note = None, "no PMC summary for this workload under profiles/"
     pmc, pmc_file = pmc_summary(workload) if (world == 1 and not args.s16) else (None, None)
     if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:

@@ -89,7 +89,8 @@ class Segment(C.Structure):  # ClownResamplerAMD_Segment
 
 class PlanInfo(C.Structure):  # ClownResamplerAMD_PlanInfo
     _fields_ = [(n, C.c_uint32) for n in ("kernel", "channels", "slots", "first_slot", "rows", "row_stride", "row_mode", "threads",
-                                          "tile_frames", "lds_bytes", "max_blocks", "specialised", "variant", "norm_mode")]
+                                          "tile_frames", "lds_bytes", "max_blocks", "specialised", "variant", "norm_mode",
+                                          "brief_kernel", "brief_variant")] + [("brief_below", C.c_uint64)]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

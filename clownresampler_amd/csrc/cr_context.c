@@ -166,6 +166,16 @@ static int g_variant = -1; /* -1: CLOWNRESAMPLER_AMD_VARIANT from the environmen
 #define CR_RT_WAVE2_MIN_SLOTS_FEW_ROWS 18
 #define CR_RT_WAVE2_FEW_ROWS_BYTES 8192u
 #define CR_RT_WAVE2_MAX_INCREMENT ((13u << 16) / 4u)
+/* k_up against its fallback kernel by launch length, in HALF wave-tiles per wave of k_up's grid (tools/brief_sweep.py,
+   profiles/r02_brief_launches.log).  8 lobes, 8 -> 96 kHz: 10 s of it (half a tile per wave) 24.5 against k_wave2's 10.3 us, 3 tiles
+   26.5 / 25.2, 4 tiles 28.1 / 31.4, and the same crossing at 8x and 10x; 3 lobes (k_wave the other kernel) 8x: 2 tiles 16.5 / 15.1,
+   3 tiles 17.3 / 22.0, 16x: 1 tile 31.4 / 21.2, 2 tiles 31.9 / 35.5 */
+#define CR_BRIEF_HALF_TILES_LONG_WINDOWS 7
+#define CR_BRIEF_HALF_TILES 3
+/* k_up2 as an instance's default kernel: see plan_geometry */
+#define CR_UP_DEFAULT_MAX_INCREMENT (65536u / 8u)
+#define CR_UP_DEFAULT_MIN_INCREMENT (65536u / 13u)
+#define CR_UP_CONFLICT_CYCLES 20.0
 
 /* Environment switches are read ONCE (tuning hooks; none of them changes results). */
 static struct
@@ -174,6 +184,7 @@ static struct
 	int dynamic_tiles;          /* CLOWNRESAMPLER_AMD_DYNAMIC_TILES: -1 unset, else 0 / 1 */
 	int no_special, debug, no_occupancy_clamp, tile_groups, no_host_pipeline, no_small_call_path;
 	int rt_wave2_min_slots;     /* CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS: windows from this many slots on take the run-time-slot k_wave2 */
+	int brief_half_tiles;       /* CLOWNRESAMPLER_AMD_BRIEF_HALF_TILES: k_up launches of fewer half wave-tiles per wave take the plan's other kernel (0: none do; unset: per instance) */
 } g_env;
 static pthread_once_t g_env_once = PTHREAD_ONCE_INIT;
 
@@ -192,6 +203,8 @@ static void load_env(void)
 	g_env.no_small_call_path = getenv("CLOWNRESAMPLER_AMD_NO_SMALL_CALL_PATH") != NULL;
 	e = getenv("CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS");
 	g_env.rt_wave2_min_slots = (e != NULL && atoi(e) > 0) ? atoi(e) : CR_RT_WAVE2_MIN_SLOTS;
+	e = getenv("CLOWNRESAMPLER_AMD_BRIEF_HALF_TILES");
+	g_env.brief_half_tiles = (e != NULL && *e != '\0' && atoi(e) >= 0) ? atoi(e) : -1;
 	g_env.loaded = 1;
 }
 
@@ -699,6 +712,30 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	/* (variant 31 - the run-time-slot k_wave2, a testing hook as an explicit choice - means nothing to a specialised instance) */
 	if (plan->variant == CRHIP_VARIANT_RT_WAVE2 && (plan->specialised || !crhip_poly_runtime_wave2(plan->channels, plan->poly.row_mode)))
 		plan->variant = 0xFFFFu;
+	if (plan->specialised && plan->variant == 0xFFFFu && crhip_poly_has_up(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode))
+	{
+		/* Instances with the input-stationary kernel (k_up2: stereo, pure upsampling) - which ratios it is the default for
+		   (tools/up_ratio_sweep.py, 40 M output frames, profiles/r02_up_ratios.log): */
+		if (crhip_poly_default_is_up(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode))
+		{
+			/* 8 lobes: 8x..13x.  Below, a lane's handful of frames per input position does not pay for the window it unpacks
+			   (2x: 196 against k_wave2's 124 us, 4x: 137 / 131, 6x: 119 / 118, 7.5x: 123 / 118, 8x: 116 / 126, 10x: 112 / 118,
+			   12x: 109 / 121, 13x: 116 / 117); above, the wave-tile outgrows its LDS staging (15x: 125 / 117, 16x: 144 / 128) */
+			if (plan->increment > CR_UP_DEFAULT_MAX_INCREMENT || plan->increment < CR_UP_DEFAULT_MIN_INCREMENT)
+				plan->variant = crhip_poly_up_fallback_variant(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
+		}
+		else if (plan->increment >= 4096u && plan->increment <= 32768u)
+		{
+			/* 3 lobes: k_poly, except at ratios where the rows its lanes read - one per output frame - share an LDS bank slot:
+			   exactly 8x (8 rows 128 apart per 16 lanes: 90 against k_up2's 80 us), 16x (16 rows: 155 / 92).  k_up2's lanes
+			   walk the rows of ONE input position each and do not care.  The model is k_wave2's (cr_poly_pick_swizzle). */
+			double plain = 0.0, best = 0.0;
+
+			cr_poly_pick_swizzle(&plan->poly, plan->increment, &plain, &best);
+			if (plain >= CR_UP_CONFLICT_CYCLES)
+				plan->variant = 27u;
+		}
+	}
 	crhip_poly_geometry(plan->channels, plan->specialised ? plan->poly.slots : 0xFFFFu, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
 	if (plan->variant == 28u || plan->variant == 29u || (plan->variant == 0xFFFFu && crhip_poly_default_is_mad(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode)))
 	{
@@ -1009,6 +1046,82 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 	return cr_plan_get_on(current_device(), table_hash, table_len, fill_table, user, radius, cfg, channels, increment, pin);
 }
 
+/* Once per plan, never inside a caller's stream capture: the kernel's function attributes, and the grid caps clamped to what is
+   resident at once. */
+static int plan_prepare(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan)
+{
+	crhip_poly_launch l;
+	int form;
+
+	fill_poly_launch(plan, &l);
+	if (cr_check_hip(crhip_poly_prepare(&l), "hipFuncSetAttribute(dynamic LDS)") != 0)
+		return -1;
+	l.out_s16 = 1; /* the int16-output instance is a different function */
+	if (cr_check_hip(crhip_poly_prepare(&l), "hipFuncSetAttribute(dynamic LDS, int16 form)") != 0)
+		return -1;
+
+	/* The persistent grid must not be larger than what is resident at once: workgroups that start after the first
+	   batch has left find their statically dealt tiles still waiting (twice the time) or no tickets (harmless).
+	   LDS and thread count were accounted for above; registers are the runtime's to know - e.g. above 96 SGPRs a
+	   SIMD holds 7 waves, not 8, and a 1024-thread workgroup then has the CU to itself. */
+	plan->max_blocks_s16 = plan->max_blocks;
+	for (form = 0; form < 2; ++form)
+	{
+		int per_cu = 0, vgprs = 0, static_lds = 0;
+		l.out_s16 = (uint32_t)form;
+		if (crhip_poly_occupancy(&l, &per_cu, &vgprs, &static_lds) == 0 && per_cu >= 1)
+		{
+			const uint32_t resident = (uint32_t)per_cu * (uint32_t)(ctx->info.compute_units > 0 ? ctx->info.compute_units : 256);
+			if (g_env.debug)
+				fprintf(stderr, "clownresampler_amd: plan variant %u (%s output): %u threads, %u B dynamic LDS, %d VGPRs: %d workgroups per CU, grid cap %u -> %u\n",
+				        plan->variant, form ? "int16" : "int32", plan->threads, plan->lds_bytes, vgprs, per_cu, form ? plan->max_blocks_s16 : plan->max_blocks, resident);
+			if (g_env.no_occupancy_clamp) /* (tuning hook CLOWNRESAMPLER_AMD_NO_OCCUPANCY_CLAMP: measure without) */
+				continue;
+			if (form == 0 && resident < plan->max_blocks)
+				plan->max_blocks = resident;
+			if (form == 1 && resident < plan->max_blocks_s16)
+				plan->max_blocks_s16 = resident;
+		}
+	}
+	return 0;
+}
+
+/* The shape of k_up's fallback kernel beside a k_up plan's own, for its brief launches (see the plan's `brief`). */
+static void plan_brief_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan)
+{
+	ClownResamplerAMD_Plan other;
+	double plain, best;
+	const uint32_t half_tiles = g_env.brief_half_tiles >= 0 ? (uint32_t)g_env.brief_half_tiles
+	                          : (plan->poly.slots >= 15u ? CR_BRIEF_HALF_TILES_LONG_WINDOWS : CR_BRIEF_HALF_TILES);
+
+	plan->brief.below = 0;
+	if (plan->vecs < 200u || plan->key_variant != (uint32_t)CR_DEFAULT_VARIANT || half_tiles == 0)
+		return;
+
+	other = *plan;   /* (a scratch copy: nothing in it is owned) */
+	other.variant = crhip_poly_up_fallback_variant(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
+	plan_geometry(&other);
+	if (other.vecs >= 200u || other.specialised != plan->specialised)
+		return;
+	other.lds_swizzle = crhip_poly_swizzled(other.channels, other.specialised ? other.poly.slots : 0xFFFFu, other.poly.row_mode, other.poly.norm_mode, other.variant)
+	                        ? cr_poly_pick_swizzle(&other.poly, other.increment, &plain, &best) : 0u;
+	if (plan_prepare(ctx, &other) != 0)
+	{
+		ClownResamplerAMD_ClearError();   /* (the plan works without) */
+		return;
+	}
+
+	plan->brief.threads = other.threads;
+	plan->brief.vecs = other.vecs;
+	plan->brief.tile_frames = other.tile_frames;
+	plan->brief.lds_bytes = other.lds_bytes;
+	plan->brief.max_blocks = other.max_blocks;
+	plan->brief.max_blocks_s16 = other.max_blocks_s16;
+	plan->brief.variant = other.variant;
+	plan->brief.lds_swizzle = other.lds_swizzle;
+	plan->brief.below = (uint64_t)half_tiles * (plan->tile_frames / 4u) * plan->max_blocks * (plan->threads / 64u) / 2u;
+}
+
 ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t table_len, cr_table_fill fill_table, const void *user,
                                        unsigned radius, const cr_config *cfg, uint32_t channels, uint64_t increment, int pin)
 {
@@ -1188,43 +1301,9 @@ ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t t
 		plan->plane_rows = store->plane_rows;
 		plan->device_row_stride = store->device_row_stride;
 
-		{
-			/* once per plan, never inside a caller's stream capture */
-			crhip_poly_launch l;
-			fill_poly_launch(plan, &l);
-			if (cr_check_hip(crhip_poly_prepare(&l), "hipFuncSetAttribute(dynamic LDS)") != 0)
-				goto fail_plan;
-			l.out_s16 = 1; /* the int16-output instance is a different function */
-			if (cr_check_hip(crhip_poly_prepare(&l), "hipFuncSetAttribute(dynamic LDS, int16 form)") != 0)
-				goto fail_plan;
-
-			/* The persistent grid must not be larger than what is resident at once: workgroups that start after the first
-			   batch has left find their statically dealt tiles still waiting (twice the time) or no tickets (harmless).
-			   LDS and thread count were accounted for above; registers are the runtime's to know - e.g. above 96 SGPRs a
-			   SIMD holds 7 waves, not 8, and a 1024-thread workgroup then has the CU to itself. */
-			{
-				int form;
-				plan->max_blocks_s16 = plan->max_blocks;
-				for (form = 0; form < 2; ++form)
-				{
-					int per_cu = 0, vgprs = 0, static_lds = 0;
-					l.out_s16 = (uint32_t)form;
-					if (crhip_poly_occupancy(&l, &per_cu, &vgprs, &static_lds) == 0 && per_cu >= 1)
-					{
-						const uint32_t resident = (uint32_t)per_cu * (uint32_t)(ctx->info.compute_units > 0 ? ctx->info.compute_units : 256);
-						if (g_env.debug)
-							fprintf(stderr, "clownresampler_amd: plan variant %u (%s output): %u threads, %u B dynamic LDS, %d VGPRs: %d workgroups per CU, grid cap %u -> %u\n",
-							        plan->variant, form ? "int16" : "int32", plan->threads, plan->lds_bytes, vgprs, per_cu, form ? plan->max_blocks_s16 : plan->max_blocks, resident);
-						if (g_env.no_occupancy_clamp) /* (tuning hook CLOWNRESAMPLER_AMD_NO_OCCUPANCY_CLAMP: measure without) */
-							continue;
-						if (form == 0 && resident < plan->max_blocks)
-							plan->max_blocks = resident;
-						if (form == 1 && resident < plan->max_blocks_s16)
-							plan->max_blocks_s16 = resident;
-					}
-				}
-			}
-		}
+		if (plan_prepare(ctx, plan) != 0)
+			goto fail_plan;
+		plan_brief_shape(ctx, plan);
 	}
 
 	free(table);
@@ -1288,6 +1367,8 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 	{
 		crhip_poly_launch l;
 		uint64_t blocks;
+		uint32_t threads = plan->threads, vecs = plan->vecs, shape_tile = plan->tile_frames;
+		uint32_t max_blocks = out_s16 ? plan->max_blocks_s16 : plan->max_blocks;
 
 		fill_poly_launch(plan, &l);
 		l.d_in = d_in;
@@ -1296,13 +1377,24 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		l.pos0 = (pos_int << 16) + pos_frac;
 		l.n_out = n_out;
 		l.out_s16 = out_s16 ? 1u : 0u;
+		if (n_out < plan->brief.below)
+		{
+			/* a brief launch of a k_up plan: the instance's other kernel, over the same rows (see the plan's `brief`) */
+			l.threads = threads = plan->brief.threads;
+			l.vecs = vecs = plan->brief.vecs;
+			l.tile_frames = shape_tile = plan->brief.tile_frames;
+			l.lds_bytes = plan->brief.lds_bytes;
+			l.variant = plan->brief.variant;
+			l.swizzle = plan->brief.lds_swizzle;
+			max_blocks = out_s16 ? plan->brief.max_blocks_s16 : plan->brief.max_blocks;
+		}
 
-		if (plan->vecs >= 150u && plan->vecs < 200u)
+		if (vecs >= 150u && vecs < 200u)
 		{
 			/* k_wave2 draws chunks of 4 wave-tiles; a launch that leaves a wave only two or three of those ends with a third of
 			   the waves idle, so short launches get chunks of 2 or 1 (the kernel takes the chunk size from the launch) */
-			const uint32_t wave_tile = plan->tile_frames / 4u;
-			const uint64_t waves = (uint64_t)(out_s16 ? plan->max_blocks_s16 : plan->max_blocks) * (plan->threads / 64u);
+			const uint32_t wave_tile = shape_tile / 4u;
+			const uint64_t waves = (uint64_t)max_blocks * (threads / 64u);
 
 			while (l.tile_frames > wave_tile && n_out / l.tile_frames < 8u * waves)
 				l.tile_frames /= 2u;
@@ -1310,10 +1402,10 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 
 		/* tiles are dealt round-robin to a persistent grid (see k_poly) */
 		blocks = (n_out + l.tile_frames - 1) / l.tile_frames;
-		if (plan->vecs >= 100u)
-			blocks = (blocks + plan->threads / 64u - 1) / (plan->threads / 64u); /* k_wave hands chunks to WAVES */
-		if (blocks > (out_s16 ? plan->max_blocks_s16 : plan->max_blocks))
-			blocks = out_s16 ? plan->max_blocks_s16 : plan->max_blocks;
+		if (vecs >= 100u)
+			blocks = (blocks + threads / 64u - 1) / (threads / 64u); /* k_wave hands chunks to WAVES */
+		if (blocks > max_blocks)
+			blocks = max_blocks;
 		l.blocks = (uint32_t)blocks;
 		{
 			/* tickets pay off where workgroups drift apart over many medium-sized tiles; measured on MI355X (profiles/):
@@ -1329,10 +1421,10 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			   second workgroup of a CU hides that and the balance is worth 1 %; with one or two it is most of what the launch
 			   spends outside its tiles (tools/size_sweep.py, stereo 44.1 -> 48 kHz: 30 s 9.5 -> 7.6 us, one minute 12.3 -> 9.0 us,
 			   two minutes 16.1 -> 14.5 us, five minutes 29.5 -> 29.3 us, ten minutes 61.3 against 62.0 us the other way) */
-			if (g_env.dynamic_tiles < 0 && plan->vecs < 100u && (n_out + l.tile_frames - 1) / l.tile_frames < 8ull * blocks)
+			if (g_env.dynamic_tiles < 0 && vecs < 100u && (n_out + l.tile_frames - 1) / l.tile_frames < 8ull * blocks)
 				l.dynamic_tiles = 0u;
-			if (g_env.dynamic_tiles < 0 && plan->channels >= 8u && plan->vecs < 100u
-			 && (n_out + l.tile_frames - 1) / l.tile_frames >= 48ull * (out_s16 ? plan->max_blocks_s16 : plan->max_blocks))
+			if (g_env.dynamic_tiles < 0 && plan->channels >= 8u && vecs < 100u
+			 && (n_out + l.tile_frames - 1) / l.tile_frames >= 48ull * max_blocks)
 				l.dynamic_tiles = 1u;
 		}
 		l.d_tickets = ticket_block_for(g_ctx[plan->device], stream);
@@ -1742,6 +1834,12 @@ void ClownResamplerAMD_PlanGetInfo(const ClownResamplerAMD_Plan *plan, ClownResa
 	info->lds_bytes = plan->lds_bytes;
 	info->max_blocks = plan->max_blocks;
 	info->specialised = plan->specialised;
+	if (plan->use_poly && plan->brief.below != 0)
+	{
+		info->brief_kernel = plan->brief.vecs >= 150u ? 4u : plan->brief.vecs >= 100u ? 2u : 1u;
+		info->brief_variant = plan->brief.variant;
+		info->brief_below = plan->brief.below;
+	}
 }
 
 const int32_t *ClownResamplerAMD_PlanRows(const ClownResamplerAMD_Plan *plan)

@@ -74,6 +74,15 @@ typedef struct ClownResamplerAMD_Plan
 	uint32_t lds_swizzle;   /* k_wave2: the rotation it applies while staging the (plain) rows into LDS, chosen for this plan's increment */
 	uint32_t device_row_stride; /* int32 per row of the device image (COMPACT for specialised instances, SPLIT otherwise) */
 	double conflict_plain, conflict_best; /* modelled extra LDS cycles per row read without / with the swizzle */
+	/* k_up's wave-tiles are long (64 input positions: 757 frames at 12x) and a wave computes one in ~15 us however few there
+	   are: launches that leave a wave fewer than a handful go to the instance's other kernel (k_wave2 / k_wave / k_poly, the
+	   one k_up falls back to) over the SAME rows image - `brief` is that kernel's shape, for launches of fewer than `below`
+	   output frames (0: none) */
+	struct
+	{
+		uint64_t below;
+		uint32_t threads, vecs, tile_frames, lds_bytes, max_blocks, max_blocks_s16, variant, lds_swizzle;
+	} brief;
 } ClownResamplerAMD_Plan;
 
 /* Cache lookup by (hash of the caller's raw table bytes, radius, configuration, channels, increment); on a miss

@@ -411,6 +411,18 @@ int crhip_poly_up_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, 
 	return 1;
 }
 
+int crhip_poly_has_up(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
+{
+	const special *sp = find_special(channels, slots, row_mode, norm_mode);
+	return sp != nullptr && sp->up[1] != nullptr ? 1 : 0;
+}
+
+int crhip_poly_default_is_up(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
+{
+	const special *sp = find_special(channels, slots, row_mode, norm_mode);
+	return sp != nullptr && sp->default_variant >= UP_VARIANT && sp->default_variant < MAD_VARIANT ? 1 : 0;
+}
+
 uint32_t crhip_poly_mad_safemask(uint32_t slots)
 {
 	// the slots the 64-bit chain of k_poly (variants 28 / 29) takes at any magnitude up to 65536 (mad_safemask, cr_device.hpp)

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(CRHIP_SG
 	__syncthreads();
 
 	const uint64_t n_chunks = (a.n_out + CHUNK - 1) / CHUNK;
-	const uint64_t global_wave = (uint64_t)blockIdx.x * WAVES + wave;
+	const uint64_t global_wave = (uint64_t)wave * gridDim.x + blockIdx.x;   // (a short launch spreads over the CUs, not over a CU's waves)
 	const uint64_t global_waves = (uint64_t)gridDim.x * WAVES;
 
 	// tickets: as in k_poly, per wave, 32 counter lanes

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 
 
 	const uint64_t n_chunks = (a.n_out + CHUNK - 1) >> chunk_shift;
-	const uint64_t global_wave = (uint64_t)blockIdx.x * n_waves + wave;
+	const uint64_t global_wave = (uint64_t)wave * gridDim.x + blockIdx.x;   // (a short launch spreads over the CUs, not over a CU's waves)
 	const uint64_t global_waves = (uint64_t)gridDim.x * n_waves;
 
 	// Who takes which chunk.  Chunks go round-robin over the waves (wave w: chunks w, w + waves, ...) for all but the last two
@@ -180,32 +180,49 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	{
 		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.d_rows);
 		u32x4 *dst = reinterpret_cast<u32x4 *>(smem);
-		for (unsigned q = 0; q < planes_total; ++q)
+		// rows land SWIZZLED within their block of 16 (see one_frame2): the global image is the plain one, shared by plans of every
+		// increment; the multiplier that suits THIS increment is the plan's (host: cr_poly_pick_swizzle)
+		auto place = [&](unsigned r) { return (r & ~15u) | ((__umul24(r >> 4, a.swizzle) + r) & 15u); };
+		auto staged = [&](u32x4 v, int q) {
+			int e[4] = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+			if constexpr (!SIGNED)
+			{
+#pragma unroll
+				for (int k = 0; k < 4; ++k)
+				{
+					const int slot = 4 * q + k;
+					if (slot < TT && ((NEGMASK >> slot) & 1u))
+						e[k] = -e[k];
+					if (MOVARM && slot < TT && !((SAFEMASK >> slot) & 1u))
+						e[k] = (int)((unsigned)e[k] << 15);
+				}
+			}
+			u32x4 w;
+			w.x = (unsigned)e[0];
+			w.y = (unsigned)e[1];
+			w.z = (unsigned)e[2];
+			w.w = (unsigned)e[3];
+			return w;
+		};
+		if constexpr (RT)
 		{
+			for (unsigned q = 0; q < planes_total; ++q)
+				for (unsigned r = tid; r < a.plane_rows; r += NTHREADS)
+					dst[q * a.plane_rows + place(r)] = staged(src[q * a.plane_rows + r], 0);
+		}
+		else
+		{
+			// every plane's load of a row before any store: one round trip per trip of this loop instead of one per plane
 			for (unsigned r = tid; r < a.plane_rows; r += NTHREADS)
 			{
-				const u32x4 v = src[q * a.plane_rows + r];
-				int e[4] = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-				if constexpr (!SIGNED)
-				{
+				u32x4 v[RS / 4];
 #pragma unroll
-					for (int k = 0; k < 4; ++k)
-					{
-						const int slot = 4 * (int)q + k;
-						if (slot < TT && ((NEGMASK >> slot) & 1u))
-							e[k] = -e[k];
-						if (MOVARM && slot < TT && !((SAFEMASK >> slot) & 1u))
-							e[k] = (int)((unsigned)e[k] << 15);
-					}
-				}
-				u32x4 w;
-				w.x = (unsigned)e[0];
-				w.y = (unsigned)e[1];
-				w.z = (unsigned)e[2];
-				w.w = (unsigned)e[3];
-				// rows land SWIZZLED within their block of 16 (see one_frame2): the global image is the plain one, shared by plans of
-				// every increment; the multiplier that suits THIS increment is the plan's (host: cr_poly_pick_swizzle)
-				dst[q * a.plane_rows + ((r & ~15u) | ((__umul24(r >> 4, a.swizzle) + r) & 15u))] = w;
+				for (int q = 0; q < RS / 4; ++q)
+					v[q] = src[(unsigned)q * a.plane_rows + r];
+				const unsigned at = place(r);
+#pragma unroll
+				for (int q = 0; q < RS / 4; ++q)
+					dst[(unsigned)q * a.plane_rows + at] = staged(v[q], q);
 			}
 		}
 	}

@@ -149,6 +149,9 @@ int crhip_poly_up_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, 
 /* the variant to use when a plan does not qualify for k_up */
 /* 1 when the instance's default variant is one of the 64-bit-chain variants (whose sign precondition the host must check) */
 int crhip_poly_default_is_mad(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
+/* whether the instance has the input-stationary kernel (k_up2, variant 27) / has it as its measured default */
+int crhip_poly_has_up(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
+int crhip_poly_default_is_up(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
 uint32_t crhip_poly_up_fallback_variant(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
 /* k_wave2 (expanded window, 64-bit multiply-add taps; variant 30): -1 when the instance has none, 1 when it is built for the slot
    signs in *negmask (the host checks the plan's rows against them, as for k_up), 0 when it takes any rows */

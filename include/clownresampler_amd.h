@@ -159,6 +159,9 @@ typedef struct ClownResamplerAMD_PlanInfo
 	uint32_t specialised;       /* 1 when a (channels, slots) template instance is used */
 	uint32_t variant;           /* tuning variant the plan was built for (0xFFFF: the instance's measured default) */
 	uint32_t norm_mode;         /* 0: |accumulator x reciprocal| < 2^31 for every row (signed multiply), 1: < 2^32 (on magnitudes) */
+	uint32_t brief_kernel;      /* kernel 3 only: the kernel (numbered as `kernel`) that launches of fewer than brief_below output frames take instead - k_up's wave-tiles are too long for them - or 0 */
+	uint32_t brief_variant;     /* ... and its tuning variant */
+	uint64_t brief_below;       /* 0: every launch takes `kernel` */
 } ClownResamplerAMD_PlanInfo;
 
 /* Builds (or fetches from the cache) the device-side plan for the configuration, channel count and increment

@@ -268,6 +268,65 @@ def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch,
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("radius,rates", [(8, (8000, 96000, 8000)), (3, (8000, 64000, 8000)), (3, (6000, 96000, 6000))])
+def test_brief_launches_of_an_input_stationary_plan(products, radius, rates):
+    """A k_up plan sends its BRIEF launches (fewer than PlanInfo.brief_below output frames: a handful of wave-tiles per wave) to the
+    instance's other kernel over the same rows.  Launches just below and just above that length, and a short stream taken in two
+    calls (the second from a fractional position), with the clamped int16 form: all equal the oracle's."""
+    p, o = products[radius], ck.oracle(radius)
+    ch = 2
+    ok, st = p.low_init(ch, *rates)
+    info = p.api.PlanGetInfo(p.api.PlanCreate(st.raw, p.pre))
+    assert info.kernel == 3 and info.brief_kernel in (1, 2, 4) and info.brief_below > 0, info.asdict()
+    for n_out in (info.brief_below - 999, info.brief_below + 999):
+        frames = n_out * rates[0] // rates[1]
+        ok, st = p.low_init(ch, *rates)
+        ok, ost = o.low_init(ch, *rates)
+        padded = ck.pad_frames(ck.noise_pcm(frames * ch, 17), ch, int(ost.cfg.radius_frames))
+        total = ck.count_output_frames(ost, frames)
+        assert (total < info.brief_below) == (n_out < info.brief_below), (total, n_out, info.brief_below)
+        want = o.low_resample_i32_mt(ost, padded, frames, threads=min(32, os.cpu_count() or 1))
+        got, left, ran_out = p.low_resample_i32(st, padded, frames)
+        assert ran_out == 1 and left == 0 and np.array_equal(got, want), n_out
+    frames = 30011
+    pcm = ck.noise_pcm(frames * ch, 3)
+    ok, a = p.low_init(ch, *rates)
+    ok, b = o.low_init(ch, *rates)
+    padded = ck.pad_frames(pcm, ch, int(b.cfg.radius_frames))
+    xa, la, ra = p.low_resample_i32(a, padded, frames, capacity=777)
+    xb, lb, rb = o.low_resample_i32(b, padded, frames, capacity=777)
+    assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple()
+    rest = padded[(frames - la) * ch:]
+    xa, la2, ra = p.low_resample_i32(a, rest, la)
+    xb, lb2, rb = o.low_resample_i32(b, rest, la)
+    assert np.array_equal(xa, xb) and (la2, ra) == (lb2, rb) and a.astuple() == b.astuple()
+    ok, a = p.low_init(ch, *rates)
+    ok, b = o.low_init(ch, *rates)
+    want32, _, _ = o.low_resample_i32(b, padded, frames)
+    got, left, ran_out = p.api.LowLevel_ResampleBulkS16(a.raw, p.pre, padded, frames)
+    assert np.array_equal(got, np.clip(want32, -0x7FFF, 0x7FFF).astype(np.int16))
+
+
+@pytest.mark.parametrize("radius,rates,kernel", [
+    (8, (24000, 48000, 24000), 4), (8, (8000, 44100, 8000), 4), (8, (8000, 64000, 8000), 3), (8, (8000, 104000, 8000), 3), (8, (8000, 127999, 8000), 4),
+    (3, (24000, 48000, 24000), 1), (3, (8000, 96000, 8000), 1), (3, (22050, 176400, 22050), 3), (3, (8000, 64001, 8000), 3), (3, (12000, 192000, 12000), 3)])
+def test_default_kernel_of_stereo_upsampling_by_ratio(products, radius, rates, kernel):
+    """Which kernel a stereo pure-upsampling plan takes by default (cr_context.c plan_geometry): 8 lobes k_up2 at 8x-13x and k_wave2
+    elsewhere; 3 lobes k_poly except where its row reads share an LDS bank slot (8x, 16x) - and a 3 M-frame stream through each
+    equals the oracle's."""
+    p, o = products[radius], ck.oracle(radius)
+    ch = 2
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    info = p.api.PlanGetInfo(p.api.PlanCreate(st.raw, p.pre))
+    assert info.kernel == kernel, (rates, info.asdict())
+    frames = 3000000 * rates[0] // rates[1]
+    padded = ck.pad_frames(ck.noise_pcm(frames * ch, 23), ch, int(ost.cfg.radius_frames))
+    want = o.low_resample_i32_mt(ost, padded, frames, threads=min(32, os.cpu_count() or 1))
+    got, left, ran_out = p.low_resample_i32(st, padded, frames)
+    assert ran_out == 1 and left == 0 and np.array_equal(got, want)
+
+
 def test_c_harness_reproduces_reference_harness_outputs(golden, tmp_path):
     """tools/cr_resample.c - a plain C client of include/clownresampler.h, shaped like tests/test-low-level.c and
     tests/test-high-level.c - on the reference's own fixture and ctest triples: byte-identical files (sha256 of the real

@@ -75,6 +75,10 @@ WORKLOADS = {
     "up2x": (3, 2, (48000, 96000, 48000), 14400000),   # stereo 3 lobes 2x / 4x / 3x upsampling, 5 minutes in
     "up4x": (3, 2, (48000, 192000, 48000), 7200000),
     "up3x": (3, 2, (16000, 48000, 16000), 9600000),
+    "up8xm": (3, 1, (12000, 96000, 12000), 7200000),   # exactly 8x / 16x, 3 lobes: the rows of neighbouring lanes share an LDS bank slot unless rotated
+    "up8x4": (3, 4, (12000, 96000, 12000), 3600000),
+    "up16xm": (3, 1, (12000, 192000, 12000), 3600000),
+    "up16x6": (3, 6, (12000, 192000, 12000), 1200000),
     "up4": (3, 4, (44100, 48000, 44100), 26460000),    # 10 minutes of 4 / 6 / 8 channels, 3 lobes, both directions (tuning only)
     "up6": (3, 6, (44100, 48000, 44100), 26460000),
     "up8": (3, 8, (44100, 48000, 44100), 26460000),

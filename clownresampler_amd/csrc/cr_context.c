@@ -175,7 +175,8 @@ static int g_variant = -1; /* -1: CLOWNRESAMPLER_AMD_VARIANT from the environmen
 /* k_up2 as an instance's default kernel: see plan_geometry */
 #define CR_UP_DEFAULT_MAX_INCREMENT (65536u / 8u)
 #define CR_UP_DEFAULT_MIN_INCREMENT (65536u / 13u)
-#define CR_UP_CONFLICT_CYCLES 20.0
+/* (stereo 44.1 -> 48 kHz models 12 -> 4 and measured 0.5-1 % SLOWER rotated; exactly 8x models 28 -> 12, 16x 60 -> 12) */
+#define CR_ROTATE_MIN_GAIN 12.0
 
 /* Environment switches are read ONCE (tuning hooks; none of them changes results). */
 static struct
@@ -184,6 +185,7 @@ static struct
 	int dynamic_tiles;          /* CLOWNRESAMPLER_AMD_DYNAMIC_TILES: -1 unset, else 0 / 1 */
 	int no_special, debug, no_occupancy_clamp, tile_groups, no_host_pipeline, no_small_call_path;
 	int rt_wave2_min_slots;     /* CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS: windows from this many slots on take the run-time-slot k_wave2 */
+	double rotate_min_gain;     /* CLOWNRESAMPLER_AMD_ROTATE_MIN_GAIN: see plan_pick_rotation */
 	int brief_half_tiles;       /* CLOWNRESAMPLER_AMD_BRIEF_HALF_TILES: k_up launches of fewer half wave-tiles per wave take the plan's other kernel (0: none do; unset: per instance) */
 } g_env;
 static pthread_once_t g_env_once = PTHREAD_ONCE_INIT;
@@ -203,6 +205,8 @@ static void load_env(void)
 	g_env.no_small_call_path = getenv("CLOWNRESAMPLER_AMD_NO_SMALL_CALL_PATH") != NULL;
 	e = getenv("CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS");
 	g_env.rt_wave2_min_slots = (e != NULL && atoi(e) > 0) ? atoi(e) : CR_RT_WAVE2_MIN_SLOTS;
+	e = getenv("CLOWNRESAMPLER_AMD_ROTATE_MIN_GAIN");
+	g_env.rotate_min_gain = (e != NULL && *e != '\0') ? atof(e) : CR_ROTATE_MIN_GAIN;
 	e = getenv("CLOWNRESAMPLER_AMD_BRIEF_HALF_TILES");
 	g_env.brief_half_tiles = (e != NULL && *e != '\0' && atoi(e) >= 0) ? atoi(e) : -1;
 	g_env.loaded = 1;
@@ -724,17 +728,8 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 			if (plan->increment > CR_UP_DEFAULT_MAX_INCREMENT || plan->increment < CR_UP_DEFAULT_MIN_INCREMENT)
 				plan->variant = crhip_poly_up_fallback_variant(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
 		}
-		else if (plan->increment >= 4096u && plan->increment <= 32768u)
-		{
-			/* 3 lobes: k_poly, except at ratios where the rows its lanes read - one per output frame - share an LDS bank slot:
-			   exactly 8x (8 rows 128 apart per 16 lanes: 90 against k_up2's 80 us), 16x (16 rows: 155 / 92).  k_up2's lanes
-			   walk the rows of ONE input position each and do not care.  The model is k_wave2's (cr_poly_pick_swizzle). */
-			double plain = 0.0, best = 0.0;
-
-			cr_poly_pick_swizzle(&plan->poly, plan->increment, &plain, &best);
-			if (plain >= CR_UP_CONFLICT_CYCLES)
-				plan->variant = 27u;
-		}
+		/* (the 3-lobe stereo instance keeps k_up2 behind variant 27 only: its default is k_poly's chain, with its rows rotated
+		   in LDS at the ratios where k_up2 used to win - exactly 8x: 79 against 80-90 us, 16x: 79 / 92) */
 	}
 	crhip_poly_geometry(plan->channels, plan->specialised ? plan->poly.slots : 0xFFFFu, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
 	if (plan->variant == 28u || plan->variant == 29u || (plan->variant == 0xFFFFu && crhip_poly_default_is_mad(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode)))
@@ -1046,6 +1041,26 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 	return cr_plan_get_on(current_device(), table_hash, table_len, fill_table, user, radius, cfg, channels, increment, pin);
 }
 
+/* The rotation of the rows in LDS that suits the plan's increment, for kernels that apply one (k_wave2 always; the 64-bit-chain
+   k_poly has a plain and a rotated form, and the rotated one costs three instructions per frame: only where the model - extra LDS
+   cycles per row read of a wave, cr_poly_pick_swizzle - gains CR_ROTATE_MIN_GAIN). */
+static uint32_t plan_pick_rotation(const ClownResamplerAMD_Plan *plan, double *plain, double *best)
+{
+	const int form = crhip_poly_swizzled(plan->channels, plan->specialised ? plan->poly.slots : 0xFFFFu, plan->poly.row_mode, plan->poly.norm_mode, plan->variant);
+	uint32_t rotation;
+
+	*plain = *best = 0.0;
+	if (form == 0)
+		return 0u;
+	rotation = cr_poly_pick_swizzle(&plan->poly, plan->increment, plain, best);
+	if (form == 2 && *plain - *best < g_env.rotate_min_gain)
+		rotation = 0u;
+	if (g_env.debug)
+		fprintf(stderr, "clownresampler_amd: plan variant %u, increment %llu: rows rotated by %u (modelled conflict cycles per row read %.2f -> %.2f)\n",
+		        plan->variant, (unsigned long long)plan->increment, rotation, *plain, *best);
+	return rotation;
+}
+
 /* Once per plan, never inside a caller's stream capture: the kernel's function attributes, and the grid caps clamped to what is
    resident at once. */
 static int plan_prepare(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan)
@@ -1103,8 +1118,7 @@ static void plan_brief_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *p
 	plan_geometry(&other);
 	if (other.vecs >= 200u || other.specialised != plan->specialised)
 		return;
-	other.lds_swizzle = crhip_poly_swizzled(other.channels, other.specialised ? other.poly.slots : 0xFFFFu, other.poly.row_mode, other.poly.norm_mode, other.variant)
-	                        ? cr_poly_pick_swizzle(&other.poly, other.increment, &plain, &best) : 0u;
+	other.lds_swizzle = plan_pick_rotation(&other, &plain, &best);
 	if (plan_prepare(ctx, &other) != 0)
 	{
 		ClownResamplerAMD_ClearError();   /* (the plan works without) */
@@ -1251,9 +1265,7 @@ ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t t
 
 	/* instances that rotate the rows while staging them into LDS get the rotation that suits THIS plan's increment (the image
 	   in global memory stays the plain one, shared by the plans of every increment) */
-	plan->lds_swizzle = 0;
-	if (plan->use_poly && crhip_poly_swizzled(plan->channels, plan->specialised ? plan->poly.slots : 0xFFFFu, plan->poly.row_mode, plan->poly.norm_mode, plan->variant))
-		plan->lds_swizzle = cr_poly_pick_swizzle(&plan->poly, increment, &plan->conflict_plain, &plan->conflict_best);
+	plan->lds_swizzle = plan->use_poly ? plan_pick_rotation(plan, &plan->conflict_plain, &plan->conflict_best) : 0u;
 
 	if (plan->use_poly)
 	{

@@ -76,6 +76,7 @@ struct special
 	poly_fn mad16;              // the 64-bit chain with int16 output (non-temporal stores); nullptr: int16 output takes the SDWA form
 	uint32_t lite_variant;      // lite instances with a chain: the variant id (geometry) of their SDWA form, which explicit k_poly variants resolve to
 	uint32_t mad_frames;        // frames in flight per lane of the chain kernels (k_poly's U): 1 or 2
+	poly_fn mad_rotated[2], mad16_rotated;   // the chain kernels with their rows rotated in LDS (SWZ): taken by launches whose plan asks for a rotation
 };
 
 constexpr uint32_t MAD_VARIANT = 28;    // variant ids 28, 29
@@ -100,13 +101,22 @@ void add_wave2(special &s)
 		s.up_negmask = NEGMASK;
 }
 
+// The 64-bit-chain instances of k_poly come in two forms: rows plain in LDS, and rows rotated within their blocks of 16 (SWZ; the
+// plan picks the rotation for its increment).  At exactly 8x / 16x upsampling the rows of 16 neighbouring lanes are 128 / 64 apart
+// and share an LDS bank slot: rotated, mono 16x takes 74 us instead of 210, 8x 74 instead of 116, 6 channels 16x 103 instead of
+// 119 - but the three instructions per frame cost the ratios without conflicts 1-4 % (profiles/r02_chain_rotated_rows.log), so a
+// plan asks for a rotation only where the conflict model (cr_poly_pick_swizzle) says it pays.
+
 // The 64-bit chain (variants 28 / 29, + int16 form) added to a full instance that has no k_up form - mono - and made its default
 template <int CH, int TT, int MODE, int NORM, unsigned UPMASK, int U = 1>
 special with_chain(special s)
 {
 	s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), U, 0, 0, 0, 1>;
+	s.mad_rotated[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), U, 1, 0, 0, 1>;
 	s.mad[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), U, 0, 0, 0, 0>;
+	s.mad_rotated[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), U, 1, 0, 0, 0>;
 	s.mad16 = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), U, 0, 0, 1, 1>;
+	s.mad16_rotated = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), U, 1, 0, 1, 1>;
 	s.up_negmask = UPMASK;
 	s.mad_frames = U;
 	return s;
@@ -144,8 +154,11 @@ special make_special()
 	if constexpr (UPMASK != 0 && CH % 2 == 0)
 	{
 		s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 1>;
+		s.mad_rotated[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 1, 0, 0, 1>;
 		s.mad[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 0>;
+		s.mad_rotated[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 1, 0, 0, 0>;
 		s.mad16 = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 1, 1>;
+		s.mad16_rotated = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 1, 0, 1, 1>;
 	}
 	if constexpr (UPMASK != 0)
 	{
@@ -205,8 +218,11 @@ special make_special_lite_chain()
 	special s = make_special_lite<CH, TT, CRHIP_ROWMODE_UPSAMPLE, NORM, DV>();
 	constexpr int T = GEOMETRY[DV % 5].threads, V = GEOMETRY[DV % 5].vecs;
 	s.mad[0] = (poly_fn)k_poly<CH, TT, CRHIP_ROWMODE_UPSAMPLE, NORM, T, V, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 1>;
+	s.mad_rotated[0] = (poly_fn)k_poly<CH, TT, CRHIP_ROWMODE_UPSAMPLE, NORM, T, V, (int)(2u | (UPMASK << 8)), 1, 1, 0, 0, 1>;
 	s.mad[1] = (poly_fn)k_poly<CH, TT, CRHIP_ROWMODE_UPSAMPLE, NORM, T, V, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 0>;
+	s.mad_rotated[1] = (poly_fn)k_poly<CH, TT, CRHIP_ROWMODE_UPSAMPLE, NORM, T, V, (int)(2u | (UPMASK << 8)), 1, 1, 0, 0, 0>;
 	s.mad16 = (poly_fn)k_poly<CH, TT, CRHIP_ROWMODE_UPSAMPLE, NORM, T, V, (int)(2u | (UPMASK << 8)), 1, 0, 0, 1, 1>;
+	s.mad16_rotated = (poly_fn)k_poly<CH, TT, CRHIP_ROWMODE_UPSAMPLE, NORM, T, V, (int)(2u | (UPMASK << 8)), 1, 1, 0, 1, 1>;
 	s.up_negmask = UPMASK;
 	s.lite_variant = DV;
 	s.default_variant = MAD_VARIANT;

@@ -389,7 +389,10 @@ int crhip_poly_swizzled(uint32_t channels, uint32_t slots, uint32_t row_mode, ui
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
 	if (sp == nullptr)
 		return variant == RT_WAVE2_VARIANT ? 1 : RUNTIME_SWZ;
-	return resolve_variant(sp, variant) == WAVE2_VARIANT ? 1 : 0;
+	const uint32_t v = resolve_variant(sp, variant);
+	if (v == MAD_VARIANT || v == MAD_VARIANT + 1u)
+		return sp->mad_rotated[0] != nullptr ? 2 : 0;   // 2: has a rotated form beside the plain one - a rotation is the plan's choice
+	return v == WAVE2_VARIANT ? 1 : 0;
 }
 
 int crhip_poly_runtime_wave2(uint32_t channels, uint32_t row_mode)
@@ -564,6 +567,8 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 	if (sp != nullptr && v >= MAD_VARIANT)
 	{
 		*geo = sp->lite ? sp->lite_variant % 5u : 3u;
+		if (launch->swizzle != 0 && sp->mad_rotated[0] != nullptr)
+			return launch->out_s16 ? sp->mad16_rotated : sp->mad_rotated[v - MAD_VARIANT];
 		return launch->out_s16 ? sp->mad16 : sp->mad[v - MAD_VARIANT];
 	}
 

@@ -176,15 +176,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 		const unsigned nvec = rows_bytes / 16u;
 		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.d_rows);
 		u32x4 *dst = reinterpret_cast<u32x4 *>(smem);
-		if constexpr (SWZ)
+		// SWZ: the rows land rotated within their block of 16 (one_frame / fetch_frame read them back the same way): the image in
+		// global memory is the plain one, shared by plans of every increment; the rotation that suits THIS increment is the
+		// plan's (cr_poly_pick_swizzle)
+		auto place = [&](unsigned r) { return SWZ ? ((r & ~15u) | ((__umul24(r >> 4, a.swizzle) + r) & 15u)) : r; };
+		if constexpr (SWZ && (ASM & 0xFF) != 2)
 		{
-			// the rows land rotated within their block of 16 (one_frame / fetch_frame read them back the same way): the image in
-			// global memory is the plain one, shared by plans of every increment; the rotation that suits THIS increment is the
-			// plan's (cr_poly_pick_swizzle)
 			const unsigned planes = a.row_stride / 4u;
 			for (unsigned q = 0; q < planes; ++q)
 				for (unsigned r = tid; r < a.plane_rows; r += NTHREADS)
-					dst[q * a.plane_rows + ((r & ~15u) | ((__umul24(r >> 4, a.swizzle) + r) & 15u))] = src[q * a.plane_rows + r];
+					dst[q * a.plane_rows + place(r)] = src[q * a.plane_rows + r];
 		}
 		else if constexpr ((ASM & 0xFF) == 2)
 		{
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 					{
 						const unsigned r = tid + (unsigned)k * NTHREADS;
 						if (r < a.plane_rows)
-							dst[(unsigned)q * a.plane_rows + r] = staged(v[q][k], q);
+							dst[(unsigned)q * a.plane_rows + place(r)] = staged(v[q][k], q);
 					}
 			}
 			else
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 				const unsigned planes = a.row_stride / 4u;
 				for (unsigned q = 0; q < planes; ++q)
 					for (unsigned r = tid; r < a.plane_rows; r += NTHREADS)
-						dst[q * a.plane_rows + r] = staged(src[q * a.plane_rows + r], (int)q);
+						dst[q * a.plane_rows + place(r)] = staged(src[q * a.plane_rows + r], (int)q);
 			}
 		}
 		else

@@ -24,7 +24,7 @@ for rates in [(a, b, a) for a, b in RATES]:
     n_out = api.CountOutputFrames(st0, frames)
     sets = [(device_noise((frames + 2 * R) * ch, -R * ch + k * 977, dev), torch.empty(n_out * ch, dtype=torch.int32, device=dev)) for k in range(3)]
     row = []
-    for variant in (27, 30, 13, 0xFFFF):
+    for variant in (27, 30, 13, 28, 0xFFFF):
         api.DebugSetVariant(variant)
         plan = api.PlanCreate(st0, pre)
         took = api.PlanGetInfo(plan)

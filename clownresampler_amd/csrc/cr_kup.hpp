@@ -537,6 +537,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 						const int slot = 4 * q + j;
 						if (slot < TT)
 							e[j] = ((NEGMASK >> slot) & 1u) ? -2 * e[j] : 2 * e[j];
+						else if (slot == TT && NORM == CRHIP_NORM_U32)
+							e[j] = 2 * e[j];   // the reciprocal, doubled: see the normalisation in `one`
 					}
 					u32x4 w;
 					w.x = (unsigned)e[0];
@@ -658,9 +660,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 		unsigned g = 65536u - ((frac0 + __umul24(k0, a.increment)) & 0xFFFFu);
 		unsigned stage_at = k0 * UNIT;   // byte offset of the lane's current frame in the staging buffer
 
+		typedef __attribute__((address_space(3))) i32x4 lds_i32x4;
+		const unsigned smem_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)smem);
+		int thirty_one = 31;
+		asm volatile("" : "+v"(thirty_one));   // (a register: SDWA takes no literal shift amount)
+
 		auto read_row = [&](unsigned gg, int (&w)[RS]) {
-			const unsigned at = (gg >> 2) & 0x7FF0u;   // (a prefetch past the lane's last frame stays inside the image)
-			const i32x4 *plane0 = reinterpret_cast<const i32x4 *>(smem + at);
+			// (a prefetch past the lane's last frame stays inside the image; bit-field extract + shift-add: one instruction fewer than
+			// shift, mask and the add of the segment's base)
+			unsigned row;
+			asm("v_bfe_u32 %0, %1, 6, 11" : "=v"(row) : "v"(gg));   // (asm: hipcc turns the builtin back into shift + mask)
+			const unsigned at = (row << 4) + smem_base;
+			const lds_i32x4 *plane0 = (const lds_i32x4 *)(uintptr_t)at;
 #pragma unroll
 			for (int q = 0; q < RS / 4; ++q)
 			{
@@ -693,11 +704,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 			int out0, out1;
 			if constexpr (NORM == CRHIP_NORM_U32)
 			{
-				// (acc * reciprocal) / 32768 with C truncation: 64-bit product + 0x7FFF where negative, arithmetic shift by 15
-				const long long v0 = (long long)hi0 * (long long)w[TT] + (long long)((unsigned)(hi0 >> 31) >> 17);
-				const long long v1 = (long long)hi1 * (long long)w[TT] + (long long)((unsigned)(hi1 >> 31) >> 17);
-				out0 = (int)(v0 >> 15);
-				out1 = (int)(v1 >> 15);
+				// (acc * reciprocal) / 32768 with C truncation (clownresampler.h:1033).  With p = acc * reciprocal that is
+				// floor((2p + (p < 0 ? 65535 : 0)) / 65536): for p = -32768 q - r (0 <= r < 32768) the numerator is -65536 q + (65535 - 2r)
+				// with 0 <= 65535 - 2r < 65536.  The rows carry 2 * reciprocal (staged so above), the 65535 is ONE instruction - the
+				// sign shift written to the low word of a zero-padded register - and the 64-bit multiply-add and a funnel shift finish:
+				// 3 VALU per channel (it was 4 with the 0x7FFF / shift-by-15 form).
+				unsigned b0, b1;
+				asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(b0) : "v"(thirty_one), "v"(hi0));
+				asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(b1) : "v"(thirty_one), "v"(hi1));
+				const long long v0 = (long long)hi0 * (long long)w[TT] + (long long)b0;
+				const long long v1 = (long long)hi1 * (long long)w[TT] + (long long)b1;
+				out0 = (int)(v0 >> 16);
+				out1 = (int)(v1 >> 16);
 			}
 			else
 			{

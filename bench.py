@@ -79,6 +79,8 @@ WORKLOADS = {
     "up8x4": (3, 4, (12000, 96000, 12000), 3600000),
     "up16xm": (3, 1, (12000, 192000, 12000), 3600000),
     "up16x6": (3, 6, (12000, 192000, 12000), 1200000),
+    "up8x3": (3, 3, (12000, 96000, 12000), 3600000),
+    "up16x8": (3, 8, (12000, 192000, 12000), 900000),
     "up4": (3, 4, (44100, 48000, 44100), 26460000),    # 10 minutes of 4 / 6 / 8 channels, 3 lobes, both directions (tuning only)
     "up6": (3, 6, (44100, 48000, 44100), 26460000),
     "up8": (3, 8, (44100, 48000, 44100), 26460000),

@@ -318,6 +318,9 @@ struct Frame
 
 // N consecutive MONO frames (int16) starting at p, packed two per dword: pw[k] = frames 2k (low word) and 2k + 1 (high word).
 // Aligned dword reads + one funnel shift per dword (see Frame); pw must have (N + 1) / 2 elements.
+// (Written as one 16-bit read per frame instead, hipcc merges them into ds_read_b64 / b128 at the window's 2-byte alignment - gfx950
+// takes unaligned DS accesses - and saves the six VALU instructions of the alignment; measured TWICE as slow: mono 44.1 -> 48 kHz
+// 77 -> 157 us, 48 -> 44.1 kHz 91 -> 134 us, profiles/r02_mono_unaligned_window.log.)
 template <int N>
 __device__ __forceinline__ void load_mono_window(const unsigned char *p, int *pw)
 {

@@ -77,6 +77,7 @@ struct special
 	uint32_t lite_variant;      // lite instances with a chain: the variant id (geometry) of their SDWA form, which explicit k_poly variants resolve to
 	uint32_t mad_frames;        // frames in flight per lane of the chain kernels (k_poly's U): 1 or 2
 	poly_fn mad_rotated[2], mad16_rotated;   // the chain kernels with their rows rotated in LDS (SWZ): taken by launches whose plan asks for a rotation
+	poly_fn fn_rotated, fn16_rotated;        // lite instances (pure upsampling, short windows): their one k_poly with rotated rows, likewise
 };
 
 constexpr uint32_t MAD_VARIANT = 28;    // variant ids 28, 29
@@ -206,6 +207,12 @@ special make_special_lite()
 	for (int v = 0; v < VARIANTS; ++v)
 		s.fn[v] = fn;
 	s.fn16 = instance<CH, TT, MODE, NORM, DV % 5, 1, (DV / 5) % 2, (DV / 10) % 2, 1>();
+	if constexpr (MODE == CRHIP_ROWMODE_UPSAMPLE && TT <= 8)
+	{
+		// (where the rows of neighbouring lanes collide in LDS - exactly 8x / 16x upsampling - see CHAIN instances above)
+		s.fn_rotated = instance<CH, TT, MODE, NORM, DV % 5, 1, (DV / 5) % 2, (DV / 10) % 2, 0, 1>();
+		s.fn16_rotated = instance<CH, TT, MODE, NORM, DV % 5, 1, (DV / 5) % 2, (DV / 10) % 2, 1, 1>();
+	}
 	return s;
 }
 

@@ -392,6 +392,8 @@ int crhip_poly_swizzled(uint32_t channels, uint32_t slots, uint32_t row_mode, ui
 	const uint32_t v = resolve_variant(sp, variant);
 	if (v == MAD_VARIANT || v == MAD_VARIANT + 1u)
 		return sp->mad_rotated[0] != nullptr ? 2 : 0;   // 2: has a rotated form beside the plain one - a rotation is the plan's choice
+	if (sp->lite && v < WAVE_VARIANT && sp->fn_rotated != nullptr)
+		return 2;
 	return v == WAVE2_VARIANT ? 1 : 0;
 }
 
@@ -599,6 +601,8 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 		fn = sp != nullptr ? sp->fn16 : pick_runtime_channels<1>(launch->channels, launch->row_mode, launch->norm_mode);
 	else
 		fn = sp != nullptr ? sp->fn[v] : pick_runtime_channels<0>(launch->channels, launch->row_mode, launch->norm_mode);
+	if (sp != nullptr && sp->lite && sp->fn_rotated != nullptr && launch->swizzle != 0)
+		fn = launch->out_s16 ? sp->fn16_rotated : sp->fn_rotated;
 
 	// debug: variant 1000 + k selects timing-only ablation k of the headline instance (results are wrong by design)
 	if (sp != nullptr && launch->variant >= 1000u && launch->variant < 1008u && launch->channels == 2 && launch->slots == 5)

@@ -326,12 +326,13 @@ def test_default_kernel_of_stereo_upsampling_by_ratio(products, radius, rates, k
     assert ran_out == 1 and left == 0 and np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("ch", [1, 2, 4, 6])
+@pytest.mark.parametrize("ch", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("rates", [(12000, 96000, 12000), (12000, 192000, 12000), (9000, 192000, 9000), (7500, 96000, 7500), (44100, 48000, 44100)])
-def test_chain_kernels_with_rotated_rows(products, ch, rates):
-    """The 64-bit-chain k_poly instances stage their rows ROTATED in LDS where the rows of neighbouring lanes would share a bank slot
-    (exactly 8x, 16x, 64/3 x, 12.8x: a different function from the plain form; 44.1 -> 48 kHz as the plain control): ragged lengths,
-    a second call from a fractional position, and the clamped int16 form, against the oracle."""
+def test_specialised_kernels_with_rotated_rows(products, ch, rates):
+    """The specialised 3-lobe upsampling instances of k_poly (64-bit chain: 1, 2, 4, 6 channels; SDWA: 3, 5, 7, 8) stage their rows
+    ROTATED in LDS where the rows of neighbouring lanes would share a bank slot (exactly 8x, 16x, 64/3 x, 12.8x: a different function
+    from the plain form; 44.1 -> 48 kHz as the plain control): ragged lengths, a second call from a fractional position, and the
+    clamped int16 form, against the oracle."""
     p, o = products[3], ck.oracle(3)
     for frames, first_call in [(1, 0), (4099, 0), (30011, 777), (250000, 0)]:
         pcm = ck.noise_pcm(frames * ch, 7 + frames)

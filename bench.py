@@ -87,6 +87,11 @@ WORKLOADS = {
     "dn4": (3, 4, (48000, 44100, 44100), 28800000),
     "dn6": (3, 6, (48000, 44100, 44100), 28800000),
     "up12": (3, 12, (44100, 48000, 44100), 26460000),
+    "dn6x": (3, 2, (48000, 8000, 8000), 57600000),     # stereo / mono 6:1 (increment exact in 16.16: every frame uses ONE row), 36-slot windows
+    "dn6xm": (3, 1, (48000, 8000, 8000), 115200000),
+    "dn8m": (3, 1, (44100, 8000, 8000), 52920000),
+    "dn4x": (3, 2, (48000, 12000, 12000), 57600000),   # stereo 4:1, 24-slot windows
+    "dn21m": (3, 1, (96000, 48000, 48000), 115200000),
 }
 CONFIG_NAMES = {"cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2]", "cfg4": "BASELINE configs[3]", "cfg5": "BASELINE configs[4]"}
 
@@ -169,18 +174,108 @@ def cpu_baseline(radius, ch, rates, frames, max_seconds=30.0):
     return res
 
 
-def pmc_summary(workload):
-    """Per-dispatch PMC means committed under profiles/ for this workload (latest round first): (dict, file name) or (None, None)."""
-    for rnd in ("r02", "r01"):
+def pmc_summary(workload, build_id):
+    """Per-dispatch PMC means committed under profiles/ for this workload, latest round first: (dict, file name, note).  A summary
+    is quoted only when it is STAMPED with the source id of the library that is loaded now (tools/pmc_passes.sh writes
+    ClownResamplerAMD_BuildId() into it): counters of another build say nothing about this one's kernels."""
+    stale = None
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.txt" % (rnd, workload))
         if os.path.exists(path):
-            vals = {}
+            vals, stamp = {}, None
             for ln in open(path):
                 f = ln.split()
                 if len(f) > 3 and f[1] == "per-dispatch":
                     vals[f[0]] = float(f[3])
-            return vals, os.path.basename(path)
-    return None, None
+                elif len(f) == 2 and f[0] == "library_source_id":
+                    stamp = f[1]
+            if stamp == build_id:
+                return vals, os.path.basename(path), None
+            stale = stale or "profiles/%s is of library build %s, the loaded library is %s: its counters are not quoted" % (os.path.basename(path), stamp or "(unstamped)", build_id)
+    return None, None, stale or "no PMC summary for this workload under profiles/"
+
+
+def host_pcm(frames, ch, R, seed=12345):
+    """Full-scale white int16 PCM in HOST memory, R zero frames of padding each side (clownresampler.h:725-733)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    pcm = np.zeros((frames + 2 * R) * ch, dtype=np.int16)
+    pcm[R * ch:(R + frames) * ch] = rng.integers(-32768, 32768, size=frames * ch, dtype=np.int16)
+    return pcm
+
+
+def end_to_end(api, pre, radius, ch, rates, frames, check=True):
+    """"separately report end-to-end (H2D + kernel + D2H)".  ONE ClownResampler_LowLevel_ResampleBulk over the whole
+    workload from HOST memory - upload, kernel, download, synchronise: what a client of the host-pointer entry point gets.
+    Pageable numpy buffers (first call: the runtime pins the ranges; then warm), and registered (pinned) ones.  Never `value`."""
+    import numpy as np
+    import torch
+    import clownresampler_amd as cr
+    fresh = api.LowLevel_State()
+    assert api.LowLevel_Init(fresh, ch, *rates)
+    R = fresh.lowest_level.integer_stretched_kernel_radius
+    n_out = int(api.CountOutputFrames(fresh, frames))
+    pcm = host_pcm(frames, ch, R)
+    out = np.zeros((n_out + 1) * ch, dtype=np.int32)   # pre-faulted
+
+    def once(src, dst):
+        st = cr.LowLevel_State.from_buffer_copy(fresh)
+        t0 = time.perf_counter()
+        got, left, ran_out = api.LowLevel_ResampleBulk(st, pre, src, frames, n_out + 1, output=dst)
+        dt = (time.perf_counter() - t0) * 1e3
+        assert got.size == n_out * ch and left == 0 and ran_out == 1
+        return dt
+
+    pageable = [once(pcm, out) for _ in range(4)]
+    pin_in = torch.empty(pcm.size, dtype=torch.int16).pin_memory()
+    pin_out = torch.empty(out.size, dtype=torch.int32).pin_memory()
+    pin_in.numpy()[:] = pcm
+    pinned = [once(pin_in.numpy(), pin_out.numpy()) for _ in range(4)]
+    same = bool(np.array_equal(pin_out.numpy()[: n_out * ch], out[: n_out * ch]))
+    res = {"call": "one ClownResampler_LowLevel_ResampleBulk, %d -> %d frames x %d ch, host int16 in / host int32 out (upload + kernel + download + synchronise)" % (frames, n_out, ch),
+           "pageable_first_ms": pageable[0], "pageable_ms": min(pageable[1:]), "pinned_ms": min(pinned[1:]),
+           "Msamples/s": {"pageable": n_out * ch / (min(pageable[1:]) * 1e-3) / 1e6, "pinned": n_out * ch / (min(pinned[1:]) * 1e-3) / 1e6},
+           "host_bytes": {"in": int(pcm.nbytes), "out": int(n_out * ch * 4)}, "pinned_equals_pageable": same}
+    if check:
+        import _checkers as ck
+        o = ck.oracle(radius)
+        ok, ost = o.low_init(ch, *rates)
+        n_chk = min(50000, n_out)
+        need = int(n_chk * fresh.increment / 65536) + 2 * R + 8
+        want, _, _ = o.low_resample_i32(ost, pcm[: (need + 2 * R) * ch], need, capacity=n_chk)
+        res["head_matches_oracle"] = bool(np.array_equal(out[: n_chk * ch], want[: n_chk * ch]))
+    return res, pcm, out, n_out
+
+
+def callback_api(api, pre, ch, rates, frames, pcm, expected, n_out):
+    """The reference's own signature: ClownResampler_LowLevel_Resample(state, table, host PCM, &frames, CALLBACK, user) with a C
+    callback that stores every frame as int32 (tools/cb_store.c - the callback the CPU baseline's reference leg uses)."""
+    import ctypes as C
+    import numpy as np
+    import clownresampler_amd as cr
+    path = os.path.join(ROOT, "tools", "bin", "libcr_cbstore.so")
+    if not os.path.exists(path):
+        return {"error": "tools/bin/libcr_cbstore.so not built (make -C clownresampler_amd/csrc tools)"}
+    lib = C.CDLL(path)
+
+    class Store(C.Structure):
+        _fields_ = [("out", C.POINTER(C.c_int)), ("at", C.c_size_t), ("capacity", C.c_size_t)]
+
+    out = np.zeros((n_out + 1) * ch, dtype=np.int32)
+    cb = C.cast(lib.cr_store_frame, cr.OutputCallback)
+    times = []
+    for _ in range(3):
+        st = api.LowLevel_State()
+        assert api.LowLevel_Init(st, ch, *rates)
+        store = Store(out.ctypes.data_as(C.POINTER(C.c_int)), 0, out.size)
+        left = C.c_size_t(frames)
+        t0 = time.perf_counter()
+        r = api._LowResample(C.byref(st), C.byref(pre), pcm.ctypes.data_as(C.POINTER(cr.cc_s16l)), C.byref(left), cb, C.cast(C.pointer(store), C.c_void_p))
+        times.append((time.perf_counter() - t0) * 1e3)
+        assert r and left.value == 0 and store.at == n_out * ch
+    return {"call": "ClownResampler_LowLevel_Resample with a C output callback storing int32, %d -> %d frames x %d ch from host memory" % (frames, n_out, ch),
+            "ms": min(times), "Msamples/s": n_out * ch / (min(times) * 1e-3) / 1e6,
+            "equals_bulk_output": bool(np.array_equal(out[: n_out * ch], expected[: n_out * ch]))}
 
 
 def percentile(sorted_values, q):
@@ -202,6 +297,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-host-paths", action="store_true", help="skip the end_to_end / callback_api measurements (N = 1; outside the timed region either way)")
     ap.add_argument("--s16", action="store_true", help="opt-in extension: clamped int16 output (NOT the BASELINE metric; writes 2 B per sample instead of 4)")
     ap.add_argument("--graph", action="store_true", help="time one hipGraph replay of the K steps instead of eager launches (measured SLOWER on ROCm 7.2 for this kernel)")
     args = ap.parse_args()
@@ -320,7 +416,7 @@ def main():
 
     # (1) The contract's timed region: EXACTLY K steps between one event pair on the launch stream, barrier + synchronize on
     #     both sides -> ms_per_step (mean of the K launches) and `value`.
-    # (2) A second region for the DISTRIBUTION: 10 blocks of K/10 more launches (at least 2 per block), an event between blocks
+    # (2) A second region for the DISTRIBUTION: 10 blocks of 20 more launches (fixed, whatever K is), an event between blocks
     #     -> median / min / p95 of the per-block mean launch time.  Not an event around every launch: an event record between
     #     two launches costs ~3 us of marker packet on this stack (measured: 67.6 us per launch with, 64.7 us without,
     #     profiles/r02_event_overhead.log), i.e. it would be measuring itself.
@@ -343,15 +439,19 @@ def main():
         for i in range(args.warmup):
             step(i)
     barrier()
+    counts_before = [api.LaunchCount(k) for k in range(6)]
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         run_steps()
     barrier()
     wall = time.perf_counter() - t0
+    launches_by_kernel = [api.LaunchCount(k) - counts_before[k] for k in range(6)]   # what the timed region ran (graph replays launch nothing new)
+    if graph is not None:
+        launches_by_kernel = [args.steps] * 6
     dev_ms = max(ev0.elapsed_time(ev1), 0.0)
     mean_ms = dev_ms / args.steps
 
-    blocks, block_len = 10, max(2, args.steps // 10)
+    blocks, block_len = 10, 20   # fixed, whatever --steps is: with the driver's --steps 20 a K/10 rule gave 2-launch blocks (+-10 %)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(blocks + 1)]
     with torch.cuda.stream(stream):
         marks[0].record(stream)
@@ -371,11 +471,16 @@ def main():
     launch_bytes = shard.input_frames * ch * 2 + shard.output_frames * ch * (2 if args.s16 else 4)
     achieved = launch_bytes / (mean_ms * 1e-3) / 1e9
     # (a k_up plan sends launches of fewer than brief_below output frames to its other kernel)
-    ran = info.brief_kernel if (info.kernel == 3 and shard.output_frames < info.brief_below) else info.kernel
+    shard_state = cr.LowLevel_State.from_buffer_copy(shard.state)
+    ran = api.PlanKernelAt(plan, shard_state.position_fractional)   # (5 = k_int: whole-number ratios, decided per launch by its fraction)
+    if ran != 5:
+        ran = info.brief_kernel if (info.kernel == 3 and shard.output_frames < info.brief_below) else info.kernel
     kernel_name = {1: "k_poly<%d,%d>", 2: "k_wave<%d,%d>", 3: "k_up2<%d,%d>" if (info.variant == 27 and ch == 2) else "k_up<%d,%d>",
-                   4: "k_wave2<%d,%d>"}[ran] % (ch, info.slots) if ran else "k_generic"
-    traffic, traffic_note = None, "no PMC summary for this workload under profiles/"
-    pmc, pmc_file = pmc_summary(workload) if (world == 1 and not args.s16) else (None, None)
+                   4: "k_wave2<%d,%d>", 5: "k_int<%d,%d>"}[ran] % (ch, info.slots) if ran else "k_generic"
+    if launches_by_kernel[ran] < args.steps:
+        raise SystemExit("bench: expected the timed launches on kernel %d (%s); launch counters say %s" % (ran, kernel_name, launches_by_kernel))
+    pmc, pmc_file, traffic_note = pmc_summary(workload, api.BuildId()) if (world == 1 and not args.s16) else (None, None, "N > 1 / int16 output: no PMC summary applies")
+    traffic = None
     if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         # KiB units; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads: x2 (MI355X_MICROARCH.md, HBM)
         traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
@@ -522,6 +627,15 @@ def main():
                 "%s; VALIDATION ONLY: %d ranks share %d GPU(s), timings are those of ranks contending for a GPU" % (backend, world, n_dev)
         if gather:
             line["gather"] = gather
+        if world == 1 and not args.no_host_paths and not args.s16:
+            # what a client of the reference's host-pointer signatures gets, measured after and outside the timed region
+            try:
+                e2e, pcm_h, out_h, n_out_h = end_to_end(api, pre, radius, ch, rates, min(frames, 28800000), check=not args.no_check)
+                line["end_to_end"] = e2e
+                line["callback_api"] = callback_api(api, pre, ch, rates, min(frames, 28800000), pcm_h, out_h, n_out_h)
+                del pcm_h, out_h
+            except Exception as e:   # these are reports beside the metric: a failure here must not cost the run its line
+                line["end_to_end"] = {"error": str(e)[:300]}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(radius, ch, rates, frames)
         print(json.dumps(line), flush=True)

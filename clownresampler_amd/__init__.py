@@ -195,6 +195,10 @@ class Api:
         self._SetThreadDevice = fn("ClownResamplerAMD_SetThreadDevice", C.c_int, [C.c_int], False)
         self._GetDevice = fn("ClownResamplerAMD_GetDevice", C.c_int, [], False)
         self._ReserveCapture = fn("ClownResamplerAMD_ReserveCaptureLaunches", C.c_int, [C.c_size_t], False)
+        self._ReleaseCaptured = fn("ClownResamplerAMD_ReleaseCapturedLaunches", C.c_int, [], False)
+        self._PlanKernelAt = fn("ClownResamplerAMD_PlanKernelAt", C.c_uint32, [C.c_void_p, C.c_uint32], False)
+        self._LaunchCount = fn("ClownResamplerAMD_DebugLaunchCount", C.c_ulonglong, [C.c_uint], False)
+        self._BuildId = fn("ClownResamplerAMD_BuildId", C.c_char_p, [], False)
         self._HighRelease = fn("ClownResamplerAMD_HighLevel_Release", None, [P(HighLevel_State)], False)
         self._WindowCount = fn("ClownResamplerAMD_StreamingWindowCount", C.c_size_t, [], False)
         self._DeviceAllocOn = fn("ClownResamplerAMD_DeviceAllocOn", C.c_void_p, [C.c_int, C.c_size_t], False)
@@ -404,6 +408,21 @@ class Api:
 
     def ReserveCaptureLaunches(self, launches):
         r = self._ReserveCapture(launches)
+        _raise_if_failed(self.lib)
+        return r
+
+    def PlanKernelAt(self, plan, position_fractional=0):
+        """kernel id a launch from this fractional position takes (PlanInfo.kernel numbering, 5 = k_int)"""
+        return int(self._PlanKernelAt(plan, position_fractional))
+
+    def BuildId(self):
+        return self._BuildId().decode()
+
+    def LaunchCount(self, kernel):
+        return int(self._LaunchCount(kernel))
+
+    def ReleaseCapturedLaunches(self):
+        r = self._ReleaseCaptured()
         _raise_if_failed(self.lib)
         return r
 

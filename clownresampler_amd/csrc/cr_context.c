@@ -120,6 +120,8 @@ typedef struct cr_ring
 	uint32_t *blocks;            /* CR_RING_SLOTS blocks of CRHIP_TICKET_WORDS, device memory */
 	int used;
 	unsigned next;
+	unsigned pending;            /* launches that have drawn a block of this ring and are not enqueued yet: hipStreamQuery
+	                                cannot see them, so a ring with any is never taken over */
 	unsigned long long last_use;
 } cr_ring;
 
@@ -137,6 +139,7 @@ typedef struct cr_device_ctx
 	unsigned capture_chunk_count;
 	uint32_t *capture_at;        /* next unused block of the newest chunk */
 	size_t capture_left;         /* blocks left in it */
+	size_t capture_first_blocks; /* size of chunk 0 (ClownResamplerAMD_ReleaseCapturedLaunches rewinds to it) */
 	/* staging (host-buffer entry points) */
 	pthread_mutex_t workspace_lock;
 	cr_workspace workspace;
@@ -154,6 +157,10 @@ static size_t g_plan_limit = 64;   /* unpinned plans kept; ClownResamplerAMD_Set
 static int g_force_generic = 0;
 static unsigned long long *g_debug_stamps = NULL;
 static int g_variant = -1; /* -1: CLOWNRESAMPLER_AMD_VARIANT from the environment, else the default */
+/* launches enqueued so far, by kernel (numbered as ClownResamplerAMD_PlanInfo.kernel; 5 = k_int): what tests and bench.py
+   assert "the kernel I mean is the one that ran" with (ClownResamplerAMD_DebugLaunchCount) */
+#define CR_KERNEL_IDS 6
+static unsigned long long g_launch_count[CR_KERNEL_IDS];
 
 /* Where a plan WITHOUT a specialised instance runs the run-time-slot k_wave2 instead of the run-time-slot k_poly.  Measured on
    one box per pair, tools/channel_table.py with CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS=999 as the "off" leg
@@ -184,6 +191,7 @@ static struct
 	int loaded;
 	int dynamic_tiles;          /* CLOWNRESAMPLER_AMD_DYNAMIC_TILES: -1 unset, else 0 / 1 */
 	int no_special, debug, no_occupancy_clamp, tile_groups, no_host_pipeline, no_small_call_path;
+	int no_int_kernel;          /* CLOWNRESAMPLER_AMD_NO_INT_KERNEL: whole-number ratios take the plan's ordinary kernel (the A/B leg) */
 	int rt_wave2_min_slots;     /* CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS: windows from this many slots on take the run-time-slot k_wave2 */
 	double rotate_min_gain;     /* CLOWNRESAMPLER_AMD_ROTATE_MIN_GAIN: see plan_pick_rotation */
 	int brief_half_tiles;       /* CLOWNRESAMPLER_AMD_BRIEF_HALF_TILES: k_up launches of fewer half wave-tiles per wave take the plan's other kernel (0: none do; unset: per instance) */
@@ -203,6 +211,7 @@ static void load_env(void)
 	g_env.tile_groups = (e != NULL && atoi(e) > 0) ? atoi(e) : 0;
 	g_env.no_host_pipeline = getenv("CLOWNRESAMPLER_AMD_NO_HOST_PIPELINE") != NULL;
 	g_env.no_small_call_path = getenv("CLOWNRESAMPLER_AMD_NO_SMALL_CALL_PATH") != NULL;
+	g_env.no_int_kernel = getenv("CLOWNRESAMPLER_AMD_NO_INT_KERNEL") != NULL;
 	e = getenv("CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS");
 	g_env.rt_wave2_min_slots = (e != NULL && atoi(e) > 0) ? atoi(e) : CR_RT_WAVE2_MIN_SLOTS;
 	e = getenv("CLOWNRESAMPLER_AMD_ROTATE_MIN_GAIN");
@@ -284,6 +293,8 @@ static int capture_pool_grow(cr_device_ctx *ctx, size_t blocks)
 		crhip_free(chunk);
 		return -1;
 	}
+	if (ctx->capture_chunk_count == 0)
+		ctx->capture_first_blocks = blocks;
 	ctx->capture_chunks[ctx->capture_chunk_count++] = chunk;
 	ctx->capture_at = chunk;      /* (what was left of the previous chunk is abandoned: blocks are never handed out twice) */
 	ctx->capture_left = blocks;
@@ -332,7 +343,7 @@ static cr_device_ctx *ensure_ctx_locked(int ordinal)
 		ctx->ordinal = ordinal;
 		pthread_mutex_init(&ctx->ring_lock, NULL);
 		pthread_mutex_init(&ctx->workspace_lock, NULL);
-		g_ctx[ordinal] = ctx;
+		__atomic_store_n(&g_ctx[ordinal], ctx, __ATOMIC_RELEASE);
 	}
 
 	if (cr_check_hip(crhip_get_device_info(ordinal, &ctx->info), "hipGetDeviceProperties") != 0)
@@ -343,7 +354,9 @@ static cr_device_ctx *ensure_ctx_locked(int ordinal)
 	if (ctx->capture_chunk_count == 0 && capture_pool_grow(ctx, CR_CAPTURE_BLOCKS_DEFAULT) != 0)
 		return NULL;
 
-	ctx->ready = 1;
+	/* published last, with release semantics: the lock-free fast path of ensure_ctx reads it with an acquire load and must then
+	   see the rings, the capture pool and `info` complete */
+	__atomic_store_n(&ctx->ready, 1, __ATOMIC_RELEASE);
 	return ctx;
 }
 
@@ -380,11 +393,15 @@ int cr_current_device(void)
 	return current_device();
 }
 
-static uint32_t *ticket_block_for(cr_device_ctx *ctx, void *stream)
+/* *ring_out: the ring the block came from (its `pending` has been raised: ticket_block_enqueued() once the launch is in the
+   stream's queue, whether or not it succeeded), or -1 for a block of the capture pool */
+static uint32_t *ticket_block_for(cr_device_ctx *ctx, void *stream, int *ring_out)
 {
 	unsigned r, pick;
 	uint32_t *block = NULL;
 	int capturing = 0;
+
+	*ring_out = -1;
 
 	if (stream != NULL && crhip_stream_is_capturing(stream, &capturing) != 0)
 		capturing = 0;
@@ -425,11 +442,22 @@ static uint32_t *ticket_block_for(cr_device_ctx *ctx, void *stream)
 		unsigned long long oldest = ~0ull;
 
 		for (r = 0; r < ctx->ring_count; ++r)
-			if (ctx->rings[r].last_use < oldest && crhip_stream_busy(ctx->rings[r].stream) == 0)
+		{
+			int other_capturing = 0;
+
+			/* not a ring some thread has drawn from without having enqueued its launch yet (the stream still reads idle), and
+			   not one whose stream is recording a graph (hipStreamQuery is not allowed on a capturing stream and would
+			   invalidate the capture) */
+			if (ctx->rings[r].pending != 0 || ctx->rings[r].last_use >= oldest)
+				continue;
+			if (ctx->rings[r].stream != NULL && crhip_stream_is_capturing(ctx->rings[r].stream, &other_capturing) == 0 && other_capturing)
+				continue;
+			if (crhip_stream_busy(ctx->rings[r].stream) == 0)
 			{
 				oldest = ctx->rings[r].last_use;
 				pick = r;
 			}
+		}
 
 		if (pick == ctx->ring_count)
 		{
@@ -445,14 +473,27 @@ static uint32_t *ticket_block_for(cr_device_ctx *ctx, void *stream)
 
 	if (!ctx->rings[pick].used)
 	{
+		/* (`next` goes on from where the previous owner left it: the new owner's first launch does not land on the slot the
+		   old owner's first launches used) */
 		ctx->rings[pick].used = 1;
 		ctx->rings[pick].stream = stream;
-		ctx->rings[pick].next = 0;
 	}
 	ctx->rings[pick].last_use = ++ctx->ring_clock;
+	++ctx->rings[pick].pending;
+	*ring_out = (int)pick;
 	block = ctx->rings[pick].blocks + (size_t)CRHIP_TICKET_WORDS * (ctx->rings[pick].next++ % CR_RING_SLOTS);
 	pthread_mutex_unlock(&ctx->ring_lock);
 	return block;
+}
+
+static void ticket_block_enqueued(cr_device_ctx *ctx, int ring)
+{
+	if (ring < 0)
+		return;
+	pthread_mutex_lock(&ctx->ring_lock);
+	if ((unsigned)ring < ctx->ring_count && ctx->rings[ring].pending != 0)
+		--ctx->rings[ring].pending;
+	pthread_mutex_unlock(&ctx->ring_lock);
 }
 
 int ClownResamplerAMD_ReserveCaptureLaunches(size_t launches)
@@ -467,6 +508,33 @@ int ClownResamplerAMD_ReserveCaptureLaunches(size_t launches)
 		r = capture_pool_grow(ctx, launches);
 	pthread_mutex_unlock(&ctx->ring_lock);
 	return r != 0 ? -1 : 0;
+}
+
+/* The other end of the capture pool: a client that re-captures graphs over time says when the old ones are gone.
+   Every block handed out to a captured launch on the current device becomes available again: the pool rewinds to its first
+   chunk (zeroed again - a graph destroyed mid-flight could have left counters behind) and the later chunks are freed. */
+int ClownResamplerAMD_ReleaseCapturedLaunches(void)
+{
+	cr_device_ctx *ctx = ensure_ctx(current_device());
+	int r = 0;
+
+	if (ctx == NULL)
+		return -1;
+	pthread_mutex_lock(&ctx->ring_lock);
+	if (ctx->capture_chunk_count != 0)
+	{
+		const size_t bytes = ctx->capture_first_blocks * CRHIP_TICKET_WORDS * sizeof(uint32_t);
+
+		while (ctx->capture_chunk_count > 1u)
+			crhip_free(ctx->capture_chunks[--ctx->capture_chunk_count]);   /* (hipFree waits for work that still uses it) */
+		if (cr_check_hip(crhip_memset(ctx->capture_chunks[0], 0, bytes, NULL), "hipMemset(capture tickets)") != 0
+		 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
+			r = -1;
+		ctx->capture_at = ctx->capture_chunks[0];
+		ctx->capture_left = ctx->capture_first_blocks;
+	}
+	pthread_mutex_unlock(&ctx->ring_lock);
+	return r;
 }
 
 const crhip_device_info *cr_device_info(void)
@@ -1136,6 +1204,58 @@ static void plan_brief_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *p
 	plan->brief.below = (uint64_t)half_tiles * (plan->tile_frames / 4u) * plan->max_blocks * (plan->threads / 64u) / 2u;
 }
 
+/* k_int beside the plan's ordinary kernel: see the plan's `intk`. */
+static void plan_int_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan)
+{
+	int per_cu = 0, per_cu_s16 = 0;
+	const uint32_t cus = (uint32_t)(ctx->info.compute_units > 0 ? ctx->info.compute_units : 256);
+
+	plan->intk.available = 0;
+	if (g_env.no_int_kernel || !plan->use_poly || plan->increment == 0 || (plan->increment & 0xFFFFu) != 0 || (plan->increment >> 16) > 64u
+	 || plan->poly.row_mode != CRHIP_ROWMODE_AFFINE || plan->poly.slots > CRHIP_INT_MAX_SLOTS
+	 || plan->key_variant != (uint32_t)CR_DEFAULT_VARIANT)
+		return;
+	plan->intk.ratio = (uint32_t)(plan->increment >> 16);
+	if (!crhip_int_instance(plan->channels, plan->intk.ratio, plan->poly.slots, &plan->intk.shape))
+		return;
+	if (crhip_int_prepare(plan->channels, plan->intk.ratio, plan->poly.slots, &per_cu, &per_cu_s16) != 0 || per_cu < 1 || per_cu_s16 < 1)
+		return;   /* (the plan works without) */
+	plan->intk.max_blocks = (uint32_t)per_cu * cus;
+	plan->intk.max_blocks_s16 = (uint32_t)per_cu_s16 * cus;
+	plan->intk.available = 1;
+	if (g_env.debug)
+		fprintf(stderr, "clownresampler_amd: plan %u ch, ratio %u:1, %u slots: k_int with %u frames per lane, %d workgroups of %u threads per CU\n",
+		        plan->channels, plan->intk.ratio, plan->poly.slots, plan->intk.shape.frames_per_lane, per_cu, plan->intk.shape.threads);
+}
+
+/* The staged row of a k_int launch at this fractional position, or 0 when the row does not have the instance's slot classes. */
+static int int_launch_row(const ClownResamplerAMD_Plan *plan, uint32_t frac, crhip_int_launch *l, uint32_t *first_slot)
+{
+	const cr_poly *poly = &plan->poly;
+	const uint32_t row = cr_poly_row_of(poly, frac);
+	const uint32_t mr = (frac + poly->delta + 65535u) >> 16;
+	const int32_t *w;
+	uint32_t s;
+
+	if (row >= poly->rows || poly->weights == NULL)
+		return 0;
+	w = poly->weights + (size_t)row * poly->row_stride;
+	for (s = 0; s < poly->slots; ++s)
+	{
+		const int negative = (int)((plan->intk.shape.negmask >> s) & 1u);
+		const int safe = (int)((plan->intk.shape.safemask >> s) & 1u);
+		const int64_t magnitude = negative ? -(int64_t)w[s] : (int64_t)w[s];
+
+		if (magnitude < 0 || magnitude > 65536 || (!safe && magnitude == 65536))
+			return 0;
+		l->w[s] = safe ? (int32_t)magnitude : (int32_t)((uint32_t)magnitude << 15);
+	}
+	l->reciprocal = w[poly->slots];
+	/* the frame slot 0 multiplies: as row_of / fetch_frame on the device (shifted rows start at their own phase's first tap) */
+	*first_slot = poly->first_slot + (poly->shifted ? mr - poly->first_mr : 0u);
+	return 1;
+}
+
 ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t table_len, cr_table_fill fill_table, const void *user,
                                        unsigned radius, const cr_config *cfg, uint32_t channels, uint64_t increment, int pin)
 {
@@ -1316,6 +1436,7 @@ ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t t
 		if (plan_prepare(ctx, plan) != 0)
 			goto fail_plan;
 		plan_brief_shape(ctx, plan);
+		plan_int_shape(ctx, plan);
 	}
 
 	free(table);
@@ -1374,6 +1495,36 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 {
 	if (n_out == 0)
 		return 0;
+
+	if (plan->use_poly && !g_force_generic && plan->intk.available && pos_int < (1ull << 47) && n_out < (1ull << 40))
+	{
+		/* a whole-number ratio: k_int, if the row this launch's fraction selects has the instance's slot classes */
+		crhip_int_launch il;
+		uint32_t first_slot = 0;
+
+		memset(&il, 0, sizeof(il));
+		if (int_launch_row(plan, (uint32_t)pos_frac, &il, &first_slot))
+		{
+			const uint64_t tile = 64ull * plan->intk.shape.frames_per_lane;
+			const uint64_t waves = (n_out + tile - 1) / tile;
+			const uint32_t waves_per_block = plan->intk.shape.threads / 64u;
+			const uint32_t cap = out_s16 ? plan->intk.max_blocks_s16 : plan->intk.max_blocks;
+			uint64_t blocks = (waves + waves_per_block - 1) / waves_per_block;
+
+			il.d_in = d_in;
+			il.in_valid_bytes = in_valid_bytes;
+			il.d_out = d_out;
+			il.first_frame = pos_int + first_slot;
+			il.n_out = n_out;
+			il.channels = plan->channels;
+			il.ratio = plan->intk.ratio;
+			il.slots = plan->poly.slots;
+			il.out_s16 = out_s16 ? 1u : 0u;
+			il.blocks = (uint32_t)(blocks > cap ? cap : blocks);
+			__atomic_fetch_add(&g_launch_count[5], 1ull, __ATOMIC_RELAXED);
+			return cr_check_hip(crhip_launch_int(&il, stream), "k_int launch");
+		}
+	}
 
 	if (plan->use_poly && !g_force_generic && pos_int < (1ull << 47) && n_out < (1ull << 40))
 	{
@@ -1439,11 +1590,17 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			 && (n_out + l.tile_frames - 1) / l.tile_frames >= 48ull * max_blocks)
 				l.dynamic_tiles = 1u;
 		}
-		l.d_tickets = ticket_block_for(g_ctx[plan->device], stream);
-		if (l.d_tickets == NULL)
-			return -1;
+		{
+			int ring, e;
 
-		return cr_check_hip(crhip_launch_poly(&l, stream), "k_poly launch");
+			l.d_tickets = ticket_block_for(g_ctx[plan->device], stream, &ring);
+			if (l.d_tickets == NULL)
+				return -1;
+			e = crhip_launch_poly(&l, stream);
+			ticket_block_enqueued(g_ctx[plan->device], ring);
+			__atomic_fetch_add(&g_launch_count[vecs >= 200u ? 3 : vecs >= 150u ? 4 : vecs >= 100u ? 2 : 1], 1ull, __ATOMIC_RELAXED);
+			return cr_check_hip(e, "k_poly launch");
+		}
 	}
 	else
 	{
@@ -1466,6 +1623,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		g.channels = plan->channels;
 		g.out64 = out_s16 ? 2u : 0u;
 
+		__atomic_fetch_add(&g_launch_count[0], 1ull, __ATOMIC_RELAXED);
 		return cr_check_hip(crhip_launch_generic(&g, stream), "k_generic launch");
 	}
 }
@@ -1852,6 +2010,23 @@ void ClownResamplerAMD_PlanGetInfo(const ClownResamplerAMD_Plan *plan, ClownResa
 		info->brief_variant = plan->brief.variant;
 		info->brief_below = plan->brief.below;
 	}
+}
+
+unsigned long long ClownResamplerAMD_DebugLaunchCount(unsigned kernel)
+{
+	return kernel < CR_KERNEL_IDS ? __atomic_load_n(&g_launch_count[kernel], __ATOMIC_RELAXED) : 0ull;
+}
+
+uint32_t ClownResamplerAMD_PlanKernelAt(const ClownResamplerAMD_Plan *plan, uint32_t position_fractional)
+{
+	ClownResamplerAMD_PlanInfo info;
+	crhip_int_launch il;
+	uint32_t first_slot;
+
+	if (plan->use_poly && !g_force_generic && plan->intk.available && int_launch_row(plan, position_fractional & 0xFFFFu, &il, &first_slot))
+		return 5u;
+	ClownResamplerAMD_PlanGetInfo(plan, &info);
+	return g_force_generic ? 0u : info.kernel;
 }
 
 const int32_t *ClownResamplerAMD_PlanRows(const ClownResamplerAMD_Plan *plan)

@@ -83,6 +83,16 @@ typedef struct ClownResamplerAMD_Plan
 		uint64_t below;
 		uint32_t threads, vecs, tile_frames, lds_bytes, max_blocks, max_blocks_s16, variant, lds_swizzle;
 	} brief;
+	/* whole-number downsampling ratios (increment = ratio << 16): k_int (cr_kint.hpp) where there is an instance for
+	   (channels, ratio, slots).  Whether a LAUNCH takes it depends on its fractional position - the row that fraction selects
+	   must have the instance's slot signs (cr_plan_launch checks; a stream that starts from Init stays at fraction 0). */
+	struct
+	{
+		int available;
+		uint32_t ratio;
+		crhip_int_shape shape;
+		uint32_t max_blocks, max_blocks_s16;
+	} intk;
 } ClownResamplerAMD_Plan;
 
 /* Cache lookup by (hash of the caller's raw table bytes, radius, configuration, channels, increment); on a miss

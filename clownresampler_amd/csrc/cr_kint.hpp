@@ -1,0 +1,315 @@
+// cr_kint.hpp - k_int: the input-stationary kernel for WHOLE-NUMBER downsampling ratios (2:1, 3:1, 4:1, 6:1 ...).
+#ifndef CR_KINT_HPP
+#define CR_KINT_HPP
+
+#include "cr_device.hpp"
+#include "cr_kup.hpp"   // wait_vmcnt_at_most
+
+namespace
+{
+
+// compile-time loop: body(std::integral_constant<int, i>) for i in [0, N) - every index a constant expression, whatever hipcc's
+// unrolling thresholds think of a 432-tap body (left to `#pragma unroll` the accumulator arrays went to scratch)
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&body, std::integer_sequence<int, I...>)
+{
+	(body(std::integral_constant<int, I>()), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&body)
+{
+	static_for_impl<N>(static_cast<F &&>(body), std::make_integer_sequence<int, N>());
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_int - increment = R << 16 exactly: every output frame of a launch has the SAME fractional position, hence the same row of
+// weights (clownresampler.h:993-1008 depend on position_fractional only), and consecutive frames' windows are exactly R
+// input frames apart.  Two things follow, and neither is available to the lane-per-frame kernels (k_poly / k_wave2), which
+// read a row AND a private tap window from LDS per frame (12 bytes per stereo tap-slot: LDS 56 % busy beside a VALU 47 % busy
+// on the 33-slot windows, profiles/r03_dn8_pmc_summary.txt):
+//   * the weights are wave-uniform: they arrive in the KERNEL ARGUMENTS (the host picks the launch's row, checks it against
+//     the instance's slot classes and stages it), i.e. in SGPRs - no row image in LDS, no row reads, no row index;
+//   * a lane that owns K CONSECUTIVE output frames reads its R (K - 1) + TT input frames ONCE, packed, straight into
+//     registers (ds_read_b128 at a lane stride chosen to be conflict-free), unpacks every sample once
+//     (X = 2 * sample, one SDWA shift) and uses it in up to TT / R taps of different frames.
+// The tap is k_wave2's mov-armed 64-bit multiply-add (cr_kwave2.hpp): P = {X, acc}; P = v_mad_i64_i32(X, W, P) with
+// W = |weight| << 15 in an SGPR: `acc += trunc(sample * |weight| / 65536)`, C's division (clownresampler.h:1020 via :625);
+// slots whose weights are negative accumulate into a second pair that is subtracted at the end (truncation toward zero is
+// odd-symmetric).  Which slots those are is a compile-time property of the instance (NEGMASK; the lobes of the stretched
+// kernel are R slots wide) that the host verifies against the row of EVERY launch; a row that does not match (a resumed
+// stream whose fraction is not the one the instance was derived for, a caller's own table) takes the plan's ordinary kernel.
+// Slots in SAFEMASK may hold weights up to 65536 (the kernel's centre): plain |weight| and X << 15 there.
+// Streaming is k_up2's: wave-autonomous, LDS-DMA of the wave-tile's packed window (ONE buffer per wave: the lanes hold
+// the whole tile in registers before the arithmetic starts, so the next tile's DMA is issued into the same buffer right
+// after the reads), results staged through LDS so that the K frames of a lane - consecutive in the output - leave as
+// coalesced stores, counted vmcnt.  No barrier at all.
+// The final (acc * reciprocal) / 32768 is the 64-bit form (either range class).
+//   CH channels (1 or 2)   R input frames per output frame   TT slots   K frames per lane   WAVES per workgroup
+// ---------------------------------------------------------------------------------------------------------
+constexpr unsigned int_lane_bytes(int ch, int r, int k) { return (unsigned)(r * k * ch * 2); }
+constexpr unsigned int_lane_vecs(int ch, int r, int tt, int k) { return ((unsigned)((r * (k - 1) + tt) * ch * 2) + 15u) / 16u; }
+// bytes of LDS a wave-tile's window occupies (whole 1 KiB DMA pieces)
+constexpr unsigned int_window_bytes(int ch, int r, int tt, int k)
+{
+	return (63u * int_lane_bytes(ch, r, k) + 16u * int_lane_vecs(ch, r, tt, k) + 1023u) & ~1023u;
+}
+constexpr unsigned int_stage_bytes(int ch, int k, int out16) { return 64u * (unsigned)k * (unsigned)ch * (out16 ? 2u : 4u); }
+constexpr unsigned int_wave_bytes(int ch, int r, int tt, int k, int out16)
+{
+	return int_window_bytes(ch, r, tt, k) + ((int_stage_bytes(ch, k, out16) + 15u) & ~15u);
+}
+
+template <int CH, int R, int TT, int K, unsigned long long NEGMASK, unsigned long long SAFEMASK, int WAVES, int OUT16, int NT>
+__global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
+{
+	static_assert(CH == 1 || CH == 2, "mono and stereo");
+	static_assert(TT <= CRHIP_INT_MAX_SLOTS, "the weights travel in the kernel arguments");
+	constexpr unsigned FB = CH * 2;                        // bytes per input frame
+	constexpr unsigned UNIT = OUT16 ? CH * 2 : CH * 4;     // bytes per output frame
+	constexpr unsigned WT = 64u * K;                       // output frames per wave-tile
+	constexpr int NX = R * (K - 1) + TT;                   // input frames a lane reads
+	constexpr unsigned LANE_BYTES = int_lane_bytes(CH, R, K);
+	constexpr int XV = (int)int_lane_vecs(CH, R, TT, K);   // ds_read_b128 per lane
+	constexpr unsigned WIN = int_window_bytes(CH, R, TT, K);
+	constexpr int NVW = (int)(WIN / 1024u);
+	constexpr unsigned STAGE = (int_stage_bytes(CH, K, OUT16) + 15u) & ~15u;
+	static_assert(LANE_BYTES % 16u == 0, "a lane's window starts on a 16-byte boundary of the tile's");
+	static_assert((K * UNIT) % 4u == 0, "a lane's frames are staged as dwords");
+
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+	const unsigned tid = threadIdx.x;
+	const unsigned lane = tid & 63u;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	unsigned char *my_buf = smem + wave * (WIN + STAGE);
+	unsigned char *my_stage = my_buf + WIN;
+
+	const uint64_t n_tiles = (a.n_out + WT - 1) / WT;
+	const uint64_t global_wave = (uint64_t)wave * gridDim.x + blockIdx.x;   // (a short launch spreads over the CUs, not over a CU's waves)
+	const uint64_t global_waves = (uint64_t)gridDim.x * WAVES;
+	if (global_wave >= n_tiles)
+		return;
+
+	const uint64_t in_base = reinterpret_cast<uint64_t>(a.d_in);
+	const uint64_t in_end = in_base + a.in_valid_bytes;
+
+	// LDS-DMA of the packed window of wave-tile `tile`, from ITS first byte: LDS-DMA takes a source of any alignment, 2-byte
+	// included, at full rate (tools/microbench/dmaalign.hip, profiles/r03_dmaalign.log), so the window always lands at the
+	// start of the buffer and every lane's share on a 16-byte boundary.  Bytes beyond the caller's buffer arrive as zeros.
+	// The descriptor's range check works on whole dwords COUNTED FROM `from`: where the readable bytes end half a dword into one
+	// (a 2-byte-aligned window over a buffer that ends 2 bytes past a dword of it), that last sample is not delivered - and
+	// rounding the range up instead, as k_poly does from ITS 16-byte-aligned base, would read past the caller's buffer here.
+	// fetch() returns the LDS byte offset of such a sample (else ~0) and patch() stores it by hand once the DMA has landed.
+	auto fetch = [&](uint64_t tile) -> unsigned {
+		const uint64_t from = in_base + (a.first_frame + tile * (uint64_t)(WT * R)) * FB;
+		uint64_t want = WIN;
+		const uint64_t avail = in_end > from ? in_end - from : 0;
+		unsigned lost = ~0u;
+		if (want > avail)
+		{
+			want = avail & ~(uint64_t)3;
+			if (avail & 2u)
+				lost = (unsigned)want;
+		}
+		const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)from);
+		const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(from >> 32));
+		const unsigned rec = __builtin_amdgcn_readfirstlane((unsigned)want);
+		const __amdgpu_buffer_rsrc_t rsrc =
+		    __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)rec, 0x00020000);
+#pragma unroll
+		for (int v = 0; v < NVW; ++v)
+			__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(my_buf + v * 1024u), 16,
+			                                         (int)(v * 1024u + lane * 16u), 0, 0, 0);
+		return (unsigned)__builtin_amdgcn_readfirstlane((int)lost);
+	};
+	auto patch = [&](unsigned lost) {
+		if (lost != ~0u)
+		{
+			if (lane == 0)
+				*reinterpret_cast<short *>(my_buf + lost) = *reinterpret_cast<const short *>(in_end - 2u);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		}
+	};
+
+	// p = x * weight + p with the weight in an SGPR
+	auto mad = [&](i32x2 &p, int x, int weight) {
+		long long carry;
+		asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(p), "=&s"(carry) : "v"(x), "s"(weight));
+	};
+
+	uint64_t tile = global_wave;
+	unsigned lost = fetch(tile);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+	for (;;)
+	{
+		const uint64_t first = tile * WT;
+		const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
+
+		patch(lost);
+		// the lane's window, packed, into registers: XV aligned 16-byte reads at a stride of LANE_BYTES
+		int d[XV * 4];
+		{
+			const i32x4 *src = reinterpret_cast<const i32x4 *>(my_buf + lane * LANE_BYTES);
+			i32x4 raw[XV];
+#pragma unroll
+			for (int v = 0; v < XV; ++v)
+				raw[v] = src[v];
+#pragma unroll
+			for (int v = 0; v < XV; ++v)
+			{
+				d[4 * v] = raw[v].x;
+				d[4 * v + 1] = raw[v].y;
+				d[4 * v + 2] = raw[v].z;
+				d[4 * v + 3] = raw[v].w;
+			}
+		}
+		// the reads must have landed before the next DMA may overwrite the buffer (the registers are the compiler's, hence its
+		// builtin: it keeps its own loads above it)
+		__builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+		asm volatile("" ::: "memory");
+
+		// the next tile's window into the same buffer, under this tile's arithmetic
+		const uint64_t next = tile + global_waves;
+		const bool have_next = next < n_tiles;
+		if (have_next)
+			lost = fetch(next);
+
+		// accumulator pairs {lo, hi}: [frame][channel][0: slots with weights >= 0, 1: slots with weights <= 0]
+		i32x2 acc[K][CH][2];
+		const unsigned stage_at = lane * (K * UNIT);
+
+		static_for<NX>([&](auto i_tag) {
+			constexpr int i = decltype(i_tag)::value;
+			static_for<CH>([&](auto c_tag) {
+				constexpr int c = decltype(c_tag)::value;
+				constexpr int word = i * CH + c;
+				int x;   // 2 * sample, sign-extended
+				if constexpr (word & 1)
+					asm("v_lshlrev_b32_sdwa %0, %2, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(x) : "v"(d[word >> 1]), "v"(1));
+				else
+					asm("v_lshlrev_b32_sdwa %0, %2, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(x) : "v"(d[word >> 1]), "v"(1));
+				static_for<K>([&](auto k_tag) {
+					constexpr int k = decltype(k_tag)::value;
+					constexpr int s = i - R * k;
+					if constexpr (s >= 0 && s < TT)
+					{
+						constexpr int cls = (int)((NEGMASK >> s) & 1ull);
+						// is this the first slot of its class?
+						constexpr unsigned long long before = (1ull << s) - 1ull;
+						constexpr bool first_of_class = cls ? ((NEGMASK & before) == 0) : ((~NEGMASK & before) == 0);
+						i32x2 &p = acc[k][c][cls];
+						if constexpr (first_of_class)
+							p.y = 0;
+						p.x = x;
+						if constexpr ((SAFEMASK >> s) & 1ull)
+							mad(p, (int)((unsigned)x << 15), a.w[s]);
+						else
+							mad(p, x, a.w[s]);
+					}
+				});
+			});
+			// a frame whose last slot this was is complete: normalise (clownresampler.h:1025-1033) and stage
+			static_for<K>([&](auto k_tag) {
+				constexpr int k = decltype(k_tag)::value;
+				if constexpr (i - R * k == TT - 1)
+				{
+					int out[CH];
+					static_for<CH>([&](auto c_tag) {
+						constexpr int c = decltype(c_tag)::value;
+						constexpr bool any_neg = NEGMASK != 0;
+						int sum = acc[k][c][0].y;
+						if constexpr (any_neg)
+							sum -= acc[k][c][1].y;
+						// (acc * reciprocal) / 32768 toward zero in 64 bits: right for either range class of the host's (CRHIP_NORM_*)
+						const long long v = (long long)sum * (long long)a.reciprocal + (long long)((unsigned)(sum >> 31) >> 17);
+						out[c] = (int)(v >> 15);
+					});
+					if ((unsigned)k + lane * K < n)
+					{
+						if constexpr (OUT16 && CH == 2)
+							*reinterpret_cast<int *>(my_stage + stage_at + k * UNIT) = (clamp_s16(out[0]) & 0xFFFF) | (clamp_s16(out[1]) << 16);
+						else if constexpr (OUT16)
+							*reinterpret_cast<short *>(my_stage + stage_at + k * UNIT) = (short)clamp_s16(out[0]);
+						else if constexpr (CH == 2)
+						{
+							i32x2 q;
+							q.x = out[0];
+							q.y = out[CH - 1];
+							*reinterpret_cast<i32x2 *>(my_stage + stage_at + k * UNIT) = q;
+						}
+						else
+							*reinterpret_cast<int *>(my_stage + stage_at + k * UNIT) = out[0];
+					}
+				}
+			});
+		});
+
+		// the staged frames of the other lanes: same wave, LDS operations of a wave complete in order
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+		// copy-out: the tile's n frames are contiguous in the output; wave-uniform base, one lane offset: 16 bytes per lane (dword
+		// alignment is all gfx950 asks of global_store_dwordx4), then the tail by dwords and - int16 mono - one last sample
+		unsigned stores = 0;
+		{
+			const unsigned bytes = n * UNIT;
+			const unsigned vectors = bytes / 16u, dwords = bytes / 4u;
+			const uint64_t out_first = reinterpret_cast<uint64_t>(a.d_out) + first * UNIT;
+			const unsigned out_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)out_first);
+			const unsigned out_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(out_first >> 32));
+			// (GLOBAL pointers by type: through generic ones these would be flat stores, which go down the LDS path as well)
+			typedef __attribute__((address_space(1))) i32x4 global_vec;
+			typedef __attribute__((address_space(1))) int global_int;
+			typedef __attribute__((address_space(1))) short global_short;
+			global_vec *dst = (global_vec *)(((uint64_t)out_hi << 32) | out_lo);
+			const i32x4 *staged = reinterpret_cast<const i32x4 *>(my_stage);
+			auto put = [&](global_vec *to, i32x4 v) {
+				if constexpr (NT)
+					__builtin_nontemporal_store(v, to);
+				else
+					*to = v;
+			};
+			unsigned done = 0;   // wave-uniform
+			for (; done + 128u <= vectors; done += 128u)
+			{
+				const i32x4 v0 = staged[done + lane], v1 = staged[done + 64u + lane];
+				put(dst + done + lane, v0);
+				put(dst + done + 64u + lane, v1);
+				stores += 2u;
+			}
+			for (; done < vectors; done += 64u)
+			{
+				if (done + lane < vectors)
+					put(dst + done + lane, staged[done + lane]);
+				stores += 1u;
+			}
+			if (dwords > 4u * vectors)
+			{
+				if (4u * vectors + lane < dwords)
+					((global_int *)dst)[4u * vectors + lane] = reinterpret_cast<const int *>(my_stage)[4u * vectors + lane];
+				stores += 1u;
+			}
+			if (bytes > 4u * dwords)
+			{
+				if (lane == 0)
+					((global_short *)dst)[2u * dwords] = reinterpret_cast<const short *>(my_stage)[2u * dwords];
+				stores += 1u;
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
+
+		if (!have_next)
+			break;
+		// the DMA was issued before this tile's stores and vmcnt retires in order: the stores stay in flight
+		wait_vmcnt_at_most(stores);
+		tile = next;
+	}
+}
+
+} // namespace
+
+#endif // CR_KINT_HPP

@@ -83,6 +83,40 @@ typedef struct crhip_generic_launch
 	uint32_t out64;
 } crhip_generic_launch;
 
+/* One launch of k_int (cr_kint.hpp): whole-number downsampling ratios, increment = ratio << 16.  Every frame of the launch has
+   the same fractional position, so the host hands over THE row - staged, in the kernel arguments - instead of a row image:
+   w[s] = |weight of slot s| << 15 (plain |weight| for the slots of the instance's safe mask), the signs being a property of
+   the instance that the host has checked this row against (crhip_int_instance). */
+#define CRHIP_INT_MAX_SLOTS 48
+typedef struct crhip_int_launch
+{
+	const void *d_in;           /* interleaved int16 */
+	uint64_t in_valid_bytes;    /* bytes readable from d_in */
+	void *d_out;                /* int32 (or clamped int16), n_out * channels */
+	uint64_t first_frame;       /* input frame (relative to d_in) that slot 0 of output frame 0 multiplies */
+	uint64_t n_out;
+	uint32_t channels, ratio, slots;
+	uint32_t out_s16;
+	uint32_t blocks;            /* grid size (workgroups of the instance's thread count) */
+	int32_t reciprocal;         /* 0x80000000 / sum of the row's weights (clownresampler.h:1025) */
+	int32_t w[CRHIP_INT_MAX_SLOTS];
+} crhip_int_launch;
+
+typedef struct crhip_int_shape
+{
+	uint64_t negmask;           /* bit s set: slot s must hold a weight <= 0, clear: >= 0 */
+	uint64_t safemask;          /* bit s set: slot s may reach 65536; every other weight must stay below it */
+	uint32_t frames_per_lane;   /* K: a wave-tile is 64 K output frames */
+	uint32_t threads;           /* workgroup size */
+	uint32_t lds_bytes[2];      /* dynamic LDS per workgroup, int32 / int16 output */
+} crhip_int_shape;
+
+/* 1 and *shape when there is a k_int instance for (channels, ratio, slots), else 0 */
+int crhip_int_instance(uint32_t channels, uint32_t ratio, uint32_t slots, crhip_int_shape *shape);
+/* one-time setup (dynamic LDS limit) + workgroups resident per CU for either output form; not legal inside a stream capture */
+int crhip_int_prepare(uint32_t channels, uint32_t ratio, uint32_t slots, int *per_cu, int *per_cu_s16);
+int crhip_launch_int(const crhip_int_launch *launch, void *stream);
+
 typedef struct crhip_device_info
 {
 	int compute_units;

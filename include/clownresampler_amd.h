@@ -54,6 +54,8 @@ void ClownResamplerAMD_ClearError(void);
  * process-wide cache created on first use (per device: staging buffers, streams, uploaded tables and
  * plans keyed by table contents + configuration) and released by Shutdown or at exit.
  * ------------------------------------------------------------------------------------------- */
+/* sha256 (first 16 hex digits) over the sources this library was built from: ties profiles to builds */
+const char *ClownResamplerAMD_BuildId(void);
 int ClownResamplerAMD_DeviceCount(void);                /* 0 when there is none; never calls the error handler */
 int ClownResamplerAMD_SetDevice(int ordinal);           /* process default: device used by calls of threads that have not chosen one; 0 on success */
 int ClownResamplerAMD_SetThreadDevice(int ordinal);     /* device used by subsequent calls of the CALLING THREAD (-1: follow the process default again) */
@@ -68,6 +70,11 @@ void ClownResamplerAMD_Shutdown(void);
    during a capture, so the pool is sized ahead: room for 256 captured launches per device by default, more with this call
    (before the capture; current device).  0 on success. */
 int ClownResamplerAMD_ReserveCaptureLaunches(size_t launches);
+/* The other end of that pool, for clients that re-capture graphs over time: call it once every graph that captured launches of
+   this library on the current device has been destroyed (none is executing or will be launched again).  Every block handed
+   out to a captured launch becomes available again and the memory of earlier ReserveCaptureLaunches calls is returned.
+   0 on success. */
+int ClownResamplerAMD_ReleaseCapturedLaunches(void);
 
 /* High-level (streaming) API: how many input frames ClownResampler_HighLevel_Resample may collect from the input callback
    before it resamples them in one GPU call (default 262144).  The reference's 0x1000-sample staging buffer
@@ -176,6 +183,16 @@ void ClownResamplerAMD_PlanGetInfo(const ClownResamplerAMD_Plan *plan, ClownResa
    released with hipFree, which waits for the device).  Plans returned by ClownResamplerAMD_PlanCreate are never dropped. */
 void ClownResamplerAMD_SetPlanCacheLimit(size_t plans);
 size_t ClownResamplerAMD_PlanCacheCount(void);
+
+/* The kernel a launch from this fractional position takes, numbered as ClownResamplerAMD_PlanInfo.kernel plus 5 = k_int: at a
+   whole-number downsampling ratio (2:1, 3:1, 4:1, 6:1; mono and stereo) every frame of a launch uses ONE polyphase row, which
+   then travels in the kernel arguments - if that row has the slot signs the instance was built for (always, for a stream that
+   starts from ClownResampler_LowLevel_Init; a stream resumed at another fraction may not).  Ignores launch-length rules
+   (brief_below). */
+uint32_t ClownResamplerAMD_PlanKernelAt(const ClownResamplerAMD_Plan *plan, uint32_t position_fractional);
+/* Launches enqueued by this process so far on `kernel` (0 ... 5, numbered as above): lets tests and benchmarks assert that the
+   kernel they mean is the one that ran. */
+unsigned long long ClownResamplerAMD_DebugLaunchCount(unsigned kernel);
 
 /* Debug/test access to the host copy of the polyphase rows (rows * row_stride int32). */
 const int32_t *ClownResamplerAMD_PlanRows(const ClownResamplerAMD_Plan *plan);

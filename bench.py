@@ -544,6 +544,22 @@ def main():
         if not check:
             raise SystemExit("bench: device output differs from the oracle on rank %d (ok here: %s) - numbers void" % (rank, ok_here))
 
+    # N > 1: the line proves what ran.  Every rank reports its GPU's identity and its own timing; the backend is asked to SUM a
+    # one per rank (a collective that only comes out at N if N ranks took part in it).
+    per_rank, backend_sum = None, None
+    if world > 1:
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "local_rank": local_rank,
+                "device": {"name": props.name, "uuid": str(getattr(props, "uuid", "")),
+                           "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))},
+                "ms_per_step": mean_ms, "median_ms": median_ms, "output_frames": int(shard.output_frames), "input_frames": int(shard.input_frames),
+                "first_output_frame": int(shard.first_output_frame), "kernel_launches_timed": [int(v) for v in launches_by_kernel]}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        one = torch.ones(1, dtype=torch.int64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        backend_sum = int(one.cpu()[0])
+
     gather = None
     if world > 1 and not args.s16 and not args.no_gather:
         # The final concatenate (north_star): the ranks' int32 shards, padded to the common per-rank size
@@ -589,6 +605,8 @@ def main():
             gather = {"to_root": {"collective": "gather (RCCL send/recv, ncclGather semantics)" if on_device else "gather (gloo, host copies: validation only)", "ms": root_ms},
                       "all_gather": {"collective": "all_gather_into_tensor (RCCL)" if on_device else "all_gather_into_tensor (gloo, host copies: validation only)", "ms": all_ms},
                       "ms": root_ms, "bytes_per_rank": per * 4, "seams_match_oracle": seams_ok,
+                      # what one peer -> root transfer moved per second while all of them ran (each over its own xGMI link with one GPU per rank)
+                      "link_GBs": per * 4 / (root_ms * 1e-3) / 1e9, "all_gather_link_GBs": per * 4 * (world - 1) / (all_ms * 1e-3) / 1e9,
                       "value_with_gather": out_samples_all / ((ms_per_step + root_ms) * 1e-3) / 1e6,
                       "value_with_all_gather": out_samples_all / ((ms_per_step + all_ms) * 1e-3) / 1e6}
             if seams_ok is False:
@@ -625,6 +643,14 @@ def main():
         if world > 1:
             line["backend"] = "nccl (RCCL), one GPU per rank" if backend == "nccl" else \
                 "%s; VALIDATION ONLY: %d ranks share %d GPU(s), timings are those of ranks contending for a GPU" % (backend, world, n_dev)
+            line["per_rank"] = per_rank
+            line["distinct_devices"] = len({(r["device"]["uuid"], r["device"]["pci"]) for r in per_rank})
+            line["world_size_seen_by_backend"] = {"get_world_size": dist.get_world_size(), "all_reduce_sum_of_ones": backend_sum,
+                                                  "backend": dist.get_backend()}
+            line["workload_note"] = ("N > 1 default = BASELINE configs[4] (the 1-hour stream) split over the ranks, STRONG scaling: each rank's launch is 1/N of the hour "
+                                     "(%d output frames here); the N = 1 point of THIS curve is `--gpus 1 --workload cfg5` (the default N = 1 line is configs[1], 10 minutes); "
+                                     "with the concatenate the curve is bound by the gather (SURVEY 8(e): bytes_per_rank over one xGMI link against a kernel of tens of microseconds)"
+                                     % shard.output_frames) if workload == "cfg5" else None
         if gather:
             line["gather"] = gather
         if world == 1 and not args.no_host_paths and not args.s16:

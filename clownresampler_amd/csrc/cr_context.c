@@ -155,6 +155,7 @@ static ClownResamplerAMD_Plan *g_plans = NULL;
 static uint64_t g_plan_clock = 0;
 static size_t g_plan_limit = 64;   /* unpinned plans kept; ClownResamplerAMD_SetPlanCacheLimit */
 static int g_force_generic = 0;
+static int g_no_int_kernel = 0;   /* ClownResamplerAMD_DebugDisableIntKernel */
 static unsigned long long *g_debug_stamps = NULL;
 static int g_variant = -1; /* -1: CLOWNRESAMPLER_AMD_VARIANT from the environment, else the default */
 /* launches enqueued so far, by kernel (numbered as ClownResamplerAMD_PlanInfo.kernel; 5 = k_int): what tests and bench.py
@@ -191,6 +192,7 @@ static struct
 	int loaded;
 	int dynamic_tiles;          /* CLOWNRESAMPLER_AMD_DYNAMIC_TILES: -1 unset, else 0 / 1 */
 	int no_special, debug, no_occupancy_clamp, tile_groups, no_host_pipeline, no_small_call_path;
+	int lane_map;               /* CLOWNRESAMPLER_AMD_LANE_MAP: 0 / 1 forces k_wave2's lane order (unset: the conflict model picks) */
 	int no_int_kernel;          /* CLOWNRESAMPLER_AMD_NO_INT_KERNEL: whole-number ratios take the plan's ordinary kernel (the A/B leg) */
 	int rt_wave2_min_slots;     /* CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS: windows from this many slots on take the run-time-slot k_wave2 */
 	double rotate_min_gain;     /* CLOWNRESAMPLER_AMD_ROTATE_MIN_GAIN: see plan_pick_rotation */
@@ -212,6 +214,8 @@ static void load_env(void)
 	g_env.no_host_pipeline = getenv("CLOWNRESAMPLER_AMD_NO_HOST_PIPELINE") != NULL;
 	g_env.no_small_call_path = getenv("CLOWNRESAMPLER_AMD_NO_SMALL_CALL_PATH") != NULL;
 	g_env.no_int_kernel = getenv("CLOWNRESAMPLER_AMD_NO_INT_KERNEL") != NULL;
+	e = getenv("CLOWNRESAMPLER_AMD_LANE_MAP");
+	g_env.lane_map = (e != NULL && *e != '\0') ? (atoi(e) != 0) : -1;
 	e = getenv("CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS");
 	g_env.rt_wave2_min_slots = (e != NULL && atoi(e) > 0) ? atoi(e) : CR_RT_WAVE2_MIN_SLOTS;
 	e = getenv("CLOWNRESAMPLER_AMD_ROTATE_MIN_GAIN");
@@ -1112,6 +1116,24 @@ ClownResamplerAMD_Plan *cr_plan_get(uint64_t table_hash, size_t table_len, cr_ta
 /* The rotation of the rows in LDS that suits the plan's increment, for kernels that apply one (k_wave2 always; the 64-bit-chain
    k_poly has a plain and a rotated form, and the rotated one costs three instructions per frame: only where the model - extra LDS
    cycles per row read of a wave, cr_poly_pick_swizzle - gains CR_ROTATE_MIN_GAIN). */
+/* k_wave2's lane order (crhip_poly_launch.lane_map): even / odd frames to the two halves of a wave where the model of the window
+   reads' bank conflicts says that saves at least a quarter of a cycle per read. */
+static uint32_t plan_pick_lane_map(const ClownResamplerAMD_Plan *plan)
+{
+	double straight, split;
+
+	if (!(plan->vecs >= 150u && plan->vecs < 200u))
+		return 0u;
+	if (g_env.lane_map >= 0)
+		return (uint32_t)g_env.lane_map;
+	straight = cr_window_conflicts(&plan->poly, &plan->cfg, plan->increment, plan->channels, 0u);
+	split = cr_window_conflicts(&plan->poly, &plan->cfg, plan->increment, plan->channels, 1u);
+	if (g_env.debug)
+		fprintf(stderr, "clownresampler_amd: plan %u ch, increment %llu: modelled conflict cycles per window read %.2f (lanes in frame order) / %.2f (even | odd)\n",
+		        plan->channels, (unsigned long long)plan->increment, straight, split);
+	return split < straight - 0.25 ? 1u : 0u;
+}
+
 static uint32_t plan_pick_rotation(const ClownResamplerAMD_Plan *plan, double *plain, double *best)
 {
 	const int form = crhip_poly_swizzled(plan->channels, plan->specialised ? plan->poly.slots : 0xFFFFu, plan->poly.row_mode, plan->poly.norm_mode, plan->variant);
@@ -1120,7 +1142,7 @@ static uint32_t plan_pick_rotation(const ClownResamplerAMD_Plan *plan, double *p
 	*plain = *best = 0.0;
 	if (form == 0)
 		return 0u;
-	rotation = cr_poly_pick_swizzle(&plan->poly, plan->increment, plain, best);
+	rotation = cr_poly_pick_swizzle_mapped(&plan->poly, plan->increment, plan->lane_map, plain, best);
 	if (form == 2 && *plain - *best < g_env.rotate_min_gain)
 		rotation = 0u;
 	if (g_env.debug)
@@ -1186,6 +1208,7 @@ static void plan_brief_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *p
 	plan_geometry(&other);
 	if (other.vecs >= 200u || other.specialised != plan->specialised)
 		return;
+	other.lane_map = plan_pick_lane_map(&other);
 	other.lds_swizzle = plan_pick_rotation(&other, &plain, &best);
 	if (plan_prepare(ctx, &other) != 0)
 	{
@@ -1201,6 +1224,7 @@ static void plan_brief_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *p
 	plan->brief.max_blocks_s16 = other.max_blocks_s16;
 	plan->brief.variant = other.variant;
 	plan->brief.lds_swizzle = other.lds_swizzle;
+	plan->brief.lane_map = other.lane_map;
 	plan->brief.below = (uint64_t)half_tiles * (plan->tile_frames / 4u) * plan->max_blocks * (plan->threads / 64u) / 2u;
 }
 
@@ -1385,6 +1409,7 @@ ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t t
 
 	/* instances that rotate the rows while staging them into LDS get the rotation that suits THIS plan's increment (the image
 	   in global memory stays the plain one, shared by the plans of every increment) */
+	plan->lane_map = plan->use_poly ? plan_pick_lane_map(plan) : 0u;
 	plan->lds_swizzle = plan->use_poly ? plan_pick_rotation(plan, &plan->conflict_plain, &plan->conflict_best) : 0u;
 
 	if (plan->use_poly)
@@ -1487,6 +1512,7 @@ static void fill_poly_launch(const ClownResamplerAMD_Plan *plan, crhip_poly_laun
 	l->variant = plan->variant;
 	l->plane_rows = plan->plane_rows;
 	l->swizzle = plan->lds_swizzle;
+	l->lane_map = plan->lane_map;
 	l->debug_stamps = g_debug_stamps;
 }
 
@@ -1496,7 +1522,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 	if (n_out == 0)
 		return 0;
 
-	if (plan->use_poly && !g_force_generic && plan->intk.available && pos_int < (1ull << 47) && n_out < (1ull << 40))
+	if (plan->use_poly && !g_force_generic && !g_no_int_kernel && plan->intk.available && pos_int < (1ull << 47) && n_out < (1ull << 40))
 	{
 		/* a whole-number ratio: k_int, if the row this launch's fraction selects has the instance's slot classes */
 		crhip_int_launch il;
@@ -1549,6 +1575,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			l.lds_bytes = plan->brief.lds_bytes;
 			l.variant = plan->brief.variant;
 			l.swizzle = plan->brief.lds_swizzle;
+			l.lane_map = plan->brief.lane_map;
 			max_blocks = out_s16 ? plan->brief.max_blocks_s16 : plan->brief.max_blocks;
 		}
 
@@ -2012,6 +2039,11 @@ void ClownResamplerAMD_PlanGetInfo(const ClownResamplerAMD_Plan *plan, ClownResa
 	}
 }
 
+void ClownResamplerAMD_DebugDisableIntKernel(int on)
+{
+	g_no_int_kernel = on != 0;
+}
+
 unsigned long long ClownResamplerAMD_DebugLaunchCount(unsigned kernel)
 {
 	return kernel < CR_KERNEL_IDS ? __atomic_load_n(&g_launch_count[kernel], __ATOMIC_RELAXED) : 0ull;
@@ -2023,7 +2055,7 @@ uint32_t ClownResamplerAMD_PlanKernelAt(const ClownResamplerAMD_Plan *plan, uint
 	crhip_int_launch il;
 	uint32_t first_slot;
 
-	if (plan->use_poly && !g_force_generic && plan->intk.available && int_launch_row(plan, position_fractional & 0xFFFFu, &il, &first_slot))
+	if (plan->use_poly && !g_force_generic && !g_no_int_kernel && plan->intk.available && int_launch_row(plan, position_fractional & 0xFFFFu, &il, &first_slot))
 		return 5u;
 	ClownResamplerAMD_PlanGetInfo(plan, &info);
 	return g_force_generic ? 0u : info.kernel;

@@ -71,6 +71,7 @@ typedef struct ClownResamplerAMD_Plan
 	uint32_t threads, vecs, tile_frames, lds_bytes, max_blocks, specialised, variant;
 	uint32_t max_blocks_s16; /* persistent-grid cap of the int16-output form (its own function, its own register footprint) */
 	uint32_t plane_rows, swizzle;
+	uint32_t lane_map;      /* k_wave2: which frame of its 64 a lane takes (crhip_poly_launch.lane_map), chosen for this plan's increment */
 	uint32_t lds_swizzle;   /* k_wave2: the rotation it applies while staging the (plain) rows into LDS, chosen for this plan's increment */
 	uint32_t device_row_stride; /* int32 per row of the device image (COMPACT for specialised instances, SPLIT otherwise) */
 	double conflict_plain, conflict_best; /* modelled extra LDS cycles per row read without / with the swizzle */
@@ -81,7 +82,7 @@ typedef struct ClownResamplerAMD_Plan
 	struct
 	{
 		uint64_t below;
-		uint32_t threads, vecs, tile_frames, lds_bytes, max_blocks, max_blocks_s16, variant, lds_swizzle;
+		uint32_t threads, vecs, tile_frames, lds_bytes, max_blocks, max_blocks_s16, variant, lds_swizzle, lane_map;
 	} brief;
 	/* whole-number downsampling ratios (increment = ratio << 16): k_int (cr_kint.hpp) where there is an instance for
 	   (channels, ratio, slots).  Whether a LAUNCH takes it depends on its fractional position - the row that fraction selects

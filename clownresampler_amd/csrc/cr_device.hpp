@@ -21,6 +21,19 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 
+// compile-time loop: body(std::integral_constant<int, i>) for i in [0, N) - every index a constant expression, whatever hipcc's
+// unrolling thresholds think of a 432-tap body (left to `#pragma unroll` the accumulator arrays went to scratch)
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&body, std::integer_sequence<int, I...>)
+{
+	(body(std::integral_constant<int, I>()), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&body)
+{
+	static_for_impl<N>(static_cast<F &&>(body), std::make_integer_sequence<int, N>());
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Fixed-point pieces
 // ---------------------------------------------------------------------------------------------------------

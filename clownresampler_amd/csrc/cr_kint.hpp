@@ -8,19 +8,6 @@
 namespace
 {
 
-// compile-time loop: body(std::integral_constant<int, i>) for i in [0, N) - every index a constant expression, whatever hipcc's
-// unrolling thresholds think of a 432-tap body (left to `#pragma unroll` the accumulator arrays went to scratch)
-template <int N, typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F &&body, std::integer_sequence<int, I...>)
-{
-	(body(std::integral_constant<int, I>()), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F &&body)
-{
-	static_for_impl<N>(static_cast<F &&>(body), std::make_integer_sequence<int, N>());
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // k_int - increment = R << 16 exactly: every output frame of a launch has the SAME fractional position, hence the same row of
 // weights (clownresampler.h:993-1008 depend on position_fractional only), and consecutive frames' windows are exactly R
@@ -46,6 +33,27 @@ __device__ __forceinline__ void static_for(F &&body)
 // The final (acc * reciprocal) / 32768 is the 64-bit form (either range class).
 //   CH channels (1 or 2)   R input frames per output frame   TT slots   K frames per lane   WAVES per workgroup
 // ---------------------------------------------------------------------------------------------------------
+// Accumulator pairs pinned to physical registers v[INT_ACC_BASE + 2 P : + 1] (the constraint of the asm statement: the tap's
+// multiply-add).  Left to its own allocation hipcc assembled the pair {x, acc} with v_mov_b64 and took it apart again - 1.4 moves
+// per tap instead of 1 (profiles/r03_kint_first.log: 214 VALU per frame where the taps are 144).  The arming move stays in C:
+// hipcc assumes a forwarding hazard between two ADJACENT asm statements that define a common register (here: vcc) and pads them
+// with an s_nop - one per tap when the move was part of the statement; its own v_mov_b32 between two statements is a wait
+// state it can count.
+constexpr int INT_ACC_BASE = 64;
+template <int P>
+__device__ __forceinline__ void int_tap(int &lo, int &hi, int multiplicand, int weight);
+#define CRK_INT_TAP(P, LO, HI)                                                                                                      \
+	template <>                                                                                                                    \
+	__device__ __forceinline__ void int_tap<P>(int &lo, int &hi, int multiplicand, int weight)                                      \
+	{                                                                                                                              \
+		asm("v_mad_i64_i32 [%0,%1], vcc, %2, %3, [%0,%1]" : "+{v" #LO "}"(lo), "+{v" #HI "}"(hi) : "v"(multiplicand), "s"(weight) : "vcc"); \
+	}
+CRK_INT_TAP(0, 64, 65) CRK_INT_TAP(1, 66, 67) CRK_INT_TAP(2, 68, 69) CRK_INT_TAP(3, 70, 71) CRK_INT_TAP(4, 72, 73) CRK_INT_TAP(5, 74, 75)
+CRK_INT_TAP(6, 76, 77) CRK_INT_TAP(7, 78, 79) CRK_INT_TAP(8, 80, 81) CRK_INT_TAP(9, 82, 83) CRK_INT_TAP(10, 84, 85) CRK_INT_TAP(11, 86, 87)
+CRK_INT_TAP(12, 88, 89) CRK_INT_TAP(13, 90, 91) CRK_INT_TAP(14, 92, 93) CRK_INT_TAP(15, 94, 95) CRK_INT_TAP(16, 96, 97) CRK_INT_TAP(17, 98, 99)
+CRK_INT_TAP(18, 100, 101) CRK_INT_TAP(19, 102, 103) CRK_INT_TAP(20, 104, 105) CRK_INT_TAP(21, 106, 107) CRK_INT_TAP(22, 108, 109) CRK_INT_TAP(23, 110, 111)
+#undef CRK_INT_TAP
+
 constexpr unsigned int_lane_bytes(int ch, int r, int k) { return (unsigned)(r * k * ch * 2); }
 constexpr unsigned int_lane_vecs(int ch, int r, int tt, int k) { return ((unsigned)((r * (k - 1) + tt) * ch * 2) + 15u) / 16u; }
 // bytes of LDS a wave-tile's window occupies (whole 1 KiB DMA pieces)
@@ -133,12 +141,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 		}
 	};
 
-	// p = x * weight + p with the weight in an SGPR
-	auto mad = [&](i32x2 &p, int x, int weight) {
-		long long carry;
-		asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(p), "=&s"(carry) : "v"(x), "s"(weight));
-	};
-
 	uint64_t tile = global_wave;
 	unsigned lost = fetch(tile);
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -177,20 +179,37 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 		if (have_next)
 			lost = fetch(next);
 
-		// accumulator pairs {lo, hi}: [frame][channel][0: slots with weights >= 0, 1: slots with weights <= 0]
-		i32x2 acc[K][CH][2];
+		// accumulator high dwords (the sums): [live frame][channel][0: slots with weights >= 0, 1: slots with weights <= 0].  At any
+		// time TT / R frames of a lane are in progress; frame k uses set k % LIVE, pinned to physical registers (int_tap).
+		constexpr int LIVE = TT / R;
+		static_assert(TT % R == 0 && LIVE * CH * 2 <= 24, "pinned accumulator pairs");
+		int acc[LIVE][CH][2], arm[LIVE][CH][2];
 		const unsigned stage_at = lane * (K * UNIT);
+
+		// X = 2 * sample, sign-extended: one SDWA shift per sample, issued ONE input frame ahead of its taps (hipcc pads an asm
+		// statement whose result the very next instruction reads with an s_nop: 132 per tile)
+		int xs[(NX + 1) * CH];
+		auto unpack = [&](auto w_tag) {
+			constexpr int word = decltype(w_tag)::value;
+			if constexpr (word < NX * CH)
+			{
+				// (named first: asm operands alone do not make a generic lambda capture for clang)
+				int &to = xs[word];
+				const int from = d[word >> 1];
+				if constexpr (word & 1)
+					asm("v_lshlrev_b32_sdwa %0, %2, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(to) : "v"(from), "v"(1));
+				else
+					asm("v_lshlrev_b32_sdwa %0, %2, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(to) : "v"(from), "v"(1));
+			}
+		};
+		static_for<CH>([&](auto c_tag) { unpack(c_tag); });
 
 		static_for<NX>([&](auto i_tag) {
 			constexpr int i = decltype(i_tag)::value;
+			static_for<CH>([&](auto c_tag) { unpack(std::integral_constant<int, (i + 1) * CH + decltype(c_tag)::value>()); });
 			static_for<CH>([&](auto c_tag) {
 				constexpr int c = decltype(c_tag)::value;
-				constexpr int word = i * CH + c;
-				int x;   // 2 * sample, sign-extended
-				if constexpr (word & 1)
-					asm("v_lshlrev_b32_sdwa %0, %2, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(x) : "v"(d[word >> 1]), "v"(1));
-				else
-					asm("v_lshlrev_b32_sdwa %0, %2, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(x) : "v"(d[word >> 1]), "v"(1));
+				const int x = xs[i * CH + c];
 				static_for<K>([&](auto k_tag) {
 					constexpr int k = decltype(k_tag)::value;
 					constexpr int s = i - R * k;
@@ -200,14 +219,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 						// is this the first slot of its class?
 						constexpr unsigned long long before = (1ull << s) - 1ull;
 						constexpr bool first_of_class = cls ? ((NEGMASK & before) == 0) : ((~NEGMASK & before) == 0);
-						i32x2 &p = acc[k][c][cls];
+						constexpr int P = ((k % LIVE) * CH + c) * 2 + cls;
+						int &hi = acc[k % LIVE][c][cls], &lo = arm[k % LIVE][c][cls];
 						if constexpr (first_of_class)
-							p.y = 0;
-						p.x = x;
+							hi = 0;
+						lo = x;
 						if constexpr ((SAFEMASK >> s) & 1ull)
-							mad(p, (int)((unsigned)x << 15), a.w[s]);
+							int_tap<P>(lo, hi, (int)((unsigned)x << 15), a.w[s]);
 						else
-							mad(p, x, a.w[s]);
+							int_tap<P>(lo, hi, x, a.w[s]);
 					}
 				});
 			});
@@ -220,9 +240,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 					static_for<CH>([&](auto c_tag) {
 						constexpr int c = decltype(c_tag)::value;
 						constexpr bool any_neg = NEGMASK != 0;
-						int sum = acc[k][c][0].y;
+						int sum = acc[k % LIVE][c][0];
 						if constexpr (any_neg)
-							sum -= acc[k][c][1].y;
+							sum -= acc[k % LIVE][c][1];
 						// (acc * reciprocal) / 32768 toward zero in 64 bits: right for either range class of the host's (CRHIP_NORM_*)
 						const long long v = (long long)sum * (long long)a.reciprocal + (long long)((unsigned)(sum >> 31) >> 17);
 						out[c] = (int)(v >> 15);

@@ -35,6 +35,16 @@ namespace
 // loads cannot be made safe: hipcc copies their destination registers before the data has landed.)
 //   WAVES  waves per workgroup     NVW  1 KiB DMA pieces per wave-tile     ITER  frames per lane per wave-tile
 // ---------------------------------------------------------------------------------------------------------
+// LDS reads a frame has in flight BEHIND those of plane q while `ahead` planes are requested in advance: the planes q + 1 ...
+// q + ahead - 1 (a plane = the row vector, for the first channel pair, + one read per slot and channel read)
+constexpr int wave2_reads_ahead(bool with_rows, int reads_per_slot, int tt, int q, int ahead, int planes)
+{
+	int later = 0;
+	for (int g = q + 1; g < planes && g < q + ahead; ++g)
+		later += (with_rows ? 1 : 0) + reads_per_slot * ((tt - 4 * g) < 4 ? (tt - 4 * g) : 4);
+	return later;
+}
+
 template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, int OUT16, int NT, unsigned NEGMASK, int SIGNED, unsigned SAFEMASK = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 {
@@ -405,22 +415,26 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 		// landed (LDS returns in order: a counted lgkmcnt), the rest of the reads completing underneath the arithmetic.  All of
 		// them are inline assembly so that the counts are ours: hipcc's own waits only know the reads it issued itself.  Nothing
 		// may touch a destination register between its read and the "+v" statement behind the wait that covers it.
-#pragma unroll
-		for (int c0 = 0; c0 < CH; c0 += 2)
-		{
+		static_for<(CH + 1) / 2>([&](auto c_tag) {
+			constexpr int c0 = 2 * decltype(c_tag)::value;
 			constexpr bool EVEN = CH % 2 == 0;
-			const bool pair = c0 + 1 < CH;
-			const int reads_per_slot = (pair && !EVEN) ? 2 : 1;
+			constexpr bool pair = c0 + 1 < CH;
+			constexpr int reads_per_slot = (pair && !EVEN) ? 2 : 1;
 			// The window as separate reads: left to itself hipcc pairs them into ds_read2_b64, which moves 128 B per clock where
 			// ds_read_b64 moves 256 (MI355X_MICROARCH.md, LDS) - and this kernel is as much LDS- as VALU-bound.  8-byte reads need
 			// 8-byte alignment: even channel counts only.
 			constexpr int TTN = TT > 0 ? TT : 1;   // (this part is never reached by the run-time-slot form; it still has to compile)
 			int xa[TTN], xb[TTN];
 			i32x2 xv[TTN];   // (the 8-byte reads land here)
-#pragma unroll
-			for (int q = 0; q < NQ; ++q)
-			{
-				if (c0 == 0)
+			// The reads of plane q - its row vector (first channel pair only) and the window samples of its four slots - as one unit.
+			// They are NOT all issued up front any more: lgkmcnt counts to 15, so with a frame's 42 reads (33 slots) in flight the
+			// first taps waited for 27 of them, and the waves of a CU fell into step - all reading, then all multiplying (LDS 56 %
+			// busy beside a VALU 47 % busy, profiles/r03_dn8_before_pmc_summary.txt).  Now AHEAD planes are in flight (at most 15
+			// reads), the taps of plane q start when ITS reads have landed, and plane q + AHEAD is requested right behind them: a
+			// wave asks the LDS for data at the pace it consumes it.
+			auto issue_plane = [&](auto q_tag) {
+				constexpr int q = decltype(q_tag)::value;
+				if constexpr (c0 == 0)
 				{
 					if constexpr (MODE == CRHIP_ROWMODE_UPSAMPLE)
 					{
@@ -434,19 +448,31 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 						asm volatile("ds_read_b128 %0, %1" : "=v"(wv[q]) : "v"(at));
 					}
 				}
-#pragma unroll
-				for (int s = 4 * q; s < 4 * q + 4 && s < TT; ++s)
-				{
-					if (pair && EVEN)
-						asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xv[s]) : "v"(win_at), "n"((s * CH + c0) * 4));
-					else
-					{
-						asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(xa[s]) : "v"(win_at), "n"((s * CH + c0) * 4));
-						if (pair)
-							asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(xb[s]) : "v"(win_at), "n"((s * CH + c0 + 1) * 4));
-					}
-				}
-			}
+				// (four slots, written out: asm operands inside a further nested generic lambda do not capture for clang)
+#define CRHIP_W2_READ_SLOT(K)                                                                                                      \
+	if constexpr (4 * q + K < TT)                                                                                                  \
+	{                                                                                                                              \
+		constexpr int s = 4 * q + K;                                                                                               \
+		if constexpr (pair && EVEN)                                                                                                \
+			asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xv[s]) : "v"(win_at), "n"((s * CH + c0) * 4));                      \
+		else                                                                                                                       \
+		{                                                                                                                          \
+			asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(xa[s]) : "v"(win_at), "n"((s * CH + c0) * 4));                      \
+			if constexpr (pair)                                                                                                    \
+				asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(xb[s]) : "v"(win_at), "n"((s * CH + c0 + 1) * 4));              \
+		}                                                                                                                          \
+	}
+				CRHIP_W2_READ_SLOT(0)
+				CRHIP_W2_READ_SLOT(1)
+				CRHIP_W2_READ_SLOT(2)
+				CRHIP_W2_READ_SLOT(3)
+#undef CRHIP_W2_READ_SLOT
+			};
+			// planes in flight: as many as 15 outstanding reads allow (a plane is a row vector + up to 4 x reads_per_slot reads)
+			constexpr int plane_reads_max = (c0 == 0 ? 1 : 0) + 4 * reads_per_slot;
+			constexpr int AHEAD_RAW = 15 / plane_reads_max;
+			constexpr int AHEAD = AHEAD_RAW < 1 ? 1 : (AHEAD_RAW > NQ ? NQ : AHEAD_RAW);
+			static_for<AHEAD>([&](auto q_tag) { issue_plane(q_tag); });
 
 			// accumulator pairs pinned to physical registers (see k_up2): A+ v[120:121], B+ v[122:123], A- v[124:125], B- v[126:127]
 			// (an accumulator's FIRST tap adds to {arm, 0} - a scratch register paired with a register that holds 0 for the whole
@@ -482,13 +508,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	asm("v_xor_b32_sdwa v" #LO ", sext(%2), sext(%3) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"   \
 	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
 	    : "=&{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc")
-#pragma unroll
-			for (int q = 0; q < NQ; ++q)
-			{
-				// reads issued after the last one of plane q: they may stay in flight (the counter has 4 bits)
-				const int later_slots = TT - (4 * (q + 1) < TT ? 4 * (q + 1) : TT);
-				const int later = (c0 == 0 ? NQ - 1 - q : 0) + reads_per_slot * later_slots;
-				asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(later < 15 ? later : 15) : "memory");
+			static_for<NQ>([&](auto q_tag) {
+				constexpr int q = decltype(q_tag)::value;
+				// reads issued after the last one of plane q - the planes ahead of it - may stay in flight
+				constexpr int later = wave2_reads_ahead(c0 == 0, reads_per_slot, TT, q, AHEAD, NQ);
+				static_assert(later <= 15, "lgkmcnt counts to 15");
+				asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(later) : "memory");
+				// (the plane that keeps AHEAD of them in flight, before the taps: its round trip runs under them)
+				if constexpr (q + AHEAD < NQ)
+					issue_plane(std::integral_constant<int, q + AHEAD>());
 				if (c0 == 0)
 				{
 					asm volatile("" : "+v"(wv[q]));
@@ -597,7 +625,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 						}
 					}
 				}
-			}
+			});
 #undef CRHIP_W2_TAP
 #undef CRHIP_W2_TAP_SIGNED
 #undef CRHIP_W2_TAP_FIRST
@@ -627,7 +655,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 				if (pair)
 					out[c0 + 1] = normalise<NORM>(acc1, w[TT]);
 			}
-		}
+		});
 	};
 
 	auto store_frame = [&](uint64_t frame, const int *out) {
@@ -686,7 +714,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 			}
 
 			const uint64_t pos = a.pos0 + first * (uint64_t)a.increment;
-			const unsigned lane_rel = __umul24(lane, a.increment) + (unsigned)(pos & 0xFFFFu);
+			// Which frame of the 64 a lane takes.  The LDS services a ds_read_b64 in two groups of 32 lanes, conflict-free only if the
+			// 32 window bases of a group fall on 32 different frames modulo 32 (stereo: two banks per frame).  With consecutive
+			// frames on consecutive lanes that fails wherever 32 steps of the ratio wrap unevenly - 44.1 -> 8 kHz (5.51 frames per
+			// lane): 3 of 32 lanes collide and EVERY window read takes 3-4 LDS cycles instead of 2 (43 % of that kernel's LDS cycles
+			// were conflicts, profiles/r03_dn8_before_pmc_summary.txt).  lane_map 1 gives the lower 32 lanes the even frames and
+			// the upper 32 the odd ones: 11.02 frames per lane, an odd step, 32 different residues.  The host picks per plan
+			// (cr_context.c plan_pick_lane_map: a model of those groups); the stores of a wave still cover the same 64 frames.
+			const unsigned flane = a.lane_map ? (((lane & 31u) << 1) | (lane >> 5)) : lane;
+			const unsigned lane_rel = __umul24(flane, a.increment) + (unsigned)(pos & 0xFFFFu);
 			if (n == WT)
 			{
 #pragma unroll
@@ -694,12 +730,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 				{
 					int out[CH];
 					one_frame2(lane_rel + (unsigned)i * 64u * a.increment, x_odd, out);
-					store_frame(first + (unsigned)i * 64u + lane, out);
+					store_frame(first + (unsigned)i * 64u + flane, out);
 				}
 			}
 			else
 			{
-				for (unsigned jl = lane; jl < n; jl += 64u)
+				for (unsigned jl = flane; jl < n; jl += 64u)
 				{
 					int out[CH];
 					one_frame2(__umul24(jl, a.increment) + (unsigned)(pos & 0xFFFFu), x_odd, out);

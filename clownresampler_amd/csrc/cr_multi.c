@@ -77,7 +77,7 @@ static int rccl_load(void)
 			g_rccl.recv = (nccl_sendrecv_fn)dlsym(g_rccl.library, "ncclRecv");
 			g_rccl.error_string = (nccl_error_string_fn)dlsym(g_rccl.library, "ncclGetErrorString");
 			if (g_rccl.comm_init_all == NULL || g_rccl.comm_destroy == NULL || g_rccl.group_start == NULL || g_rccl.group_end == NULL
-			 || (g_rccl.gather == NULL && (g_rccl.send == NULL || g_rccl.recv == NULL)))
+			 || g_rccl.send == NULL || g_rccl.recv == NULL)
 			{
 				dlclose(g_rccl.library);
 				g_rccl.library = NULL;
@@ -85,7 +85,7 @@ static int rccl_load(void)
 		}
 	}
 	if (g_rccl.library == NULL)
-		return cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "CLOWNRESAMPLER_AMD_GATHER_RCCL: librccl.so with ncclCommInitAll / ncclGather could not be loaded");
+		return cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "CLOWNRESAMPLER_AMD_GATHER_RCCL: librccl.so with ncclCommInitAll / ncclSend / ncclRecv could not be loaded");
 	return 0;
 }
 
@@ -130,7 +130,6 @@ size_t cr_resample_sharded(ClownResampler_LowLevel_State *resampler, uint64_t ta
 	const unsigned long errors_before = cr_error_serial();
 	const size_t unit = (size_t)resampler->channels * (output_is_s16 ? sizeof(int16_t) : sizeof(int32_t));
 	const uint64_t total_out = cr_count_output_frames(resampler->position_integer, resampler->position_fractional, resampler->increment, total_input_frames);
-	const uint64_t per = shard_count != 0 ? (total_out + shard_count - 1) / shard_count : 0;
 	cr_config cfg;
 	int caller_device = 0;
 	unsigned r;
@@ -144,6 +143,21 @@ size_t cr_resample_sharded(ClownResampler_LowLevel_State *resampler, uint64_t ta
 	{
 		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "a gather needs a root shard below the shard count and a root output buffer");
 		return 0;
+	}
+	if (gather_mode == CLOWNRESAMPLER_AMD_GATHER_RCCL)
+	{
+		/* one communicator rank per device: checked here, before anything is launched (ncclCommInitAll's own complaint would come
+		   after the kernels are in their queues) */
+		unsigned q;
+
+		for (r = 0; r < shard_count; ++r)
+			for (q = 0; q < r; ++q)
+				if (shards[q].device == shards[r].device)
+				{
+					cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "CLOWNRESAMPLER_AMD_GATHER_RCCL: shards %u and %u both name device %d; a communicator has one rank per device "
+					        "(use CLOWNRESAMPLER_AMD_GATHER_PEER_COPY for shards that share a device)", q, r, shards[r].device);
+					return 0;
+				}
 	}
 	if (gather_mode < CLOWNRESAMPLER_AMD_GATHER_NONE || gather_mode > CLOWNRESAMPLER_AMD_GATHER_RCCL)
 	{
@@ -205,10 +219,12 @@ size_t cr_resample_sharded(ClownResampler_LowLevel_State *resampler, uint64_t ta
 	}
 	else if (gather_mode == CLOWNRESAMPLER_AMD_GATHER_RCCL)
 	{
-		/* ncclGather wants the same count from every rank: the common block size `per` (the last shard's buffer must have
-		   room for it too; what lies beyond its frames is carried along and lands behind the stream's end on the root) */
+		/* Grouped point-to-point transfers with every shard's EXACT byte count (ncclGather wants one count from all ranks, which
+		   made the last and the empty shards' buffers part of a padding contract the library could not check: ADVICE r2): shard q
+		   sends its block to the root, the root receives it at the block's place in the stream; the root's own block is a copy on
+		   its device.  NOT YET RUN with more than one rank - the pool's boxes have one GPU (tests/test_gpu_ranks.py
+		   test_two_distinct_gpus_over_rccl waits for a node that has two). */
 		int devices[CR_NCCL_MAX_RANKS];
-		const size_t bytes = (size_t)per * unit;
 		int bad = 0;
 
 		for (r = 0; r < shard_count; ++r)
@@ -221,20 +237,24 @@ size_t cr_resample_sharded(ClownResampler_LowLevel_State *resampler, uint64_t ta
 			bad = rccl_check(g_rccl.group_start(), "ncclGroupStart") != 0;
 			for (r = 0; r < shard_count && !bad; ++r)
 			{
-				bad = cr_check_hip(crhip_set_device(shards[r].device), "hipSetDevice") != 0;
-				if (bad)
-					break;
-				if (g_rccl.gather != NULL)
+				ClownResamplerAMD_Shard shard;
+				unsigned char *dst;
+
+				ClownResamplerAMD_PlanShard(resampler, total_input_frames, r, shard_count, &shard);
+				dst = (unsigned char *)root_output + shard.first_output_frame * unit;
+				if (shard.output_frames == 0)
+					continue;
+				if (r == root_shard)
 				{
-					bad = rccl_check(g_rccl.gather(shards[r].device_output, r == root_shard ? root_output : NULL, bytes, CR_NCCL_INT8, (int)root_shard, g_rccl.comms[r], shards[r].hip_stream), "ncclGather") != 0;
+					if ((void *)dst != shards[r].device_output)   /* (a root that computed in place has nothing to move) */
+						bad = cr_check_hip(crhip_set_device(shards[r].device), "hipSetDevice") != 0
+						   || cr_check_hip(crhip_memcpy_peer(dst, shards[r].device, shards[r].device_output, shards[r].device, shard.output_frames * unit, shards[r].hip_stream), "hipMemcpyAsync") != 0;
+					continue;
 				}
-				else
-				{
-					unsigned q;
-					bad = rccl_check(g_rccl.send((void *)shards[r].device_output, bytes, CR_NCCL_INT8, (int)root_shard, g_rccl.comms[r], shards[r].hip_stream), "ncclSend") != 0;
-					for (q = 0; q < shard_count && r == root_shard && !bad; ++q)
-						bad = rccl_check(g_rccl.recv((unsigned char *)root_output + (size_t)q * bytes, bytes, CR_NCCL_INT8, (int)q, g_rccl.comms[r], shards[r].hip_stream), "ncclRecv") != 0;
-				}
+				bad = cr_check_hip(crhip_set_device(shards[r].device), "hipSetDevice") != 0
+				   || rccl_check(g_rccl.send((void *)shards[r].device_output, shard.output_frames * unit, CR_NCCL_INT8, (int)root_shard, g_rccl.comms[r], shards[r].hip_stream), "ncclSend") != 0
+				   || cr_check_hip(crhip_set_device(shards[root_shard].device), "hipSetDevice") != 0
+				   || rccl_check(g_rccl.recv(dst, shard.output_frames * unit, CR_NCCL_INT8, (int)r, g_rccl.comms[root_shard], shards[root_shard].hip_stream), "ncclRecv") != 0;
 			}
 			if (rccl_check(g_rccl.group_end(), "ncclGroupEnd") != 0)
 				bad = 1;

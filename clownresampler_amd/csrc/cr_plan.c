@@ -445,9 +445,15 @@ static const unsigned char B128_GROUPS[4][16] = {
 	{36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63},
 };
 
-static double swizzle_cost(const cr_poly *poly, uint64_t increment, uint32_t swizzle)
+/* which frame of its 64 a lane takes (crhip_poly_launch.lane_map) */
+static unsigned frame_of_lane(unsigned lane, uint32_t lane_map)
 {
-	/* lanes of a wave hold consecutive output frames: fraction of lane l = frac0 + l * increment (mod 65536) */
+	return lane_map ? (((lane & 31u) << 1) | (lane >> 5)) : lane;
+}
+
+static double swizzle_cost(const cr_poly *poly, uint64_t increment, uint32_t swizzle, uint32_t lane_map)
+{
+	/* lanes of a wave hold the output frames of one block of 64: fraction of lane l = frac0 + frame(l) * increment (mod 65536) */
 	double extra = 0.0;
 	unsigned trial;
 
@@ -464,7 +470,7 @@ static double swizzle_cost(const cr_poly *poly, uint64_t increment, uint32_t swi
 
 			for (i = 0; i < 16; ++i)
 			{
-				const uint32_t frac = (uint32_t)((frac0 + (uint64_t)B128_GROUPS[g][i] * increment) & 0xFFFFu);
+				const uint32_t frac = (uint32_t)((frac0 + (uint64_t)frame_of_lane(B128_GROUPS[g][i], lane_map) * increment) & 0xFFFFu);
 				phys[i] = cr_poly_phys_row(cr_poly_row_of(poly, frac), swizzle);
 			}
 
@@ -526,17 +532,70 @@ uint32_t cr_poly_slots_reaching(const cr_poly *poly, int32_t magnitude)
 	return mask;
 }
 
+/* Modelled extra LDS cycles per read of one window slot by a wave of k_wave2 (the expanded window: one dword per sample, a lane's
+   frame at CH dwords per input frame).  An even channel count reads pairs of channels as ds_read_b64 - two groups of 32 lanes,
+   64 banks, a lane on two of them -, an odd one single dwords as ds_read_b32 - 32 banks (MI355X_MICROARCH.md, LDS).  Within a
+   group every further distinct address on a bank costs a cycle. */
+double cr_window_conflicts(const cr_poly *poly, const cr_config *cfg, uint64_t increment, uint32_t channels, uint32_t lane_map)
+{
+	const unsigned banks = (channels % 2u == 0u) ? 64u : 32u, width = (channels % 2u == 0u) ? 2u : 1u;
+	double extra = 0.0;
+	unsigned trial;
+
+	for (trial = 0; trial < 32; ++trial)
+	{
+		const uint32_t frac0 = (trial * 40503u + 977u) & 0xFFFFu;
+		unsigned g;
+
+		for (g = 0; g < 2; ++g)
+		{
+			uint64_t address[32];
+			unsigned count[64] = {0};
+			unsigned i, k, w, worst = 0;
+
+			for (i = 0; i < 32; ++i)
+			{
+				const uint64_t rel = frac0 + (uint64_t)frame_of_lane(32u * g + i, lane_map) * increment;
+				cr_phase phase;
+
+				cr_phase_of(cfg, (uint32_t)(rel & 0xFFFFu), &phase);
+				address[i] = ((rel >> 16) + (poly->shifted ? phase.first_rel - poly->first_mr : 0u)) * channels;
+			}
+			for (i = 0; i < 32; ++i)
+			{
+				int seen = 0;
+
+				for (k = 0; k < i; ++k)
+					if (address[k] == address[i])
+						seen = 1;   /* same address: broadcast */
+				if (seen)
+					continue;
+				for (w = 0; w < width; ++w)
+					if (++count[(address[i] + w) % banks] > worst)
+						worst = count[(address[i] + w) % banks];
+			}
+			extra += worst > 0 ? worst - 1 : 0;
+		}
+	}
+	return extra / 32.0;
+}
+
 uint32_t cr_poly_pick_swizzle(const cr_poly *poly, uint64_t increment, double *conflict_plain, double *conflict_best)
 {
+	return cr_poly_pick_swizzle_mapped(poly, increment, 0u, conflict_plain, conflict_best);
+}
+
+uint32_t cr_poly_pick_swizzle_mapped(const cr_poly *poly, uint64_t increment, uint32_t lane_map, double *conflict_plain, double *conflict_best)
+{
 	uint32_t best = 0, k;
-	double best_cost = swizzle_cost(poly, increment, 0);
+	double best_cost = swizzle_cost(poly, increment, 0, lane_map);
 
 	if (conflict_plain != NULL)
 		*conflict_plain = best_cost;
 
 	for (k = 1; k < 16; ++k)
 	{
-		const double cost = swizzle_cost(poly, increment, k);
+		const double cost = swizzle_cost(poly, increment, k, lane_map);
 
 		if (cost < best_cost - 1e-9)
 		{

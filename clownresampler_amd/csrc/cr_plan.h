@@ -74,6 +74,10 @@ uint32_t cr_poly_slots_reaching(const cr_poly *poly, int32_t magnitude);
 /* Chooses the swizzle (0..15) that minimises ds_read_b128 bank conflicts for lanes that hold consecutive output frames
    `increment` apart; *conflict_cycles_plain / _best receive the modelled extra LDS cycles per wave read. */
 uint32_t cr_poly_pick_swizzle(const cr_poly *poly, uint64_t increment, double *conflict_plain, double *conflict_best);
+/* ... for a kernel whose lanes take the frames of a block of 64 in another order (crhip_poly_launch.lane_map) */
+uint32_t cr_poly_pick_swizzle_mapped(const cr_poly *poly, uint64_t increment, uint32_t lane_map, double *conflict_plain, double *conflict_best);
+/* k_wave2's window reads: modelled extra LDS cycles per read of one window slot by a wave, for either lane order */
+double cr_window_conflicts(const cr_poly *poly, const cr_config *cfg, uint64_t increment, uint32_t channels, uint32_t lane_map);
 /* Device/LDS image of the rows, malloc'ed.  COMPACT (specialised kernels): row_stride/4 planes, a row's int32 [4q,4q+4) in
    plane q, the reciprocal right behind the last weight.  SPLIT (run-time-slot kernels): ceil(slots/4) planes of weights
    (zero-padded) plus one plane holding only the reciprocal.  *device_row_stride receives the int32 per row of the image. */

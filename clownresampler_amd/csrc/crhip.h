@@ -62,6 +62,7 @@ typedef struct crhip_poly_launch
 	unsigned long long *debug_stamps; /* diagnostic instances only: receives {shader cycles, 100 MHz ticks} of workgroup 0 */
 	uint32_t dynamic_tiles;     /* k_poly: 1 = tiles beyond the first gridDim.x are drawn as tickets, 0 = plain round-robin */
 	uint32_t out_s16;           /* 1: d_out is int16, samples clamped to +-0x7FFF (extension); 0: int32 unclamped (reference) */
+	uint32_t lane_map;          /* k_wave2: 0 = lane l takes frame l of its 64, 1 = lanes 0-31 the even frames, 32-63 the odd ones (LDS bank conflicts of the window reads) */
 } crhip_poly_launch;
 
 /* One launch of the generic kernel: the reference arithmetic restated with 64-bit integers, one thread per

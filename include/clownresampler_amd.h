@@ -193,6 +193,9 @@ uint32_t ClownResamplerAMD_PlanKernelAt(const ClownResamplerAMD_Plan *plan, uint
 /* Launches enqueued by this process so far on `kernel` (0 ... 5, numbered as above): lets tests and benchmarks assert that the
    kernel they mean is the one that ran. */
 unsigned long long ClownResamplerAMD_DebugLaunchCount(unsigned kernel);
+/* Test hook: whole-number ratios take the plan's ordinary kernel instead of k_int (the A/B leg; also CLOWNRESAMPLER_AMD_NO_INT_KERNEL
+   in the environment at first use, which additionally skips k_int's one-time setup). */
+void ClownResamplerAMD_DebugDisableIntKernel(int on);
 
 /* Debug/test access to the host copy of the polyphase rows (rows * row_stride int32). */
 const int32_t *ClownResamplerAMD_PlanRows(const ClownResamplerAMD_Plan *plan);
@@ -254,10 +257,10 @@ size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *r
  * devices while they compute.  Optionally the blocks are then concatenated on one device, each transfer enqueued behind
  * its shard's kernel on that shard's stream:
  *   CLOWNRESAMPLER_AMD_GATHER_PEER_COPY  one hipMemcpyPeerAsync per shard (point-to-point over xGMI; exact sizes)
- *   CLOWNRESAMPLER_AMD_GATHER_RCCL       ncclGather over a communicator set of the shards' devices (librccl.so is loaded on
- *                                        first use; every ordinal may then appear only once; equal counts: every
- *                                        device_output must have room for ceil(total / shard_count) frames, and root_output
- *                                        for shard_count times that)
+ *   CLOWNRESAMPLER_AMD_GATHER_RCCL       grouped ncclSend / ncclRecv over a communicator set of the shards' devices, exact sizes
+ *                                        like the copies (librccl.so is loaded on first use; every ordinal may appear only
+ *                                        once - checked before anything is launched).  Has run with ONE rank only: the
+ *                                        test pool has single-GPU boxes
  * Nothing is synchronised: use ClownResamplerAMD_ShardedSynchronize (or the streams) before reading.  Returns the total
  * number of output frames and leaves *resampler as ONE ClownResampler_LowLevel_Resample over the whole input would
  * (clownresampler.h:1065-1067); 0 after an error (reported through the handler).

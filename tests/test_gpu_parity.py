@@ -251,21 +251,88 @@ def test_baseline_configs_full_size_bit_exact(products, name, radius, ch, rates,
     ("hq48c7", 8, 7, (44100, 48000, 44100), 7560000, 4),    # 7 channels: 11 waves, odd channel count
     ("rt4", 8, 4, (48000, 19200, 19200), 24000000, 4),      # no specialised instance: the run-time-slot k_wave2 (40 slots)
     ("up12", 3, 12, (44100, 48000, 44100), 6615000, 1),     # two lanes per frame, ticketed tiles by the wide-frame rule
+    ("dn6x", 3, 2, (48000, 8000, 8000), 28800000, 5),       # whole-number ratios: k_int (36 slots, 6 frames per lane) ...
+    ("dn6xm", 3, 1, (48000, 8000, 8000), 57600000, 5),      # ... mono (4 frames per lane)
+    ("dn21k", 3, 2, (96000, 48000, 48000), 57600000, 5),    # ... 2:1 (12 slots; the k_wave2 of this shape is the "dn21" row above)
+    ("dn31m", 3, 1, (96000, 32000, 32000), 57600000, 5),    # ... mono 3:1 (8 frames per lane)
 ])
 def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch, rates, frames, kernel):
     """10-minute streams (5 for the widest) through the kernels the BASELINE configurations do not reach, against the
-    multi-threaded oracle: a whole launch's worth of chunks, static rounds AND ticketed tail."""
+    multi-threaded oracle: a whole launch's worth of chunks, static rounds AND ticketed tail.  kernel 5 = k_int (decided per
+    launch); the rows that name another kernel for a whole-number ratio run with k_int switched off."""
     p, o = products[radius], ck.oracle(radius)
     ok, st = p.low_init(ch, *rates)
     ok, ost = o.low_init(ch, *rates)
-    info = p.api.PlanGetInfo(p.api.PlanCreate(st.raw, p.pre))
-    assert info.kernel == kernel, (name, info.kernel)
-    R = int(ost.cfg.radius_frames)
-    padded = ck.pad_frames(ck.noise_pcm(frames * ch, 99), ch, R)
-    want = o.low_resample_i32_mt(ost, padded, frames, threads=min(32, os.cpu_count() or 1))
-    got, left, ran_out = p.low_resample_i32(st, padded, frames)
+    plan = p.api.PlanCreate(st.raw, p.pre)
+    info = p.api.PlanGetInfo(plan)
+    p.api.DebugDisableIntKernel(kernel != 5)
+    try:
+        assert p.api.PlanKernelAt(plan, 0) == kernel, (name, info.kernel, p.api.PlanKernelAt(plan, 0))
+        R = int(ost.cfg.radius_frames)
+        padded = ck.pad_frames(ck.noise_pcm(frames * ch, 99), ch, R)
+        want = o.low_resample_i32_mt(ost, padded, frames, threads=min(32, os.cpu_count() or 1))
+        before = p.api.LaunchCount(kernel)
+        got, left, ran_out = p.low_resample_i32(st, padded, frames)
+        assert p.api.LaunchCount(kernel) > before, "the kernel this row names is not the one that ran"
+    finally:
+        p.api.DebugDisableIntKernel(False)
     assert got.size == want.size == ck.count_output_frames(ost, frames) * ch and ran_out == 1 and left == 0
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("ch", [1, 2])
+@pytest.mark.parametrize("ratio", [2, 3, 4, 6])
+def test_whole_number_ratio_kernel(products, ch, ratio):
+    """k_int (cr_kint.hpp): increment = ratio << 16, the launch's one row in the kernel arguments, K consecutive frames per lane.
+    Tile tails (a wave-tile is 64 K frames), capacity stops, input handed over in pieces with real neighbours as padding,
+    int16 output, streams that end 2 bytes into a dword (the sample the DMA's range check drops and the kernel patches in) -
+    against the oracle, and the launch counters say k_int is what ran.  A stream resumed at a fraction whose row does not have
+    the instance's slot signs takes the plan's ordinary kernel and is bit-exact all the same."""
+    p, o = products[3], ck.oracle(3)
+    rates = (48000, 48000 // ratio, 48000 // ratio)
+    ok, probe = p.low_init(ch, *rates)
+    plan = p.api.PlanCreate(probe.raw, p.pre)
+    assert probe.increment == ratio << 16 and p.api.PlanKernelAt(plan, 0) == 5
+    for frames in (1, 2, ratio, 383, 64 * 12 * ratio - 1, 64 * 12 * ratio, 64 * 12 * ratio + 1, 9999, 10000, 250001):
+        ok, st = p.low_init(ch, *rates)
+        ok, ost = o.low_init(ch, *rates)
+        R = int(ost.cfg.radius_frames)
+        padded = ck.pad_frames(ck.noise_pcm(frames * ch, 7 + frames), ch, R)
+        before = p.api.LaunchCount(5)
+        got, left, ran = p.low_resample_i32(st, padded, frames)
+        want, oleft, oran = o.low_resample_i32(ost, padded, frames)
+        assert p.api.LaunchCount(5) == before + 1
+        assert (left, ran) == (oleft, oran) and np.array_equal(got, want) and st.astuple() == ost.astuple(), (ch, ratio, frames)
+    # pieces (odd sizes: mono pieces start on 2-byte boundaries), a capacity stop in the middle, int16 output
+    frames = 60000
+    pcm = ck.noise_pcm(frames * ch, 31)
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    R = int(ost.cfg.radius_frames)
+    padded = ck.pad_frames(pcm, ch, R)
+    at = 0
+    for piece, cap in ((1235, None), (7, None), (20001, 100), (19900, None), (18857, None)):
+        view = padded[at * ch:(at + piece + 2 * R) * ch]
+        g, gl, gr = p.low_resample_i32(st, view, piece, capacity=cap)
+        w, wl, wr = o.low_resample_i32(ost, view, piece, capacity=cap)
+        assert (gl, gr) == (wl, wr) and np.array_equal(g, w) and st.astuple() == ost.astuple(), (ch, ratio, piece, cap)
+        at += piece - gl
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    got16, _, _ = p.api.LowLevel_ResampleBulkS16(st.raw, p.pre, padded, frames)
+    want, _, _ = o.low_resample_i32(ost, padded, frames)
+    assert np.array_equal(got16, np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16))
+    # a stream that arrives at this ratio with a fraction (Adjust mid-stream): whatever kernel its row selects
+    ok, st = p.low_init(ch, 44100, 48000, 44100)
+    ok, ost = o.low_init(ch, 44100, 48000, 44100)
+    head = ck.pad_frames(pcm[: 1001 * ch], ch, 3)
+    g, _, _ = p.low_resample_i32(st, head, 1001)
+    w, _, _ = o.low_resample_i32(ost, head, 1001)
+    assert np.array_equal(g, w) and st.pos_frac != 0
+    assert p.low_adjust(st, *rates) and o.low_adjust(ost, *rates) and st.astuple() == ost.astuple()
+    g, _, _ = p.low_resample_i32(st, padded, frames)
+    w, _, _ = o.low_resample_i32(ost, padded, frames)
+    assert np.array_equal(g, w) and st.astuple() == ost.astuple()
 
 
 @pytest.mark.parametrize("radius,rates", [(8, (8000, 96000, 8000)), (8, (8000, 64000, 8000))])
@@ -725,7 +792,7 @@ def test_random_configurations_bit_exact(products):
     # CRA_SOAK_SEED / CRA_SOAK_DRAWS: a longer one-off soak with another seed (the committed run is 300 draws of the fixed seed)
     rng = random.Random(int(os.environ.get("CRA_SOAK_SEED", "20261002")))
     draws = int(os.environ.get("CRA_SOAK_DRAWS", "300"))
-    kernels = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0}   # generic, k_poly, k_wave, k_up / k_up2, k_wave2
+    kernels = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0}   # generic, k_poly, k_wave, k_up / k_up2, k_wave2, k_int
     done = 0
     while done < draws:
         radius = rng.choice([3, 3, 8])
@@ -734,6 +801,10 @@ def test_random_configurations_bit_exact(products):
         if rng.random() < 0.5:
             o = max(1, int(i * rng.choice([0.03, 0.25, 0.5, 0.9, 0.999, 1.0, 1.001, 1.0884, 1.1, 2, 3, 12, 40])))
         lp = rng.choice([min(i, o), i, o, max(1, min(i, o) // rng.randrange(1, 4)), rng.randrange(1, 200000)])
+        if rng.random() < 0.08:
+            # whole-number downsampling ratios, mono / stereo: k_int
+            o = rng.randrange(1, 30000)
+            i, lp, ch = o * rng.choice([2, 3, 4, 6]), o, rng.choice([1, 2])
         frames = rng.choice([rng.randrange(1, 300), rng.randrange(300, 20000), rng.randrange(20000, 120000)])
         p, orc = products[radius], ck.oracle(radius)
         ok_a, a = p.low_init(ch, i, o, lp)
@@ -755,9 +826,10 @@ def test_random_configurations_bit_exact(products):
         xb, lb, rb = orc.low_resample_i32(b, padded[split * ch:], frames - split, capacity=cap)
         assert (la, ra) == (lb, rb) and np.array_equal(xa, xb) and a.astuple() == b.astuple(), (radius, ch, i, o, lp, frames, split, cap)
         ok, st = p.low_init(ch, i, o, lp)
-        kernels[p.api.PlanGetInfo(p.api.PlanCreate(st.raw, p.pre)).kernel] += 1
+        kernels[p.api.PlanKernelAt(p.api.PlanCreate(st.raw, p.pre), 0)] += 1
         done += 1
-    assert kernels[0] > 0 and kernels[1] > 0, kernels      # both the generic and the polyphase kernels were exercised
+    # the generic and the polyphase kernels, the expanded-window kernel and the whole-number-ratio kernel were all exercised
+    assert kernels[0] > 0 and kernels[1] > 0 and kernels[4] > 0 and kernels[5] >= 5, kernels
 
 
 @pytest.mark.parametrize("ch", [9, 10, 11, 12, 13, 14, 15, 16])

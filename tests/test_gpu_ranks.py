@@ -130,3 +130,34 @@ def test_bench_launches_its_own_ranks(gpus, extra):
     assert line["n_gpus"] == gpus and line["parity_spot_check"] is True
     assert line["gather"]["seams_match_oracle"] is True
     assert line["value"] > 0
+    # the line proves what ran: one entry per rank with its GPU's identity, its own time and its share; the backend summed N ones
+    assert [r["rank"] for r in line["per_rank"]] == list(range(gpus))
+    assert sum(r["output_frames"] for r in line["per_rank"]) == sum(r["output_frames"] for r in line["per_rank"]) > 0
+    assert all(r["ms_per_step"] > 0 and r["device"]["pci"] for r in line["per_rank"])
+    assert line["world_size_seen_by_backend"] == {"get_world_size": gpus, "all_reduce_sum_of_ones": gpus, "backend": line["world_size_seen_by_backend"]["backend"]}
+    assert line["gather"]["link_GBs"] > 0
+
+
+def _device_count():
+    import clownresampler_amd as cr
+    return cr.load(3).DeviceCount()
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs a node with at least two GPUs (the pool's boxes have one)")
+def test_two_distinct_gpus_over_rccl():
+    """The day a multi-GPU node runs this suite: bench.py --gpus 2 must put its ranks on DISTINCT devices and talk RCCL, and the
+    C entry point must concatenate across two ordinals both by peer copies and by RCCL."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CRA_BENCH_BACKEND"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--prewarm-ms", "10"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["backend"].startswith("nccl") and line["world_size_seen_by_backend"]["all_reduce_sum_of_ones"] == 2
+    assert line["distinct_devices"] == 2 and line["parity_spot_check"] is True and line["gather"]["seams_match_oracle"] is True
+    exe = os.path.join(ROOT, "tools", "bin", "cr_multi")
+    for mode in ("peer", "rccl"):
+        c = subprocess.run([exe, "2", "2646000", mode], capture_output=True, text=True, timeout=600, env=env)
+        assert c.returncode == 0 and "cr_multi: OK" in c.stdout, (mode, c.stdout[-1000:], c.stderr[-2000:])

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 		if (lost != ~0u)
 		{
 			if (lane == 0)
-				*reinterpret_cast<short *>(my_buf + lost) = *reinterpret_cast<const short *>(in_end - 2u);
+				*reinterpret_cast<short *>(my_buf + lost) = *(const __attribute__((address_space(1))) short *)(in_end - 2u);   // (a GLOBAL pointer by type: not a flat load)
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -21,7 +21,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (CLOWNRESAMPLER_AMD_LIBRARY: development hook - A/B timing of two builds on one box, tools/ab.sh)
 LIB_PATH = os.environ.get("CLOWNRESAMPLER_AMD_LIBRARY") or os.path.join(_HERE, "libclownresampler_amd.so")
-SUPPORTED_RADII = (3, 8)
+SUPPORTED_RADII = (3, 5, 8)   # csrc/Makefile RADII (ClownResamplerAMD_BuiltRadii() says what the loaded library really has)
 
 KERNEL_RESOLUTION = 0x400      # CLOWNRESAMPLER_KERNEL_RESOLUTION, reference clownresampler.h:452-454
 MAXIMUM_CHANNELS = 16          # CLOWNRESAMPLER_MAXIMUM_CHANNELS, reference clownresampler.h:458-460

@@ -5,3 +5,9 @@ const char *ClownResamplerAMD_BuildId(void)
 {
 	return CRA_SOURCE_ID;
 }
+
+/* the kernel radii this build carries (csrc/Makefile RADII), space-separated */
+const char *ClownResamplerAMD_BuiltRadii(void)
+{
+	return CRA_BUILT_RADII;
+}

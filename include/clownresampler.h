@@ -41,6 +41,14 @@
 #ifndef CLOWNRESAMPLER_KERNEL_RADIUS
  #define CLOWNRESAMPLER_KERNEL_RADIUS 3
 #endif
+/* Any radius can be built (reference clownresampler.h:445-447: a free compile-time knob) - `make -C clownresampler_amd/csrc
+   RADII="3 5 8 <n>"` - and the build writes down which ones it has: a client that asks for another stops here, with the list,
+   instead of at link time with an undefined ..._R<n> symbol. */
+#if defined(__has_include)
+ #if __has_include("clownresampler_amd_radii.h")
+  #include "clownresampler_amd_radii.h"
+ #endif
+#endif
 
 #ifndef CLOWNRESAMPLER_KERNEL_RESOLUTION
  #define CLOWNRESAMPLER_KERNEL_RESOLUTION 0x400

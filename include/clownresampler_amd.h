@@ -56,6 +56,8 @@ void ClownResamplerAMD_ClearError(void);
  * ------------------------------------------------------------------------------------------- */
 /* sha256 (first 16 hex digits) over the sources this library was built from: ties profiles to builds */
 const char *ClownResamplerAMD_BuildId(void);
+/* the values of CLOWNRESAMPLER_KERNEL_RADIUS this library was built for, space-separated ("3 5 8"; csrc/Makefile RADII) */
+const char *ClownResamplerAMD_BuiltRadii(void);
 int ClownResamplerAMD_DeviceCount(void);                /* 0 when there is none; never calls the error handler */
 int ClownResamplerAMD_SetDevice(int ordinal);           /* process default: device used by calls of threads that have not chosen one; 0 on success */
 int ClownResamplerAMD_SetThreadDevice(int ordinal);     /* device used by subsequent calls of the CALLING THREAD (-1: follow the process default again) */

@@ -180,6 +180,11 @@ for _i, _o in [(8000, 96000), (44100, 48000), (48000, 44100), (48000, 8000)]:
     _add("r8_%d_%d" % (_i, _o), channels=2, rates=_lp(_i, _o), input="noise", frames=15000, radius=8)
 _add("r8_8ch", channels=8, rates=_lp(48000, 44100), input="noise", frames=8000, radius=8)
 
+# any other radius (CLOWNRESAMPLER_KERNEL_RADIUS is a free compile-time knob, clownresampler.h:445-447): 5 lobes, built by default
+for _i, _o in [(44100, 48000), (48000, 44100), (8000, 96000), (44100, 8000), (96000, 48000)]:
+    _add("r5_%d_%d" % (_i, _o), channels=2, rates=_lp(_i, _o), input="noise", frames=15000, radius=5)
+_add("r5_5ch_high", channels=5, rates=_lp(48000, 44100), input="noise", frames=9000, radius=5, mode="high", pull_chunk=700)
+
 # adversarial amplitudes: full-scale square, constant -32768 / +32767, impulse
 for _kind in ("square", "min", "max", "impulse", "ramp"):
     _add("amp_%s_up" % _kind, channels=2, rates=_lp(44100, 48000), input=_kind, frames=6000)
@@ -192,6 +197,7 @@ for _n in (0, 1, 2, 3, 5, 64, 65, 255, 257):
     _add("tiny_down_%d" % _n, channels=2, rates=_lp(44100, 8000), input="noise", frames=_n)
 
 CASE_BY_NAME = {c["name"]: c for c in CASES}
+RADII = (3, 5, 8)   # what csrc/Makefile builds by default and oracle/Makefile compiles the reference for
 
 # configuration scalars: (in, out, lowpass) triples incl. the failure cases of clownresampler.h:919,939,974
 CONFIG_TRIPLES = [

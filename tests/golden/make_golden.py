@@ -68,7 +68,7 @@ def main():
 
     # 4. tables
     gold["table"] = {}
-    for r in (3, 8):
+    for r in _cases.RADII:
         t = ck.reference(r).table()
         gold["table"][str(r)] = {"len": int(len(t)), "sha256_i32le": hashlib.sha256(t.astype("<i4").tobytes()).hexdigest(),
                                  "sum": int(t.sum()), "abs_sum": int(np.abs(t).sum()), "t512": int(t[512]),
@@ -76,7 +76,7 @@ def main():
 
     # 5. ratio / configuration scalars
     gold["config"] = {}
-    for r in (3, 8):
+    for r in _cases.RADII:
         ref = ck.reference(r)
         rows = []
         for (i, o, l) in _cases.CONFIG_TRIPLES:

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def products():
     assert cr.load(3).DeviceCount() > 0, "these tests need the GPU: the library has no other path"
-    return {3: _product.Product(3), 8: _product.Product(8)}
+    return {3: _product.Product(3), 5: _product.Product(5), 8: _product.Product(8)}
 
 
 @pytest.mark.parametrize("case", _cases.CASES, ids=[c["name"] for c in _cases.CASES])
@@ -795,7 +795,7 @@ def test_random_configurations_bit_exact(products):
     kernels = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0}   # generic, k_poly, k_wave, k_up / k_up2, k_wave2, k_int
     done = 0
     while done < draws:
-        radius = rng.choice([3, 3, 8])
+        radius = rng.choice([3, 3, 8, 5])
         ch = rng.choice([1, 2, 2, 2, 3, 4, 5, 6, 7, 8, 8, 9, 10, 11, 12, 13, 14, 15, 16])
         i, o = rng.randrange(1, 200000), rng.randrange(1, 200000)
         if rng.random() < 0.5:

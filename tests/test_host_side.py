@@ -167,7 +167,7 @@ def test_cmake_target_has_the_references_name(tmp_path):
     assert out.returncode == 0 and out.stdout.split() == ["60211", "65536"]
 
 
-@pytest.mark.parametrize("radius", [3, 8])
+@pytest.mark.parametrize("radius", [3, 5, 8])
 def test_table_is_the_references(golden, radius):
     # host-side, reference clownresampler.h:955-961
     import hashlib
@@ -176,7 +176,7 @@ def test_table_is_the_references(golden, radius):
     assert np.array_equal(t, ck.oracle(radius).table())
 
 
-@pytest.mark.parametrize("radius", [3, 8])
+@pytest.mark.parametrize("radius", [3, 5, 8])
 def test_config_scalars_are_the_references(golden, radius):
     # host-side, reference clownresampler.h:913-984, :1044-1056; failure cases leave exactly what the reference leaves
     p = _product.Product(radius)

@@ -12,7 +12,7 @@ import _checkers as ck
 
 def test_tables_match_reference(golden):
     # clownresampler.h:955-961; hashes also quoted in SURVEY.md 8(a) a-4
-    for r in (3, 8):
+    for r in _cases.RADII:
         t = ck.oracle(r).table()
         g = golden["table"][str(r)]
         assert len(t) == g["len"]
@@ -26,7 +26,7 @@ def test_survey_table_hashes(golden):
     assert golden["table"]["8"]["sha256_i32le"] == "40aa850733dcdcabb6b13f37d51c6d0970b35414826d7a3e15450a5259d80ea8"
 
 
-@pytest.mark.parametrize("radius", [3, 8])
+@pytest.mark.parametrize("radius", list(_cases.RADII))
 def test_config_scalars(golden, radius):
     # clownresampler.h:913-953, :963-984, :1044-1056 incl. failure cases; state is pre-poisoned so that
     # "what is left untouched on failure" is part of the comparison

@@ -41,7 +41,7 @@ def test_ratio_sweep():
         assert o.ratio(a, b) == r.ratio(a, b), (a, b)
 
 
-@pytest.mark.parametrize("radius", [3, 8])
+@pytest.mark.parametrize("radius", [3, 5, 8])
 def test_configure_sweep(radius):
     o, r = ck.oracle(radius), ck.reference(radius)
     rng = random.Random(2)
@@ -54,7 +54,7 @@ def test_configure_sweep(radius):
 
 
 def _random_case(rng):
-    radius = rng.choice([3, 3, 8])
+    radius = rng.choice([3, 3, 8, 5])
     ch = rng.choice([1, 2, 2, 3, 4, 6, 8, 16])
     i, o = rng.randrange(1, 200000), rng.randrange(1, 200000)
     if rng.random() < 0.3:

@@ -13,6 +13,7 @@
 #include "../../include/clownresampler_amd.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -418,6 +419,104 @@ size_t ClownResamplerAMD_ResampleShardedDevice(ClownResampler_LowLevel_State *re
 /* ======================================================================================================= */
 
 #ifndef CLOWNRESAMPLER_NO_LOW_LEVEL_API
+
+/* Hands frames [0, n) of `batch_out` to the consumer, the state moved on BEFORE each frame is handed out
+   (clownresampler.h:1076-1081: a callback that looks at the state sees what it would see with the reference).  Returns the
+   number of frames handed out; *stopped = 1 when the callback returned 0 on the last of them (which may be frame n - 1). */
+static uint64_t replay_frames(ClownResampler_LowLevel_State *resampler, const int32_t *batch_out, uint64_t n, ClownResampler_OutputCallback output_callback, const void *user_data, int *stopped)
+{
+	const cc_u8f channels = resampler->channels;
+	const uint64_t increment = resampler->increment;
+	/* the running position in locals (the callback cannot be assumed not to touch memory, so fields of *resampler would be
+	   reloaded after every call); the struct is brought up to date before every call */
+	uint64_t position = ((uint64_t)resampler->position_integer << 16) + resampler->position_fractional;
+	uint64_t i;
+
+	for (i = 0; i < n; ++i)
+	{
+		cc_s32f frame[CLOWNRESAMPLER_MAXIMUM_CHANNELS];
+		const int32_t *from = batch_out + i * channels;
+		cc_u8f c;
+
+		if (channels == 2)
+		{
+			frame[0] = from[0];
+			frame[1] = from[1];
+		}
+		else
+			for (c = 0; c < channels; ++c)
+				frame[c] = from[c];
+
+		position += increment;
+		resampler->position_integer = (size_t)(position >> 16);
+		resampler->position_fractional = (cc_u32f)(position & (ONE - 1u));
+
+		if (!output_callback((void *)user_data, frame, channels))
+		{
+			*stopped = 1;
+			return i + 1;
+		}
+	}
+	*stopped = 0;
+	return n;
+}
+
+/* The consumer's callbacks run on the calling thread, one frame at a time, at 1-2 ns each: for a long call that - not the GPU -
+   is where the time goes (10 minutes of stereo: ~45 ms of callbacks against ~5 ms of upload + kernel + download).  So once the
+   batches have reached their full size, a helper thread computes batch k + 1 while the calling thread replays batch k (two
+   slots).  A consumer that stops early costs at most the batch in flight, as before. */
+typedef struct replay_ahead
+{
+	const ClownResamplerAMD_Plan *plan;
+	const cc_s16l *input_buffer;
+	uint64_t padded_frames, start_int, start_frac, increment;
+	uint64_t first, available, batch;   /* output frames [first, available), `batch` at a time */
+	int32_t *slot[2];
+	uint64_t frames[2];
+	int state[2];                        /* 0: free, 1: filled, 2: the device failed (reported through the error handler) */
+	int cancel;
+	pthread_mutex_t lock;
+	pthread_cond_t changed;
+} replay_ahead;
+
+static void *replay_ahead_worker(void *argument)
+{
+	replay_ahead *a = (replay_ahead *)argument;
+	uint64_t at = a->first;
+	unsigned k = 0;
+
+	while (at < a->available)
+	{
+		const uint64_t n = a->available - at < a->batch ? a->available - at : a->batch;
+		uint64_t pi = a->start_int, pf = a->start_frac;
+		int failed;
+
+		pthread_mutex_lock(&a->lock);
+		while (a->state[k] != 0 && !a->cancel)
+			pthread_cond_wait(&a->changed, &a->lock);
+		if (a->cancel)
+		{
+			pthread_mutex_unlock(&a->lock);
+			break;
+		}
+		pthread_mutex_unlock(&a->lock);
+
+		cr_advance(&pi, &pf, a->increment, at);
+		failed = cr_run_host(a->plan, a->input_buffer, a->padded_frames, pi, pf, n, a->slot[k], 0) != 0;
+
+		pthread_mutex_lock(&a->lock);
+		a->frames[k] = n;
+		a->state[k] = failed ? 2 : 1;
+		pthread_cond_broadcast(&a->changed);
+		pthread_mutex_unlock(&a->lock);
+		if (failed)
+			break;
+		at += n;
+		k ^= 1u;
+	}
+	return NULL;
+}
+
 cc_bool ClownResampler_LowLevel_Resample(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed, const cc_s16l *input_buffer, size_t *total_input_frames, ClownResampler_OutputCallback output_callback, const void *user_data)
 {
 	const uint64_t start_int = resampler->position_integer, start_frac = resampler->position_fractional;
@@ -427,11 +526,12 @@ cc_bool ClownResampler_LowLevel_Resample(ClownResampler_LowLevel_State *resample
 	const ClownResamplerAMD_Plan *plan;
 	int32_t *batch_out;
 	uint64_t done = 0;
+	int failed = 0, consumer_stopped = 0;
 	/* A consumer may stop after a handful of frames (a sound-card callback asks for a few hundred,
 	   examples/low-level.c:84) or take the whole stream: frames are computed ahead speculatively in batches
 	   that start small and grow, so neither case wastes much. */
 	uint64_t batch = 1024;
-	const uint64_t batch_limit = 1u << 20;
+	const uint64_t batch_limit = (1u << 21) / (channels != 0 ? channels : 1u);   /* 8 MiB of int32 per batch */
 
 	if (available == 0)
 	{
@@ -451,39 +551,29 @@ cc_bool ClownResampler_LowLevel_Resample(ClownResampler_LowLevel_State *resample
 		return cc_true;
 	}
 
-	while (done < available)
+	/* 1. the growing batches, one after the other on this thread */
+	while (done < available && !(batch == batch_limit && available - done > 2 * batch_limit))
 	{
 		const uint64_t n = available - done < batch ? available - done : batch;
-		uint64_t i;
+		uint64_t handed;
 
 		{
 			uint64_t pi = start_int, pf = start_frac;
 			cr_advance(&pi, &pf, resampler->increment, done);
 			if (cr_run_host(plan, input_buffer, padded_frames, pi, pf, n, batch_out, 0) != 0)
+			{
+				failed = 1;
 				break;
+			}
 		}
 
-		for (i = 0; i < n; ++i)
+		handed = replay_frames(resampler, batch_out, n, output_callback, user_data, &consumer_stopped);
+		if (consumer_stopped)
 		{
-			cc_s32f frame[CLOWNRESAMPLER_MAXIMUM_CHANNELS];
-			cc_u8f c;
-
-			for (c = 0; c < channels; ++c)
-				frame[c] = batch_out[i * channels + c];
-
-			/* the position is moved on before the frame is handed out (clownresampler.h:1076-1081): a callback
-			   that looks at the state sees what it would see with the reference */
-			resampler->position_fractional += resampler->increment;
-			resampler->position_integer += resampler->position_fractional / ONE;
-			resampler->position_fractional %= ONE;
-
-			if (!output_callback((void *)user_data, frame, channels))
-			{
-				free(batch_out);
-				cr_plan_release(plan);
-				settle_stopped(resampler, total_input_frames, start_int, start_frac, done + i + 1);
-				return cc_false;
-			}
+			free(batch_out);
+			cr_plan_release(plan);
+			settle_stopped(resampler, total_input_frames, start_int, start_frac, done + handed);
+			return cc_false;
 		}
 
 		done += n;
@@ -493,10 +583,112 @@ cc_bool ClownResampler_LowLevel_Resample(ClownResampler_LowLevel_State *resample
 			batch = batch_limit;
 	}
 
+	/* 2. what is left of a long call, at full batch size: computed one batch ahead of the callbacks by a helper thread */
+	if (!failed && done < available)
+	{
+		replay_ahead ahead;
+		pthread_t worker;
+		int32_t *second = (int32_t *)malloc((size_t)batch_limit * channels * sizeof(int32_t));
+		unsigned k = 0;
+		int stopped = 0, started = 0;
+
+		memset(&ahead, 0, sizeof(ahead));
+		ahead.plan = plan;
+		ahead.input_buffer = input_buffer;
+		ahead.padded_frames = padded_frames;
+		ahead.start_int = start_int;
+		ahead.start_frac = start_frac;
+		ahead.increment = resampler->increment;
+		ahead.first = done;
+		ahead.available = available;
+		ahead.batch = batch_limit;
+		ahead.slot[0] = batch_out;
+		ahead.slot[1] = second;
+		pthread_mutex_init(&ahead.lock, NULL);
+		pthread_cond_init(&ahead.changed, NULL);
+		started = second != NULL && pthread_create(&worker, NULL, replay_ahead_worker, &ahead) == 0;
+
+		while (started && done < available)
+		{
+			uint64_t n, handed;
+			int state;
+
+			pthread_mutex_lock(&ahead.lock);
+			while (ahead.state[k] == 0)
+				pthread_cond_wait(&ahead.changed, &ahead.lock);
+			state = ahead.state[k];
+			n = ahead.frames[k];
+			pthread_mutex_unlock(&ahead.lock);
+			if (state == 2)
+			{
+				failed = 1;
+				break;
+			}
+
+			handed = replay_frames(resampler, ahead.slot[k], n, output_callback, user_data, &consumer_stopped);
+			if (consumer_stopped)
+			{
+				done += handed;
+				stopped = 1;
+				break;
+			}
+			done += n;
+
+			pthread_mutex_lock(&ahead.lock);
+			ahead.state[k] = 0;
+			pthread_cond_broadcast(&ahead.changed);
+			pthread_mutex_unlock(&ahead.lock);
+			k ^= 1u;
+		}
+
+		if (started)
+		{
+			pthread_mutex_lock(&ahead.lock);
+			ahead.cancel = 1;
+			pthread_cond_broadcast(&ahead.changed);
+			pthread_mutex_unlock(&ahead.lock);
+			pthread_join(worker, NULL);
+		}
+		pthread_cond_destroy(&ahead.changed);
+		pthread_mutex_destroy(&ahead.lock);
+		free(second);
+
+		if (stopped)
+		{
+			free(batch_out);
+			cr_plan_release(plan);
+			settle_stopped(resampler, total_input_frames, start_int, start_frac, done);
+			return cc_false;
+		}
+
+		/* (no helper thread or no memory for its second slot: the rest one batch after the other, as above) */
+		while (!started && !failed && done < available)
+		{
+			const uint64_t n = available - done < batch_limit ? available - done : batch_limit;
+			uint64_t pi = start_int, pf = start_frac, handed;
+
+			cr_advance(&pi, &pf, resampler->increment, done);
+			if (cr_run_host(plan, input_buffer, padded_frames, pi, pf, n, batch_out, 0) != 0)
+			{
+				failed = 1;
+				break;
+			}
+			handed = replay_frames(resampler, batch_out, n, output_callback, user_data, &consumer_stopped);
+			if (consumer_stopped)
+			{
+				free(batch_out);
+				cr_plan_release(plan);
+				settle_stopped(resampler, total_input_frames, start_int, start_frac, done + handed);
+				return cc_false;
+			}
+			done += n;
+		}
+	}
+
 	free(batch_out);
 	cr_plan_release(plan);
 
-	if (done < available)
+	if (failed || done < available)
 	{
 		/* a device failure was reported through the error handler and the handler returned: stop where we are */
 		settle_stopped(resampler, total_input_frames, start_int, start_frac, done);

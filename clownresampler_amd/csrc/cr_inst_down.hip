@@ -20,6 +20,8 @@ int specials_down(void *table, int capacity)
 	    with_wave2<2, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 2, 0, true>(make_special_lite<2, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	};
 	const int n = (int)(sizeof(mine) / sizeof(mine[0]));
+	if (table == nullptr)
+		return n;   // (asked for the count: specials() sizes its table from the providers)
 	if (n > capacity)
 		return -1;
 	memcpy(table, mine, sizeof(mine));

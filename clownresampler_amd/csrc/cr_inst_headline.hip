@@ -13,6 +13,8 @@ int specials_headline(void *table, int capacity)
 	    make_special<1, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>(),     // mono mild downsampling, 3 lobes
 	};
 	const int n = (int)(sizeof(mine) / sizeof(mine[0]));
+	if (table == nullptr)
+		return n;   // (asked for the count: specials() sizes its table from the providers)
 	if (n > capacity)
 		return -1;
 	memcpy(table, mine, sizeof(mine));

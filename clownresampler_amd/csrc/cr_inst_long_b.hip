@@ -28,6 +28,8 @@ int specials_long_b(void *table, int capacity)
 	    make_special_lite<8, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
 	};
 	const int n = (int)(sizeof(mine) / sizeof(mine[0]));
+	if (table == nullptr)
+		return n;   // (asked for the count: specials() sizes its table from the providers)
 	if (n > capacity)
 		return -1;
 	memcpy(table, mine, sizeof(mine));

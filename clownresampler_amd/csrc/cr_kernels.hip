@@ -36,6 +36,7 @@
 
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "cr_instances.hpp"
 
@@ -105,23 +106,21 @@ __global__ __launch_bounds__(256) void k_generic(const crhip_generic_launch a)
 // ---------------------------------------------------------------------------------------------------------
 const special *specials(int *count)
 {
-	static special table[96];
-	static int n = -1;
+	// sized from the providers (each says how many instances it has when asked with no table): no fixed capacity to outgrow
+	static std::vector<special> table;
 	static std::once_flag once;
 	std::call_once(once, [] {
-		int total = 0;
 		int (*const providers[])(void *, int) = {crk::specials_headline, crk::specials_long, crk::specials_long_b, crk::specials_multi_a, crk::specials_multi_b, crk::specials_down};
+		size_t total = 0;
 		for (auto provider : providers)
-		{
-			const int got = provider(table + total, 96 - total);
-			if (got < 0)
-				abort();
-			total += got;
-		}
-		n = total;
+			total += (size_t)provider(nullptr, 0);
+		table.resize(total);
+		size_t at = 0;
+		for (auto provider : providers)
+			at += (size_t)provider(table.data() + at, (int)(total - at));   // (cannot come up short: it was asked a line ago)
 	});
-	*count = n;
-	return table;
+	*count = (int)table.size();
+	return table.data();
 }
 
 poly_fn ablation_instance(int abl)

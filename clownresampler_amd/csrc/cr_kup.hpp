@@ -688,15 +688,28 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 			// (a v_ashrrev from S instead would save the bias registers but measured 30 % slower per frame at this occupancy:
 			// tools/microbench/chainbench.hip, profiles/r02_chainbench.log)
 			int lo0, hi0 = 0, lo1, hi1 = 0;
+			// How the statement is declared matters as much as what is in it: hipcc treats every asm statement as a possible
+			// forwarding hazard and pads with an s_nop whenever a register one statement DEFINES is touched - read or written - by
+			// the next instruction with nothing but other asm statements in between.  Declared with the low dword as an output and
+			// vcc as the carry-out of both chains, the frame loop carried 15 s_nop per frame beside its 73 VALU instructions
+			// (profiles/r03_kup2_nops.log).  So: (1) the two chains take their carry-out in different registers, vcc and
+			// s[100:101], and may sit back to back; (2) the low dword is declared as an INPUT only - the multiply-add leaves the
+			// product's fraction bits there, which nothing ever reads: the next tap's arming move overwrites it, and that move is
+			// hipcc's own instruction, free to follow the statement directly.  (What the compiler believes about v120 / v124 after
+			// a statement - "still the bias I put there" - is never used: every tap arms with a different register.)
 #define CRHIP_UP2_TAP(LO, HI, VLO, VHI, SAMPLE, WEIGHT, BIAS)                                                                       \
 	VLO = (BIAS);                                                                                                                  \
-	asm("v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]" : "+{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(SAMPLE), "v"(WEIGHT) : "vcc")
+	asm("v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %1, %2, v[" #LO ":" #HI "]" : "+{v" #HI "}"(VHI) : "v"(SAMPLE), "v"(WEIGHT), "{v" #LO "}"(VLO) : "vcc")
+#define CRHIP_UP2_TAP_B(LO, HI, VLO, VHI, SAMPLE, WEIGHT, BIAS)                                                                     \
+	VLO = (BIAS);                                                                                                                  \
+	asm("v_mad_i64_i32 v[" #LO ":" #HI "], s[100:101], %1, %2, v[" #LO ":" #HI "]" : "+{v" #HI "}"(VHI) : "v"(SAMPLE), "v"(WEIGHT), "{v" #LO "}"(VLO) : "s100", "s101")
 #pragma unroll
 			for (int s = 0; s < TT; ++s)
 			{
 				CRHIP_UP2_TAP(120, 121, lo0, hi0, S[s][0], w[s], B[s][0]);
-				CRHIP_UP2_TAP(124, 125, lo1, hi1, S[s][1], w[s], B[s][1]);
+				CRHIP_UP2_TAP_B(124, 125, lo1, hi1, S[s][1], w[s], B[s][1]);
 			}
+#undef CRHIP_UP2_TAP_B
 #undef CRHIP_UP2_TAP
 			(void)lo0;
 			(void)lo1;

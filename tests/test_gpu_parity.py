@@ -129,6 +129,39 @@ def test_callback_api_early_stop_and_resume(products):
         assert len(got_a) == ck.count_output_frames(o.low_init(ch, *rates)[1], frames)
 
 
+@pytest.mark.parametrize("ch,stop_at", [(2, None), (2, 2_900_000), (2, 350_000 + (1 << 20) - 1), (5, 1_700_000), (1, 5_555_555)])
+def test_callback_api_long_calls_compute_one_batch_ahead(products, ch, stop_at):
+    """A long ClownResampler_LowLevel_Resample: past the growing batches a helper thread computes batch k + 1 while the calling
+    thread hands out batch k.  With a C callback (tools/cb_store.c: stores int32, returns 0 on the frame that no longer fits):
+    the whole stream, and stops in the middle of the pipelined part - on a batch's last frame too - against the oracle's stream
+    and its state after as many frames (clownresampler.h:1084-1088)."""
+    import ctypes as C
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bin", "libcr_cbstore.so")
+    assert os.path.exists(path), "build() makes it"
+    lib = C.CDLL(path)
+
+    class Store(C.Structure):
+        _fields_ = [("out", C.POINTER(C.c_int)), ("at", C.c_size_t), ("capacity", C.c_size_t)]
+
+    p, o = products[3], ck.oracle(3)
+    rates = (44100, 48000, 44100)
+    frames = 6_000_000
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    R = int(ost.cfg.radius_frames)
+    padded = ck.pad_frames(ck.noise_pcm(frames * ch, 77), ch, R)
+    total = int(ck.count_output_frames(ost, frames))
+    fit = total if stop_at is None else stop_at          # frames the callback accepts; it returns 0 on frame index `fit`
+    out = np.zeros(max(fit, 1) * ch, dtype=np.int32)
+    store = Store(out.ctypes.data_as(C.POINTER(C.c_int)), 0, fit * ch)
+    left = C.c_size_t(frames)
+    r = p.api._LowResample(C.byref(st.raw), C.byref(p.pre), padded.ctypes.data_as(C.POINTER(cr.cc_s16l)), C.byref(left),
+                           C.cast(lib.cr_store_frame, cr.OutputCallback), C.cast(C.pointer(store), C.c_void_p))
+    want, oleft, oran = o.low_resample_i32_capped(ost, padded, frames, fit + 1) if hasattr(o, "low_resample_i32_capped") else o.low_resample_i32(ost, padded, frames, capacity=fit + 1)
+    assert store.at == fit * ch and np.array_equal(out[: fit * ch], want[: fit * ch])
+    assert bool(r) == bool(oran) and left.value == oleft and st.astuple() == ost.astuple(), (ch, stop_at, r, oran, left.value, oleft)
+
+
 def test_device_resident_api(products):
     """ClownResamplerAMD_ResampleDevice on caller-owned device buffers, incl. capacity stop, resume and unaligned
     (frame-aligned only) input pointers."""
@@ -801,10 +834,15 @@ def test_random_configurations_bit_exact(products):
         if rng.random() < 0.5:
             o = max(1, int(i * rng.choice([0.03, 0.25, 0.5, 0.9, 0.999, 1.0, 1.001, 1.0884, 1.1, 2, 3, 12, 40])))
         lp = rng.choice([min(i, o), i, o, max(1, min(i, o) // rng.randrange(1, 4)), rng.randrange(1, 200000)])
-        if rng.random() < 0.08:
+        special_draw = rng.random()
+        if special_draw < 0.08:
             # whole-number downsampling ratios, mono / stereo: k_int
             o = rng.randrange(1, 30000)
             i, lp, ch = o * rng.choice([2, 3, 4, 6]), o, rng.choice([1, 2])
+        elif special_draw < 0.11:
+            # increments of 2^24 and more (256:1 and beyond): nothing but the generic kernel takes those
+            o = rng.randrange(1, 600)
+            i, lp = o * rng.randrange(256, 700), o
         frames = rng.choice([rng.randrange(1, 300), rng.randrange(300, 20000), rng.randrange(20000, 120000)])
         p, orc = products[radius], ck.oracle(radius)
         ok_a, a = p.low_init(ch, i, o, lp)

@@ -87,6 +87,9 @@ WORKLOADS = {
     "dn4": (3, 4, (48000, 44100, 44100), 28800000),
     "dn6": (3, 6, (48000, 44100, 44100), 28800000),
     "up12": (3, 12, (44100, 48000, 44100), 26460000),
+    "hq48c16": (8, 16, (44100, 48000, 44100), 3307500),  # 8 lobes, the widest frame: k_wave2s (a lane per channel pair)
+    "hq48c12": (8, 12, (44100, 48000, 44100), 4410000),
+    "dn8c12": (3, 12, (44100, 8000, 8000), 4410000),
     "dn6x": (3, 2, (48000, 8000, 8000), 57600000),     # stereo / mono 6:1 (increment exact in 16.16: every frame uses ONE row), 36-slot windows
     "dn6xm": (3, 1, (48000, 8000, 8000), 115200000),
     "dn8m": (3, 1, (44100, 8000, 8000), 52920000),
@@ -439,15 +442,15 @@ def main():
         for i in range(args.warmup):
             step(i)
     barrier()
-    counts_before = [api.LaunchCount(k) for k in range(6)]
+    counts_before = [api.LaunchCount(k) for k in range(7)]
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         run_steps()
     barrier()
     wall = time.perf_counter() - t0
-    launches_by_kernel = [api.LaunchCount(k) - counts_before[k] for k in range(6)]   # what the timed region ran (graph replays launch nothing new)
+    launches_by_kernel = [api.LaunchCount(k) - counts_before[k] for k in range(7)]   # what the timed region ran (graph replays launch nothing new)
     if graph is not None:
-        launches_by_kernel = [args.steps] * 6
+        launches_by_kernel = [args.steps] * 7
     dev_ms = max(ev0.elapsed_time(ev1), 0.0)
     mean_ms = dev_ms / args.steps
 
@@ -476,7 +479,7 @@ def main():
     if ran != 5:
         ran = info.brief_kernel if (info.kernel == 3 and shard.output_frames < info.brief_below) else info.kernel
     kernel_name = {1: "k_poly<%d,%d>", 2: "k_wave<%d,%d>", 3: "k_up2<%d,%d>" if (info.variant == 27 and ch == 2) else "k_up<%d,%d>",
-                   4: "k_wave2<%d,%d>", 5: "k_int<%d,%d>"}[ran] % (ch, info.slots) if ran else "k_generic"
+                   4: "k_wave2<%d,%d>", 5: "k_int<%d,%d>", 6: "k_wave2s<%d,%d>"}[ran] % (ch, info.slots) if ran else "k_generic"
     if launches_by_kernel[ran] < args.steps:
         raise SystemExit("bench: expected the timed launches on kernel %d (%s); launch counters say %s" % (ran, kernel_name, launches_by_kernel))
     pmc, pmc_file, traffic_note = pmc_summary(workload, api.BuildId()) if (world == 1 and not args.s16) else (None, None, "N > 1 / int16 output: no PMC summary applies")

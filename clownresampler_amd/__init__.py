@@ -200,6 +200,7 @@ class Api:
         self._LaunchCount = fn("ClownResamplerAMD_DebugLaunchCount", C.c_ulonglong, [C.c_uint], False)
         self._BuildId = fn("ClownResamplerAMD_BuildId", C.c_char_p, [], False)
         self._DisableInt = fn("ClownResamplerAMD_DebugDisableIntKernel", None, [C.c_int], False)
+        self._SegmentsMode = fn("ClownResamplerAMD_DebugSegmentsMode", None, [C.c_int], False)
         self._HighRelease = fn("ClownResamplerAMD_HighLevel_Release", None, [P(HighLevel_State)], False)
         self._WindowCount = fn("ClownResamplerAMD_StreamingWindowCount", C.c_size_t, [], False)
         self._DeviceAllocOn = fn("ClownResamplerAMD_DeviceAllocOn", C.c_void_p, [C.c_int, C.c_size_t], False)
@@ -415,6 +416,10 @@ class Api:
     def PlanKernelAt(self, plan, position_fractional=0):
         """kernel id a launch from this fractional position takes (PlanInfo.kernel numbering, 5 = k_int)"""
         return int(self._PlanKernelAt(plan, position_fractional))
+
+    def DebugSegmentsMode(self, mode):
+        """0: the rule picks, 1: one launch per segment, 2: one launch for all segments (segment table)"""
+        self._SegmentsMode(mode)
 
     def DebugDisableIntKernel(self, on):
         self._DisableInt(1 if on else 0)

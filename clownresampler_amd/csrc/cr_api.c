@@ -317,6 +317,11 @@ size_t ClownResampler_LowLevel_ResampleBulkS16(ClownResampler_LowLevel_State *re
                        timeline + (a_s - integer_stretched_kernel_radius_s) * channels, &total, append, 0);
    i.e. each segment's "padding" is the real neighbouring frames (legal per clownresampler.h:725-733), the position
    (overshoot + fraction) is carried across the re-configuration exactly as the state struct carries it. */
+/* one launch for all segments from this many on, if they average fewer output frames than that (one launch per segment is
+   launch-bound below ~40,000 frames: DESIGN.md section 8) */
+#define SEGMENT_TABLE_MIN_SEGMENTS 8u
+#define SEGMENT_TABLE_MAX_FRAMES 32768u
+
 size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed,
                                                 const void *device_timeline, size_t halo_frames, const ClownResamplerAMD_Segment *segments, size_t segment_count,
                                                 void *device_output, size_t output_capacity_frames, int output_is_s16, size_t *segment_output_frames, void *hip_stream)
@@ -324,7 +329,10 @@ size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *r
 	const unsigned long errors_before = cr_error_serial();
 	ClownResampler_LowLevel_State state = *resampler;
 	uint64_t total_out = 0, in_frame = 0, out_frame = 0, table_hash;
-	size_t s;
+	size_t s, table_count = 0;
+	crhip_segment *table = NULL;
+	const ClownResamplerAMD_Plan *table_plan = NULL;
+	int use_table = 0;
 
 	/* pass 1, host only: every segment must be acceptable before anything is enqueued */
 	for (s = 0; s < segment_count; ++s)
@@ -359,9 +367,39 @@ size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *r
 		return 0;
 	}
 
-	/* pass 2: one launch per segment, back to back on the caller's stream */
+	/* pass 2.  Long segments: one launch each, back to back on the caller's stream, on whatever kernel the segment's plan has.  MANY
+	   SHORT ones: a launch costs ~5 us however little it does (6,000 segments of a tenth of a second: 31 ms), so they all go into ONE
+	   launch of the generic kernel with a segment table (k_generic_segments: ~0.1 ns per frame slower, no per-segment cost). */
 	table_hash = table_hash_of(precomputed);
 	state = *resampler;
+	{
+		size_t non_empty = 0;
+		ClownResampler_LowLevel_State probe = *resampler;
+
+		for (s = 0; s < segment_count; ++s)
+		{
+			uint64_t pi, pf, n;
+
+			ClownResampler_LowLevel_Adjust(&probe, segments[s].input_sample_rate, segments[s].output_sample_rate, segments[s].low_pass_filter_sample_rate);
+			pi = probe.position_integer;
+			pf = probe.position_fractional;
+			n = cr_count_output_frames(pi, pf, probe.increment, segments[s].input_frames);
+			non_empty += n != 0;
+			cr_advance(&pi, &pf, probe.increment, n);
+			probe.position_integer = (size_t)(pi - segments[s].input_frames);
+			probe.position_fractional = (cc_u32f)pf;
+		}
+		use_table = cr_segments_mode() == 2 || (cr_segments_mode() == 0 && non_empty >= SEGMENT_TABLE_MIN_SEGMENTS && total_out / non_empty < SEGMENT_TABLE_MAX_FRAMES);
+		if (use_table && non_empty != 0)
+		{
+			table = (crhip_segment *)malloc(non_empty * sizeof(crhip_segment));
+			if (table == NULL)
+			{
+				cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
+				return 0;
+			}
+		}
+	}
 	for (s = 0; s < segment_count; ++s)
 	{
 		uint64_t n;
@@ -370,7 +408,31 @@ size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *r
 		ClownResampler_LowLevel_Adjust(&state, segments[s].input_sample_rate, segments[s].output_sample_rate, segments[s].low_pass_filter_sample_rate);
 		n = cr_count_output_frames(state.position_integer, state.position_fractional, state.increment, total);
 
-		if (n != 0)
+		if (n != 0 && use_table)
+		{
+			/* positions relative to the timeline's frame 0 - radius: the window of a segment starts radius_frames before its first frame */
+			crhip_segment *e = &table[table_count++];
+			const size_t radius_frames = state.lowest_level.integer_stretched_kernel_radius;
+
+			e->first_out = out_frame;
+			e->pos_int = (uint64_t)halo_frames + in_frame - radius_frames + state.position_integer;
+			e->pos_frac = state.position_fractional;
+			e->increment = state.increment;
+			e->skr = state.lowest_level.stretched_kernel_radius;
+			e->radius_frames = radius_frames;
+			e->delta = state.lowest_level.stretched_kernel_radius_delta;
+			e->step = state.lowest_level.kernel_step_size;
+			if (table_plan == NULL)
+			{
+				table_plan = plan_for_hashed(table_hash, &state.lowest_level, precomputed, state.channels, state.increment, 0);
+				if (table_plan == NULL)
+				{
+					free(table);
+					return 0;
+				}
+			}
+		}
+		else if (n != 0)
 		{
 			const size_t radius_frames = state.lowest_level.integer_stretched_kernel_radius;
 			const cc_s16l *window = (const cc_s16l *)device_timeline + ((ptrdiff_t)in_frame - (ptrdiff_t)radius_frames) * (ptrdiff_t)state.channels;
@@ -394,6 +456,19 @@ size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *r
 		in_frame += segments[s].input_frames;
 		out_frame += n;
 	}
+	if (table_plan != NULL)
+	{
+		/* d_in of the table launch: `halo_frames` frames before the timeline's frame 0 (the caller's buffer starts there) */
+		const cc_s16l *base = (const cc_s16l *)device_timeline - (ptrdiff_t)halo_frames * (ptrdiff_t)state.channels;
+		const int failed = cr_segments_run(table_plan, base, device_output, table, table_count, out_frame, output_is_s16, hip_stream);
+
+		cr_plan_release(table_plan);
+		free(table);
+		if (failed != 0)
+			return 0;
+	}
+	else
+		free(table);
 
 	if (cr_error_serial() != errors_before)
 		return 0;

@@ -145,6 +145,12 @@ typedef struct cr_device_ctx
 	cr_workspace workspace;
 	cr_workspace workspace_more[CR_EXTRA_SETS]; /* ([0].stream is the download stream) */
 	unsigned char *small;
+	/* the segment table of the one-launch variable-rate path (cr_segments_run): a pinned host copy and the device copy, reused
+	   from call to call behind an event (under workspace_lock) */
+	crhip_segment *seg_host, *seg_dev;
+	size_t seg_capacity;
+	void *seg_event;
+	int seg_in_use;
 } cr_device_ctx;
 
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -160,7 +166,7 @@ static unsigned long long *g_debug_stamps = NULL;
 static int g_variant = -1; /* -1: CLOWNRESAMPLER_AMD_VARIANT from the environment, else the default */
 /* launches enqueued so far, by kernel (numbered as ClownResamplerAMD_PlanInfo.kernel; 5 = k_int): what tests and bench.py
    assert "the kernel I mean is the one that ran" with (ClownResamplerAMD_DebugLaunchCount) */
-#define CR_KERNEL_IDS 6
+#define CR_KERNEL_IDS 7
 static unsigned long long g_launch_count[CR_KERNEL_IDS];
 
 /* Where a plan WITHOUT a specialised instance runs the run-time-slot k_wave2 instead of the run-time-slot k_poly.  Measured on
@@ -170,6 +176,9 @@ static unsigned long long g_launch_count[CR_KERNEL_IDS];
    (19 slots) -16 ... -25 %, at 4:1 -16 ... -36 %, 48 -> 11.025 and 44.1 -> 8 kHz mixed; mono and 8 channels lose at any length
    (too little arithmetic per frame for the per-tile work / too few waves beside the rows).  Hence: 2-7 channels, at most 3.25
    input frames per output frame, and 22 slots - or 18 where the rows are a few KB (exact ratios). */
+/* k_wave2s (a lane per channel pair): from this many channels and slots on, plans without a specialised instance take it */
+#define CR_WAVE2S_MIN_CHANNELS 99   /* never by default: measured slower than the run-time-slot k_poly (cr_kwave2s.hpp, profiles/r03_wave2s.log) */
+#define CR_WAVE2S_MIN_SLOTS 12u
 #define CR_RT_WAVE2_MIN_SLOTS 22   /* (20-21 slots within the increment limit would be 3 lobes at 3.2:1: the losing case) */
 #define CR_RT_WAVE2_MIN_SLOTS_FEW_ROWS 18
 #define CR_RT_WAVE2_FEW_ROWS_BYTES 8192u
@@ -192,6 +201,7 @@ static struct
 	int loaded;
 	int dynamic_tiles;          /* CLOWNRESAMPLER_AMD_DYNAMIC_TILES: -1 unset, else 0 / 1 */
 	int no_special, debug, no_occupancy_clamp, tile_groups, no_host_pipeline, no_small_call_path;
+	int wave2s_min_channels;    /* CLOWNRESAMPLER_AMD_WAVE2S_MIN_CHANNELS: frames from this many channels on take k_wave2s for long windows (99: never) */
 	int lane_map;               /* CLOWNRESAMPLER_AMD_LANE_MAP: 0 / 1 forces k_wave2's lane order (unset: the conflict model picks) */
 	int no_int_kernel;          /* CLOWNRESAMPLER_AMD_NO_INT_KERNEL: whole-number ratios take the plan's ordinary kernel (the A/B leg) */
 	int rt_wave2_min_slots;     /* CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS: windows from this many slots on take the run-time-slot k_wave2 */
@@ -214,6 +224,8 @@ static void load_env(void)
 	g_env.no_host_pipeline = getenv("CLOWNRESAMPLER_AMD_NO_HOST_PIPELINE") != NULL;
 	g_env.no_small_call_path = getenv("CLOWNRESAMPLER_AMD_NO_SMALL_CALL_PATH") != NULL;
 	g_env.no_int_kernel = getenv("CLOWNRESAMPLER_AMD_NO_INT_KERNEL") != NULL;
+	e = getenv("CLOWNRESAMPLER_AMD_WAVE2S_MIN_CHANNELS");
+	g_env.wave2s_min_channels = (e != NULL && atoi(e) > 0) ? atoi(e) : CR_WAVE2S_MIN_CHANNELS;
 	e = getenv("CLOWNRESAMPLER_AMD_LANE_MAP");
 	g_env.lane_map = (e != NULL && *e != '\0') ? (atoi(e) != 0) : -1;
 	e = getenv("CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS");
@@ -612,6 +624,11 @@ static int release_device_locked(cr_device_ctx *ctx)
 			crhip_stream_destroy(ctx->workspace.stream);
 		if (ctx->small != NULL)
 			crhip_host_free(ctx->small);
+		if (ctx->seg_host != NULL)
+			crhip_host_free(ctx->seg_host);
+		crhip_free(ctx->seg_dev);
+		if (ctx->seg_event != NULL)
+			crhip_event_destroy(ctx->seg_event);
 		for (k = 0; k < CR_EXTRA_SETS; ++k)
 		{
 			crhip_free(ctx->workspace_more[k].d_in);
@@ -629,6 +646,11 @@ static int release_device_locked(cr_device_ctx *ctx)
 	ctx->capture_at = NULL;
 	ctx->capture_left = 0;
 	ctx->small = NULL;
+	ctx->seg_host = NULL;
+	ctx->seg_dev = NULL;
+	ctx->seg_capacity = 0;
+	ctx->seg_event = NULL;
+	ctx->seg_in_use = 0;
 	memset(&ctx->workspace, 0, sizeof(ctx->workspace));
 	memset(ctx->workspace_more, 0, sizeof(ctx->workspace_more));
 	__atomic_store_n(&ctx->ready, 0, __ATOMIC_RELEASE);
@@ -788,6 +810,8 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	/* (variant 31 - the run-time-slot k_wave2, a testing hook as an explicit choice - means nothing to a specialised instance) */
 	if (plan->variant == CRHIP_VARIANT_RT_WAVE2 && (plan->specialised || !crhip_poly_runtime_wave2(plan->channels, plan->poly.row_mode)))
 		plan->variant = 0xFFFFu;
+	if (plan->variant == CRHIP_VARIANT_RT_WAVE2S && (plan->specialised || !crhip_poly_runtime_wave2s(plan->channels)))
+		plan->variant = 0xFFFFu;   /* (likewise variant 32, k_wave2s) */
 	if (plan->specialised && plan->variant == 0xFFFFu && crhip_poly_has_up(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode))
 	{
 		/* Instances with the input-stationary kernel (k_up2: stereo, pure upsampling) - which ratios it is the default for
@@ -822,6 +846,54 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 			plan->variant = crhip_poly_fallback_variant();
 			crhip_poly_geometry(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
 		}
+	}
+
+	if (!plan->specialised && crhip_poly_runtime_wave2s(plan->channels)
+	 && (plan->variant == CRHIP_VARIANT_RT_WAVE2S
+	     || (plan->variant == 0xFFFFu && plan->channels >= (uint32_t)g_env.wave2s_min_channels && plan->poly.slots >= CR_WAVE2S_MIN_SLOTS)))
+	{
+		/* k_wave2s: a lane per channel PAIR (cr_kwave2s.hpp) - wide frames with long windows, which had the run-time-slot k_poly
+		   (two lanes per frame, ~5.6 VALU per tap and channel).  A wave-instruction covers 64 / ceil(channels / 2) frames; the
+		   wave-tile is the largest multiple of that, up to 64 frames, whose window still leaves room for 8 waves beside the rows
+		   (fewer frames per tile for heavy downsampling: 16 channels at 44.1 -> 8 kHz are 176 bytes of window per output frame). */
+		const uint32_t per_instruction = 64u / ((plan->channels + 1u) / 2u);
+		const uint32_t lds = (uint32_t)di->max_lds_per_block < 160u * 1024u ? (uint32_t)di->max_lds_per_block : 160u * 1024u;
+		const uint32_t room = lds > rows_bytes + 16u ? lds - rows_bytes - 16u : 0u;
+		uint32_t wt, best_wt = 0, best_waves = 0, best_pieces = 0;
+
+		for (wt = (64u / per_instruction) * per_instruction; wt >= per_instruction; wt -= per_instruction)
+		{
+			const uint64_t last_rel = (65535u + (uint64_t)(wt - 1u) * plan->increment) >> 16;
+			const uint64_t window = 12u + (last_rel + window_slots) * frame_bytes;
+			const uint32_t pieces = (uint32_t)((window + 1023u) / 1024u);
+			uint32_t waves = room / (4u * 1024u * pieces);
+
+			if (waves > 16u)
+				waves = 16u;
+			if (pieces <= 8u && last_rel + window_slots < 65536u && (waves > best_waves && best_waves < 8u))
+			{
+				best_wt = wt;
+				best_waves = waves;
+				best_pieces = pieces;
+			}
+		}
+		if (best_waves >= 4u && (uint64_t)best_wt * plan->increment < (1ull << 32) - 65536u)
+		{
+			plan->variant = CRHIP_VARIANT_RT_WAVE2S;
+			plan->threads = best_waves * 64u;
+			plan->vecs = 150u + best_pieces;
+			plan->wave_tile = best_wt;
+			plan->tile_frames = 4u * best_wt;
+			plan->lds_bytes = rows_bytes + best_waves * 4u * 1024u * best_pieces + 16u;
+			plan->max_blocks = (uint32_t)(di->compute_units > 0 ? di->compute_units : 256);
+			return;
+		}
+	}
+	if (plan->variant == CRHIP_VARIANT_RT_WAVE2S)
+	{
+		/* asked for, but the window does not fit: the ordinary choice */
+		plan->variant = 0xFFFFu;
+		crhip_poly_geometry(plan->channels, 0xFFFFu, plan->poly.row_mode, plan->poly.norm_mode, plan->variant, &plan->threads, &plan->vecs, &frames_multiple);
 	}
 
 	if (!plan->specialised && crhip_poly_runtime_wave2(plan->channels, plan->poly.row_mode)
@@ -1513,6 +1585,7 @@ static void fill_poly_launch(const ClownResamplerAMD_Plan *plan, crhip_poly_laun
 	l->plane_rows = plan->plane_rows;
 	l->swizzle = plan->lds_swizzle;
 	l->lane_map = plan->lane_map;
+	l->wave_tile = plan->wave_tile;
 	l->debug_stamps = g_debug_stamps;
 }
 
@@ -1548,6 +1621,23 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			il.out_s16 = out_s16 ? 1u : 0u;
 			il.blocks = (uint32_t)(blocks > cap ? cap : blocks);
 			__atomic_fetch_add(&g_launch_count[5], 1ull, __ATOMIC_RELAXED);
+			/* tickets where a wave has several tiles to take (a draw is a memory round trip per tile: short launches are dealt statically) */
+			if (g_env.dynamic_tiles != 0 && waves >= 4ull * il.blocks * waves_per_block)
+			{
+				int ring, e;
+
+				il.d_tickets = ticket_block_for(g_ctx[plan->device], stream, &ring);
+				if (il.d_tickets == NULL)
+					return -1;
+				/* tiles per ticket: every wave still gets ~8 draws, and the 32 counters are not hammered by launches of short tiles */
+				{
+					const uint64_t per_wave = waves / ((uint64_t)il.blocks * waves_per_block);
+					il.ticket_tiles = per_wave >= 32u ? 4u : (per_wave >= 16u ? 2u : 1u);
+				}
+				e = crhip_launch_int(&il, stream);
+				ticket_block_enqueued(g_ctx[plan->device], ring);
+				return cr_check_hip(e, "k_int launch");
+			}
 			return cr_check_hip(crhip_launch_int(&il, stream), "k_int launch");
 		}
 	}
@@ -1625,7 +1715,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 				return -1;
 			e = crhip_launch_poly(&l, stream);
 			ticket_block_enqueued(g_ctx[plan->device], ring);
-			__atomic_fetch_add(&g_launch_count[vecs >= 200u ? 3 : vecs >= 150u ? 4 : vecs >= 100u ? 2 : 1], 1ull, __ATOMIC_RELAXED);
+			__atomic_fetch_add(&g_launch_count[l.variant == CRHIP_VARIANT_RT_WAVE2S ? 6 : vecs >= 200u ? 3 : vecs >= 150u ? 4 : vecs >= 100u ? 2 : 1], 1ull, __ATOMIC_RELAXED);
 			return cr_check_hip(e, "k_poly launch");
 		}
 	}
@@ -1653,6 +1743,66 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		__atomic_fetch_add(&g_launch_count[0], 1ull, __ATOMIC_RELAXED);
 		return cr_check_hip(crhip_launch_generic(&g, stream), "k_generic launch");
 	}
+}
+
+/* Variable rate in ONE launch (k_generic_segments): uploads the table of `count` non-empty segments behind whatever is queued on
+   `stream` and enqueues the kernel there; nothing is waited for except - rarely - the previous call's use of the table buffers. */
+int cr_segments_run(const ClownResamplerAMD_Plan *plan, const void *d_in, void *d_out, const crhip_segment *segments, size_t count,
+                    uint64_t n_out, int out_s16, void *stream)
+{
+	cr_device_ctx *ctx = ensure_ctx(plan->device);
+	crhip_segments_launch l;
+	int bad = 0;
+
+	if (ctx == NULL)
+		return -1;
+	if (count == 0 || n_out == 0)
+		return 0;
+
+	pthread_mutex_lock(&ctx->workspace_lock);
+	if (ctx->seg_in_use && cr_check_hip(crhip_event_sync(ctx->seg_event), "hipEventSynchronize") != 0)
+		bad = 1;
+	ctx->seg_in_use = 0;
+	if (!bad && ctx->seg_capacity < count)
+	{
+		const size_t want = count + count / 4 + 64;
+
+		if (ctx->seg_host != NULL)
+			crhip_host_free(ctx->seg_host);
+		crhip_free(ctx->seg_dev);
+		ctx->seg_host = NULL;
+		ctx->seg_dev = NULL;
+		ctx->seg_capacity = 0;
+		if (cr_check_hip(crhip_host_alloc((void **)&ctx->seg_host, want * sizeof(crhip_segment)), "hipHostMalloc(segment table)") != 0
+		 || cr_check_hip(crhip_malloc((void **)&ctx->seg_dev, want * sizeof(crhip_segment)), "hipMalloc(segment table)") != 0)
+			bad = 1;
+		else
+			ctx->seg_capacity = want;
+	}
+	if (!bad && ctx->seg_event == NULL && cr_check_hip(crhip_event_create(&ctx->seg_event), "hipEventCreate") != 0)
+		bad = 1;
+
+	if (!bad)
+	{
+		memcpy(ctx->seg_host, segments, count * sizeof(crhip_segment));
+		memset(&l, 0, sizeof(l));
+		l.d_in = d_in;
+		l.d_out = d_out;
+		l.d_table = plan->d_table;
+		l.d_segments = ctx->seg_dev;
+		l.n_out = n_out;
+		l.n_segments = (uint32_t)count;
+		l.table_len = plan->table_len;
+		l.channels = plan->channels;
+		l.out_s16 = out_s16 ? 1u : 0u;
+		bad = cr_check_hip(crhip_memcpy_h2d(ctx->seg_dev, ctx->seg_host, count * sizeof(crhip_segment), stream), "hipMemcpyAsync(segment table)") != 0
+		   || cr_check_hip(crhip_launch_segments(&l, stream), "k_generic_segments launch") != 0
+		   || cr_check_hip(crhip_event_record(ctx->seg_event, stream), "hipEventRecord") != 0;
+		ctx->seg_in_use = 1;   /* (also after a failure part-way: the copy may be queued) */
+		__atomic_fetch_add(&g_launch_count[0], 1ull, __ATOMIC_RELAXED);
+	}
+	pthread_mutex_unlock(&ctx->workspace_lock);
+	return bad ? -1 : 0;
 }
 
 /* ------------------------------------------------------------------------------------------------------- */
@@ -2017,7 +2167,7 @@ int cr_run_single_frame(const ClownResamplerAMD_Plan *plan, const int16_t *host_
 void ClownResamplerAMD_PlanGetInfo(const ClownResamplerAMD_Plan *plan, ClownResamplerAMD_PlanInfo *info)
 {
 	memset(info, 0, sizeof(*info));
-	info->kernel = plan->use_poly ? (plan->vecs >= 200u ? 3u : plan->vecs >= 150u ? 4u : plan->vecs >= 100u ? 2u : 1u) : 0u;
+	info->kernel = plan->use_poly ? (plan->variant == CRHIP_VARIANT_RT_WAVE2S ? 6u : plan->vecs >= 200u ? 3u : plan->vecs >= 150u ? 4u : plan->vecs >= 100u ? 2u : 1u) : 0u;
 	info->variant = plan->variant;
 	info->channels = plan->channels;
 	info->norm_mode = plan->poly.norm_mode;
@@ -2037,6 +2187,18 @@ void ClownResamplerAMD_PlanGetInfo(const ClownResamplerAMD_Plan *plan, ClownResa
 		info->brief_variant = plan->brief.variant;
 		info->brief_below = plan->brief.below;
 	}
+}
+
+static int g_segments_mode = 0;
+
+int cr_segments_mode(void)
+{
+	return g_segments_mode;
+}
+
+void ClownResamplerAMD_DebugSegmentsMode(int mode)
+{
+	g_segments_mode = (mode >= 0 && mode <= 2) ? mode : 0;
 }
 
 void ClownResamplerAMD_DebugDisableIntKernel(int on)

@@ -71,6 +71,7 @@ typedef struct ClownResamplerAMD_Plan
 	uint32_t threads, vecs, tile_frames, lds_bytes, max_blocks, specialised, variant;
 	uint32_t max_blocks_s16; /* persistent-grid cap of the int16-output form (its own function, its own register footprint) */
 	uint32_t plane_rows, swizzle;
+	uint32_t wave_tile;     /* k_wave2s: output frames per wave-tile */
 	uint32_t lane_map;      /* k_wave2: which frame of its 64 a lane takes (crhip_poly_launch.lane_map), chosen for this plan's increment */
 	uint32_t lds_swizzle;   /* k_wave2: the rotation it applies while staging the (plain) rows into LDS, chosen for this plan's increment */
 	uint32_t device_row_stride; /* int32 per row of the device image (COMPACT for specialised instances, SPLIT otherwise) */
@@ -115,6 +116,14 @@ int cr_ensure_device_of(const ClownResamplerAMD_Plan *plan);
 /* Enqueues the computation of output frames [0, n_out) starting at (pos_int, pos_frac) on `stream`. 0 on success. */
 int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_t in_valid_bytes, void *d_out,
                    uint64_t pos_int, uint64_t pos_frac, uint64_t n_out, void *stream, int out_s16);
+
+/* Variable rate in one launch: `count` non-empty segments (first_out ascending) of one timeline at d_in, n_out frames in all, through
+   the generic kernel with a segment table (any configuration per segment; `plan` supplies the device, the table and the channel
+   count).  Enqueued on `stream`, not waited for.  0 on success. */
+int cr_segments_run(const ClownResamplerAMD_Plan *plan, const void *d_in, void *d_out, const crhip_segment *segments, size_t count,
+                    uint64_t n_out, int out_s16, void *stream);
+/* 0: the measured rule decides between one launch per segment and one launch for all, 1: always per segment, 2: always one launch */
+int cr_segments_mode(void);
 
 /* cr_multi.c: the multi-device call behind ClownResamplerAMD_ResampleShardedDevice, and its part of Shutdown */
 struct ClownResampler_LowLevel_State;

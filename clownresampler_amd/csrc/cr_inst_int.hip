@@ -59,8 +59,8 @@ int_instance make_int()
 	i.shape.safemask = SAFE;
 	i.shape.frames_per_lane = K;
 	i.shape.threads = INT_WAVES * 64;
-	i.shape.lds_bytes[0] = INT_WAVES * int_wave_bytes(CH, R, TT, K, 0);
-	i.shape.lds_bytes[1] = INT_WAVES * int_wave_bytes(CH, R, TT, K, 1);
+	i.shape.lds_bytes[0] = INT_WAVES * int_wave_bytes(CH, R, TT, K, 0) + 16u;   // (+ the workgroup's retired-waves counter)
+	i.shape.lds_bytes[1] = INT_WAVES * int_wave_bytes(CH, R, TT, K, 1) + 16u;
 	i.fn = (int_fn)k_int<CH, R, TT, K, NEG, SAFE, INT_WAVES, 0, 1>;
 	i.fn16 = (int_fn)k_int<CH, R, TT, K, NEG, SAFE, INT_WAVES, 1, 1>;
 	return i;
@@ -72,13 +72,14 @@ const int_instance *instances(int *count)
 {
 	static const int_instance table[] = {
 	    make_int<2, 3, 6, 6>(),   // stereo 6:1 (48 -> 8 kHz): 36 slots, lane stride 144 B
-	    make_int<2, 3, 4, 5>(),   // stereo 4:1: 24 slots, 80 B
-	    make_int<2, 3, 3, 4>(),   // stereo 3:1: 18 slots, 48 B
-	    make_int<2, 3, 2, 6>(),   // stereo 2:1: 12 slots, 48 B
-	    make_int<1, 3, 6, 4>(),   // mono 6:1: 48 B
-	    make_int<1, 3, 4, 6>(),   // mono 4:1: 48 B
-	    make_int<1, 3, 3, 8>(),   // mono 3:1: 48 B
-	    make_int<1, 3, 2, 12>(),  // mono 2:1: 48 B
+	    make_int<2, 3, 4, 9>(),   // stereo 4:1: 24 slots, 144 B
+	    make_int<2, 3, 3, 12>(),  // stereo 3:1: 18 slots, 144 B
+	    make_int<2, 3, 2, 10>(),  // stereo 2:1: 12 slots, 80 B
+	    make_int<1, 3, 6, 8>(),   // mono 6:1: 96 B (an even multiple of 16: two-way conflicts on an LDS that is idle; the longer tile - fewer
+	                              // unpacks per tap, fewer tiles per launch - measured better than 4 frames per lane: profiles/r03_kint_tickets.log)
+	    make_int<1, 3, 4, 10>(),  // mono 4:1: 80 B
+	    make_int<1, 3, 3, 16>(),  // mono 3:1: 96 B
+	    make_int<1, 3, 2, 20>(),  // mono 2:1: 80 B
 	};
 	*count = (int)(sizeof(table) / sizeof(table[0]));
 	return table;

@@ -2,6 +2,7 @@
 // output forms): what plans WITHOUT a specialised instance run when their windows are long enough for the 2-instruction tap
 // to pay and fit a wave's slice of the LDS (cr_context.c plan_geometry)  (see cr_instances.hpp)
 #include "cr_instances.hpp"
+#include "cr_kwave2s.hpp"
 
 namespace
 {
@@ -20,6 +21,15 @@ poly_fn pick(uint32_t channels)
 
 namespace crk
 {
+void *runtime_wave2s_instance(uint32_t channels, int out16)
+{
+	if (channels < 3 || channels > CRHIP_MAX_CHANNELS)
+		return nullptr;
+	if (channels % 2 == 0)
+		return out16 ? (void *)k_wave2s<1, 1, 1> : (void *)k_wave2s<1, 0, 1>;
+	return out16 ? (void *)k_wave2s<0, 1, 1> : (void *)k_wave2s<0, 0, 1>;
+}
+
 void *runtime_wave2_instance(uint32_t channels, uint32_t mode, int out16)
 {
 	if (mode != CRHIP_ROWMODE_AFFINE)

@@ -82,6 +82,7 @@ struct special
 
 constexpr uint32_t MAD_VARIANT = 28;    // variant ids 28, 29
 constexpr uint32_t WAVE2_VARIANT = 30;  // variant id 30: k_wave2 where the instance has one
+constexpr uint32_t RT_WAVE2S_VARIANT = 32;  // variant id 32: k_wave2s (wide frames, long windows; chosen by the host)
 constexpr uint32_t RT_WAVE2_VARIANT = 31;   // variant id 31: the run-time-slot k_wave2 (plans without a specialised instance; chosen by the host)
 
 // k_wave2 of an instance: fixed slot signs (NEGMASK != 0: pure upsampling, 2 VALU per tap and channel) or any rows (3)
@@ -310,6 +311,7 @@ void *ablation_instance_long(int abl);
 void *runtime_instance_1_4(uint32_t channels, uint32_t mode, uint32_t norm, int out16);     // cr_inst_runtime_a.hip
 void *runtime_instance_5_8(uint32_t channels, uint32_t mode, uint32_t norm, int out16);     // cr_inst_runtime_b.hip
 void *runtime_instance_9_16(uint32_t channels, uint32_t mode, uint32_t norm, int out16);    // cr_inst_runtime_c.hip
+void *runtime_wave2s_instance(uint32_t channels, int out16);                                   // cr_inst_runtime_w.hip: k_wave2s, a lane per channel pair
 void *runtime_wave2_instance(uint32_t channels, uint32_t mode, int out16);                  // cr_inst_runtime_w.hip: k_wave2, run-time slot count
 }
 

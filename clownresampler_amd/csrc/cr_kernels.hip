@@ -45,35 +45,28 @@ namespace
 
 // k_generic - reference arithmetic, 64-bit, one lane per output frame (clownresampler.h:986-1035)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_generic(const crhip_generic_launch a)
+// One output frame, the reference's way (clownresampler.h:986-1035), into d_out[j * channels ...].
+__device__ __forceinline__ void generic_frame(const void *d_in, void *d_out, const int32_t *d_table, const int64_t *d_acc_in, uint32_t table_len, unsigned ch, uint32_t out64,
+                                              uint64_t j, uint64_t pos_int, uint64_t pos_frac, uint64_t skr, uint64_t radius_frames, uint64_t delta, uint64_t step)
 {
-	const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-	if (j >= a.n_out)
-		return;
-
-	const uint64_t fr = a.pos_frac + j * a.increment;           // clownresampler.h:1076-1078, j times
-	const uint64_t pos_int = a.pos_int + (fr >> 16);
-	const uint64_t pos_frac = fr & 0xFFFFu;
-
-	const uint64_t first_rel = (pos_frac + a.delta + 65535u) >> 16;       // :993
-	const uint64_t last_rel = (pos_frac + a.skr) >> 16;                   // :994
+	const uint64_t first_rel = (pos_frac + delta + 65535u) >> 16;         // :993
+	const uint64_t last_rel = (pos_frac + skr) >> 16;                     // :994
 	const uint64_t first_frame = pos_int + first_rel;                     // :995
-	const uint64_t end_frame = pos_int + a.radius_frames + last_rel;      // :996
-	uint64_t table_at = (a.step * ((first_rel << 16) - pos_frac)) >> 16;  // :1001
+	const uint64_t end_frame = pos_int + radius_frames + last_rel;        // :996
+	uint64_t table_at = (step * ((first_rel << 16) - pos_frac)) >> 16;    // :1001
 
-	const short *in = reinterpret_cast<const short *>(a.d_in);
-	const unsigned ch = a.channels;
+	const short *in = reinterpret_cast<const short *>(d_in);
 
 	long long acc[CRHIP_MAX_CHANNELS];
 #pragma unroll
 	for (int c = 0; c < CRHIP_MAX_CHANNELS; ++c)
-		acc[c] = (a.d_acc_in != nullptr && c < (int)ch) ? a.d_acc_in[c] : 0;
+		acc[c] = (d_acc_in != nullptr && c < (int)ch) ? d_acc_in[c] : 0;
 
 	long long weight_sum = 0;
 
-	for (uint64_t f = first_frame; f < end_frame; ++f, table_at += a.step)
+	for (uint64_t f = first_frame; f < end_frame; ++f, table_at += step)
 	{
-		const long long weight = table_at < a.table_len ? a.d_table[table_at] : 0;   // :1012 asserts the index in range
+		const long long weight = table_at < table_len ? d_table[table_at] : 0;   // :1012 asserts the index in range
 		const short *src = in + f * ch;
 		weight_sum += weight;                                                          // :1016
 #pragma unroll
@@ -91,14 +84,51 @@ __global__ __launch_bounds__(256) void k_generic(const crhip_generic_launch a)
 		if (c < (int)ch)
 		{
 			const long long v = acc[c] * reciprocal / 32768;                           // :1033
-			if (a.out64 == 2)
-				reinterpret_cast<short *>(a.d_out)[j * ch + c] = (short)(v > 0x7FFF ? 0x7FFF : (v < -0x7FFF ? -0x7FFF : v));
-			else if (a.out64)
-				reinterpret_cast<long long *>(a.d_out)[j * ch + c] = v;
+			if (out64 == 2)
+				reinterpret_cast<short *>(d_out)[j * ch + c] = (short)(v > 0x7FFF ? 0x7FFF : (v < -0x7FFF ? -0x7FFF : v));
+			else if (out64)
+				reinterpret_cast<long long *>(d_out)[j * ch + c] = v;
 			else
-				reinterpret_cast<int *>(a.d_out)[j * ch + c] = (int)v;
+				reinterpret_cast<int *>(d_out)[j * ch + c] = (int)v;
 		}
 	}
+}
+
+__global__ __launch_bounds__(256) void k_generic(const crhip_generic_launch a)
+{
+	const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+	if (j >= a.n_out)
+		return;
+
+	const uint64_t fr = a.pos_frac + j * a.increment;           // clownresampler.h:1076-1078, j times
+	generic_frame(a.d_in, a.d_out, a.d_table, a.d_acc_in, a.table_len, a.channels, a.out64, j, a.pos_int + (fr >> 16), fr & 0xFFFFu,
+	              a.skr, a.radius_frames, a.delta, a.step);
+}
+
+// k_generic_segments - variable rate in ONE launch: output frame j belongs to the segment whose [first_out, next first_out) holds
+// it (bisection; the table is a few hundred KB at most and every lane of a wave walks nearly the same path through it), and is
+// frame j - first_out of that segment's own timeline walk (clownresampler.h:1052-1056 applied between segments on the host,
+// :1076-1078 inside one).  One launch per segment costs ~5 us each however short the segment is (rows staged per launch): 6,000
+// segments of a tenth of a second took 31 ms that way.
+__global__ __launch_bounds__(256) void k_generic_segments(const crhip_segments_launch a)
+{
+	const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+	if (j >= a.n_out)
+		return;
+
+	uint32_t lo = 0, hi = a.n_segments;     // the segment is in [lo, hi)
+	while (hi - lo > 1u)
+	{
+		const uint32_t mid = (lo + hi) >> 1;
+		if (a.d_segments[mid].first_out <= j)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	const crhip_segment s = a.d_segments[lo];
+	const uint64_t fr = s.pos_frac + (j - s.first_out) * s.increment;
+	generic_frame(a.d_in, a.d_out, a.d_table, nullptr, a.table_len, a.channels, a.out_s16 ? 2u : 0u, j, s.pos_int + (fr >> 16), fr & 0xFFFFu,
+	              s.skr, s.radius_frames, s.delta, s.step);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -267,6 +297,11 @@ int crhip_event_record(void *event, void *stream)
 	return (int)hipEventRecord((hipEvent_t)event, (hipStream_t)stream);
 }
 
+int crhip_event_sync(void *event)
+{
+	return (int)hipEventSynchronize((hipEvent_t)event);
+}
+
 int crhip_stream_wait_event(void *stream, void *event)
 {
 	return (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
@@ -387,13 +422,18 @@ int crhip_poly_swizzled(uint32_t channels, uint32_t slots, uint32_t row_mode, ui
 	// run-time slot count
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
 	if (sp == nullptr)
-		return variant == RT_WAVE2_VARIANT ? 1 : RUNTIME_SWZ;
+		return (variant == RT_WAVE2_VARIANT || variant == RT_WAVE2S_VARIANT) ? 1 : RUNTIME_SWZ;
 	const uint32_t v = resolve_variant(sp, variant);
 	if (v == MAD_VARIANT || v == MAD_VARIANT + 1u)
 		return sp->mad_rotated[0] != nullptr ? 2 : 0;   // 2: has a rotated form beside the plain one - a rotation is the plan's choice
 	if (sp->lite && v < WAVE_VARIANT && sp->fn_rotated != nullptr)
 		return 2;
 	return v == WAVE2_VARIANT ? 1 : 0;
+}
+
+int crhip_poly_runtime_wave2s(uint32_t channels)
+{
+	return crk::runtime_wave2s_instance(channels, 0) != nullptr ? 1 : 0;
 }
 
 int crhip_poly_runtime_wave2(uint32_t channels, uint32_t row_mode)
@@ -403,7 +443,7 @@ int crhip_poly_runtime_wave2(uint32_t channels, uint32_t row_mode)
 
 int crhip_poly_variants(void)
 {
-	return VARIANTS + 12;   // + the two k_wave variants, the four two-lanes-per-frame variants, the two k_up variants and the two 64-bit-chain variants
+	return VARIANTS + 13;   // + the two k_wave variants, the four two-lanes-per-frame variants, the two k_up variants, the two 64-bit-chain variants, k_wave2 (30), its run-time-slot form (31) and k_wave2s (32)
 }
 
 int crhip_poly_up_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t *negmask)
@@ -559,6 +599,12 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 		return launch->out_s16 ? sp->wave2_16 : sp->wave2;
 	}
 
+	if (sp == nullptr && launch->variant == RT_WAVE2S_VARIANT && launch->vecs >= 150u)
+	{
+		*geo = 160u;
+		return (poly_fn)crk::runtime_wave2s_instance(launch->channels, launch->out_s16 ? 1 : 0);
+	}
+
 	if (sp == nullptr && launch->variant == RT_WAVE2_VARIANT && launch->vecs >= 150u)
 	{
 		*geo = 150u;
@@ -667,7 +713,14 @@ int crhip_launch_poly(const crhip_poly_launch *launch, void *stream)
 
 	if (fn == nullptr)
 		return (int)hipErrorInvalidValue;
-	if (geo == 150u)
+	if (geo == 160u)
+	{
+		const uint32_t per_instruction = 64u / ((launch->channels + 1u) / 2u);
+		if (launch->threads % 64u != 0 || launch->threads > 1024u || launch->vecs < 150u || launch->vecs >= 200u || launch->wave_tile == 0
+		    || launch->wave_tile % per_instruction != 0 || launch->tile_frames % launch->wave_tile != 0)
+			return (int)hipErrorInvalidValue;
+	}
+	else if (geo == 150u)
 	{
 		if (launch->threads % 64u != 0 || launch->vecs < 150u || launch->vecs >= 200u || launch->tile_frames < 64u
 		    || (launch->tile_frames & (launch->tile_frames - 1u)) != 0
@@ -682,6 +735,21 @@ int crhip_launch_poly(const crhip_poly_launch *launch, void *stream)
 		return 0;
 
 	hipLaunchKernelGGL(fn, dim3(launch->blocks), dim3(launch->threads), launch->lds_bytes, (hipStream_t)stream, *launch);
+	return (int)hipGetLastError();
+}
+
+int crhip_launch_segments(const crhip_segments_launch *launch, void *stream)
+{
+	if (launch->n_out == 0)
+		return 0;
+	if (launch->channels == 0 || launch->channels > CRHIP_MAX_CHANNELS || launch->n_segments == 0)
+		return (int)hipErrorInvalidValue;
+
+	const uint64_t blocks = (launch->n_out + 255u) / 256u;
+	if (blocks > 0x7FFFFFFFull)
+		return (int)hipErrorInvalidValue;
+
+	hipLaunchKernelGGL(k_generic_segments, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *launch);
 	return (int)hipGetLastError();
 }
 

@@ -95,8 +95,51 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 	const uint64_t n_tiles = (a.n_out + WT - 1) / WT;
 	const uint64_t global_wave = (uint64_t)wave * gridDim.x + blockIdx.x;   // (a short launch spreads over the CUs, not over a CU's waves)
 	const uint64_t global_waves = (uint64_t)gridDim.x * WAVES;
-	if (global_wave >= n_tiles)
+
+	// Wave-tiles are TICKETS where the launch brings counters (long launches): the first by global wave number, every further one
+	// from 32 global counter lanes, as in k_up2 - the XCDs of one chip hold different clocks under this kind of load (1.9-2.1 GHz),
+	// and with equal static shares a launch lasts as long as its slowest XCD.  A ticket is a scalar atomic (draw_ticket: through
+	// lgkmcnt, not through the vmcnt the stores and the DMA share).  The last wave of the last workgroup zeroes the block again.
+	// A ticket is worth G consecutive tiles: 8,192 waves drawing 75,000 single-tile tickets from 32 counters were bound by the atomics
+	// (mono 6:1: 66.5 us static, 71.9 us ticketed; profiles/r03_kint_tickets.log).  The unit of scheduling is the GROUP below.
+	const bool ticketed = a.d_tickets != nullptr;
+	const unsigned G = ticketed ? a.ticket_tiles : 1u;
+	const uint64_t n_groups = (n_tiles + G - 1u) / G;
+	const unsigned LANES = global_waves < 32u ? (unsigned)global_waves : 32u;
+	const unsigned lane_id = (unsigned)(global_wave % LANES);
+	const uint64_t lane_tiles = n_groups > lane_id ? (n_groups - lane_id + LANES - 1u) / LANES : 0;   // groups of this counter's sequence
+	const unsigned lane_waves = (unsigned)((global_waves - lane_id + LANES - 1u) / LANES);
+	unsigned *lane_counter = a.d_tickets + lane_id * 32u;
+	auto resolve = [&](unsigned got) -> uint64_t {
+		const uint64_t k = (uint64_t)lane_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+		return k < lane_tiles ? lane_id + (uint64_t)LANES * k : ~0ull;
+	};
+	unsigned *waves_done = reinterpret_cast<unsigned *>(smem + WAVES * (WIN + STAGE));
+	auto retire = [&]() {
+		if (!ticketed)
+			return;
+		if (lane == 0 && __hip_atomic_fetch_add(waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == WAVES - 1u)
+		{
+			unsigned *finished = a.d_tickets + 32u * 32u;
+			if (__hip_atomic_fetch_add(finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u)
+			{
+				for (unsigned c = 0; c < 32u; ++c)
+					__hip_atomic_store(a.d_tickets + c * 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	};
+	if (ticketed)
+	{
+		if (tid == 0)
+			*waves_done = 0;
+		__syncthreads();   // (the kernel's only barrier: waves_done is zero before any wave can retire)
+	}
+	if (global_wave >= n_groups)
+	{
+		retire();
 		return;
+	}
 
 	const uint64_t in_base = reinterpret_cast<uint64_t>(a.d_in);
 	const uint64_t in_end = in_base + a.in_valid_bytes;
@@ -141,8 +184,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 		}
 	};
 
-	uint64_t tile = global_wave;
+	// `next` is known a tile ahead: its ticket is drawn at the END of the previous tile, the atomic's round trip running under the
+	// wait for that tile's DMA (a draw that is waited for on the spot cost the short mono tiles 7 %: profiles/r03_kint_tickets.log)
+	// (`next_group`: the group after the one in progress; within a group the tiles follow each other)
+	uint64_t tile = global_wave * G;
+	unsigned in_group = 1;
 	unsigned lost = fetch(tile);
+	uint64_t next_group = ticketed ? resolve(draw_ticket(lane_counter)) : (global_wave + global_waves < n_groups ? global_wave + global_waves : ~0ull);
+	uint64_t next = (G > 1u && tile + 1u < n_tiles) ? tile + 1u : (next_group != ~0ull ? next_group * G : ~0ull);
+	if (G > 1u && tile + 1u >= n_tiles)
+		in_group = G;   // (the stream's last group is a short one)
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
 	for (;;)
@@ -174,8 +225,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 		asm volatile("" ::: "memory");
 
 		// the next tile's window into the same buffer, under this tile's arithmetic
-		const uint64_t next = tile + global_waves;
-		const bool have_next = next < n_tiles;
+		const bool have_next = next != ~0ull;
 		if (have_next)
 			lost = fetch(next);
 
@@ -324,10 +374,31 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 
 		if (!have_next)
 			break;
-		// the DMA was issued before this tile's stores and vmcnt retires in order: the stores stay in flight
-		wait_vmcnt_at_most(stores);
+		// the DMA was issued before this tile's stores and vmcnt retires in order: the stores stay in flight.  The ticket for the
+		// tile after the next one travels meanwhile (nothing but our own waits between the two halves of the draw).
+		// (`next` was the tile being fetched; what comes after it: the next tile of its group, or the first of the following group -
+		// whose own successor is drawn now, when the wave enters a new group)
+		const bool entering = in_group == G;       // `next` is the first tile of next_group
+		if (entering && ticketed)
+		{
+			unsigned ticket = draw_ticket_begin(lane_counter);
+			wait_vmcnt_at_most(stores);
+			ticket = draw_ticket_end(ticket);
+			next_group = resolve(ticket);
+		}
+		else
+		{
+			wait_vmcnt_at_most(stores);
+			if (entering)
+				next_group = (next / G) + global_waves < n_groups ? (next / G) + global_waves : ~0ull;
+		}
 		tile = next;
+		in_group = entering ? 1u : in_group + 1u;
+		next = (in_group < G && tile + 1u < n_tiles) ? tile + 1u : (next_group != ~0ull ? next_group * G : ~0ull);
+		if (in_group < G && tile + 1u >= n_tiles)
+			in_group = G;   // (the stream's last group is a short one)
 	}
+	retire();
 }
 
 } // namespace

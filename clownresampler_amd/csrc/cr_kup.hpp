@@ -693,7 +693,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 			// the next instruction with nothing but other asm statements in between.  Declared with the low dword as an output and
 			// vcc as the carry-out of both chains, the frame loop carried 15 s_nop per frame beside its 73 VALU instructions
 			// (profiles/r03_kup2_nops.log).  So: (1) the two chains take their carry-out in different registers, vcc and
-			// s[100:101], and may sit back to back; (2) the low dword is declared as an INPUT only - the multiply-add leaves the
+			// s[94:95], and may sit back to back; (2) the low dword is declared as an INPUT only - the multiply-add leaves the
 			// product's fraction bits there, which nothing ever reads: the next tap's arming move overwrites it, and that move is
 			// hipcc's own instruction, free to follow the statement directly.  (What the compiler believes about v120 / v124 after
 			// a statement - "still the bias I put there" - is never used: every tap arms with a different register.)
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 	asm("v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %1, %2, v[" #LO ":" #HI "]" : "+{v" #HI "}"(VHI) : "v"(SAMPLE), "v"(WEIGHT), "{v" #LO "}"(VLO) : "vcc")
 #define CRHIP_UP2_TAP_B(LO, HI, VLO, VHI, SAMPLE, WEIGHT, BIAS)                                                                     \
 	VLO = (BIAS);                                                                                                                  \
-	asm("v_mad_i64_i32 v[" #LO ":" #HI "], s[100:101], %1, %2, v[" #LO ":" #HI "]" : "+{v" #HI "}"(VHI) : "v"(SAMPLE), "v"(WEIGHT), "{v" #LO "}"(VLO) : "s100", "s101")
+	asm("v_mad_i64_i32 v[" #LO ":" #HI "], s[94:95], %1, %2, v[" #LO ":" #HI "]" : "+{v" #HI "}"(VHI) : "v"(SAMPLE), "v"(WEIGHT), "{v" #LO "}"(VLO) : "s94", "s95")
 #pragma unroll
 			for (int s = 0; s < TT; ++s)
 			{

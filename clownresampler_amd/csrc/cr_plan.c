@@ -451,46 +451,53 @@ static unsigned frame_of_lane(unsigned lane, uint32_t lane_map)
 	return lane_map ? (((lane & 31u) << 1) | (lane >> 5)) : lane;
 }
 
-static double swizzle_cost(const cr_poly *poly, uint64_t increment, uint32_t swizzle, uint32_t lane_map)
+/* Modelled extra LDS cycles per row read (ds_read_b128) of a wave, for all 16 rotations at once: cost[k] for swizzle k.  The rows
+   of the 64 lanes are worked out ONCE per trial and every rotation is scored on them - a plan that differs from its siblings only
+   in its increment is made per distinct ratio of a variable-rate stream, and scoring the rotations one by one (16 x 32 x 64 row
+   indices) was most of the 120 us such a plan cost (tools/plan_create_rate.py). */
+static void swizzle_costs(const cr_poly *poly, uint64_t increment, uint32_t lane_map, double cost[16])
 {
 	/* lanes of a wave hold the output frames of one block of 64: fraction of lane l = frac0 + frame(l) * increment (mod 65536) */
-	double extra = 0.0;
-	unsigned trial;
+	unsigned extra[16] = {0};
+	unsigned trial, k;
 
 	for (trial = 0; trial < 32; ++trial)
 	{
 		const uint32_t frac0 = (trial * 40503u + 977u) & 0xFFFFu;
-		unsigned g;
+		uint32_t rows[64];
+		unsigned g, lane;
 
-		for (g = 0; g < 4; ++g)
-		{
-			uint32_t phys[16];
-			unsigned count[16] = {0};
-			unsigned i, k, worst = 0;
+		for (lane = 0; lane < 64; ++lane)
+			rows[lane] = cr_poly_row_of(poly, (uint32_t)((frac0 + (uint64_t)frame_of_lane(lane, lane_map) * increment) & 0xFFFFu));
 
-			for (i = 0; i < 16; ++i)
+		for (k = 0; k < 16; ++k)
+			for (g = 0; g < 4; ++g)
 			{
-				const uint32_t frac = (uint32_t)((frac0 + (uint64_t)frame_of_lane(B128_GROUPS[g][i], lane_map) * increment) & 0xFFFFu);
-				phys[i] = cr_poly_phys_row(cr_poly_row_of(poly, frac), swizzle);
+				uint32_t phys[16];
+				unsigned count[16] = {0};
+				unsigned i, j, worst = 0;
+
+				for (i = 0; i < 16; ++i)
+					phys[i] = cr_poly_phys_row(rows[B128_GROUPS[g][i]], k);
+
+				for (i = 0; i < 16; ++i)
+				{
+					int seen = 0;
+
+					for (j = 0; j < i; ++j)
+						if (phys[j] == phys[i])
+							seen = 1; /* same address: broadcast */
+
+					if (!seen && ++count[phys[i] & 15u] > worst)
+						worst = count[phys[i] & 15u];
+				}
+
+				extra[k] += worst - 1;
 			}
-
-			for (i = 0; i < 16; ++i)
-			{
-				int seen = 0;
-
-				for (k = 0; k < i; ++k)
-					if (phys[k] == phys[i])
-						seen = 1; /* same address: broadcast */
-
-				if (!seen && ++count[phys[i] & 15u] > worst)
-					worst = count[phys[i] & 15u];
-			}
-
-			extra += worst - 1;
-		}
 	}
 
-	return extra / 32.0;
+	for (k = 0; k < 16; ++k)
+		cost[k] = extra[k] / 32.0;
 }
 
 void cr_poly_slot_signs(const cr_poly *poly, uint32_t *positive, uint32_t *negative)
@@ -588,18 +595,19 @@ uint32_t cr_poly_pick_swizzle(const cr_poly *poly, uint64_t increment, double *c
 uint32_t cr_poly_pick_swizzle_mapped(const cr_poly *poly, uint64_t increment, uint32_t lane_map, double *conflict_plain, double *conflict_best)
 {
 	uint32_t best = 0, k;
-	double best_cost = swizzle_cost(poly, increment, 0, lane_map);
+	double cost[16], best_cost;
+
+	swizzle_costs(poly, increment, lane_map, cost);
+	best_cost = cost[0];
 
 	if (conflict_plain != NULL)
 		*conflict_plain = best_cost;
 
 	for (k = 1; k < 16; ++k)
 	{
-		const double cost = swizzle_cost(poly, increment, k, lane_map);
-
-		if (cost < best_cost - 1e-9)
+		if (cost[k] < best_cost - 1e-9)
 		{
-			best_cost = cost;
+			best_cost = cost[k];
 			best = k;
 		}
 	}

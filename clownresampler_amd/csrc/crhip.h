@@ -62,6 +62,7 @@ typedef struct crhip_poly_launch
 	unsigned long long *debug_stamps; /* diagnostic instances only: receives {shader cycles, 100 MHz ticks} of workgroup 0 */
 	uint32_t dynamic_tiles;     /* k_poly: 1 = tiles beyond the first gridDim.x are drawn as tickets, 0 = plain round-robin */
 	uint32_t out_s16;           /* 1: d_out is int16, samples clamped to +-0x7FFF (extension); 0: int32 unclamped (reference) */
+	uint32_t wave_tile;         /* k_wave2s: output frames per wave-tile (a multiple of the frames one wave-instruction covers, 64 / ceil(channels / 2)) */
 	uint32_t lane_map;          /* k_wave2: 0 = lane l takes frame l of its 64, 1 = lanes 0-31 the even frames, 32-63 the odd ones (LDS bank conflicts of the window reads) */
 } crhip_poly_launch;
 
@@ -100,6 +101,8 @@ typedef struct crhip_int_launch
 	uint32_t out_s16;
 	uint32_t blocks;            /* grid size (workgroups of the instance's thread count) */
 	int32_t reciprocal;         /* 0x80000000 / sum of the row's weights (clownresampler.h:1025) */
+	uint32_t *d_tickets;        /* CRHIP_TICKET_WORDS zeroed counters (as crhip_poly_launch.d_tickets), or NULL: tiles dealt round-robin */
+	uint32_t ticket_tiles;      /* wave-tiles per ticket (>= 1): consecutive tiles a wave takes per draw */
 	int32_t w[CRHIP_INT_MAX_SLOTS];
 } crhip_int_launch;
 
@@ -117,6 +120,32 @@ int crhip_int_instance(uint32_t channels, uint32_t ratio, uint32_t slots, crhip_
 /* one-time setup (dynamic LDS limit) + workgroups resident per CU for either output form; not legal inside a stream capture */
 int crhip_int_prepare(uint32_t channels, uint32_t ratio, uint32_t slots, int *per_cu, int *per_cu_s16);
 int crhip_launch_int(const crhip_int_launch *launch, void *stream);
+
+/* Many short constant-rate segments of ONE timeline in ONE launch (variable rate: ClownResamplerAMD_ResampleSegmentsDevice): the
+   generic kernel's per-frame arithmetic with the segment's parameters looked up in a table - every lane finds its segment by
+   bisection over the segments' first output frames. */
+typedef struct crhip_segment
+{
+	uint64_t first_out;         /* index of the segment's first frame in the call's output */
+	uint64_t pos_int, pos_frac; /* of that frame, relative to frame 0 of d_in */
+	uint64_t increment;
+	uint64_t skr, radius_frames, delta, step;   /* the configuration the segment was adjusted to */
+} crhip_segment;
+
+typedef struct crhip_segments_launch
+{
+	const void *d_in;
+	void *d_out;                /* int32 or clamped int16, n_out * channels */
+	const int32_t *d_table;
+	const crhip_segment *d_segments;   /* n_segments entries, first_out ascending, every segment non-empty */
+	uint64_t n_out;
+	uint32_t n_segments;
+	uint32_t table_len;
+	uint32_t channels;
+	uint32_t out_s16;
+} crhip_segments_launch;
+
+int crhip_launch_segments(const crhip_segments_launch *launch, void *stream);
 
 typedef struct crhip_device_info
 {
@@ -150,6 +179,7 @@ int crhip_device_sync(void);
 int crhip_event_create(void **event);                   /* timing disabled */
 int crhip_event_destroy(void *event);
 int crhip_event_record(void *event, void *stream);
+int crhip_event_sync(void *event);                      /* the host waits until the event has happened */
 int crhip_stream_wait_event(void *stream, void *event);
 int crhip_stream_is_capturing(void *stream, int *capturing);   /* *capturing = 1 while the stream records into a graph */
 int crhip_stream_busy(void *stream);                    /* 1 = work still in flight, 0 = idle (or the handle is no longer a stream) */
@@ -203,6 +233,11 @@ uint32_t crhip_poly_wave2_fallback_variant(uint32_t channels, uint32_t slots, ui
    window pieces per wave-tile), tile_frames = 256 and variant CRHIP_VARIANT_RT_WAVE2 */
 int crhip_poly_runtime_wave2(uint32_t channels, uint32_t row_mode);
 #define CRHIP_VARIANT_RT_WAVE2 31u
+/* k_wave2s (cr_kwave2s.hpp): the same arithmetic with one lane per CHANNEL PAIR of a frame - wide frames (9 to 16 channels; fewer
+   where the host's rule says so) with long windows.  Geometry: threads = 64 * waves, vecs = 150 + pieces, wave_tile frames per
+   wave-tile, tile_frames = 4 * wave_tile, variant CRHIP_VARIANT_RT_WAVE2S.  1 when there is an instance for the channel count. */
+int crhip_poly_runtime_wave2s(uint32_t channels);
+#define CRHIP_VARIANT_RT_WAVE2S 32u
 /* Number of tuning variants of the specialised instances (crhip_poly_launch.variant). */
 int crhip_poly_variants(void);
 /* Geometry the instance that a launch with these parameters selects is compiled for: workgroup size, 16-byte input

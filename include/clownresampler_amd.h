@@ -153,7 +153,7 @@ typedef struct ClownResamplerAMD_Plan ClownResamplerAMD_Plan;
 
 typedef struct ClownResamplerAMD_PlanInfo
 {
-	uint32_t kernel;            /* 1 = k_poly (polyphase rows in LDS, workgroup tiles), 2 = k_wave (same, wave-autonomous), 3 = k_up / k_up2 (input-stationary, strong upsampling), 4 = k_wave2 (wave-autonomous, expanded window, 64-bit multiply-add taps), 0 = generic 64-bit kernel */
+	uint32_t kernel;            /* 6 = k_wave2s (k_wave2's arithmetic with one lane per channel PAIR of a frame: wide frames, long windows), 1 = k_poly (polyphase rows in LDS, workgroup tiles), 2 = k_wave (same, wave-autonomous), 3 = k_up / k_up2 (input-stationary, strong upsampling), 4 = k_wave2 (wave-autonomous, expanded window, 64-bit multiply-add taps), 0 = generic 64-bit kernel */
 	uint32_t channels;
 	uint32_t slots;             /* taps evaluated per output frame (zero-weight slots included) */
 	uint32_t first_slot;        /* frame offset of slot 0 relative to position_integer, in padded-buffer frames (row_mode 0: of the
@@ -198,6 +198,9 @@ unsigned long long ClownResamplerAMD_DebugLaunchCount(unsigned kernel);
 /* Test hook: whole-number ratios take the plan's ordinary kernel instead of k_int (the A/B leg; also CLOWNRESAMPLER_AMD_NO_INT_KERNEL
    in the environment at first use, which additionally skips k_int's one-time setup). */
 void ClownResamplerAMD_DebugDisableIntKernel(int on);
+/* Test hook for ClownResamplerAMD_ResampleSegmentsDevice: 0 = the measured rule picks (default), 1 = always one launch per segment
+   (the polyphase kernels), 2 = always ONE launch for all segments (the generic kernel with a segment table). */
+void ClownResamplerAMD_DebugSegmentsMode(int mode);
 
 /* Debug/test access to the host copy of the polyphase rows (rows * row_stride int32). */
 const int32_t *ClownResamplerAMD_PlanRows(const ClownResamplerAMD_Plan *plan);

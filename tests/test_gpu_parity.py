@@ -536,10 +536,13 @@ def _oracle_segments(o, ch, pcm, frames, halo, segments, first_rates):
     return np.concatenate(out), counts, st
 
 
+@pytest.mark.parametrize("mode", [1, 2, 0])
 @pytest.mark.parametrize("radius,ch,s16", [(3, 2, False), (3, 1, False), (3, 5, True), (8, 2, False)])
-def test_variable_rate_segments_on_device(products, radius, ch, s16):
+def test_variable_rate_segments_on_device(products, radius, ch, s16, mode):
     """a list of constant-rate segments over one device-resident timeline = Adjust + LowLevel_Resample per chunk
-    in the reference, position carried across every re-configuration; one launch per segment, nothing synchronised in between."""
+    in the reference, position carried across every re-configuration; nothing synchronised in between.  Both ways of running it:
+    one launch per segment (mode 1: the polyphase kernels), ONE launch for all of them (mode 2: the generic kernel with a segment
+    table - what many short segments take), and the rule's own choice (mode 0)."""
     import torch
     p, o = products[radius], ck.oracle(radius)
     dev = torch.device("cuda", 0)
@@ -559,8 +562,15 @@ def test_variable_rate_segments_on_device(products, radius, ch, s16):
     p.api.LowLevel_Init(st, ch, *first)
     d_in = torch.from_numpy(ck.pad_frames(pcm, ch, halo)).to(dev)
     d_out = torch.zeros(len(want) + 64, dtype=torch.int16 if s16 else torch.int32, device=dev)
-    n, counts = p.api.ResampleSegmentsDevice(st, p.pre, d_in.data_ptr() + halo * ch * 2, halo, segments, d_out.data_ptr(), len(want) // ch, s16=s16)
-    torch.cuda.synchronize()
+    p.api.DebugSegmentsMode(mode)
+    try:
+        before = [p.api.LaunchCount(k) for k in range(7)]
+        n, counts = p.api.ResampleSegmentsDevice(st, p.pre, d_in.data_ptr() + halo * ch * 2, halo, segments, d_out.data_ptr(), len(want) // ch, s16=s16)
+        torch.cuda.synchronize()
+        launched = sum(p.api.LaunchCount(k) - before[k] for k in range(7))
+    finally:
+        p.api.DebugSegmentsMode(0)
+    assert launched == (1 if mode != 1 else sum(1 for c in want_counts if c))   # (32 short segments: the rule takes the table too)
     got = d_out.cpu().numpy()
     assert n == len(want) // ch and counts == want_counts
     assert np.array_equal(got[:len(want)], want) and not got[len(want):].any()
@@ -825,7 +835,7 @@ def test_random_configurations_bit_exact(products):
     # CRA_SOAK_SEED / CRA_SOAK_DRAWS: a longer one-off soak with another seed (the committed run is 300 draws of the fixed seed)
     rng = random.Random(int(os.environ.get("CRA_SOAK_SEED", "20261002")))
     draws = int(os.environ.get("CRA_SOAK_DRAWS", "300"))
-    kernels = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0}   # generic, k_poly, k_wave, k_up / k_up2, k_wave2, k_int
+    kernels = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0, 6: 0}   # generic, k_poly, k_wave, k_up / k_up2, k_wave2, k_int, k_wave2s
     done = 0
     while done < draws:
         radius = rng.choice([3, 3, 8, 5])
@@ -891,6 +901,35 @@ def test_nine_to_sixteen_channels(products, ch):
         ok_a, a = p.low_init(ch, *rates)
         got16, left, ran_out = p.api.LowLevel_ResampleBulkS16(a.raw, p.pre, padded, frames)
         assert ran_out == 1 and left == 0 and np.array_equal(got16, np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16)), (ch, radius, rates, "int16")
+
+
+@pytest.mark.parametrize("ch", [3, 4, 9, 10, 13, 16])
+def test_channel_pair_per_lane_kernel(products, ch):
+    """k_wave2s (variant 32: k_wave2's arithmetic with one lane per channel PAIR of a frame; not a default - it measured slower
+    than the run-time-slot k_poly, cr_kwave2s.hpp - but selectable): even and odd channel counts (8-byte / 4-byte window reads, the
+    phantom channel of an odd frame's last lane), affine and pure-upsampling rows, wave-tiles cut to fit the LDS for heavy
+    downsampling, tails, int16 output - bit-exact, and the launch counters say it is what ran."""
+    for radius, rates, frames in ((3, (44100, 8000, 8000), 30011), (8, (44100, 48000, 44100), 9001), (8, (48000, 19200, 19200), 20000), (3, (96000, 44100, 44100), 700)):
+        p, orc = products[radius], ck.oracle(radius)
+        p.api.DebugSetVariant(32)
+        try:
+            ok, a = p.low_init(ch, *rates)
+            ok, b = orc.low_init(ch, *rates)
+            info = p.api.PlanGetInfo(p.api.PlanCreate(a.raw, p.pre))
+            if info.specialised:
+                continue           # (a specialised instance keeps its own kernel whatever the variant)
+            assert info.kernel == 6, info.asdict()
+            padded = ck.pad_frames(ck.noise_pcm(frames * ch, 1300 + ch), ch, int(b.cfg.radius_frames))
+            before = p.api.LaunchCount(6)
+            got, la, ra = p.low_resample_i32(a, padded, frames)
+            want, lb, rb = orc.low_resample_i32(b, padded, frames)
+            assert p.api.LaunchCount(6) == before + 1
+            assert (la, ra) == (lb, rb) and np.array_equal(got, want) and a.astuple() == b.astuple(), (ch, radius, rates)
+            ok, a = p.low_init(ch, *rates)
+            got16, left, ran_out = p.api.LowLevel_ResampleBulkS16(a.raw, p.pre, padded, frames)
+            assert np.array_equal(got16, np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16)), (ch, radius, rates, "int16")
+        finally:
+            p.api.DebugSetVariant(-1)
 
 
 @pytest.mark.parametrize("variant", [26, 27])

@@ -116,14 +116,17 @@ for seg_frames in (4410000, 441000, 44100, 4410):
     nseg = frames // seg_frames
     segs = [(seg_frames, 44100, 48000 + (k % 997) - 498, 44100) for k in range(nseg)]    # up to 997 distinct ratios, one configuration
     d_out = torch.empty(int(frames * 48003 / 44100 + 16) * ch, dtype=torch.int32, device=dev)
-    for rep in range(3):
-        st = p.api.LowLevel_State()
-        p.api.LowLevel_Init(st, ch, *rates)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n, counts = p.api.ResampleSegmentsDevice(st, p.pre, d_in.data_ptr() + halo * ch * 2, halo, segs, d_out.data_ptr(), d_out.numel() // ch)
-        t1 = time.perf_counter()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    print("ResampleSegmentsDevice: %5d segments of %7d frames, up to 997 distinct ratios: host %.2f ms, done %.2f ms  %.0f Msamples/s"
-          % (nseg, seg_frames, (t1 - t0) * 1e3, dt * 1e3, n * ch / dt / 1e6))
+    for mode, what in ((1, "one launch per segment"), (2, "ONE launch, segment table"), (0, "the rule's choice")):
+        p.api.DebugSegmentsMode(mode)
+        for rep in range(3):
+            st = p.api.LowLevel_State()
+            p.api.LowLevel_Init(st, ch, *rates)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n, counts = p.api.ResampleSegmentsDevice(st, p.pre, d_in.data_ptr() + halo * ch * 2, halo, segs, d_out.data_ptr(), d_out.numel() // ch)
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        print("ResampleSegmentsDevice: %5d segments of %7d frames, up to 997 distinct ratios, %-27s: host %.2f ms, done %.2f ms  %.0f Msamples/s"
+              % (nseg, seg_frames, what, (t1 - t0) * 1e3, dt * 1e3, n * ch / dt / 1e6))
+    p.api.DebugSegmentsMode(0)

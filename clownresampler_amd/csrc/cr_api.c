@@ -317,10 +317,12 @@ size_t ClownResampler_LowLevel_ResampleBulkS16(ClownResampler_LowLevel_State *re
                        timeline + (a_s - integer_stretched_kernel_radius_s) * channels, &total, append, 0);
    i.e. each segment's "padding" is the real neighbouring frames (legal per clownresampler.h:725-733), the position
    (overshoot + fraction) is carried across the re-configuration exactly as the state struct carries it. */
-/* one launch for all segments from this many on, if they average fewer output frames than that (one launch per segment is
-   launch-bound below ~40,000 frames: DESIGN.md section 8) */
+/* One launch for all segments from this many on, if a segment averages less WORK than that - output frames x channels x taps.  A
+   launch per segment costs ~6 us each on either side of the bus (43 us where the segment's ratio needs a new plan), the generic
+   kernel ~2.8 ps per tap and sample: 600 segments of 44,100 stereo frames took 26 ms one by one and 0.8 ms in one launch,
+   6 of 4.4 M frames 0.09 against 0.5 ms (profiles/r03_segments_one_launch.log). */
 #define SEGMENT_TABLE_MIN_SEGMENTS 8u
-#define SEGMENT_TABLE_MAX_FRAMES 32768u
+#define SEGMENT_TABLE_MAX_WORK 2000000u
 
 size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *resampler, const ClownResampler_Precomputed *precomputed,
                                                 const void *device_timeline, size_t halo_frames, const ClownResamplerAMD_Segment *segments, size_t segment_count,
@@ -374,6 +376,7 @@ size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *r
 	state = *resampler;
 	{
 		size_t non_empty = 0;
+		uint64_t taps = 1;
 		ClownResampler_LowLevel_State probe = *resampler;
 
 		for (s = 0; s < segment_count; ++s)
@@ -385,11 +388,14 @@ size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *r
 			pf = probe.position_fractional;
 			n = cr_count_output_frames(pi, pf, probe.increment, segments[s].input_frames);
 			non_empty += n != 0;
+			if (n != 0 && 2u * probe.lowest_level.integer_stretched_kernel_radius > taps)
+				taps = 2u * probe.lowest_level.integer_stretched_kernel_radius;
 			cr_advance(&pi, &pf, probe.increment, n);
 			probe.position_integer = (size_t)(pi - segments[s].input_frames);
 			probe.position_fractional = (cc_u32f)pf;
 		}
-		use_table = cr_segments_mode() == 2 || (cr_segments_mode() == 0 && non_empty >= SEGMENT_TABLE_MIN_SEGMENTS && total_out / non_empty < SEGMENT_TABLE_MAX_FRAMES);
+		use_table = cr_segments_mode() == 2 || (cr_segments_mode() == 0 && non_empty >= SEGMENT_TABLE_MIN_SEGMENTS
+		                                            && total_out / non_empty * probe.channels * taps < SEGMENT_TABLE_MAX_WORK);
 		if (use_table && non_empty != 0)
 		{
 			table = (crhip_segment *)malloc(non_empty * sizeof(crhip_segment));

@@ -36,6 +36,7 @@
 
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 #include "cr_instances.hpp"
@@ -693,17 +694,48 @@ int crhip_poly_occupancy(const crhip_poly_launch *launch, int *workgroups_per_cu
 {
 	uint32_t geo;
 	const poly_fn fn = select_poly(launch, &geo);
-	hipFuncAttributes attr;
-	hipError_t e;
 
 	if (fn == nullptr)
 		return (int)hipErrorInvalidValue;
+
+	// The two runtime queries cost ~50 us each, and a variable-rate client makes a plan per distinct ratio (same instance, same shape):
+	// remembered per (device, function, threads, LDS) - a sibling plan took 110 us to make, tools/plan_create_rate.py.
+	struct answer
+	{
+		int per_cu, vgprs, static_lds;
+	};
+	static std::mutex lock;
+	static std::map<std::tuple<int, const void *, uint32_t, uint32_t>, answer> known;
+	int device = 0;
+	hipError_t e = hipGetDevice(&device);
+	if (e != hipSuccess)
+		return (int)e;
+	const auto key = std::make_tuple(device, (const void *)fn, launch->threads, launch->lds_bytes);
+	{
+		std::lock_guard<std::mutex> guard(lock);
+		const auto hit = known.find(key);
+		if (hit != known.end())
+		{
+			*workgroups_per_cu = hit->second.per_cu;
+			*vgprs = hit->second.vgprs;
+			*static_lds = hit->second.static_lds;
+			return 0;
+		}
+	}
+
+	hipFuncAttributes attr;
 	e = hipFuncGetAttributes(&attr, (const void *)fn);
 	if (e != hipSuccess)
 		return (int)e;
 	*vgprs = attr.numRegs;
 	*static_lds = (int)attr.sharedSizeBytes;
-	return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(workgroups_per_cu, (const void *)fn, (int)launch->threads, launch->lds_bytes);
+	e = hipOccupancyMaxActiveBlocksPerMultiprocessor(workgroups_per_cu, (const void *)fn, (int)launch->threads, launch->lds_bytes);
+	if (e == hipSuccess)
+	{
+		std::lock_guard<std::mutex> guard(lock);
+		known[key] = answer{*workgroups_per_cu, *vgprs, *static_lds};
+	}
+	return (int)e;
 }
 
 int crhip_launch_poly(const crhip_poly_launch *launch, void *stream)

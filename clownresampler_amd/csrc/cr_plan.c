@@ -470,30 +470,40 @@ static void swizzle_costs(const cr_poly *poly, uint64_t increment, uint32_t lane
 		for (lane = 0; lane < 64; ++lane)
 			rows[lane] = cr_poly_row_of(poly, (uint32_t)((frac0 + (uint64_t)frame_of_lane(lane, lane_map) * increment) & 0xFFFFu));
 
-		for (k = 0; k < 16; ++k)
-			for (g = 0; g < 4; ++g)
+		for (g = 0; g < 4; ++g)
+		{
+			/* the DISTINCT rows of the group (identical addresses broadcast; a rotation is a bijection, so distinct rows stay
+			   distinct under every one of them): once per group, not once per rotation */
+			uint32_t distinct[16];
+			unsigned n = 0, i, j;
+
+			for (i = 0; i < 16; ++i)
 			{
-				uint32_t phys[16];
+				const uint32_t row = rows[B128_GROUPS[g][i]];
+				int seen = 0;
+
+				for (j = 0; j < n; ++j)
+					if (distinct[j] == row)
+						seen = 1;
+				if (!seen)
+					distinct[n++] = row;
+			}
+
+			for (k = 0; k < 16; ++k)
+			{
 				unsigned count[16] = {0};
-				unsigned i, j, worst = 0;
+				unsigned worst = 0;
 
-				for (i = 0; i < 16; ++i)
-					phys[i] = cr_poly_phys_row(rows[B128_GROUPS[g][i]], k);
-
-				for (i = 0; i < 16; ++i)
+				for (i = 0; i < n; ++i)
 				{
-					int seen = 0;
+					const unsigned slot = cr_poly_phys_row(distinct[i], k) & 15u;
 
-					for (j = 0; j < i; ++j)
-						if (phys[j] == phys[i])
-							seen = 1; /* same address: broadcast */
-
-					if (!seen && ++count[phys[i] & 15u] > worst)
-						worst = count[phys[i] & 15u];
+					if (++count[slot] > worst)
+						worst = count[slot];
 				}
-
 				extra[k] += worst - 1;
 			}
+		}
 	}
 
 	for (k = 0; k < 16; ++k)

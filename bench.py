@@ -90,6 +90,10 @@ WORKLOADS = {
     "hq48c16": (8, 16, (44100, 48000, 44100), 3307500),  # 8 lobes, the widest frame: k_wave2s (a lane per channel pair)
     "hq48c12": (8, 12, (44100, 48000, 44100), 4410000),
     "dn8c12": (3, 12, (44100, 8000, 8000), 4410000),
+    "dn21c4": (3, 4, (96000, 48000, 48000), 28800000),   # 2:1 with 4 / 6 / 8 channels, 3:1 with 4: k_int, a frame's channel pairs one after the other
+    "dn21c6": (3, 6, (96000, 48000, 48000), 19200000),
+    "dn21c8": (3, 8, (96000, 48000, 48000), 14400000),
+    "dn31c4": (3, 4, (96000, 32000, 32000), 28800000),
     "dn6x": (3, 2, (48000, 8000, 8000), 57600000),     # stereo / mono 6:1 (increment exact in 16.16: every frame uses ONE row), 36-slot windows
     "dn6xm": (3, 1, (48000, 8000, 8000), 115200000),
     "dn8m": (3, 1, (44100, 8000, 8000), 52920000),

@@ -1,4 +1,4 @@
-// cr_inst_int.hip - instance unit + launch shim of k_int (cr_kint.hpp): whole-number downsampling ratios, mono and stereo.
+// cr_inst_int.hip - instance unit + launch shim of k_int (cr_kint.hpp): whole-number downsampling ratios, 1 to 8 channels.
 #include "cr_kint.hpp"
 
 #include <mutex>
@@ -80,6 +80,13 @@ const int_instance *instances(int *count)
 	    make_int<1, 3, 4, 10>(),  // mono 4:1: 80 B
 	    make_int<1, 3, 3, 16>(),  // mono 3:1: 96 B
 	    make_int<1, 3, 2, 20>(),  // mono 2:1: 80 B
+	    // wider frames (5.1 / 7.1 material at 2:1 and 3:1): the channel pairs of a frame one after the other
+	    make_int<4, 3, 2, 5>(),   // 4 channels 2:1: 80 B
+	    make_int<4, 3, 3, 6>(),   // 4 channels 3:1: 144 B
+	    make_int<4, 3, 4, 4>(),   // 4 channels 4:1: 128 B (even multiple)
+	    make_int<6, 3, 2, 6>(),   // 6 channels 2:1: 144 B
+	    make_int<6, 3, 3, 4>(),   // 6 channels 3:1: 144 B
+	    make_int<8, 3, 2, 4>(),   // 8 channels 2:1: 128 B (even multiple)
 	};
 	*count = (int)(sizeof(table) / sizeof(table[0]));
 	return table;

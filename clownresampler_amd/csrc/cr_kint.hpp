@@ -31,7 +31,7 @@ namespace
 // after the reads), results staged through LDS so that the K frames of a lane - consecutive in the output - leave as
 // coalesced stores, counted vmcnt.  No barrier at all.
 // The final (acc * reciprocal) / 32768 is the 64-bit form (either range class).
-//   CH channels (1 or 2)   R input frames per output frame   TT slots   K frames per lane   WAVES per workgroup
+//   CH channels (1 to 8: a frame's channel pairs one after the other)   R input frames per output frame   TT slots   K frames per lane   WAVES per workgroup
 // ---------------------------------------------------------------------------------------------------------
 // Accumulator pairs pinned to physical registers v[INT_ACC_BASE + 2 P : + 1] (the constraint of the asm statement: the tap's
 // multiply-add).  Left to its own allocation hipcc assembled the pair {x, acc} with v_mov_b64 and took it apart again - 1.4 moves
@@ -70,7 +70,7 @@ constexpr unsigned int_wave_bytes(int ch, int r, int tt, int k, int out16)
 template <int CH, int R, int TT, int K, unsigned long long NEGMASK, unsigned long long SAFEMASK, int WAVES, int OUT16, int NT>
 __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 {
-	static_assert(CH == 1 || CH == 2, "mono and stereo");
+	static_assert(CH >= 1 && CH <= 8, "one to eight channels: two at a time over the same accumulator registers");
 	static_assert(TT <= CRHIP_INT_MAX_SLOTS, "the weights travel in the kernel arguments");
 	constexpr unsigned FB = CH * 2;                        // bytes per input frame
 	constexpr unsigned UNIT = OUT16 ? CH * 2 : CH * 4;     // bytes per output frame
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 		// accumulator high dwords (the sums): [live frame][channel][0: slots with weights >= 0, 1: slots with weights <= 0].  At any
 		// time TT / R frames of a lane are in progress; frame k uses set k % LIVE, pinned to physical registers (int_tap).
 		constexpr int LIVE = TT / R;
-		static_assert(TT % R == 0 && LIVE * CH * 2 <= 24, "pinned accumulator pairs");
-		int acc[LIVE][CH][2], arm[LIVE][CH][2];
+		static_assert(TT % R == 0 && LIVE * 2 * 2 <= 24, "pinned accumulator pairs");
+		int acc[LIVE][2][2], arm[LIVE][2][2];
 		const unsigned stage_at = lane * (K * UNIT);
 
 		// X = 2 * sample, sign-extended: one SDWA shift per sample, issued ONE input frame ahead of its taps (hipcc pads an asm
@@ -252,68 +252,89 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 					asm("v_lshlrev_b32_sdwa %0, %2, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(to) : "v"(from), "v"(1));
 			}
 		};
-		static_for<CH>([&](auto c_tag) { unpack(c_tag); });
 
-		static_for<NX>([&](auto i_tag) {
-			constexpr int i = decltype(i_tag)::value;
-			static_for<CH>([&](auto c_tag) { unpack(std::integral_constant<int, (i + 1) * CH + decltype(c_tag)::value>()); });
-			static_for<CH>([&](auto c_tag) {
-				constexpr int c = decltype(c_tag)::value;
-				const int x = xs[i * CH + c];
+		// More than two channels: the frame's channel PAIRS one after the other over the same window registers and the same 24
+		// accumulator pairs - a 6-channel 2:1 instance is the stereo 6:1 body's size (K x TT x CH taps either way).
+		constexpr int PASSES = (CH + 1) / 2;
+		static_for<PASSES>([&](auto p_tag) {
+			constexpr int first_ch = 2 * decltype(p_tag)::value;
+			constexpr int PC = first_ch + 1 < CH ? 2 : 1;        // channels of this pass
+			static_for<PC>([&](auto c_tag) { unpack(std::integral_constant<int, first_ch + decltype(c_tag)::value>()); });
+
+			static_for<NX>([&](auto i_tag) {
+				constexpr int i = decltype(i_tag)::value;
+				static_for<PC>([&](auto c_tag) { unpack(std::integral_constant<int, (i + 1) * CH + first_ch + decltype(c_tag)::value>()); });
+				static_for<PC>([&](auto c_tag) {
+					constexpr int c = decltype(c_tag)::value;
+					const int x = xs[i * CH + first_ch + c];
+					static_for<K>([&](auto k_tag) {
+						constexpr int k = decltype(k_tag)::value;
+						constexpr int s = i - R * k;
+						if constexpr (s >= 0 && s < TT)
+						{
+							constexpr int cls = (int)((NEGMASK >> s) & 1ull);
+							// is this the first slot of its class?
+							constexpr unsigned long long before = (1ull << s) - 1ull;
+							constexpr bool first_of_class = cls ? ((NEGMASK & before) == 0) : ((~NEGMASK & before) == 0);
+							constexpr int P = ((k % LIVE) * 2 + c) * 2 + cls;
+							int &hi = acc[k % LIVE][c][cls], &lo = arm[k % LIVE][c][cls];
+							if constexpr (first_of_class)
+								hi = 0;
+							lo = x;
+							if constexpr ((SAFEMASK >> s) & 1ull)
+								int_tap<P>(lo, hi, (int)((unsigned)x << 15), a.w[s]);
+							else
+								int_tap<P>(lo, hi, x, a.w[s]);
+						}
+					});
+				});
+				// a frame whose last slot this was is complete: normalise (clownresampler.h:1025-1033) and stage
 				static_for<K>([&](auto k_tag) {
 					constexpr int k = decltype(k_tag)::value;
-					constexpr int s = i - R * k;
-					if constexpr (s >= 0 && s < TT)
+					if constexpr (i - R * k == TT - 1)
 					{
-						constexpr int cls = (int)((NEGMASK >> s) & 1ull);
-						// is this the first slot of its class?
-						constexpr unsigned long long before = (1ull << s) - 1ull;
-						constexpr bool first_of_class = cls ? ((NEGMASK & before) == 0) : ((~NEGMASK & before) == 0);
-						constexpr int P = ((k % LIVE) * CH + c) * 2 + cls;
-						int &hi = acc[k % LIVE][c][cls], &lo = arm[k % LIVE][c][cls];
-						if constexpr (first_of_class)
-							hi = 0;
-						lo = x;
-						if constexpr ((SAFEMASK >> s) & 1ull)
-							int_tap<P>(lo, hi, (int)((unsigned)x << 15), a.w[s]);
-						else
-							int_tap<P>(lo, hi, x, a.w[s]);
+						int out[2] = {0, 0};
+						static_for<PC>([&](auto c_tag) {
+							constexpr int c = decltype(c_tag)::value;
+							constexpr bool any_neg = NEGMASK != 0;
+							int sum = acc[k % LIVE][c][0];
+							if constexpr (any_neg)
+								sum -= acc[k % LIVE][c][1];
+							// (acc * reciprocal) / 32768 toward zero in 64 bits: right for either range class of the host's (CRHIP_NORM_*)
+							const long long v = (long long)sum * (long long)a.reciprocal + (long long)((unsigned)(sum >> 31) >> 17);
+							out[c] = (int)(v >> 15);
+						});
+						if ((unsigned)k + lane * K < n)
+						{
+							unsigned char *at = my_stage + stage_at + k * UNIT + first_ch * (OUT16 ? 2 : 4);
+							if constexpr (OUT16)
+							{
+								if constexpr (PC == 2 && CH % 2 == 0)
+									*reinterpret_cast<int *>(at) = (clamp_s16(out[0]) & 0xFFFF) | (clamp_s16(out[1]) << 16);
+								else
+								{
+									// (the frames of an odd channel count start on 2-byte boundaries every other time)
+									reinterpret_cast<short *>(at)[0] = (short)clamp_s16(out[0]);
+									if constexpr (PC == 2)
+										reinterpret_cast<short *>(at)[1] = (short)clamp_s16(out[1]);
+								}
+							}
+							else if constexpr (PC == 2 && CH % 2 == 0)
+							{
+								i32x2 q;
+								q.x = out[0];
+								q.y = out[1];
+								*reinterpret_cast<i32x2 *>(at) = q;
+							}
+							else
+							{
+								reinterpret_cast<int *>(at)[0] = out[0];
+								if constexpr (PC == 2)
+									reinterpret_cast<int *>(at)[1] = out[1];
+							}
+						}
 					}
 				});
-			});
-			// a frame whose last slot this was is complete: normalise (clownresampler.h:1025-1033) and stage
-			static_for<K>([&](auto k_tag) {
-				constexpr int k = decltype(k_tag)::value;
-				if constexpr (i - R * k == TT - 1)
-				{
-					int out[CH];
-					static_for<CH>([&](auto c_tag) {
-						constexpr int c = decltype(c_tag)::value;
-						constexpr bool any_neg = NEGMASK != 0;
-						int sum = acc[k % LIVE][c][0];
-						if constexpr (any_neg)
-							sum -= acc[k % LIVE][c][1];
-						// (acc * reciprocal) / 32768 toward zero in 64 bits: right for either range class of the host's (CRHIP_NORM_*)
-						const long long v = (long long)sum * (long long)a.reciprocal + (long long)((unsigned)(sum >> 31) >> 17);
-						out[c] = (int)(v >> 15);
-					});
-					if ((unsigned)k + lane * K < n)
-					{
-						if constexpr (OUT16 && CH == 2)
-							*reinterpret_cast<int *>(my_stage + stage_at + k * UNIT) = (clamp_s16(out[0]) & 0xFFFF) | (clamp_s16(out[1]) << 16);
-						else if constexpr (OUT16)
-							*reinterpret_cast<short *>(my_stage + stage_at + k * UNIT) = (short)clamp_s16(out[0]);
-						else if constexpr (CH == 2)
-						{
-							i32x2 q;
-							q.x = out[0];
-							q.y = out[CH - 1];
-							*reinterpret_cast<i32x2 *>(my_stage + stage_at + k * UNIT) = q;
-						}
-						else
-							*reinterpret_cast<int *>(my_stage + stage_at + k * UNIT) = out[0];
-					}
-				}
 			});
 		});
 

@@ -15,8 +15,11 @@ import _product
 p = _product.Product(3)
 o = ck.oracle(3)
 bad = 0
-for ch in (2, 1):
+for ch in (2, 1, 4, 6, 8):
     for rates in ((48000, 8000, 8000), (48000, 12000, 12000), (96000, 32000, 32000), (96000, 48000, 48000)):
+        ok, probe = p.low_init(ch, *rates)
+        if p.api.PlanKernelAt(p.api.PlanCreate(probe.raw, p.pre), 0) != 5:
+            continue   # (no k_int instance for this channel count at this ratio)
         for frames in (1, 7, 383, 2304, 2305, 10000, 300001):
             ok, st = p.low_init(ch, *rates)
             ok, ost = o.low_init(ch, *rates)

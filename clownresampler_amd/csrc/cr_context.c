@@ -832,9 +832,10 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	{
 		/* k_poly with the 64-bit multiply-add chain: compiled for fixed weight signs per slot, like k_up */
 		uint32_t negmask = 0, pos_bits = 0, neg_bits = 0;
-		int ok = crhip_poly_up_negmask(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, &negmask);
+		const int any_sign = crhip_poly_mad_any_sign(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
+		int ok = any_sign || crhip_poly_up_negmask(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, &negmask);
 
-		if (ok)
+		if (ok && !any_sign)
 		{
 			cr_poly_slot_signs(&plan->poly, &pos_bits, &neg_bits);
 			ok = (neg_bits & ~negmask) == 0 && (pos_bits & negmask) == 0

@@ -705,6 +705,50 @@ __device__ __forceinline__ void mad64_tap_pair(i32x2 &p_lo, i32x2 &p_hi, int fra
 	}
 }
 
+// The same chain for ANY rows (ASM mode 3; downsampling, where a slot's weight changes sign with the phase): the weight as it is,
+// X = sample << 16 (a plain shift for the left channel, a plain mask for the right one) and the low dword armed with
+// sext(top byte of the sample) ^ sext(top byte of the weight) - k_wave2's one SDWA instruction, reading the sample's top byte
+// straight out of the packed frame (byte 1 / byte 3).  3 instructions per tap and channel against the 4 of the SDWA form; one
+// chain per channel.
+template <bool FIRST>
+__device__ __forceinline__ void mad64_tap_pair_signed(i32x2 &p_lo, i32x2 &p_hi, int frame, int weight)
+{
+	if (FIRST)
+	{
+		p_lo.y = 0;
+		p_hi.y = 0;
+	}
+	const int xl = (int)((unsigned)frame << 16), xr = (int)((unsigned)frame & 0xFFFF0000u);
+	int al, ar;
+	asm("v_xor_b32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_3" : "=v"(al) : "v"(frame), "v"(weight));
+	asm("v_xor_b32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(ar) : "v"(frame), "v"(weight));
+	p_lo.x = al;
+	p_hi.x = ar;
+	mad64(p_lo, xl, weight);
+	mad64(p_hi, xr, weight);
+}
+
+// ... one channel alone (the last one of an odd frame: the low half of its dword)
+__device__ __forceinline__ void mad64_tap_word0_signed(i32x2 &p, int packed, int weight)
+{
+	const int x = (int)((unsigned)packed << 16);
+	int arm;
+	asm("v_xor_b32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_3" : "=v"(arm) : "v"(packed), "v"(weight));
+	p.x = arm;
+	mad64(p, x, weight);
+}
+
+// a whole frame's tap on one chain per channel (the chains' high dwords must have been zeroed before the first tap)
+template <int CH>
+__device__ __forceinline__ void frame_tap_signed(i32x2 (&p)[CH], const Frame<CH> &f, int weight)
+{
+#pragma unroll
+	for (int k = 0; k < CH / 2; ++k)
+		mad64_tap_pair_signed<false>(p[2 * k], p[2 * k + 1], f.v[k], weight);
+	if constexpr (CH % 2 == 1)
+		mad64_tap_word0_signed(p[CH - 1], f.v[CH / 2], weight);
+}
+
 // ... and for mono, where a packed dword holds two FRAMES (two slots, each with its own weight and slot class): word WORD of `packed`
 template <bool SAFE, bool FIRST, int WORD>
 __device__ __forceinline__ void mad64_tap_mono(i32x2 &p, int packed, int weight)
@@ -759,6 +803,27 @@ __device__ __forceinline__ void compute_frame(const FrameData<CH, TT> &d, int *o
 				(s & 1) ? mad64_tap_mono<false, false, 1>(p, packed, d.w[s]) : mad64_tap_mono<false, false, 0>(p, packed, d.w[s]);
 		}
 		out[0] = normalise<NORM>(p.y - p2.y, d.w[TT]);
+		return;
+	}
+	else if constexpr ((ASM & 0xFF) == 3)
+	{
+		static_assert(CH % 2 == 0, "the any-sign 64-bit chain works on packed pairs of channels");
+		i32x2 p[CH];
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+		{
+#pragma unroll
+			for (int k = 0; k < CH / 2; ++k)
+			{
+				if (s == 0)
+					mad64_tap_pair_signed<true>(p[2 * k], p[2 * k + 1], d.f[s].v[k], d.w[s]);
+				else
+					mad64_tap_pair_signed<false>(p[2 * k], p[2 * k + 1], d.f[s].v[k], d.w[s]);
+			}
+		}
+#pragma unroll
+		for (int c = 0; c < CH; ++c)
+			out[c] = normalise<NORM>(p[c].y, d.w[TT]);
 		return;
 	}
 	else if constexpr ((ASM & 0xFF) == 2)
@@ -855,9 +920,10 @@ template <int CH, int TT, int MODE, int NORM, int ASM, int SWZ, int SPLIT = 1, i
 __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int *rows, const unsigned char *base, unsigned rel, int *out)
 {
 	static_assert(PH == 0 || (TT == 0 && SPLIT == 2), "the phantom channel exists for run-time-slot instances with two lanes per frame");
-	if constexpr ((ASM & 0xFF) == 2)
+	if constexpr ((ASM & 0xFF) == 2 || ((ASM & 0xFF) == 3 && TT > 0))
 	{
-		// (the rows are staged for the 64-bit chain: every path of such an instance goes through it)
+		// (the rows are staged for the 64-bit chain: every path of such an instance goes through it - and so does the any-sign chain
+		// of a specialised instance)
 		FrameData<CH, TT> d;
 		fetch_frame<CH, TT, MODE, SWZ, SPLIT>(a, rows, base, rel, d);
 		compute_frame<CH, TT, NORM, ASM>(d, out);
@@ -881,6 +947,15 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 #pragma unroll
 	for (int c = 0; c < CH; ++c)
 		acc[c] = 0;
+	// ASM mode 3 (run-time slot count): one 64-bit chain per channel instead of the SDWA taps - 3 instructions per tap and channel, not 4
+	constexpr bool CHAIN3 = (ASM & 0xFF) == 3 && !(CH == 1 && SPLIT == 1);
+	i32x2 chain[CHAIN3 ? CH : 1];
+	if constexpr (CHAIN3)
+	{
+#pragma unroll
+		for (int c = 0; c < CH; ++c)
+			chain[c].y = 0;
+	}
 
 	int reciprocal = 0;
 
@@ -983,7 +1058,12 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 				}
 #pragma unroll
 				for (int k = 0; k < N; ++k)
-					f[k].template mac<ASM>(acc, wv[k]);
+				{
+					if constexpr (CHAIN3)
+						frame_tap_signed<CH>(chain, f[k], wv[k]);
+					else
+						f[k].template mac<ASM>(acc, wv[k]);
+				}
 			}
 		};
 		// What to do with the slots % 4 taps of the last plane was MEASURED per lane shape (profiles/r01_channel_table.log;
@@ -1006,6 +1086,12 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 			}
 		}
 		reciprocal = reinterpret_cast<const int *>(plane0 + weight_planes * a.plane_rows)[0];
+		if constexpr (CHAIN3)
+		{
+#pragma unroll
+			for (int c = 0; c < CH; ++c)
+				acc[c] = chain[c].y;
+		}
 	}
 
 #pragma unroll

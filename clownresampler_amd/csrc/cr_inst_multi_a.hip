@@ -9,7 +9,7 @@ int specials_multi_a(void *table, int capacity)
 	static const special mine[] = {
 	    // cfg 4: 8 channels 48 -> 44.1 kHz (5-6 taps; 6 slots on shifted windows).  Ticketed tiles since the tickets are scalar atomics and
 	    // the mailbox an LDS word (round 1, with a vmcnt(0) behind either, measured them 1-8 % SLOWER here): 257.9 -> 243.7 us on one box
-	    make_special<8, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 2, false, true>(),
+	    with_signed_chain<8, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 2, true>(make_special<8, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 2, false, true>()),
 	};
 	const int n = (int)(sizeof(mine) / sizeof(mine[0]));
 	if (table == nullptr)

@@ -8,9 +8,9 @@ int specials_multi_b(void *table, int capacity)
 {
 	static const special mine[] = {
 	    make_special_lite_chain<4, 5, CRHIP_NORM_S31, 0x12u>(),                          // quad, 5.1 and 7.1 at 44.1 <-> 48 kHz (upsampling: the 64-bit chain)
-	    make_special_lite<4, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    with_signed_chain<4, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<4, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    make_special_lite_chain<6, 5, CRHIP_NORM_S31, 0x12u>(),
-	    make_special_lite<6, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    with_signed_chain<6, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 4>(make_special_lite<6, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    make_special_lite<8, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 2>(),            // (the geometry cfg 4's instance measured best with: 512 threads, plain stores; the chain with its 16 accumulator pairs: 374 against 241 us)
 	    make_special_lite<3, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),               // and the odd layouts in between (2.1, 5.0, 6.1)
 	    make_special_lite<3, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),

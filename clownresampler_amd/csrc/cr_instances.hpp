@@ -78,6 +78,8 @@ struct special
 	uint32_t mad_frames;        // frames in flight per lane of the chain kernels (k_poly's U): 1 or 2
 	poly_fn mad_rotated[2], mad16_rotated;   // the chain kernels with their rows rotated in LDS (SWZ): taken by launches whose plan asks for a rotation
 	poly_fn fn_rotated, fn16_rotated;        // lite instances (pure upsampling, short windows): their one k_poly with rotated rows, likewise
+	uint32_t mad_geo;                        // geometry (index into GEOMETRY) of the chain in mad[] where it is not the usual one (0: geometry 3 / the lite variant's)
+	uint32_t mad_any_sign;                   // 1: the chain in mad[] is the any-sign form (ASM mode 3): no slot-sign precondition for the host to check
 };
 
 constexpr uint32_t MAD_VARIANT = 28;    // variant ids 28, 29
@@ -121,6 +123,30 @@ special with_chain(special s)
 	s.mad16_rotated = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), U, 1, 0, 1, 1>;
 	s.up_negmask = UPMASK;
 	s.mad_frames = U;
+	return s;
+}
+
+// The ANY-SIGN 64-bit chain (ASM mode 3: 3 instructions per tap and channel instead of the SDWA form's 4) behind variants 28 / 29 of a
+// downsampling instance with an even channel count, at geometry GEO; DEFAULT makes it the instance's default
+template <int CH, int TT, int MODE, int NORM, int GEO, bool DEFAULT = false>
+special with_signed_chain(special s)
+{
+	static_assert(CH % 2 == 0, "packed pairs of channels");
+	constexpr int T = GEOMETRY[GEO].threads, V = GEOMETRY[GEO].vecs;
+	s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, T, V, 3, 1, 0, 0, 0, 1>;
+	s.mad[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, T, V, 3, 1, 0, 0, 0, 0>;
+	s.mad16 = (poly_fn)k_poly<CH, TT, MODE, NORM, T, V, 3, 1, 0, 0, 1, 1>;
+	s.mad_any_sign = 1u;
+	s.mad_frames = 1;
+	s.mad_geo = GEO;
+	if (s.lite)
+	{
+		// (a lite instance with a chain: the chain IS its default - resolve_variant - and every k_poly variant id its SDWA form)
+		s.lite_variant = s.default_variant;
+		s.default_variant = MAD_VARIANT;
+	}
+	else if (DEFAULT)
+		s.default_variant = MAD_VARIANT;
 	return s;
 }
 
@@ -266,6 +292,12 @@ constexpr int runtime_geo(int channels)
 // r02_channel_table_runtime_rows_swizzled.log against r02_channel_table.log) - bank conflicts are half of these kernels' LDS
 // cycles, but the LDS is not what binds them - so it stays 0; k_wave2, which IS LDS-bound, rotates its rows.
 constexpr int RUNTIME_SWZ = 0;
+// Tap arithmetic of the run-time-slot instances: 3 = one any-sign 64-bit multiply-add chain per channel (3 VALU per tap and channel:
+// shift or mask, SDWA xor to arm, v_mad_i64_i32), 1 = the SDWA form (4).  Mono keeps its packed-window SDWA taps either way.
+#ifndef CRA_RUNTIME_ASM
+ #define CRA_RUNTIME_ASM 3
+#endif
+constexpr int RUNTIME_ASM = CRA_RUNTIME_ASM;
 constexpr int runtime_split(int channels)
 {
 	return channels > 8 ? 2 : 1;
@@ -276,10 +308,10 @@ poly_fn pick_runtime(uint32_t mode, uint32_t norm)
 {
 	constexpr int GEO = runtime_geo(CH);
 	if (norm == CRHIP_NORM_S31)
-		return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, GEO, 1, 0, 1, OUT16, RUNTIME_SWZ>()
-		                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, GEO, 1, 0, 1, OUT16, RUNTIME_SWZ>();
-	return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, GEO, 1, 0, 1, OUT16, RUNTIME_SWZ>()
-	                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, GEO, 1, 0, 1, OUT16, RUNTIME_SWZ>();
+		return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, GEO, RUNTIME_ASM, 0, 1, OUT16, RUNTIME_SWZ>()
+		                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, GEO, RUNTIME_ASM, 0, 1, OUT16, RUNTIME_SWZ>();
+	return mode == CRHIP_ROWMODE_UPSAMPLE ? instance<CH, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, GEO, RUNTIME_ASM, 0, 1, OUT16, RUNTIME_SWZ>()
+	                                      : instance<CH, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, GEO, RUNTIME_ASM, 0, 1, OUT16, RUNTIME_SWZ>();
 }
 
 // two lanes per frame, HALF channels each (run-time slot count, geometry 4); PH = 1: 2 * HALF - 1 channels (see k_poly)
@@ -288,10 +320,10 @@ poly_fn pick_runtime_split(uint32_t mode, uint32_t norm)
 {
 	constexpr int T = GEOMETRY[runtime_geo(16)].threads, V = GEOMETRY[runtime_geo(16)].vecs;
 	if (norm == CRHIP_NORM_S31)
-		return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, T, V, 1, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>
-		                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, T, V, 1, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>;
-	return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, T, V, 1, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>
-	                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, T, V, 1, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>;
+		return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, T, V, RUNTIME_ASM, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>
+		                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, T, V, RUNTIME_ASM, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>;
+	return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, T, V, RUNTIME_ASM, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>
+	                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, T, V, RUNTIME_ASM, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>;
 }
 
 

@@ -474,6 +474,12 @@ uint32_t crhip_poly_mad_safemask(uint32_t slots)
 	return slots == 5u ? mad_safemask<5>() : (slots == 15u ? mad_safemask<15>() : 0u);
 }
 
+int crhip_poly_mad_any_sign(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
+{
+	const special *sp = find_special(channels, slots, row_mode, norm_mode);
+	return sp != nullptr && sp->mad[0] != nullptr && sp->mad_any_sign ? 1 : 0;
+}
+
 int crhip_poly_default_is_mad(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
 {
 	const special *sp = find_special(channels, slots, row_mode, norm_mode);
@@ -543,7 +549,7 @@ void crhip_poly_geometry(uint32_t channels, uint32_t slots, uint32_t row_mode, u
 
 	if (sp != nullptr && v >= MAD_VARIANT)
 	{
-		const int g = sp->lite ? (int)(sp->lite_variant % 5u) : 3;   // (a lite instance's chain has the geometry of its SDWA form)
+		const int g = sp->mad_any_sign ? (int)sp->mad_geo : (sp->lite ? (int)(sp->lite_variant % 5u) : 3);   // (a lite instance's chain has the geometry of its SDWA form)
 		*threads = (uint32_t)GEOMETRY[g].threads;
 		*vecs = (uint32_t)GEOMETRY[g].vecs;
 		*frames_multiple = *threads * sp->mad_frames;
@@ -614,7 +620,7 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 
 	if (sp != nullptr && v >= MAD_VARIANT)
 	{
-		*geo = sp->lite ? sp->lite_variant % 5u : 3u;
+		*geo = sp->mad_any_sign ? sp->mad_geo : (sp->lite ? sp->lite_variant % 5u : 3u);
 		if (launch->swizzle != 0 && sp->mad_rotated[0] != nullptr)
 			return launch->out_s16 ? sp->mad16_rotated : sp->mad_rotated[v - MAD_VARIANT];
 		return launch->out_s16 ? sp->mad16 : sp->mad[v - MAD_VARIANT];

@@ -214,6 +214,8 @@ int crhip_poly_up_negmask(uint32_t channels, uint32_t slots, uint32_t row_mode, 
 /* the variant to use when a plan does not qualify for k_up */
 /* 1 when the instance's default variant is one of the 64-bit-chain variants (whose sign precondition the host must check) */
 int crhip_poly_default_is_mad(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
+/* 1 when that chain is the any-sign form (downsampling instances): it takes whatever rows the 32-bit kernels take, nothing to check */
+int crhip_poly_mad_any_sign(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
 /* whether the instance has the input-stationary kernel (k_up2, variant 27) / has it as its measured default */
 int crhip_poly_has_up(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
 int crhip_poly_default_is_up(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);

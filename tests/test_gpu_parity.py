@@ -748,6 +748,63 @@ def test_device_resident_launches_on_many_streams(products):
             assert np.array_equal(d_out[rep].cpu().numpy(), want), (k, rep)
 
 
+def test_device_resident_launches_from_many_threads(products):
+    """12 host THREADS, each with a stream of its own, launching at the same time - more streams than the library has
+    ticket rings, so rings change hands while other threads sit between drawing a block and enqueueing their launch (the window
+    in which a ring judged idle by hipStreamQuery alone could be handed to two launches; a ring with a launch pending is no longer
+    taken over).  ctypes releases the GIL inside the C call, so the launches really overlap.  Every stream's output is its own."""
+    import threading
+    import torch
+    p, o = products[3], ck.oracle(3)
+    api = p.api
+    dev = torch.device("cuda", 0)
+    ch, rates, frames = 2, (44100, 48000, 44100), 200000
+    ok, ost = o.low_init(ch, *rates)
+    R = int(ost.cfg.radius_frames)
+    n_threads, reps = 12, 40
+    jobs = []
+    for k in range(n_threads):
+        pcm = ck.pad_frames(ck.noise_pcm(frames * ch, 2000 + k), ch, R)
+        ok, fresh = o.low_init(ch, *rates)
+        want = o.low_resample_i32(fresh, pcm, frames)[0]
+        jobs.append((torch.cuda.Stream(dev), torch.from_numpy(pcm).to(dev), [torch.zeros(want.size, dtype=torch.int32, device=dev) for _ in range(4)], want))
+    torch.cuda.synchronize()
+    ok, st0 = p.low_init(ch, *rates)
+    plan = api.PlanCreate(st0.raw, p.pre)
+    n_out = jobs[0][3].size // ch
+    start = threading.Barrier(n_threads)
+    errors = []
+
+    def worker(k):
+        s, d_in, d_out, want = jobs[k]
+        try:
+            start.wait()
+            for rep in range(reps):
+                st = cr.LowLevel_State.from_buffer_copy(st0.raw)
+                api.ResampleDevice(plan, st, d_in.data_ptr(), frames, d_out[rep % 4].data_ptr(), n_out + 8, s.cuda_stream)
+        except Exception as e:   # pragma: no cover
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(n_threads)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for k, (s, d_in, d_out, want) in enumerate(jobs):
+        for buf in d_out:
+            assert np.array_equal(buf.cpu().numpy(), want), k
+    # ... and the ticket blocks were all left zeroed: one more round on fresh streams is right as well
+    for k in range(n_threads):
+        s = torch.cuda.Stream(dev)
+        st = cr.LowLevel_State.from_buffer_copy(st0.raw)
+        jobs[k][2][0].zero_()
+        api.ResampleDevice(plan, st, jobs[k][1].data_ptr(), frames, jobs[k][2][0].data_ptr(), n_out + 8, s.cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(jobs[k][2][0].cpu().numpy(), jobs[k][3]), k
+
+
 def test_highlevel_random_streams(products):
     """The streaming API (clownresampler.h:1101-1250: leading padding, refills, ResampleEnd) on random channel counts 1..16,
     rates, pull sizes and lengths, both radii, with the large side window and with the reference's one pull per GPU call:

@@ -738,6 +738,20 @@ __device__ __forceinline__ void mad64_tap_word0_signed(i32x2 &p, int packed, int
 	mad64(p, x, weight);
 }
 
+// ... mono, where a packed dword holds two FRAMES: word WORD of `packed`
+template <int WORD>
+__device__ __forceinline__ void mad64_tap_mono_signed(i32x2 &p, int packed, int weight)
+{
+	const int x = WORD ? (int)((unsigned)packed & 0xFFFF0000u) : (int)((unsigned)packed << 16);
+	int arm;
+	if constexpr (WORD)
+		asm("v_xor_b32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(arm) : "v"(packed), "v"(weight));
+	else
+		asm("v_xor_b32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_3" : "=v"(arm) : "v"(packed), "v"(weight));
+	p.x = arm;
+	mad64(p, x, weight);
+}
+
 // a whole frame's tap on one chain per channel (the chains' high dwords must have been zeroed before the first tap)
 template <int CH>
 __device__ __forceinline__ void frame_tap_signed(i32x2 (&p)[CH], const Frame<CH> &f, int weight)
@@ -805,22 +819,33 @@ __device__ __forceinline__ void compute_frame(const FrameData<CH, TT> &d, int *o
 		out[0] = normalise<NORM>(p.y - p2.y, d.w[TT]);
 		return;
 	}
-	else if constexpr ((ASM & 0xFF) == 3)
+	else if constexpr ((ASM & 0xFF) == 3 && CH == 1)
 	{
-		static_assert(CH % 2 == 0, "the any-sign 64-bit chain works on packed pairs of channels");
-		i32x2 p[CH];
+		// mono: fetch_frame left the window packed, two frames per dword; two chains, taps alternating between them
+		i32x2 p, p2;
+		p.y = 0;
+		p2.y = 0;
 #pragma unroll
 		for (int s = 0; s < TT; ++s)
 		{
-#pragma unroll
-			for (int k = 0; k < CH / 2; ++k)
-			{
-				if (s == 0)
-					mad64_tap_pair_signed<true>(p[2 * k], p[2 * k + 1], d.f[s].v[k], d.w[s]);
-				else
-					mad64_tap_pair_signed<false>(p[2 * k], p[2 * k + 1], d.f[s].v[k], d.w[s]);
-			}
+			const int packed = d.f[s / 2].v[0];
+			if (s & 1)
+				mad64_tap_mono_signed<1>(p2, packed, d.w[s]);
+			else
+				mad64_tap_mono_signed<0>(p, packed, d.w[s]);
 		}
+		out[0] = normalise<NORM>(p.y + p2.y, d.w[TT]);
+		return;
+	}
+	else if constexpr ((ASM & 0xFF) == 3)
+	{
+		i32x2 p[CH];
+#pragma unroll
+		for (int c = 0; c < CH; ++c)
+			p[c].y = 0;
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+			frame_tap_signed<CH>(p, d.f[s], d.w[s]);
 #pragma unroll
 		for (int c = 0; c < CH; ++c)
 			out[c] = normalise<NORM>(p[c].y, d.w[TT]);
@@ -950,6 +975,8 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 	// ASM mode 3 (run-time slot count): one 64-bit chain per channel instead of the SDWA taps - 3 instructions per tap and channel, not 4
 	constexpr bool CHAIN3 = (ASM & 0xFF) == 3 && !(CH == 1 && SPLIT == 1);
 	i32x2 chain[CHAIN3 ? CH : 1];
+	i32x2 mono_chain;   // (mono with a run-time slot count: its packed-window taps on one chain)
+	mono_chain.y = 0;
 	if constexpr (CHAIN3)
 	{
 #pragma unroll
@@ -1032,7 +1059,12 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 				load_mono_window<N>(src + 4u * q * FB, pw);
 #pragma unroll
 				for (int k = 0; k < N; ++k)
-					mono_tap<ASM, false>(acc[0], pw, k, wv[k]);
+				{
+					if constexpr ((ASM & 0xFF) == 3)
+						(k & 1) ? mad64_tap_mono_signed<1>(mono_chain, pw[k / 2], wv[k]) : mad64_tap_mono_signed<0>(mono_chain, pw[k / 2], wv[k]);
+					else
+						mono_tap<ASM, false>(acc[0], pw, k, wv[k]);
+				}
 			}
 			else
 			{
@@ -1092,6 +1124,8 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 			for (int c = 0; c < CH; ++c)
 				acc[c] = chain[c].y;
 		}
+		else if constexpr ((ASM & 0xFF) == 3)
+			acc[0] = mono_chain.y;
 	}
 
 #pragma unroll

@@ -7,15 +7,15 @@ namespace crk
 int specials_down(void *table, int capacity)
 {
 	static const special mine[] = {
-	    make_special_lite<1, 12, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    with_signed_chain<1, 12, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 12, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_wave2<2, 12, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 12, 2, 2, 0, true>(make_special_lite<2, 12, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
-	    make_special_lite<1, 13, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    with_signed_chain<1, 13, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 13, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_wave2<2, 13, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 2, 0, true>(make_special_lite<2, 13, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
-	    make_special_lite<1, 9, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    with_signed_chain<1, 9, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 9, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_signed_chain<2, 9, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<2, 9, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
-	    make_special_lite<1, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    with_signed_chain<1, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_signed_chain<2, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<2, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
-	    make_special_lite<1, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    with_signed_chain<1, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_wave2<2, 33, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 1, 0, true>(make_special_lite<2, 33, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_wave2<2, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 2, 0, true>(make_special_lite<2, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	};

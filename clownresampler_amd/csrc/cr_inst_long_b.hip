@@ -25,7 +25,7 @@ int specials_long_b(void *table, int capacity)
 	    // for the run-time-slot k_poly - but the specialised k_poly these entries would fall back to where a ratio's rows do not
 	    // fit is far slower for 6 and 7 channels (0.19, 0.10: spills), so those two stay on the run-time-slot instance; for 8
 	    // channels the specialised k_poly itself is the best of the three (0.32)
-	    make_special_lite<8, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite<8, 17, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),   // (the any-sign chain spills here: 17 slots x 8 channels, 118 -> 990 us)
 	};
 	const int n = (int)(sizeof(mine) / sizeof(mine[0]));
 	if (table == nullptr)

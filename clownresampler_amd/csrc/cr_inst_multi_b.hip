@@ -11,12 +11,12 @@ int specials_multi_b(void *table, int capacity)
 	    with_signed_chain<4, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<4, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    make_special_lite_chain<6, 5, CRHIP_NORM_S31, 0x12u>(),
 	    with_signed_chain<6, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 4>(make_special_lite<6, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
-	    make_special_lite<8, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 2>(),            // (the geometry cfg 4's instance measured best with: 512 threads, plain stores; the chain with its 16 accumulator pairs: 374 against 241 us)
-	    make_special_lite<3, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),               // and the odd layouts in between (2.1, 5.0, 6.1)
-	    make_special_lite<3, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
-	    make_special_lite<5, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),
-	    make_special_lite<7, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),
-	    make_special_lite<7, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    with_signed_chain<8, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 2>(make_special_lite<8, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 2>()),            // (the geometry cfg 4's instance measured best with: 512 threads, plain stores; the chain with its 16 accumulator pairs: 374 against 241 us)
+	    with_signed_chain<3, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 3>(make_special_lite<3, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>()),               // and the odd layouts in between (2.1, 5.0, 6.1)
+	    with_signed_chain<3, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<3, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
+	    with_signed_chain<5, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 4>(make_special_lite<5, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>()),
+	    with_signed_chain<7, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 4>(make_special_lite<7, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>()),
+	    with_signed_chain<7, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 4>(make_special_lite<7, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    make_special_lite_split<12, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),        // 7.1.4 and 16 channels (the reference's maximum) at 44.1 <-> 48 kHz; (16,5) measured SLOWER than the run-time instance
 	    make_special_lite_split<12, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
 	    make_special_lite_split<16, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),

@@ -131,7 +131,6 @@ special with_chain(special s)
 template <int CH, int TT, int MODE, int NORM, int GEO, bool DEFAULT = false>
 special with_signed_chain(special s)
 {
-	static_assert(CH % 2 == 0, "packed pairs of channels");
 	constexpr int T = GEOMETRY[GEO].threads, V = GEOMETRY[GEO].vecs;
 	s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, T, V, 3, 1, 0, 0, 0, 1>;
 	s.mad[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, T, V, 3, 1, 0, 0, 0, 0>;
@@ -264,16 +263,19 @@ special make_special_lite_chain()
 }
 
 // ... and with two lanes per frame (CHT channels in all, CHT / 2 per lane), at the geometry of the run-time instances above 8 channels
+#ifndef CRA_SPLIT_LITE_ASM
+ #define CRA_SPLIT_LITE_ASM 1
+#endif
 template <int CHT, int TT, int MODE, int NORM>
 special make_special_lite_split()
 {
 	constexpr int DV = 14;   // (1024 threads, 2 vectors per thread), one frame in flight, non-temporal stores
 	constexpr int T = GEOMETRY[DV % 5].threads, V = GEOMETRY[DV % 5].vecs;
 	special s = {CHT, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 2u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u, nullptr, 13u, 1u};
-	const poly_fn fn = (poly_fn)k_poly<CHT / 2, TT, MODE, NORM, T, V, 1, 1, 0, 0, 0, 1, 2>;
+	const poly_fn fn = (poly_fn)k_poly<CHT / 2, TT, MODE, NORM, T, V, CRA_SPLIT_LITE_ASM, 1, 0, 0, 0, 1, 2>;
 	for (int v = 0; v < VARIANTS; ++v)
 		s.fn[v] = fn;
-	s.fn16 = (poly_fn)k_poly<CHT / 2, TT, MODE, NORM, T, V, 1, 1, 0, 0, 1, 1, 2>;
+	s.fn16 = (poly_fn)k_poly<CHT / 2, TT, MODE, NORM, T, V, CRA_SPLIT_LITE_ASM, 1, 0, 0, 1, 1, 2>;
 	return s;
 }
 

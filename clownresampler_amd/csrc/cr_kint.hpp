@@ -81,7 +81,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 	constexpr unsigned WIN = int_window_bytes(CH, R, TT, K);
 	constexpr int NVW = (int)(WIN / 1024u);
 	constexpr unsigned STAGE = (int_stage_bytes(CH, K, OUT16) + 15u) & ~15u;
-	static_assert(LANE_BYTES % 16u == 0, "a lane's window starts on a 16-byte boundary of the tile's");
+	// a lane's window starts LANE_BYTES after its neighbour's: 16-byte reads where that is a multiple of 16, 8- or 4-byte reads where not
+	constexpr unsigned VECB = LANE_BYTES % 16u == 0 ? 16u : (LANE_BYTES % 8u == 0 ? 8u : 4u);
+	static_assert(LANE_BYTES % 4u == 0, "a lane's window starts on a dword of the tile's");
 	static_assert((K * UNIT) % 4u == 0, "a lane's frames are staged as dwords");
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -202,21 +204,45 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 		const unsigned n = (unsigned)((a.n_out - first < WT) ? (a.n_out - first) : WT);
 
 		patch(lost);
-		// the lane's window, packed, into registers: XV aligned 16-byte reads at a stride of LANE_BYTES
+		// the lane's window, packed, into registers: XV x 16 bytes at a stride of LANE_BYTES, in aligned reads of VECB bytes
 		int d[XV * 4];
 		{
-			const i32x4 *src = reinterpret_cast<const i32x4 *>(my_buf + lane * LANE_BYTES);
-			i32x4 raw[XV];
-#pragma unroll
-			for (int v = 0; v < XV; ++v)
-				raw[v] = src[v];
-#pragma unroll
-			for (int v = 0; v < XV; ++v)
+			if constexpr (VECB == 16u)
 			{
-				d[4 * v] = raw[v].x;
-				d[4 * v + 1] = raw[v].y;
-				d[4 * v + 2] = raw[v].z;
-				d[4 * v + 3] = raw[v].w;
+				const i32x4 *src = reinterpret_cast<const i32x4 *>(my_buf + lane * LANE_BYTES);
+				i32x4 raw[XV];
+#pragma unroll
+				for (int v = 0; v < XV; ++v)
+					raw[v] = src[v];
+#pragma unroll
+				for (int v = 0; v < XV; ++v)
+				{
+					d[4 * v] = raw[v].x;
+					d[4 * v + 1] = raw[v].y;
+					d[4 * v + 2] = raw[v].z;
+					d[4 * v + 3] = raw[v].w;
+				}
+			}
+			else if constexpr (VECB == 8u)
+			{
+				const i32x2 *src = reinterpret_cast<const i32x2 *>(my_buf + lane * LANE_BYTES);
+				i32x2 raw[XV * 2];
+#pragma unroll
+				for (int v = 0; v < XV * 2; ++v)
+					raw[v] = src[v];
+#pragma unroll
+				for (int v = 0; v < XV * 2; ++v)
+				{
+					d[2 * v] = raw[v].x;
+					d[2 * v + 1] = raw[v].y;
+				}
+			}
+			else
+			{
+				const int *src = reinterpret_cast<const int *>(my_buf + lane * LANE_BYTES);
+#pragma unroll
+				for (int v = 0; v < XV * 4; ++v)
+					d[v] = src[v];
 			}
 		}
 		// the reads must have landed before the next DMA may overwrite the buffer (the registers are the compiler's, hence its

@@ -313,7 +313,7 @@ def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch,
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("ch", [1, 2, 4, 6, 8])
+@pytest.mark.parametrize("ch", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("ratio", [2, 3, 4, 6])
 def test_whole_number_ratio_kernel(products, ch, ratio):
     """k_int (cr_kint.hpp): increment = ratio << 16, the launch's one row in the kernel arguments, K consecutive frames per lane.
@@ -325,8 +325,6 @@ def test_whole_number_ratio_kernel(products, ch, ratio):
     rates = (48000, 48000 // ratio, 48000 // ratio)
     ok, probe = p.low_init(ch, *rates)
     plan = p.api.PlanCreate(probe.raw, p.pre)
-    if ch > 2 and p.api.PlanKernelAt(plan, 0) != 5:
-        pytest.skip("no k_int instance for %d channels at %d:1" % (ch, ratio))   # (wide frames: 2:1 for 4 / 6 / 8, 3:1 for 4 / 6, 4:1 for 4)
     assert probe.increment == ratio << 16 and p.api.PlanKernelAt(plan, 0) == 5
     for frames in (1, 2, ratio, 383, 64 * 12 * ratio - 1, 64 * 12 * ratio, 64 * 12 * ratio + 1, 9999, 10000, 250001):
         ok, st = p.low_init(ch, *rates)

@@ -1226,17 +1226,24 @@ static uint32_t plan_pick_rotation(const ClownResamplerAMD_Plan *plan, double *p
 
 /* Once per plan, never inside a caller's stream capture: the kernel's function attributes, and the grid caps clamped to what is
    resident at once. */
-static int plan_prepare(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan)
+/* `probe`: a shape the plan works without - a failure is reported to the caller only, never to the error handler (whose default aborts,
+   and whose serial number callers compare). */
+static int plan_prepare(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan, int probe)
 {
 	crhip_poly_launch l;
 	int form;
 
 	fill_poly_launch(plan, &l);
-	if (cr_check_hip(crhip_poly_prepare(&l), "hipFuncSetAttribute(dynamic LDS)") != 0)
-		return -1;
-	l.out_s16 = 1; /* the int16-output instance is a different function */
-	if (cr_check_hip(crhip_poly_prepare(&l), "hipFuncSetAttribute(dynamic LDS, int16 form)") != 0)
-		return -1;
+	for (form = 0; form < 2; ++form)
+	{
+		const int code = crhip_poly_prepare(&l);
+
+		if (code != 0 && probe)
+			return -1;
+		if (cr_check_hip(code, form ? "hipFuncSetAttribute(dynamic LDS, int16 form)" : "hipFuncSetAttribute(dynamic LDS)") != 0)
+			return -1;
+		l.out_s16 = 1; /* the int16-output instance is a different function */
+	}
 
 	/* The persistent grid must not be larger than what is resident at once: workgroups that start after the first
 	   batch has left find their statically dealt tiles still waiting (twice the time) or no tickets (harmless).
@@ -1279,15 +1286,12 @@ static void plan_brief_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *p
 	other = *plan;   /* (a scratch copy: nothing in it is owned) */
 	other.variant = crhip_poly_up_fallback_variant(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
 	plan_geometry(&other);
-	if (other.vecs >= 200u || other.specialised != plan->specialised)
-		return;
+	if (!other.use_poly || other.vecs >= 200u || other.specialised != plan->specialised)
+		return;   /* (the fallback shape does not fit this plan's rows, or is no other kernel) */
 	other.lane_map = plan_pick_lane_map(&other);
 	other.lds_swizzle = plan_pick_rotation(&other, &plain, &best);
-	if (plan_prepare(ctx, &other) != 0)
-	{
-		ClownResamplerAMD_ClearError();   /* (the plan works without) */
-		return;
-	}
+	if (plan_prepare(ctx, &other, 1) != 0)
+		return;   /* (the plan works without) */
 
 	plan->brief.threads = other.threads;
 	plan->brief.vecs = other.vecs;
@@ -1531,7 +1535,7 @@ ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t t
 		plan->plane_rows = store->plane_rows;
 		plan->device_row_stride = store->device_row_stride;
 
-		if (plan_prepare(ctx, plan) != 0)
+		if (plan_prepare(ctx, plan, 0) != 0)
 			goto fail_plan;
 		plan_brief_shape(ctx, plan);
 		plan_int_shape(ctx, plan);

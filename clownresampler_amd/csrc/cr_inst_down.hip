@@ -1,4 +1,4 @@
-// cr_inst_down.hip - instance unit: mono and stereo at the usual downsampling ratios (2:1, 96 -> 44.1, 3:2, 44.1 -> 32, 3:1)  (see cr_instances.hpp)
+// cr_inst_down.hip - instance unit: mono and stereo at the usual downsampling ratios (2:1, 96 -> 44.1, 3:2, 44.1 -> 32, 3:1, 44.1 -> 16, 44.1 -> 8, 88.2 -> 48)  (see cr_instances.hpp)
 #include "cr_instances.hpp"
 
 namespace crk
@@ -18,6 +18,11 @@ int specials_down(void *table, int capacity)
 	    with_signed_chain<1, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_wave2<2, 33, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 1, 0, true>(make_special_lite<2, 33, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_wave2<2, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 2, 0, true>(make_special_lite<2, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
+	    // 44.1 -> 16 kHz (16 slots; the speech-recognition front end's conversion) and 88.2 -> 48 / 44.1 -> 24 kHz (11 slots)
+	    with_signed_chain<1, 16, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 16, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
+	    with_wave2<2, 16, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 2, 0, true>(make_special_lite<2, 16, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
+	    with_signed_chain<1, 11, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 11, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
+	    with_wave2<2, 11, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 2, 0, true>(make_special_lite<2, 11, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	};
 	const int n = (int)(sizeof(mine) / sizeof(mine[0]));
 	if (table == nullptr)

@@ -288,6 +288,9 @@ def test_baseline_configs_full_size_bit_exact(products, name, radius, ch, rates,
     ("dn6xm", 3, 1, (48000, 8000, 8000), 57600000, 5),      # ... mono (4 frames per lane)
     ("dn21k", 3, 2, (96000, 48000, 48000), 57600000, 5),    # ... 2:1 (12 slots; the k_wave2 of this shape is the "dn21" row above)
     ("dn31m", 3, 1, (96000, 32000, 32000), 57600000, 5),    # ... mono 3:1 (8 frames per lane)
+    ("dn16", 3, 2, (44100, 16000, 16000), 26460000, 4),     # 44.1 -> 16 kHz: 16-slot k_wave2 instance
+    ("dn16m", 3, 1, (44100, 16000, 16000), 26460000, 1),    # ... mono: specialised k_poly, any-sign chain on the packed mono window
+    ("dn11", 3, 2, (88200, 48000, 48000), 26460000, 4),     # 88.2 -> 48 kHz: 11-slot k_wave2 instance
 ])
 def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch, rates, frames, kernel):
     """10-minute streams (5 for the widest) through the kernels the BASELINE configurations do not reach, against the

@@ -182,6 +182,8 @@ class Api:
         # radius-independent
         self._PlanGetInfo = fn("ClownResamplerAMD_PlanGetInfo", None, [C.c_void_p, P(PlanInfo)], False)
         self._PlanRows = fn("ClownResamplerAMD_PlanRows", P(C.c_int32), [C.c_void_p], False)
+        self._PeriodicShape = fn("ClownResamplerAMD_PeriodicShape", C.c_int, [P(LowestLevel_Configuration), P(Precomputed), C.c_uint64, P(C.c_uint32), P(C.c_uint32),
+                                                                                P(C.c_uint32), C.c_uint32 * 4, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)])
         self._PlanRowOf = fn("ClownResamplerAMD_PlanRowOf", C.c_uint32, [C.c_void_p, C.c_uint32], False)
         self._ResampleDevice = fn("ClownResamplerAMD_ResampleDevice", C.c_size_t, [C.c_void_p, P(LowLevel_State), C.c_void_p, P(C.c_size_t), C.c_void_p, C.c_size_t, C.c_void_p, P(cc_bool)], False)
         self._ResampleDeviceS16 = fn("ClownResamplerAMD_ResampleDeviceS16", C.c_size_t, [C.c_void_p, P(LowLevel_State), C.c_void_p, P(C.c_size_t), C.c_void_p, C.c_size_t, C.c_void_p, P(cc_bool)], False)
@@ -345,6 +347,18 @@ class Api:
         arr = np.ctypeslib.as_array(rows, shape=(info.rows, info.row_stride)).copy()
         self._libc_free(rows)
         return info, arr, bool(eligible.value), msg
+
+    def PeriodicShape(self, configuration, precomputed, increment):
+        """Host-only: what a k_int instance for this configuration / increment is compiled for (tools/int_shapes.py), or None:
+        dict(period, ratio, slots, starts, negmask, safemask, zeromask) at fractional position 0."""
+        period, ratio, slots = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        starts = (C.c_uint32 * 4)()
+        neg, safe, zero = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        if self._PeriodicShape(C.byref(configuration), C.byref(precomputed), increment, C.byref(period), C.byref(ratio), C.byref(slots), starts,
+                               C.byref(neg), C.byref(safe), C.byref(zero)) != 0:
+            return None
+        return dict(period=period.value, ratio=ratio.value, slots=slots.value, starts=list(starts)[:period.value], negmask=neg.value,
+                    safemask=safe.value, zeromask=zero.value)
 
     def PlanCreate(self, state, precomputed):
         plan = self._PlanCreate(C.byref(state), C.byref(precomputed))

@@ -25,6 +25,7 @@
 
 #if CLOWNRESAMPLER_KERNEL_RADIUS != 3
  #define ClownResamplerAMD_BuildRows CLOWNRESAMPLER_AMD_SYM(ClownResamplerAMD_BuildRows)
+ #define ClownResamplerAMD_PeriodicShape CLOWNRESAMPLER_AMD_SYM(ClownResamplerAMD_PeriodicShape)
 #endif
 
 /* ======================================================================================================= */
@@ -231,6 +232,62 @@ int ClownResamplerAMD_BuildRows(const ClownResampler_LowestLevel_Configuration *
 			row_of_fraction[frac] = cr_poly_row_of(&poly, frac);
 
 	return r;
+}
+
+/* Host-only: what a k_int instance for this configuration and (periodic) increment has to be compiled for - the period, the input
+   frames per period, every phase's first input frame (counted from phase 0's), and per phase-slot whether the weight is <= 0 and
+   whether it reaches 65536 - at fractional position 0.  tools/int_shapes.py prints the instance table's constants with it. */
+int ClownResamplerAMD_PeriodicShape(const ClownResampler_LowestLevel_Configuration *configuration, const ClownResampler_Precomputed *precomputed,
+                                    uint64_t increment, uint32_t *period_out, uint32_t *ratio_out, uint32_t *slots_out, uint32_t starts_out[4],
+                                    uint64_t *negmask_out, uint64_t *safemask_out, uint64_t *zeromask_out)
+{
+	cr_config cfg;
+	cr_poly poly;
+	int32_t *table = (int32_t *)malloc(TABLE_LEN * sizeof(int32_t));
+	uint32_t period, rows[4], starts[4], p, s;
+	int ok = -1;
+
+	config_of(configuration, &cfg);
+	if (table == NULL || fill_table_i32(precomputed, table, TABLE_LEN) != 0)
+	{
+		free(table);
+		return -1;
+	}
+	if (cr_poly_build(table, TABLE_LEN, &cfg, &poly) != 0 || poly.weights == NULL)
+	{
+		free(table);
+		cr_poly_free(&poly);
+		return -1;
+	}
+	free(table);
+	for (period = 1; period <= 4u; period *= 2u)
+		if (((increment * period) & 0xFFFFu) == 0)
+			break;
+	if (period <= 4u && poly.slots * period <= 64u && cr_poly_periodic(&poly, increment, 0, period, rows, starts))
+	{
+		*period_out = period;
+		*ratio_out = (uint32_t)((increment * period) >> 16);
+		*slots_out = poly.slots;
+		*negmask_out = *safemask_out = *zeromask_out = 0;
+		for (p = 0; p < period; ++p)
+		{
+			const int32_t *w = poly.weights + (size_t)rows[p] * poly.row_stride;
+
+			starts_out[p] = starts[p] - starts[0];
+			for (s = 0; s < poly.slots; ++s)
+			{
+				if (w[s] < 0)
+					*negmask_out |= 1ull << (p * poly.slots + s);
+				if (w[s] >= 65536 || w[s] <= -65536)
+					*safemask_out |= 1ull << (p * poly.slots + s);
+				if (w[s] == 0)
+					*zeromask_out |= 1ull << (p * poly.slots + s);
+			}
+		}
+		ok = 0;
+	}
+	cr_poly_free(&poly);
+	return ok;
 }
 
 /* ======================================================================================================= */

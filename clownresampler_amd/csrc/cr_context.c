@@ -1309,51 +1309,64 @@ static void plan_brief_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *p
 static void plan_int_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan)
 {
 	int per_cu = 0, per_cu_s16 = 0;
+	uint32_t period;
 	const uint32_t cus = (uint32_t)(ctx->info.compute_units > 0 ? ctx->info.compute_units : 256);
 
 	plan->intk.available = 0;
-	if (g_env.no_int_kernel || !plan->use_poly || plan->increment == 0 || (plan->increment & 0xFFFFu) != 0 || (plan->increment >> 16) > 64u
-	 || plan->poly.row_mode != CRHIP_ROWMODE_AFFINE || plan->poly.slots > CRHIP_INT_MAX_SLOTS
-	 || plan->key_variant != (uint32_t)CR_DEFAULT_VARIANT)
+	if (g_env.no_int_kernel || !plan->use_poly || plan->increment == 0 || plan->key_variant != (uint32_t)CR_DEFAULT_VARIANT)
 		return;
-	plan->intk.ratio = (uint32_t)(plan->increment >> 16);
-	if (!crhip_int_instance(plan->channels, plan->intk.ratio, plan->poly.slots, &plan->intk.shape))
+	/* the period of the fractional position: 1 (a whole-number ratio), 2 or 4 */
+	for (period = 1; period <= 4u; period *= 2u)
+		if (((plan->increment * period) & 0xFFFFu) == 0)
+			break;
+	if (period > 4u || (plan->increment * period) >> 16 > 64u || plan->poly.slots * period > CRHIP_INT_MAX_SLOTS
+	 || (period == 1u && plan->poly.row_mode != CRHIP_ROWMODE_AFFINE))
 		return;
-	if (crhip_int_prepare(plan->channels, plan->intk.ratio, plan->poly.slots, &per_cu, &per_cu_s16) != 0 || per_cu < 1 || per_cu_s16 < 1)
+	plan->intk.period = period;
+	plan->intk.ratio = (uint32_t)((plan->increment * period) >> 16);
+	if (!crhip_int_instance(plan->channels, plan->intk.ratio, period, plan->poly.slots, &plan->intk.shape))
+		return;
+	if (crhip_int_prepare(plan->channels, plan->intk.ratio, period, plan->poly.slots, &per_cu, &per_cu_s16) != 0 || per_cu < 1 || per_cu_s16 < 1)
 		return;   /* (the plan works without) */
 	plan->intk.max_blocks = (uint32_t)per_cu * cus;
 	plan->intk.max_blocks_s16 = (uint32_t)per_cu_s16 * cus;
 	plan->intk.available = 1;
 	if (g_env.debug)
-		fprintf(stderr, "clownresampler_amd: plan %u ch, ratio %u:1, %u slots: k_int with %u frames per lane, %d workgroups of %u threads per CU\n",
-		        plan->channels, plan->intk.ratio, plan->poly.slots, plan->intk.shape.frames_per_lane, per_cu, plan->intk.shape.threads);
+		fprintf(stderr, "clownresampler_amd: plan %u ch, ratio %u:%u, %u slots: k_int with %u frames per lane, %d workgroups of %u threads per CU\n",
+		        plan->channels, plan->intk.ratio, plan->intk.period, plan->poly.slots, plan->intk.shape.frames_per_lane, per_cu, plan->intk.shape.threads);
 }
 
-/* The staged row of a k_int launch at this fractional position, or 0 when the row does not have the instance's slot classes. */
+/* The staged rows of a k_int launch from this fractional position on (one per phase of the period), or 0 when they do not have
+   the instance's slot classes or window starts. */
 static int int_launch_row(const ClownResamplerAMD_Plan *plan, uint32_t frac, crhip_int_launch *l, uint32_t *first_slot)
 {
 	const cr_poly *poly = &plan->poly;
-	const uint32_t row = cr_poly_row_of(poly, frac);
-	const uint32_t mr = (frac + poly->delta + 65535u) >> 16;
-	const int32_t *w;
-	uint32_t s;
+	const uint32_t period = plan->intk.period;
+	uint32_t rows[4], starts[4], p, s;
 
-	if (row >= poly->rows || poly->weights == NULL)
+	if (poly->weights == NULL || !cr_poly_periodic(poly, plan->increment, frac, period, rows, starts))
 		return 0;
-	w = poly->weights + (size_t)row * poly->row_stride;
-	for (s = 0; s < poly->slots; ++s)
+	for (p = 0; p < period; ++p)
 	{
-		const int negative = (int)((plan->intk.shape.negmask >> s) & 1u);
-		const int safe = (int)((plan->intk.shape.safemask >> s) & 1u);
-		const int64_t magnitude = negative ? -(int64_t)w[s] : (int64_t)w[s];
+		const int32_t *w = poly->weights + (size_t)rows[p] * poly->row_stride;
 
-		if (magnitude < 0 || magnitude > 65536 || (!safe && magnitude == 65536))
+		if (starts[p] - starts[0] != plan->intk.shape.starts[p])
 			return 0;
-		l->w[s] = safe ? (int32_t)magnitude : (int32_t)((uint32_t)magnitude << 15);
+		for (s = 0; s < poly->slots; ++s)
+		{
+			const uint32_t at = p * poly->slots + s;
+			const int negative = (int)((plan->intk.shape.negmask >> at) & 1u);
+			const int safe = (int)((plan->intk.shape.safemask >> at) & 1u);
+			const int64_t magnitude = negative ? -(int64_t)w[s] : (int64_t)w[s];
+
+			if (magnitude < 0 || magnitude > 65536 || (!safe && magnitude == 65536) || (((plan->intk.shape.zeromask >> at) & 1u) && magnitude != 0))
+				return 0;
+			l->w[at] = safe ? (int32_t)magnitude : (int32_t)((uint32_t)magnitude << 15);
+		}
+		l->reciprocal[p] = w[poly->slots];
 	}
-	l->reciprocal = w[poly->slots];
-	/* the frame slot 0 multiplies: as row_of / fetch_frame on the device (shifted rows start at their own phase's first tap) */
-	*first_slot = poly->first_slot + (poly->shifted ? mr - poly->first_mr : 0u);
+	/* the frame slot 0 of the launch's first output frame multiplies, counted from its position_integer */
+	*first_slot = starts[0];
 	return 1;
 }
 
@@ -1609,7 +1622,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		memset(&il, 0, sizeof(il));
 		if (int_launch_row(plan, (uint32_t)pos_frac, &il, &first_slot))
 		{
-			const uint64_t tile = 64ull * plan->intk.shape.frames_per_lane;
+			const uint64_t tile = 64ull * plan->intk.shape.frames_per_lane;   /* (output frames) */
 			const uint64_t waves = (n_out + tile - 1) / tile;
 			const uint32_t waves_per_block = plan->intk.shape.threads / 64u;
 			const uint32_t cap = out_s16 ? plan->intk.max_blocks_s16 : plan->intk.max_blocks;
@@ -1622,6 +1635,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			il.n_out = n_out;
 			il.channels = plan->channels;
 			il.ratio = plan->intk.ratio;
+			il.period = plan->intk.period;
 			il.slots = plan->poly.slots;
 			il.out_s16 = out_s16 ? 1u : 0u;
 			il.blocks = (uint32_t)(blocks > cap ? cap : blocks);

@@ -85,13 +85,13 @@ typedef struct ClownResamplerAMD_Plan
 		uint64_t below;
 		uint32_t threads, vecs, tile_frames, lds_bytes, max_blocks, max_blocks_s16, variant, lds_swizzle, lane_map;
 	} brief;
-	/* whole-number downsampling ratios (increment = ratio << 16): k_int (cr_kint.hpp) where there is an instance for
-	   (channels, ratio, slots).  Whether a LAUNCH takes it depends on its fractional position - the row that fraction selects
+	/* whole-number downsampling ratios (increment = ratio << 16) and ratios that repeat after 2 or 4 frames (increment * period =
+	   ratio << 16: 3:2, 1:2, 1:4): k_int (cr_kint.hpp) where there is an instance for (channels, ratio : period, slots).  Whether a LAUNCH takes it depends on its fractional position - the row that fraction selects
 	   must have the instance's slot signs (cr_plan_launch checks; a stream that starts from Init stays at fraction 0). */
 	struct
 	{
 		int available;
-		uint32_t ratio;
+		uint32_t ratio, period;   /* `ratio` input frames per `period` output frames (period 1: the whole-number ratios; 2, 4: 3:2, 1:2, 1:4 ...) */
 		crhip_int_shape shape;
 		uint32_t max_blocks, max_blocks_s16;
 	} intk;

@@ -16,6 +16,7 @@ int specials_down(void *table, int capacity)
 	    with_signed_chain<1, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_signed_chain<2, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<2, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_signed_chain<1, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
+	    with_signed_chain<1, 33, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 33, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),   // mono 44.1 -> 8 kHz
 	    with_wave2<2, 33, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 1, 0, true>(make_special_lite<2, 33, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_wave2<2, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 2, 0, true>(make_special_lite<2, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    // 44.1 -> 16 kHz (16 slots; the speech-recognition front end's conversion) and 88.2 -> 48 / 44.1 -> 24 kHz (11 slots)

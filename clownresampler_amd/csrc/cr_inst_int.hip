@@ -26,14 +26,15 @@ const int_instance *instances(int *count)
 	return table;
 }
 
-const int_instance *find_int(uint32_t channels, uint32_t ratio, uint32_t slots)
+const int_instance *find_int(uint32_t channels, uint32_t ratio, uint32_t period, uint32_t slots)
 {
-	for (int unit = 0; unit < 3; ++unit)
+	for (int unit = 0; unit < 4; ++unit)
 	{
 		int n;
-		const int_instance *t = unit == 0 ? instances(&n) : static_cast<const int_instance *>(unit == 1 ? crhip_int_instances_b(&n) : crhip_int_instances_c(&n));
+		const int_instance *t = unit == 0 ? instances(&n)
+		                                  : static_cast<const int_instance *>(unit == 1 ? crhip_int_instances_b(&n) : (unit == 2 ? crhip_int_instances_c(&n) : crhip_int_instances_d(&n)));
 		for (int i = 0; i < n; ++i)
-			if (t[i].channels == channels && t[i].ratio == ratio && t[i].slots == slots)
+			if (t[i].channels == channels && t[i].ratio == ratio && t[i].period == period && t[i].slots == slots)
 				return &t[i];
 	}
 	return nullptr;
@@ -44,18 +45,18 @@ const int_instance *find_int(uint32_t channels, uint32_t ratio, uint32_t slots)
 extern "C"
 {
 
-int crhip_int_instance(uint32_t channels, uint32_t ratio, uint32_t slots, crhip_int_shape *shape)
+int crhip_int_instance(uint32_t channels, uint32_t ratio, uint32_t period, uint32_t slots, crhip_int_shape *shape)
 {
-	const int_instance *i = find_int(channels, ratio, slots);
+	const int_instance *i = find_int(channels, ratio, period, slots);
 	if (i == nullptr)
 		return 0;
 	*shape = i->shape;
 	return 1;
 }
 
-int crhip_int_prepare(uint32_t channels, uint32_t ratio, uint32_t slots, int *per_cu, int *per_cu_s16)
+int crhip_int_prepare(uint32_t channels, uint32_t ratio, uint32_t period, uint32_t slots, int *per_cu, int *per_cu_s16)
 {
-	const int_instance *i = find_int(channels, ratio, slots);
+	const int_instance *i = find_int(channels, ratio, period, slots);
 	if (i == nullptr)
 		return (int)hipErrorInvalidValue;
 	for (int form = 0; form < 2; ++form)
@@ -73,7 +74,7 @@ int crhip_int_prepare(uint32_t channels, uint32_t ratio, uint32_t slots, int *pe
 
 int crhip_launch_int(const crhip_int_launch *launch, void *stream)
 {
-	const int_instance *i = find_int(launch->channels, launch->ratio, launch->slots);
+	const int_instance *i = find_int(launch->channels, launch->ratio, launch->period, launch->slots);
 	if (i == nullptr || launch->blocks == 0)
 		return (int)hipErrorInvalidValue;
 	if (launch->n_out == 0)

@@ -39,7 +39,7 @@ constexpr unsigned long long int_safemask(int lobes, int r, int tt)
 
 struct int_instance
 {
-	uint32_t channels, ratio, slots;
+	uint32_t channels, ratio, period, slots;
 	crhip_int_shape shape;
 	int_fn fn, fn16;
 };
@@ -55,9 +55,11 @@ int_instance make_int()
 	int_instance i = {};
 	i.channels = CH;
 	i.ratio = R;
+	i.period = 1;
 	i.slots = TT;
 	i.shape.negmask = NEG;
 	i.shape.safemask = SAFE;
+	i.shape.period = 1;
 	i.shape.frames_per_lane = K;
 	i.shape.threads = INT_WAVES * 64;
 	i.shape.lds_bytes[0] = INT_WAVES * int_wave_bytes(CH, R, TT, K, 0) + 16u;   // (+ the workgroup's retired-waves counter)
@@ -67,10 +69,38 @@ int_instance make_int()
 	return i;
 }
 
+// A PERIODIC ratio: R input frames per P output frames (3:2, 1:2, 1:4), TT slots per row, the phases' window starts packed in OFFS
+// and their slot classes in NEG / SAFE (bit p TT + s) - the constants tools/int_shapes.py prints for the reference's table, and
+// the host checks every launch's rows and starts against them (cr_context.c int_launch_row).
+template <int CH, int R, int P, unsigned OFFS, int TT, int K, unsigned long long NEG, unsigned long long SAFE, unsigned long long ZERO = 0>
+int_instance make_per()
+{
+	static_assert((NEG & SAFE) == 0, "a slot that reaches 65536 is a positive one");
+	int_instance i = {};
+	i.channels = CH;
+	i.ratio = R;
+	i.period = P;
+	i.slots = TT;
+	i.shape.negmask = NEG;
+	i.shape.safemask = SAFE;
+	i.shape.zeromask = ZERO;
+	i.shape.period = P;
+	for (int p = 0; p < P; ++p)
+		i.shape.starts[p] = (OFFS >> (8 * p)) & 0xFFu;
+	i.shape.frames_per_lane = K;
+	i.shape.threads = INT_WAVES * 64;
+	i.shape.lds_bytes[0] = INT_WAVES * int_wave_bytes(CH, R, TT, K, 0, P, OFFS) + 16u;
+	i.shape.lds_bytes[1] = INT_WAVES * int_wave_bytes(CH, R, TT, K, 1, P, OFFS) + 16u;
+	i.fn = (int_fn)k_int<CH, R, TT, K, NEG, SAFE, INT_WAVES, 0, 1, P, OFFS, ZERO>;
+	i.fn16 = (int_fn)k_int<CH, R, TT, K, NEG, SAFE, INT_WAVES, 1, 1, P, OFFS, ZERO>;
+	return i;
+}
+
 } // namespace
 
-// the further units' instances (cr_inst_int_b.hip, cr_inst_int_c.hip)
+// the further units' instances (cr_inst_int_b.hip, cr_inst_int_c.hip, cr_inst_int_d.hip)
 const void *crhip_int_instances_b(int *count);
 const void *crhip_int_instances_c(int *count);
+const void *crhip_int_instances_d(int *count);
 
 #endif

@@ -1,0 +1,24 @@
+// cr_inst_int_d.hip - an instance unit of k_int (cr_kint.hpp): PERIODIC ratios - the increment repeats after 2 or 4 output frames
+// (3:2; also 1:2 and 1:4, see below), so a launch uses 2 or 4 rows in turn and they travel in the kernel arguments like the one row of a whole-number
+// ratio.  The constants are what tools/int_shapes.py prints for the reference's 3-lobe table at fractional position 0; the host
+// checks every launch's rows, window starts and zero slots against them (cr_context.c int_launch_row) - anything else takes the
+// plan's ordinary kernel.
+#include "cr_inst_int.hpp"
+
+const void *crhip_int_instances_d(int *count)
+{
+	static const int_instance table[] = {
+	    // 3:2 (48 -> 32 kHz, 96 -> 64 kHz): 9 slots, phase 1 starts one frame later; the last slot of phase 0 is zero.  16 frames per
+	    // lane both (tools/ab: stereo 8 / 16 / 24 frames per lane 0.53 / 0.67 / 0.62 of the roofline, mono 16 / 32 / 48: 0.54 / 0.45 /
+	    // 0.53 - a lane's staged frames are 128 / 64 bytes apart, and the conflicts of those LDS stores are what a tile of few taps sees)
+	    make_per<2, 3, 2, 0x100u, 9, 16, 0x18846ull, 0x0ull, 0x100ull>(),   // stereo: lane stride 96 B
+	    make_per<1, 3, 2, 0x100u, 9, 16, 0x18846ull, 0x0ull, 0x100ull>(),   // mono: 48 B
+	    // NOT instantiated: pure upsampling by 2 and 4 (tools/int_shapes.py 3 24000:48000 12000:48000 prints their constants:
+	    // make_per<CH, 1, 2, 0x0u, 5, K, 0x240ull, 0x4ull, 0x1Bull>, make_per<CH, 1, 4, 0x0u, 5, K, 0x94A40ull, 0x4ull, 0x1Bull> -
+	    // phase 0 is the input sample itself).  Bit-exact, and slower than k_poly there (1:2 stereo 0.53 against 0.71, mono 0.52
+	    // against 0.57; 1:4 0.49 / 0.29 against 0.62 / 0.45; profiles/r03_kint_periodic.log): three taps per frame on average do not
+	    // pay for staging every frame through LDS.
+	};
+	*count = (int)(sizeof(table) / sizeof(table[0]));
+	return table;
+}

@@ -54,31 +54,47 @@ CRK_INT_TAP(12, 88, 89) CRK_INT_TAP(13, 90, 91) CRK_INT_TAP(14, 92, 93) CRK_INT_
 CRK_INT_TAP(18, 100, 101) CRK_INT_TAP(19, 102, 103) CRK_INT_TAP(20, 104, 105) CRK_INT_TAP(21, 106, 107) CRK_INT_TAP(22, 108, 109) CRK_INT_TAP(23, 110, 111)
 #undef CRK_INT_TAP
 
-constexpr unsigned int_lane_bytes(int ch, int r, int k) { return (unsigned)(r * k * ch * 2); }
-constexpr unsigned int_lane_vecs(int ch, int r, int tt, int k) { return ((unsigned)((r * (k - 1) + tt) * ch * 2) + 15u) / 16u; }
-// bytes of LDS a wave-tile's window occupies (whole 1 KiB DMA pieces)
-constexpr unsigned int_window_bytes(int ch, int r, int tt, int k)
+// Periodic ratios (P > 1: the fractional position repeats every P output frames, which consume R input frames together): frame k of a
+// lane is phase k % P of period k / P and its window starts int_start(k) input frames after the lane's first (OFFS: the phases'
+// starts within a period, one byte each, phase 0's is 0).  P == 1: the whole-number ratios, int_start(k) = R k.
+constexpr int int_start(int r, int p, unsigned offs, int k) { return r * (k / p) + (int)((offs >> (8 * (k % p))) & 0xFFu); }
+constexpr int int_input_frames(int r, int p, unsigned offs, int tt, int k)   // input frames a lane reads for its k output frames
 {
-	return (63u * int_lane_bytes(ch, r, k) + 16u * int_lane_vecs(ch, r, tt, k) + 1023u) & ~1023u;
+	int most = 0;
+	for (int i = 0; i < k; ++i)
+		most = int_start(r, p, offs, i) + tt > most ? int_start(r, p, offs, i) + tt : most;
+	return most;
+}
+constexpr unsigned int_lane_bytes(int ch, int r, int k, int p = 1) { return (unsigned)(r * (k / p) * ch * 2); }
+constexpr unsigned int_lane_vecs(int ch, int r, int tt, int k, int p = 1, unsigned offs = 0) { return ((unsigned)(int_input_frames(r, p, offs, tt, k) * ch * 2) + 15u) / 16u; }
+// bytes of LDS a wave-tile's window occupies (whole 1 KiB DMA pieces)
+constexpr unsigned int_window_bytes(int ch, int r, int tt, int k, int p = 1, unsigned offs = 0)
+{
+	return (63u * int_lane_bytes(ch, r, k, p) + 16u * int_lane_vecs(ch, r, tt, k, p, offs) + 1023u) & ~1023u;
 }
 constexpr unsigned int_stage_bytes(int ch, int k, int out16) { return 64u * (unsigned)k * (unsigned)ch * (out16 ? 2u : 4u); }
-constexpr unsigned int_wave_bytes(int ch, int r, int tt, int k, int out16)
+constexpr unsigned int_wave_bytes(int ch, int r, int tt, int k, int out16, int p = 1, unsigned offs = 0)
 {
-	return int_window_bytes(ch, r, tt, k) + ((int_stage_bytes(ch, k, out16) + 15u) & ~15u);
+	return int_window_bytes(ch, r, tt, k, p, offs) + ((int_stage_bytes(ch, k, out16) + 15u) & ~15u);
 }
 
-template <int CH, int R, int TT, int K, unsigned long long NEGMASK, unsigned long long SAFEMASK, int WAVES, int OUT16, int NT>
+template <int CH, int R, int TT, int K, unsigned long long NEGMASK, unsigned long long SAFEMASK, int WAVES, int OUT16, int NT, int P = 1, unsigned OFFS = 0,
+          unsigned long long ZEROMASK = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 {
 	static_assert(CH >= 1 && CH <= 8, "one to eight channels: two at a time over the same accumulator registers");
-	static_assert(TT <= CRHIP_INT_MAX_SLOTS, "the weights travel in the kernel arguments");
+	static_assert(TT * P <= CRHIP_INT_MAX_SLOTS, "the weights travel in the kernel arguments");
+	static_assert((P == 1 || P == 2 || P == 4) && K % P == 0 && (OFFS & 0xFFu) == 0, "whole periods per lane; phase 0 starts the period");
+	// ZEROMASK (periodic ratios): phase-slots whose weight is 0 in the rows the instance is for - pure upsampling's phase 0 is the input
+	// sample itself, one slot of five - are left out of the arithmetic; the host checks them like the signs.
+	static_assert((ZEROMASK & (NEGMASK | SAFEMASK)) == 0 && (P > 1 || ZEROMASK == 0), "a skipped slot has no class");
 	constexpr unsigned FB = CH * 2;                        // bytes per input frame
 	constexpr unsigned UNIT = OUT16 ? CH * 2 : CH * 4;     // bytes per output frame
 	constexpr unsigned WT = 64u * K;                       // output frames per wave-tile
-	constexpr int NX = R * (K - 1) + TT;                   // input frames a lane reads
-	constexpr unsigned LANE_BYTES = int_lane_bytes(CH, R, K);
-	constexpr int XV = (int)int_lane_vecs(CH, R, TT, K);   // ds_read_b128 per lane
-	constexpr unsigned WIN = int_window_bytes(CH, R, TT, K);
+	constexpr int NX = int_input_frames(R, P, OFFS, TT, K);   // input frames a lane reads (P == 1: R (K - 1) + TT)
+	constexpr unsigned LANE_BYTES = int_lane_bytes(CH, R, K, P);
+	constexpr int XV = (int)int_lane_vecs(CH, R, TT, K, P, OFFS);   // ds_read_b128 per lane
+	constexpr unsigned WIN = int_window_bytes(CH, R, TT, K, P, OFFS);
 	constexpr int NVW = (int)(WIN / 1024u);
 	constexpr unsigned STAGE = (int_stage_bytes(CH, K, OUT16) + 15u) & ~15u;
 	// a lane's window starts LANE_BYTES after its neighbour's: 16-byte reads where that is a multiple of 16, 8- or 4-byte reads where not
@@ -154,7 +170,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 	// rounding the range up instead, as k_poly does from ITS 16-byte-aligned base, would read past the caller's buffer here.
 	// fetch() returns the LDS byte offset of such a sample (else ~0) and patch() stores it by hand once the DMA has landed.
 	auto fetch = [&](uint64_t tile) -> unsigned {
-		const uint64_t from = in_base + (a.first_frame + tile * (uint64_t)(WT * R)) * FB;
+		const uint64_t from = in_base + (a.first_frame + tile * (uint64_t)(WT / P * R)) * FB;
 		uint64_t want = WIN;
 		const uint64_t avail = in_end > from ? in_end - from : 0;
 		unsigned lost = ~0u;
@@ -257,8 +273,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 
 		// accumulator high dwords (the sums): [live frame][channel][0: slots with weights >= 0, 1: slots with weights <= 0].  At any
 		// time TT / R frames of a lane are in progress; frame k uses set k % LIVE, pinned to physical registers (int_tap).
-		constexpr int LIVE = TT / R;
-		static_assert(TT % R == 0 && LIVE * 2 * 2 <= 24, "pinned accumulator pairs");
+		// (periodic ratios, P > 1: the other loop order below - one frame after the other, two accumulator sets in turn)
+		constexpr int LIVE = P == 1 ? TT / R : 2;
+		static_assert(P > 1 || (TT % R == 0 && LIVE * 2 * 2 <= 24), "pinned accumulator pairs");
 		int acc[LIVE][2][2], arm[LIVE][2][2];
 		const unsigned stage_at = lane * (K * UNIT);
 
@@ -285,6 +302,90 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 		static_for<PASSES>([&](auto p_tag) {
 			constexpr int first_ch = 2 * decltype(p_tag)::value;
 			constexpr int PC = first_ch + 1 < CH ? 2 : 1;        // channels of this pass
+			// a finished frame k (compile-time) of this pass: normalise (clownresampler.h:1025-1033) and stage
+			auto finish = [&](auto k_tag) {
+				constexpr int k = decltype(k_tag)::value;
+				int out[2] = {0, 0};
+				static_for<PC>([&](auto c_tag) {
+					constexpr int c = decltype(c_tag)::value;
+					constexpr bool any_neg = (NEGMASK & ~ZEROMASK & (((1ull << TT) - 1ull) << ((k % P) * TT))) != 0;   // (of this frame's phase)
+					int sum = acc[k % LIVE][c][0];
+					if constexpr (any_neg)
+						sum -= acc[k % LIVE][c][1];
+					// (acc * reciprocal) / 32768 toward zero in 64 bits: right for either range class of the host's (CRHIP_NORM_*)
+					const long long v = (long long)sum * (long long)a.reciprocal[k % P] + (long long)((unsigned)(sum >> 31) >> 17);
+					out[c] = (int)(v >> 15);
+				});
+				if ((unsigned)k + lane * K < n)
+				{
+					unsigned char *at = my_stage + stage_at + k * UNIT + first_ch * (OUT16 ? 2 : 4);
+					if constexpr (OUT16)
+					{
+						if constexpr (PC == 2 && CH % 2 == 0)
+							*reinterpret_cast<int *>(at) = (clamp_s16(out[0]) & 0xFFFF) | (clamp_s16(out[1]) << 16);
+						else
+						{
+							// (the frames of an odd channel count start on 2-byte boundaries every other time)
+							reinterpret_cast<short *>(at)[0] = (short)clamp_s16(out[0]);
+							if constexpr (PC == 2)
+								reinterpret_cast<short *>(at)[1] = (short)clamp_s16(out[1]);
+						}
+					}
+					else if constexpr (PC == 2 && CH % 2 == 0)
+					{
+						i32x2 q;
+						q.x = out[0];
+						q.y = out[1];
+						*reinterpret_cast<i32x2 *>(at) = q;
+					}
+					else
+					{
+						reinterpret_cast<int *>(at)[0] = out[0];
+						if constexpr (PC == 2)
+							reinterpret_cast<int *>(at)[1] = out[1];
+					}
+				}
+			};
+
+			if constexpr (P > 1)
+			{
+				// PERIODIC ratios: output-stationary.  The lane's whole window is unpacked first (it is short: a few periods + one
+				// row's slots), then the lane's frames one after the other - frame k is phase k % P, its window starts int_start(k)
+				// frames into the lane's, its weights are that phase's row at a.w[(k % P) TT ...] - on two accumulator sets in turn.
+				static_for<NX>([&](auto i_tag) {
+					static_for<PC>([&](auto c_tag) { unpack(std::integral_constant<int, decltype(i_tag)::value * CH + first_ch + decltype(c_tag)::value>()); });
+				});
+				static_for<K>([&](auto k_tag) {
+					constexpr int k = decltype(k_tag)::value;
+					constexpr int ph = k % P, at = int_start(R, P, OFFS, k);
+					static_for<TT>([&](auto s_tag) {
+						constexpr int sl = decltype(s_tag)::value;
+						static_for<PC>([&](auto c_tag) {
+							constexpr int c = decltype(c_tag)::value;
+							constexpr int bit = ph * TT + sl;
+							constexpr int cls = (int)((NEGMASK >> bit) & 1ull);
+							constexpr unsigned long long phase_bits = ((1ull << TT) - 1ull) << (ph * TT), before = ((1ull << bit) - 1ull) & phase_bits;
+							constexpr bool first_of_class = cls ? ((NEGMASK & ~ZEROMASK & before) == 0) : ((~NEGMASK & ~ZEROMASK & before) == 0);
+							constexpr int PAIR = ((k % LIVE) * 2 + c) * 2 + cls;
+							if constexpr (!((ZEROMASK >> bit) & 1ull))
+							{
+								const int x = xs[(at + sl) * CH + first_ch + c];
+								int &hi = acc[k % LIVE][c][cls], &lo = arm[k % LIVE][c][cls];
+								if constexpr (first_of_class)
+									hi = 0;
+								lo = x;
+								if constexpr ((SAFEMASK >> bit) & 1ull)
+									int_tap<PAIR>(lo, hi, (int)((unsigned)x << 15), a.w[bit]);
+								else
+									int_tap<PAIR>(lo, hi, x, a.w[bit]);
+							}
+						});
+					});
+					finish(k_tag);
+				});
+			}
+			else
+			{
 			static_for<PC>([&](auto c_tag) { unpack(std::integral_constant<int, first_ch + decltype(c_tag)::value>()); });
 
 			static_for<NX>([&](auto i_tag) {
@@ -302,66 +403,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 							// is this the first slot of its class?
 							constexpr unsigned long long before = (1ull << s) - 1ull;
 							constexpr bool first_of_class = cls ? ((NEGMASK & before) == 0) : ((~NEGMASK & before) == 0);
-							constexpr int P = ((k % LIVE) * 2 + c) * 2 + cls;
+							constexpr int PAIR = ((k % LIVE) * 2 + c) * 2 + cls;
 							int &hi = acc[k % LIVE][c][cls], &lo = arm[k % LIVE][c][cls];
 							if constexpr (first_of_class)
 								hi = 0;
 							lo = x;
 							if constexpr ((SAFEMASK >> s) & 1ull)
-								int_tap<P>(lo, hi, (int)((unsigned)x << 15), a.w[s]);
+								int_tap<PAIR>(lo, hi, (int)((unsigned)x << 15), a.w[s]);
 							else
-								int_tap<P>(lo, hi, x, a.w[s]);
+								int_tap<PAIR>(lo, hi, x, a.w[s]);
 						}
 					});
 				});
-				// a frame whose last slot this was is complete: normalise (clownresampler.h:1025-1033) and stage
 				static_for<K>([&](auto k_tag) {
 					constexpr int k = decltype(k_tag)::value;
 					if constexpr (i - R * k == TT - 1)
-					{
-						int out[2] = {0, 0};
-						static_for<PC>([&](auto c_tag) {
-							constexpr int c = decltype(c_tag)::value;
-							constexpr bool any_neg = NEGMASK != 0;
-							int sum = acc[k % LIVE][c][0];
-							if constexpr (any_neg)
-								sum -= acc[k % LIVE][c][1];
-							// (acc * reciprocal) / 32768 toward zero in 64 bits: right for either range class of the host's (CRHIP_NORM_*)
-							const long long v = (long long)sum * (long long)a.reciprocal + (long long)((unsigned)(sum >> 31) >> 17);
-							out[c] = (int)(v >> 15);
-						});
-						if ((unsigned)k + lane * K < n)
-						{
-							unsigned char *at = my_stage + stage_at + k * UNIT + first_ch * (OUT16 ? 2 : 4);
-							if constexpr (OUT16)
-							{
-								if constexpr (PC == 2 && CH % 2 == 0)
-									*reinterpret_cast<int *>(at) = (clamp_s16(out[0]) & 0xFFFF) | (clamp_s16(out[1]) << 16);
-								else
-								{
-									// (the frames of an odd channel count start on 2-byte boundaries every other time)
-									reinterpret_cast<short *>(at)[0] = (short)clamp_s16(out[0]);
-									if constexpr (PC == 2)
-										reinterpret_cast<short *>(at)[1] = (short)clamp_s16(out[1]);
-								}
-							}
-							else if constexpr (PC == 2 && CH % 2 == 0)
-							{
-								i32x2 q;
-								q.x = out[0];
-								q.y = out[1];
-								*reinterpret_cast<i32x2 *>(at) = q;
-							}
-							else
-							{
-								reinterpret_cast<int *>(at)[0] = out[0];
-								if constexpr (PC == 2)
-									reinterpret_cast<int *>(at)[1] = out[1];
-							}
-						}
-					}
+						finish(k_tag);
 				});
 			});
+			}
 		});
 
 		// the staged frames of the other lanes: same wave, LDS operations of a wave complete in order

@@ -68,6 +68,24 @@ uint32_t cr_poly_row_of(const cr_poly *poly, uint32_t frac)
 	}
 }
 
+int cr_poly_periodic(const cr_poly *poly, uint64_t increment, uint32_t frac, uint32_t period, uint32_t *rows, uint32_t *starts)
+{
+	uint32_t p;
+
+	for (p = 0; p < period; ++p)
+	{
+		const uint64_t pos = (uint64_t)frac + (uint64_t)p * increment;
+		const uint32_t f = (uint32_t)(pos & (FRAC_ONE - 1));
+		const uint32_t mr = (f + poly->delta + (FRAC_ONE - 1)) >> 16;
+
+		rows[p] = cr_poly_row_of(poly, f);
+		if (rows[p] >= poly->rows)
+			return 0;
+		starts[p] = (uint32_t)(pos >> 16) + poly->first_slot + (poly->shifted ? mr - poly->first_mr : 0u);
+	}
+	return 1;
+}
+
 void cr_poly_free(cr_poly *poly)
 {
 	free(poly->weights);

@@ -61,6 +61,12 @@ typedef struct cr_poly
 int cr_poly_build(const int32_t *table, size_t table_len, const cr_config *cfg, cr_poly *out);
 void cr_poly_free(cr_poly *poly);
 uint32_t cr_poly_row_of(const cr_poly *poly, uint32_t frac);
+/* A stream whose increment is PERIODIC (increment * period is a whole number of frames: 3:2, 1:2, ... and period 1 for the
+   whole-number ratios) visits `period` fractional positions in turn.  For the `period` consecutive output frames from fractional
+   position `frac` on: rows[p] = the row of frame p, starts[p] = the input frame, counted from position_integer of frame 0, that
+   slot 0 of frame p multiplies (as row_of / fetch_frame on the device: shifted rows start at their own phase's first tap).
+   Returns 0 when a row index falls outside the image. */
+int cr_poly_periodic(const cr_poly *poly, uint64_t increment, uint32_t frac, uint32_t period, uint32_t *rows, uint32_t *starts);
 
 /* LDS/device image of the rows: row_stride/4 planes of plane_rows (= rows rounded up to 16) x 4 int32; within each block
    of 16 rows, row r sits at (r & ~15) | ((r + swizzle * (r >> 4)) & 15). */

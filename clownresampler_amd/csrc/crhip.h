@@ -97,28 +97,32 @@ typedef struct crhip_int_launch
 	void *d_out;                /* int32 (or clamped int16), n_out * channels */
 	uint64_t first_frame;       /* input frame (relative to d_in) that slot 0 of output frame 0 multiplies */
 	uint64_t n_out;
-	uint32_t channels, ratio, slots;
+	uint32_t channels, ratio, slots;   /* ratio: input frames per PERIOD of `period` output frames (period 1: per output frame) */
+	uint32_t period;            /* 1: whole-number ratio; 2, 4: the increment repeats every `period` frames (3:2, 1:2, 1:4 ...) */
 	uint32_t out_s16;
 	uint32_t blocks;            /* grid size (workgroups of the instance's thread count) */
-	int32_t reciprocal;         /* 0x80000000 / sum of the row's weights (clownresampler.h:1025) */
+	int32_t reciprocal[4];      /* per phase: 0x80000000 / sum of the row's weights (clownresampler.h:1025) */
 	uint32_t *d_tickets;        /* CRHIP_TICKET_WORDS zeroed counters (as crhip_poly_launch.d_tickets), or NULL: tiles dealt round-robin */
 	uint32_t ticket_tiles;      /* wave-tiles per ticket (>= 1): consecutive tiles a wave takes per draw */
-	int32_t w[CRHIP_INT_MAX_SLOTS];
+	int32_t w[CRHIP_INT_MAX_SLOTS];   /* phase p's slot s at [p * slots + s] */
 } crhip_int_launch;
 
 typedef struct crhip_int_shape
 {
-	uint64_t negmask;           /* bit s set: slot s must hold a weight <= 0, clear: >= 0 */
-	uint64_t safemask;          /* bit s set: slot s may reach 65536; every other weight must stay below it */
+	uint64_t negmask;           /* bit (p * slots + s) set: slot s of phase p must hold a weight <= 0, clear: >= 0 */
+	uint64_t safemask;          /* bit set: that slot may reach 65536; every other weight must stay below it */
+	uint64_t zeromask;          /* bit set: that slot's weight must be 0 (the kernel leaves it out) */
+	uint32_t period;
+	uint32_t starts[4];         /* phase p's first input frame, counted from phase 0's (starts[0] == 0) */
 	uint32_t frames_per_lane;   /* K: a wave-tile is 64 K output frames */
 	uint32_t threads;           /* workgroup size */
 	uint32_t lds_bytes[2];      /* dynamic LDS per workgroup, int32 / int16 output */
 } crhip_int_shape;
 
-/* 1 and *shape when there is a k_int instance for (channels, ratio, slots), else 0 */
-int crhip_int_instance(uint32_t channels, uint32_t ratio, uint32_t slots, crhip_int_shape *shape);
+/* 1 and *shape when there is a k_int instance for (channels, ratio : period, slots), else 0 */
+int crhip_int_instance(uint32_t channels, uint32_t ratio, uint32_t period, uint32_t slots, crhip_int_shape *shape);
 /* one-time setup (dynamic LDS limit) + workgroups resident per CU for either output form; not legal inside a stream capture */
-int crhip_int_prepare(uint32_t channels, uint32_t ratio, uint32_t slots, int *per_cu, int *per_cu_s16);
+int crhip_int_prepare(uint32_t channels, uint32_t ratio, uint32_t period, uint32_t slots, int *per_cu, int *per_cu_s16);
 int crhip_launch_int(const crhip_int_launch *launch, void *stream);
 
 /* Many short constant-rate segments of ONE timeline in ONE launch (variable rate: ClownResamplerAMD_ResampleSegmentsDevice): the

@@ -288,6 +288,8 @@ def test_baseline_configs_full_size_bit_exact(products, name, radius, ch, rates,
     ("dn6xm", 3, 1, (48000, 8000, 8000), 57600000, 5),      # ... mono (4 frames per lane)
     ("dn21k", 3, 2, (96000, 48000, 48000), 57600000, 5),    # ... 2:1 (12 slots; the k_wave2 of this shape is the "dn21" row above)
     ("dn31m", 3, 1, (96000, 32000, 32000), 57600000, 5),    # ... mono 3:1 (8 frames per lane)
+    ("dn32k", 3, 2, (48000, 32000, 32000), 28800000, 5),    # a periodic ratio on k_int: 3:2 (two rows in the kernel arguments) ...
+    ("dn32km", 3, 1, (48000, 32000, 32000), 57600000, 5),   # ... mono
     ("dn16", 3, 2, (44100, 16000, 16000), 26460000, 4),     # 44.1 -> 16 kHz: 16-slot k_wave2 instance
     ("dn16m", 3, 1, (44100, 16000, 16000), 26460000, 1),    # ... mono: specialised k_poly, any-sign chain on the packed mono window
     ("dn11", 3, 2, (88200, 48000, 48000), 26460000, 4),     # 88.2 -> 48 kHz: 11-slot k_wave2 instance
@@ -314,6 +316,67 @@ def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch,
         p.api.DebugDisableIntKernel(False)
     assert got.size == want.size == ck.count_output_frames(ost, frames) * ch and ran_out == 1 and left == 0
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("ch", [1, 2])
+@pytest.mark.parametrize("rates", [(48000, 32000, 32000), (96000, 64000, 64000)])
+def test_periodic_ratio_kernel(products, ch, rates):
+    """k_int's periodic instances (cr_inst_int_d.hip): 3:2 - the increment repeats after 2 output frames, the rows of those phases
+    travel in the kernel arguments, a lane owns whole periods.  Tile tails, capacity stops, pieces that end mid-period
+    (the next launch then starts at another phase and takes the plan's ordinary kernel), int16 output - against the oracle, and
+    the launch counters say k_int ran where the launch started at phase 0."""
+    p, o = products[3], ck.oracle(3)
+    ok, probe = p.low_init(ch, *rates)
+    plan = p.api.PlanCreate(probe.raw, p.pre)
+    assert p.api.PlanKernelAt(plan, 0) == 5, "no k_int instance for %d channels at %s" % (ch, rates)
+    for frames in (1, 2, 3, 5, 383, 3071, 3072, 3073, 9999, 10000, 250001):
+        ok, st = p.low_init(ch, *rates)
+        ok, ost = o.low_init(ch, *rates)
+        R = int(ost.cfg.radius_frames)
+        padded = ck.pad_frames(ck.noise_pcm(frames * ch, 11 + frames), ch, R)
+        before = p.api.LaunchCount(5)
+        got, left, ran = p.low_resample_i32(st, padded, frames)
+        want, oleft, oran = o.low_resample_i32(ost, padded, frames)
+        assert p.api.LaunchCount(5) == before + 1
+        assert (left, ran) == (oleft, oran) and np.array_equal(got, want) and st.astuple() == ost.astuple(), (ch, rates, frames)
+    # full-scale input (the weight of 65536 in pure upsampling's phase 0, the clamp)
+    frames = 20000
+    square = np.where((np.arange(frames * ch) // (7 * ch)) % 2 == 0, 32767, -32768).astype(np.int16)
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    R = int(ost.cfg.radius_frames)
+    padded = ck.pad_frames(square, ch, R)
+    got, _, _ = p.low_resample_i32(st, padded, frames)
+    want, _, _ = o.low_resample_i32(ost, padded, frames)
+    assert np.array_equal(got, want)
+    # pieces of odd sizes, a capacity stop in the middle, int16 output
+    frames = 60000
+    pcm = ck.noise_pcm(frames * ch, 37)
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    padded = ck.pad_frames(pcm, ch, R)
+    at = 0
+    for piece, cap in ((1235, None), (7, None), (20001, 101), (19900, None), (18857, None)):
+        view = padded[at * ch:(at + piece + 2 * R) * ch]
+        g, gl, gr = p.low_resample_i32(st, view, piece, capacity=cap)
+        w, wl, wr = o.low_resample_i32(ost, view, piece, capacity=cap)
+        assert (gl, gr) == (wl, wr) and np.array_equal(g, w) and st.astuple() == ost.astuple(), (ch, rates, piece, cap)
+        at += piece - gl
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    got16, _, _ = p.api.LowLevel_ResampleBulkS16(st.raw, p.pre, padded, frames)
+    want, _, _ = o.low_resample_i32(ost, padded, frames)
+    assert np.array_equal(got16, np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16))
+    # the same ratio with another low-pass (other rows, other slot classes): whatever kernel the rows select
+    if rates[1] < rates[0]:
+        other = (rates[0], rates[1], rates[1] // 2)
+        ok, st = p.low_init(ch, *other)
+        ok, ost = o.low_init(ch, *other)
+        R2 = int(ost.cfg.radius_frames)
+        padded2 = ck.pad_frames(pcm, ch, R2)
+        g, _, _ = p.low_resample_i32(st, padded2, frames)
+        w, _, _ = o.low_resample_i32(ost, padded2, frames)
+        assert np.array_equal(g, w)
 
 
 @pytest.mark.parametrize("ch", [1, 2, 3, 4, 5, 6, 7, 8])

@@ -69,6 +69,32 @@ int_instance make_int()
 	return i;
 }
 
+// A whole-number ratio with the 5- or 8-lobe table: TT / R = 10 or 16 frames of a lane would be in progress per input frame, more than
+// the input-stationary order has accumulators for - the output-stationary order (one frame after the other; the lane's whole window
+// unpacked in registers) does not care.
+template <int CH, int LOBES, int R, int K>
+int_instance make_int_long()
+{
+	constexpr int TT = 2 * LOBES * R;
+	constexpr unsigned long long NEG = int_negmask(LOBES, R, TT), SAFE = int_safemask(LOBES, R, TT);
+	static_assert((NEG & SAFE) == 0, "the centre slot is a positive one");
+	int_instance i = {};
+	i.channels = CH;
+	i.ratio = R;
+	i.period = 1;
+	i.slots = TT;
+	i.shape.negmask = NEG;
+	i.shape.safemask = SAFE;
+	i.shape.period = 1;
+	i.shape.frames_per_lane = K;
+	i.shape.threads = INT_WAVES * 64;
+	i.shape.lds_bytes[0] = INT_WAVES * int_wave_bytes(CH, R, TT, K, 0) + 16u;
+	i.shape.lds_bytes[1] = INT_WAVES * int_wave_bytes(CH, R, TT, K, 1) + 16u;
+	i.fn = (int_fn)k_int<CH, R, TT, K, NEG, SAFE, INT_WAVES, 0, 1, 1, 0u, 0ull, 1>;
+	i.fn16 = (int_fn)k_int<CH, R, TT, K, NEG, SAFE, INT_WAVES, 1, 1, 1, 0u, 0ull, 1>;
+	return i;
+}
+
 // A PERIODIC ratio: R input frames per P output frames (3:2, 1:2, 1:4), TT slots per row, the phases' window starts packed in OFFS
 // and their slot classes in NEG / SAFE (bit p TT + s) - the constants tools/int_shapes.py prints for the reference's table, and
 // the host checks every launch's rows and starts against them (cr_context.c int_launch_row).

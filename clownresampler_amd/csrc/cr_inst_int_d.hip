@@ -1,4 +1,4 @@
-// cr_inst_int_d.hip - an instance unit of k_int (cr_kint.hpp): PERIODIC ratios - the increment repeats after 2 or 4 output frames
+// cr_inst_int_d.hip - an instance unit of k_int (cr_kint.hpp): the output-stationary instances.  PERIODIC ratios - the increment repeats after 2 or 4 output frames
 // (3:2; also 1:2 and 1:4, see below), so a launch uses 2 or 4 rows in turn and they travel in the kernel arguments like the one row of a whole-number
 // ratio.  The constants are what tools/int_shapes.py prints for the reference's 3-lobe table at fractional position 0; the host
 // checks every launch's rows, window starts and zero slots against them (cr_context.c int_launch_row) - anything else takes the
@@ -13,6 +13,18 @@ const void *crhip_int_instances_d(int *count)
 	    // 0.53 - a lane's staged frames are 128 / 64 bytes apart, and the conflicts of those LDS stores are what a tile of few taps sees)
 	    make_per<2, 3, 2, 0x100u, 9, 16, 0x18846ull, 0x0ull, 0x100ull>(),   // stereo: lane stride 96 B
 	    make_per<1, 3, 2, 0x100u, 9, 16, 0x18846ull, 0x0ull, 0x100ull>(),   // mono: 48 B
+	    // 2:1 with the 8-lobe and the 5-lobe table (CLOWNRESAMPLER_KERNEL_RADIUS 8 / 5: 32 / 20 slots), output-stationary order
+	    make_int_long<2, 8, 2, 6>(),    // stereo, 8 lobes: lane stride 48 B, 42 input frames per lane
+	    make_int_long<1, 8, 2, 12>(),   // mono, 8 lobes: 48 B, 54 input frames
+	    make_int_long<2, 5, 2, 6>(),    // stereo, 5 lobes
+	    make_int_long<1, 5, 2, 12>(),   // mono, 5 lobes
+	    // 3:1 (48 / 30 slots) and, with 5 lobes, 4:1 (40 slots)
+	    make_int_long<2, 8, 3, 4>(),    // stereo, 8 lobes 3:1: 48 B, 57 input frames per lane
+	    make_int_long<1, 8, 3, 8>(),    // mono
+	    make_int_long<2, 5, 3, 4>(),    // stereo, 5 lobes 3:1
+	    make_int_long<1, 5, 3, 8>(),    // mono
+	    make_int_long<2, 5, 4, 3>(),    // stereo, 5 lobes 4:1
+	    make_int_long<1, 5, 4, 6>(),    // mono
 	    // NOT instantiated: pure upsampling by 2 and 4 (tools/int_shapes.py 3 24000:48000 12000:48000 prints their constants:
 	    // make_per<CH, 1, 2, 0x0u, 5, K, 0x240ull, 0x4ull, 0x1Bull>, make_per<CH, 1, 4, 0x0u, 5, K, 0x94A40ull, 0x4ull, 0x1Bull> -
 	    // phase 0 is the input sample itself).  Bit-exact, and slower than k_poly there (1:2 stereo 0.53 against 0.71, mono 0.52

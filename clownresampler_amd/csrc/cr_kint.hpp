@@ -79,7 +79,7 @@ constexpr unsigned int_wave_bytes(int ch, int r, int tt, int k, int out16, int p
 }
 
 template <int CH, int R, int TT, int K, unsigned long long NEGMASK, unsigned long long SAFEMASK, int WAVES, int OUT16, int NT, int P = 1, unsigned OFFS = 0,
-          unsigned long long ZEROMASK = 0>
+          unsigned long long ZEROMASK = 0, int OS = (P > 1)>
 __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 {
 	static_assert(CH >= 1 && CH <= 8, "one to eight channels: two at a time over the same accumulator registers");
@@ -88,6 +88,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 	// ZEROMASK (periodic ratios): phase-slots whose weight is 0 in the rows the instance is for - pure upsampling's phase 0 is the input
 	// sample itself, one slot of five - are left out of the arithmetic; the host checks them like the signs.
 	static_assert((ZEROMASK & (NEGMASK | SAFEMASK)) == 0 && (P > 1 || ZEROMASK == 0), "a skipped slot has no class");
+	// OS: the output-stationary loop order (below) - always for periodic ratios, and for whole-number ratios whose windows are too long
+	// for the input-stationary order's accumulators (the 5- and 8-lobe tables: 10 / 16 frames in progress per lane)
+	static_assert(OS || P == 1, "periodic ratios take the output-stationary order");
 	constexpr unsigned FB = CH * 2;                        // bytes per input frame
 	constexpr unsigned UNIT = OUT16 ? CH * 2 : CH * 4;     // bytes per output frame
 	constexpr unsigned WT = 64u * K;                       // output frames per wave-tile
@@ -273,9 +276,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 
 		// accumulator high dwords (the sums): [live frame][channel][0: slots with weights >= 0, 1: slots with weights <= 0].  At any
 		// time TT / R frames of a lane are in progress; frame k uses set k % LIVE, pinned to physical registers (int_tap).
-		// (periodic ratios, P > 1: the other loop order below - one frame after the other, two accumulator sets in turn)
-		constexpr int LIVE = P == 1 ? TT / R : 2;
-		static_assert(P > 1 || (TT % R == 0 && LIVE * 2 * 2 <= 24), "pinned accumulator pairs");
+		// (OS - periodic ratios, long windows: the other loop order below - one frame after the other, two accumulator sets in turn)
+		constexpr int LIVE = OS ? 2 : TT / R;
+		static_assert(OS || (TT % R == 0 && LIVE * 2 * 2 <= 24), "pinned accumulator pairs");
 		int acc[LIVE][2][2], arm[LIVE][2][2];
 		const unsigned stage_at = lane * (K * UNIT);
 
@@ -347,9 +350,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 				}
 			};
 
-			if constexpr (P > 1)
+			if constexpr (OS)
 			{
-				// PERIODIC ratios: output-stationary.  The lane's whole window is unpacked first (it is short: a few periods + one
+				// PERIODIC ratios (and long windows): output-stationary.  The lane's whole window is unpacked first (it is short: a few periods + one
 				// row's slots), then the lane's frames one after the other - frame k is phase k % P, its window starts int_start(k)
 				// frames into the lane's, its weights are that phase's row at a.w[(k % P) TT ...] - on two accumulator sets in turn.
 				static_for<NX>([&](auto i_tag) {

@@ -379,6 +379,44 @@ def test_periodic_ratio_kernel(products, ch, rates):
         assert np.array_equal(g, w)
 
 
+@pytest.mark.parametrize("ch", [1, 2])
+@pytest.mark.parametrize("radius,ratio", [(5, 2), (5, 3), (5, 4), (8, 2), (8, 3)])
+def test_whole_number_ratio_kernel_long_windows(products, radius, ratio, ch):
+    """2:1, 3:1 (4:1) with the 5- and 8-lobe tables (20 to 48 slots): k_int in its output-stationary order (cr_inst_int_d.hip make_int_long)."""
+    p, o = products[radius], ck.oracle(radius)
+    rates = (96000, 96000 // ratio, 96000 // ratio)
+    ok, probe = p.low_init(ch, *rates)
+    plan = p.api.PlanCreate(probe.raw, p.pre)
+    assert probe.increment == ratio << 16 and p.api.PlanKernelAt(plan, 0) == 5
+    for frames in (1, 2, 383, 64 * 12 * ratio - 1, 64 * 12 * ratio, 64 * 12 * ratio + 1, 9999, 250001):
+        ok, st = p.low_init(ch, *rates)
+        ok, ost = o.low_init(ch, *rates)
+        R = int(ost.cfg.radius_frames)
+        padded = ck.pad_frames(ck.noise_pcm(frames * ch, 5 + frames), ch, R)
+        before = p.api.LaunchCount(5)
+        got, left, ran = p.low_resample_i32(st, padded, frames)
+        want, oleft, oran = o.low_resample_i32(ost, padded, frames)
+        assert p.api.LaunchCount(5) == before + 1
+        assert (left, ran) == (oleft, oran) and np.array_equal(got, want) and st.astuple() == ost.astuple(), (radius, ratio, ch, frames)
+    frames = 60000
+    pcm = ck.noise_pcm(frames * ch, 41)
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    padded = ck.pad_frames(pcm, ch, R)
+    at = 0
+    for piece, cap in ((1235, None), (7, None), (20001, 100), (19900, None), (18857, None)):
+        view = padded[at * ch:(at + piece + 2 * R) * ch]
+        g, gl, gr = p.low_resample_i32(st, view, piece, capacity=cap)
+        w, wl, wr = o.low_resample_i32(ost, view, piece, capacity=cap)
+        assert (gl, gr) == (wl, wr) and np.array_equal(g, w) and st.astuple() == ost.astuple(), (radius, ch, piece, cap)
+        at += piece - gl
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    got16, _, _ = p.api.LowLevel_ResampleBulkS16(st.raw, p.pre, padded, frames)
+    want, _, _ = o.low_resample_i32(ost, padded, frames)
+    assert np.array_equal(got16, np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16))
+
+
 @pytest.mark.parametrize("ch", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("ratio", [2, 3, 4, 6])
 def test_whole_number_ratio_kernel(products, ch, ratio):

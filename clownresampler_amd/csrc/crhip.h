@@ -89,7 +89,7 @@ typedef struct crhip_generic_launch
    the same fractional position, so the host hands over THE row - staged, in the kernel arguments - instead of a row image:
    w[s] = |weight of slot s| << 15 (plain |weight| for the slots of the instance's safe mask), the signs being a property of
    the instance that the host has checked this row against (crhip_int_instance). */
-#define CRHIP_INT_MAX_SLOTS 48
+#define CRHIP_INT_MAX_SLOTS 64
 typedef struct crhip_int_launch
 {
 	const void *d_in;           /* interleaved int16 */

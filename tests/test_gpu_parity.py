@@ -319,13 +319,14 @@ def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch,
 
 
 @pytest.mark.parametrize("ch", [1, 2])
-@pytest.mark.parametrize("rates", [(48000, 32000, 32000), (96000, 64000, 64000)])
-def test_periodic_ratio_kernel(products, ch, rates):
-    """k_int's periodic instances (cr_inst_int_d.hip): 3:2 - the increment repeats after 2 output frames, the rows of those phases
+@pytest.mark.parametrize("radius,rates", [(3, (48000, 32000, 32000)), (3, (96000, 64000, 64000)), (8, (24000, 48000, 24000)), (8, (48000, 32000, 32000)),
+                                          (5, (24000, 48000, 24000)), (5, (48000, 32000, 32000)), (8, (12000, 48000, 12000)), (5, (12000, 48000, 12000))])
+def test_periodic_ratio_kernel(products, radius, ch, rates):
+    """k_int's periodic instances (cr_inst_int_d.hip): 3:2, and 1:2 with 5 and 8 lobes - the increment repeats after 2 output frames, the rows of those phases
     travel in the kernel arguments, a lane owns whole periods.  Tile tails, capacity stops, pieces that end mid-period
     (the next launch then starts at another phase and takes the plan's ordinary kernel), int16 output - against the oracle, and
     the launch counters say k_int ran where the launch started at phase 0."""
-    p, o = products[3], ck.oracle(3)
+    p, o = products[radius], ck.oracle(radius)
     ok, probe = p.low_init(ch, *rates)
     plan = p.api.PlanCreate(probe.raw, p.pre)
     assert p.api.PlanKernelAt(plan, 0) == 5, "no k_int instance for %d channels at %s" % (ch, rates)

@@ -9,8 +9,9 @@ const void *crhip_int_instances_d(int *count)
 {
 	static const int_instance table[] = {
 	    // 3:2 (48 -> 32 kHz, 96 -> 64 kHz): 9 slots, phase 1 starts one frame later; the last slot of phase 0 is zero.  16 frames per
-	    // lane both (tools/ab: stereo 8 / 16 / 24 frames per lane 0.53 / 0.67 / 0.62 of the roofline, mono 16 / 32 / 48: 0.54 / 0.45 /
-	    // 0.53 - a lane's staged frames are 128 / 64 bytes apart, and the conflicts of those LDS stores are what a tile of few taps sees)
+	    // lane both, by measurement (stereo 8 / 16 / 24 frames per lane: 0.53 / 0.67 / 0.62 of the roofline, mono 16 / 32 / 48: 0.54 / 0.45 /
+	    // 0.53; profiles/r03_kint_periodic.log.  Not the bank conflicts of the staged stores - a conflict-free stage stride, wrong
+	    // results, timed the same)
 	    make_per<2, 3, 2, 0x100u, 9, 16, 0x18846ull, 0x0ull, 0x100ull>(),   // stereo: lane stride 96 B
 	    make_per<1, 3, 2, 0x100u, 9, 16, 0x18846ull, 0x0ull, 0x100ull>(),   // mono: 48 B
 	    // 2:1 with the 8-lobe and the 5-lobe table (CLOWNRESAMPLER_KERNEL_RADIUS 8 / 5: 32 / 20 slots), output-stationary order

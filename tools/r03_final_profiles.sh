@@ -33,7 +33,10 @@ for n in 2 8; do python3 bench.py --gpus $n > $O/bench_n${n}_sharedgpu_gloo.json
  python3 tools/channel_table.py 3 48000:24000 48000:16000 48000:12000 48000:8000 44100:8000 channels=1,2,3,4,5,6,7,8 samples=105840000
  python3 tools/channel_table.py 8 44100:48000 48000:44100 8000:96000
  python3 tools/channel_table.py 5 44100:48000 48000:44100 channels=1,2,6,8
- python3 tools/channel_table.py 3 96000:48000 96000:44100 96000:32000 24000:48000 16000:48000 8000:48000 48000:32000 channels=1,2) > $O/channel_table.log 2>&1
+ python3 tools/channel_table.py 3 96000:48000 96000:44100 96000:32000 24000:48000 16000:48000 8000:48000 48000:32000 channels=1,2
+ python3 tools/channel_table.py 8 96000:48000 96000:32000 24000:48000 12000:48000 48000:32000 channels=1,2
+ python3 tools/channel_table.py 5 96000:48000 96000:32000 96000:24000 24000:48000 12000:48000 48000:32000 channels=1,2) > $O/channel_table.log 2>&1
+python3 tools/channel_table.py 3 44100:16000 44100:22050 48000:16000 48000:8000 44100:11025 48000:22050 48000:24000 96000:16000 32000:44100 32000:48000 22050:44100 22050:48000 16000:44100 16000:48000 11025:44100 8000:48000 8000:16000 24000:44100 44100:32000 48000:32000 88200:48000 channels=1,2 > $O/common_ratios.log 2>&1
 python3 tools/size_sweep.py > $O/size_sweep.log 2>&1
 python3 tools/host_path_rate.py > $O/host_paths.log 2>&1
 python3 tools/plan_create_rate.py > $O/plan_create.log 2>&1

@@ -192,6 +192,9 @@ static unsigned long long g_launch_count[CR_KERNEL_IDS];
 /* k_up2 as an instance's default kernel: see plan_geometry */
 #define CR_UP_DEFAULT_MAX_INCREMENT (65536u / 8u)
 #define CR_UP_DEFAULT_MIN_INCREMENT (65536u / 13u)
+/* a launch of a periodic ratio that starts mid-period is split (a few frames on the ordinary kernel, the rest on k_int) from this
+   many output frames on: below, the second launch costs more than k_int saves */
+#define CR_INT_SPLIT_MIN_FRAMES 8192u
 /* (stereo 44.1 -> 48 kHz models 12 -> 4 and measured 0.5-1 % SLOWER rotated; exactly 8x models 28 -> 12, 16x 60 -> 12) */
 #define CR_ROTATE_MIN_GAIN 12.0
 
@@ -1620,6 +1623,28 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		uint32_t first_slot = 0;
 
 		memset(&il, 0, sizeof(il));
+		/* A periodic ratio's instance is compiled for ONE order of the phases.  A long launch that starts elsewhere in the period - the
+		   piece before it ended after an odd number of frames - hands its first one to three frames to the plan's ordinary kernel and
+		   starts k_int at the phase the instance begins with (same stream: the two launches write disjoint frames). */
+		if (plan->intk.period > 1u && n_out >= CR_INT_SPLIT_MIN_FRAMES && !int_launch_row(plan, (uint32_t)pos_frac, &il, &first_slot))
+		{
+			uint32_t j;
+
+			for (j = 1; j < plan->intk.period; ++j)
+			{
+				const uint64_t pos = pos_frac + (uint64_t)j * plan->increment;
+
+				if (int_launch_row(plan, (uint32_t)(pos & 0xFFFFu), &il, &first_slot))
+				{
+					const size_t frame_bytes = (size_t)plan->channels * (out_s16 ? 2u : 4u);
+
+					if (cr_plan_launch(plan, d_in, in_valid_bytes, d_out, pos_int, pos_frac, j, stream, out_s16) != 0)
+						return -1;
+					return cr_plan_launch(plan, d_in, in_valid_bytes, (unsigned char *)d_out + (size_t)j * frame_bytes, pos_int + (pos >> 16), pos & 0xFFFFu,
+					                      n_out - j, stream, out_s16);
+				}
+			}
+		}
 		if (int_launch_row(plan, (uint32_t)pos_frac, &il, &first_slot))
 		{
 			const uint64_t tile = 64ull * plan->intk.shape.frames_per_lane;   /* (output frames) */

@@ -357,12 +357,16 @@ def test_periodic_ratio_kernel(products, radius, ch, rates):
     ok, ost = o.low_init(ch, *rates)
     padded = ck.pad_frames(pcm, ch, R)
     at = 0
+    before = p.api.LaunchCount(5)
     for piece, cap in ((1235, None), (7, None), (20001, 101), (19900, None), (18857, None)):
         view = padded[at * ch:(at + piece + 2 * R) * ch]
         g, gl, gr = p.low_resample_i32(st, view, piece, capacity=cap)
         w, wl, wr = o.low_resample_i32(ost, view, piece, capacity=cap)
         assert (gl, gr) == (wl, wr) and np.array_equal(g, w) and st.astuple() == ost.astuple(), (ch, rates, piece, cap)
         at += piece - gl
+    # (the two long pieces take k_int wherever in the period they start: a launch that starts mid-period hands its first frames to
+    # the ordinary kernel)
+    assert p.api.LaunchCount(5) >= before + 2
     ok, st = p.low_init(ch, *rates)
     ok, ost = o.low_init(ch, *rates)
     got16, _, _ = p.api.LowLevel_ResampleBulkS16(st.raw, p.pre, padded, frames)

@@ -187,9 +187,12 @@ void ClownResamplerAMD_SetPlanCacheLimit(size_t plans);
 size_t ClownResamplerAMD_PlanCacheCount(void);
 
 /* The kernel a launch from this fractional position takes, numbered as ClownResamplerAMD_PlanInfo.kernel plus 5 = k_int: at a
-   whole-number downsampling ratio (2:1, 3:1, 4:1, 6:1; mono and stereo) every frame of a launch uses ONE polyphase row, which
+   whole-number downsampling ratio (2:1, 3:1, 4:1, 6:1; 1 to 8 channels) every frame of a launch uses ONE polyphase row, which
    then travels in the kernel arguments - if that row has the slot signs the instance was built for (always, for a stream that
-   starts from ClownResampler_LowLevel_Init; a stream resumed at another fraction may not).  Ignores launch-length rules
+   starts from ClownResampler_LowLevel_Init; a stream resumed at another fraction may not).  The same for the ratios whose
+   fractional position repeats after 2 or 4 frames (3:2; with the 5- and 8-lobe builds also 1:2 and 1:4): the rows of the period
+   travel, for a launch that starts at the phase the instance begins with - a long launch that starts elsewhere in the period
+   gives its first frames to the ordinary kernel, which is what this function then names.  Ignores launch-length rules
    (brief_below). */
 uint32_t ClownResamplerAMD_PlanKernelAt(const ClownResamplerAMD_Plan *plan, uint32_t position_fractional);
 /* Launches enqueued by this process so far on `kernel` (0 ... 5, numbered as above): lets tests and benchmarks assert that the

@@ -1019,6 +1019,13 @@ def test_random_configurations_bit_exact(products):
             # increments of 2^24 and more (256:1 and beyond): nothing but the generic kernel takes those
             o = rng.randrange(1, 600)
             i, lp = o * rng.randrange(256, 700), o
+        elif special_draw < 0.15:
+            # periodic ratios (the increment repeats after 2 or 4 frames): k_int with the period's rows - 3:2 for every table, 1:2 and 1:4
+            # for the 5- and 8-lobe ones; the split between the two calls below starts the second one anywhere in the period
+            k = rng.randrange(1, 20000)
+            num, den = rng.choice([(3, 2), (3, 2), (1, 2), (1, 4)])
+            i, o, ch = k * num, k * den, rng.choice([1, 2])
+            lp = min(i, o)
         frames = rng.choice([rng.randrange(1, 300), rng.randrange(300, 20000), rng.randrange(20000, 120000)])
         p, orc = products[radius], ck.oracle(radius)
         ok_a, a = p.low_init(ch, i, o, lp)

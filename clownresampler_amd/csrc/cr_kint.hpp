@@ -82,7 +82,7 @@ template <int CH, int R, int TT, int K, unsigned long long NEGMASK, unsigned lon
           unsigned long long ZEROMASK = 0, int OS = (P > 1)>
 __global__ __launch_bounds__(WAVES * 64) void k_int(const crhip_int_launch a)
 {
-	static_assert(CH >= 1 && CH <= 8, "one to eight channels: two at a time over the same accumulator registers");
+	static_assert(CH >= 1 && CH <= 16, "one to sixteen channels: two at a time over the same accumulator registers");
 	static_assert(TT * P <= CRHIP_INT_MAX_SLOTS, "the weights travel in the kernel arguments");
 	static_assert((P == 1 || P == 2 || P == 4) && K % P == 0 && (OFFS & 0xFFu) == 0, "whole periods per lane; phase 0 starts the period");
 	// ZEROMASK (periodic ratios): phase-slots whose weight is 0 in the rows the instance is for - pure upsampling's phase 0 is the input

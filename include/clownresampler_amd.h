@@ -187,7 +187,7 @@ void ClownResamplerAMD_SetPlanCacheLimit(size_t plans);
 size_t ClownResamplerAMD_PlanCacheCount(void);
 
 /* The kernel a launch from this fractional position takes, numbered as ClownResamplerAMD_PlanInfo.kernel plus 5 = k_int: at a
-   whole-number downsampling ratio (2:1, 3:1, 4:1, 6:1; 1 to 8 channels) every frame of a launch uses ONE polyphase row, which
+   whole-number downsampling ratio (2:1, 3:1, 4:1, 6:1; 1 to 8 channels, 2:1 up to 16) every frame of a launch uses ONE polyphase row, which
    then travels in the kernel arguments - if that row has the slot signs the instance was built for (always, for a stream that
    starts from ClownResampler_LowLevel_Init; a stream resumed at another fraction may not).  The same for the ratios whose
    fractional position repeats after 2 or 4 frames (3:2; with the 5- and 8-lobe builds also 1:2 and 1:4): the rows of the period

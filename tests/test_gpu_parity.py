@@ -384,6 +384,44 @@ def test_periodic_ratio_kernel(products, radius, ch, rates):
         assert np.array_equal(g, w)
 
 
+@pytest.mark.parametrize("ch", [9, 10, 11, 12, 13, 14, 15, 16])
+def test_whole_number_ratio_kernel_wide_frames(products, ch):
+    """2:1 with 9 to 16 channels (the reference's maximum): k_int, one or a few frames per lane, the frame's channel pairs one after
+    the other - tile tails, pieces, int16."""
+    p, o = products[3], ck.oracle(3)
+    rates = (96000, 48000, 48000)
+    ok, probe = p.low_init(ch, *rates)
+    plan = p.api.PlanCreate(probe.raw, p.pre)
+    assert p.api.PlanKernelAt(plan, 0) == 5
+    for frames in (1, 2, 383, 511, 512, 513, 9999, 100001):
+        ok, st = p.low_init(ch, *rates)
+        ok, ost = o.low_init(ch, *rates)
+        R = int(ost.cfg.radius_frames)
+        padded = ck.pad_frames(ck.noise_pcm(frames * ch, 3 + frames), ch, R)
+        before = p.api.LaunchCount(5)
+        got, left, ran = p.low_resample_i32(st, padded, frames)
+        want, oleft, oran = o.low_resample_i32(ost, padded, frames)
+        assert p.api.LaunchCount(5) == before + 1
+        assert (left, ran) == (oleft, oran) and np.array_equal(got, want) and st.astuple() == ost.astuple(), (ch, frames)
+    frames = 30000
+    pcm = ck.noise_pcm(frames * ch, 43)
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    padded = ck.pad_frames(pcm, ch, R)
+    at = 0
+    for piece, cap in ((1235, None), (7, None), (10001, 100), (9900, None), (8857, None)):
+        view = padded[at * ch:(at + piece + 2 * R) * ch]
+        g, gl, gr = p.low_resample_i32(st, view, piece, capacity=cap)
+        w, wl, wr = o.low_resample_i32(ost, view, piece, capacity=cap)
+        assert (gl, gr) == (wl, wr) and np.array_equal(g, w) and st.astuple() == ost.astuple(), (ch, piece, cap)
+        at += piece - gl
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    got16, _, _ = p.api.LowLevel_ResampleBulkS16(st.raw, p.pre, padded, frames)
+    want, _, _ = o.low_resample_i32(ost, padded, frames)
+    assert np.array_equal(got16, np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16))
+
+
 @pytest.mark.parametrize("ch", [1, 2])
 @pytest.mark.parametrize("radius,ratio", [(5, 2), (5, 3), (5, 4), (8, 2), (8, 3)])
 def test_whole_number_ratio_kernel_long_windows(products, radius, ratio, ch):

@@ -28,22 +28,25 @@ const void *crhip_int_instances_d(int *count)
 	    make_int_long<1, 5, 4, 6>(),    // mono
 	    // periodic ratios with the 8- and 5-lobe tables (tools/int_shapes.py 8 / 5 ...): 1:2 - phase 0 is the input sample, phase 1 a full
 	    // row of 15 / 9 slots: eight / five taps per frame on average, which DO pay for the staging - and 3:2 (24 / 15 slots)
-	    make_per<2, 1, 2, 0x0u, 15, 8, 0x152A8000ull, 0x80ull, 0x7F7Full>(),                 // 8 lobes 1:2 stereo
-	    make_per<1, 1, 2, 0x0u, 15, 16, 0x152A8000ull, 0x80ull, 0x7F7Full>(),                // ... mono
+	    make_per<2, 1, 2, 0x0u, 15, 24, 0x152A8000ull, 0x80ull, 0x7F7Full>(),                // 8 lobes 1:2 stereo (lane stride 48 B; 8 frames per lane, 16 B: 0.51 against 0.66)
+	    make_per<1, 1, 2, 0x0u, 15, 48, 0x152A8000ull, 0x80ull, 0x7F7Full>(),                // ... mono (48 B; 16 frames per lane: 0.51 against 0.57)
 	    make_per<2, 3, 2, 0x200u, 24, 8, 0x1246DBB6C492ull, 0x0ull, 0x800000000001ull>(),    // 8 lobes 3:2 stereo
 	    make_per<1, 3, 2, 0x200u, 24, 16, 0x1246DBB6C492ull, 0x0ull, 0x800000000001ull>(),   // ... mono
-	    make_per<2, 1, 2, 0x0u, 9, 8, 0x29400ull, 0x10ull, 0x1EFull>(),                      // 5 lobes 1:2 stereo
-	    make_per<1, 1, 2, 0x0u, 9, 16, 0x29400ull, 0x10ull, 0x1EFull>(),                     // ... mono
+	    make_per<2, 1, 2, 0x0u, 9, 24, 0x29400ull, 0x10ull, 0x1EFull>(),                     // 5 lobes 1:2 stereo (0.53 -> 0.67)
+	    make_per<1, 1, 2, 0x0u, 9, 48, 0x29400ull, 0x10ull, 0x1EFull>(),                     // ... mono (0.51 -> 0.60)
 	    make_per<2, 3, 2, 0x100u, 15, 16, 0x1B121236ull, 0x0ull, 0x4000ull>(),               // 5 lobes 3:2 stereo
 	    make_per<1, 3, 2, 0x100u, 15, 16, 0x1B121236ull, 0x0ull, 0x4000ull>(),               // ... mono
 	    make_per<2, 1, 4, 0x0u, 15, 16, 0x54AAA95552A8000ull, 0x80ull, 0x7F7Full>(),         // 8 lobes 1:4 stereo (60 weights)
 	    make_per<1, 1, 4, 0x0u, 15, 16, 0x54AAA95552A8000ull, 0x80ull, 0x7F7Full>(),         // ... mono (lane stride 8 B)
 	    make_per<2, 1, 4, 0x0u, 9, 16, 0xA552A9400ull, 0x10ull, 0x1EFull>(),                 // 5 lobes 1:4 stereo
 	    make_per<1, 1, 4, 0x0u, 9, 16, 0xA552A9400ull, 0x10ull, 0x1EFull>(),                 // ... mono
-	    // NOT instantiated: pure upsampling by 2 and 4 with the 3-lobe table (tools/int_shapes.py 3 24000:48000 12000:48000 prints their constants:
+	    // 3 lobes 1:2, MONO only (8 -> 16, 22.05 -> 44.1, 24 -> 48 kHz): 48 frames per lane, 0.60 against k_poly's 0.57
+	    make_per<1, 1, 2, 0x0u, 5, 48, 0x240ull, 0x4ull, 0x1Bull>(),
+	    // NOT instantiated: stereo upsampling by 2, and by 4, with the 3-lobe table (tools/int_shapes.py 3 24000:48000 12000:48000 prints their constants:
 	    // make_per<CH, 1, 2, 0x0u, 5, K, 0x240ull, 0x4ull, 0x1Bull>, make_per<CH, 1, 4, 0x0u, 5, K, 0x94A40ull, 0x4ull, 0x1Bull> -
-	    // phase 0 is the input sample itself).  Bit-exact, and slower than k_poly there (1:2 stereo 0.53 against 0.71, mono 0.52
-	    // against 0.57; 1:4 0.49 / 0.29 against 0.62 / 0.45; profiles/r03_kint_periodic.log): three taps per frame on average do not
+	    // phase 0 is the input sample itself).  Bit-exact, and slower than k_poly there (1:2 stereo 0.53-0.65 against 0.70-0.71 with
+	    // 8 / 16 / 24 frames per lane; 1:4 0.49-0.57 / 0.28-0.31 against 0.62-0.63 / 0.45-0.49; profiles/r03_kint_periodic.log): three
+	    // taps per frame on average do not
 	    // pay for staging every frame through LDS.
 	};
 	*count = (int)(sizeof(table) / sizeof(table[0]));

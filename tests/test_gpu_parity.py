@@ -319,7 +319,7 @@ def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch,
 
 
 @pytest.mark.parametrize("ch", [1, 2])
-@pytest.mark.parametrize("radius,rates", [(3, (48000, 32000, 32000)), (3, (96000, 64000, 64000)), (8, (24000, 48000, 24000)), (8, (48000, 32000, 32000)),
+@pytest.mark.parametrize("radius,rates", [(3, (48000, 32000, 32000)), (3, (96000, 64000, 64000)), (3, (24000, 48000, 24000)), (8, (24000, 48000, 24000)), (8, (48000, 32000, 32000)),
                                           (5, (24000, 48000, 24000)), (5, (48000, 32000, 32000)), (8, (12000, 48000, 12000)), (5, (12000, 48000, 12000))])
 def test_periodic_ratio_kernel(products, radius, ch, rates):
     """k_int's periodic instances (cr_inst_int_d.hip): 3:2, and 1:2 with 5 and 8 lobes - the increment repeats after 2 output frames, the rows of those phases
@@ -329,8 +329,10 @@ def test_periodic_ratio_kernel(products, radius, ch, rates):
     p, o = products[radius], ck.oracle(radius)
     ok, probe = p.low_init(ch, *rates)
     plan = p.api.PlanCreate(probe.raw, p.pre)
+    if radius == 3 and rates[1] > rates[0] and ch != 1:
+        pytest.skip("3 lobes 1:2: the mono instance only (stereo is faster on k_poly)")
     assert p.api.PlanKernelAt(plan, 0) == 5, "no k_int instance for %d channels at %s" % (ch, rates)
-    for frames in (1, 2, 3, 5, 383, 3071, 3072, 3073, 9999, 10000, 250001):
+    for frames in (1, 2, 3, 5, 383, 1535, 1536, 1537, 3071, 3072, 3073, 9999, 10000, 250001):
         ok, st = p.low_init(ch, *rates)
         ok, ost = o.low_init(ch, *rates)
         R = int(ost.cfg.radius_frames)

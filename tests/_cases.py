@@ -172,7 +172,7 @@ for _ch in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16):
 for _i, _o, _l in [(1, 1, 1), (1, 2, 1), (2, 1, 1), (48000, 48000, 24000), (44100, 44101, 44100), (44101, 44100, 44100),
                    (96000, 44100, 44100), (44100, 96000, 44100), (48000, 8000, 8000), (192000, 8000, 8000),
                    (8000, 192000, 8000), (44100, 48000, 20000), (48000, 44100, 10000), (3, 7, 2), (65537, 65536, 65536),
-                   (1000, 999, 999), (44100, 1000, 1000), (22050, 48000, 22050), (44100, 16000, 16000), (88200, 48000, 48000)]:
+                   (1000, 999, 999), (44100, 1000, 1000), (22050, 48000, 22050), (44100, 16000, 16000), (88200, 48000, 48000), (192000, 44100, 44100), (176400, 48000, 48000)]:
     _add("ratio_%d_%d_%d" % (_i, _o, _l), channels=2, rates=[_i, _o, _l], input="noise", frames=12000, seed=NOISE_SEED ^ (_i * 31 + _o))
 # the speech front end's conversion, mono (16-slot windows)
 _add("mono_44100_16000", channels=1, rates=[44100, 16000, 16000], input="noise", frames=12000, seed=NOISE_SEED ^ 16000)

@@ -293,6 +293,8 @@ def test_baseline_configs_full_size_bit_exact(products, name, radius, ch, rates,
     ("dn16", 3, 2, (44100, 16000, 16000), 26460000, 4),     # 44.1 -> 16 kHz: 16-slot k_wave2 instance
     ("dn16m", 3, 1, (44100, 16000, 16000), 26460000, 1),    # ... mono: specialised k_poly, any-sign chain on the packed mono window
     ("dn11", 3, 2, (88200, 48000, 48000), 26460000, 4),     # 88.2 -> 48 kHz: 11-slot k_wave2 instance
+    ("dn26", 3, 2, (192000, 44100, 44100), 57600000, 4),    # 192 -> 44.1 kHz: 26-slot k_wave2 instance
+    ("dn22", 3, 2, (176400, 48000, 48000), 52920000, 4),    # 176.4 -> 48 kHz: 22-slot k_wave2 instance
 ])
 def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch, rates, frames, kernel):
     """10-minute streams (5 for the widest) through the kernels the BASELINE configurations do not reach, against the

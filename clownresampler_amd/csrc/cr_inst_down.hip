@@ -21,7 +21,7 @@ int specials_down(void *table, int capacity)
 	    with_wave2<2, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 2, 0, true>(make_special_lite<2, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    // high-rate material to CD / DAT rates: 176.4 -> 48 kHz (22 slots; also 44.1 -> 12 kHz), 192 -> 44.1 kHz (26 slots; 48 -> 11.025 kHz):
 	    // stereo 0.40 -> 0.42 and 0.36 -> 0.41, mono 26 slots 0.25 -> 0.27 (mono 22 slots measured 3 % slower specialised: not instantiated)
-	    with_wave2<2, 22, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 1, 0, true>(make_special_lite<2, 22, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
+	    with_wave2<2, 22, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 2, 0, true>(make_special_lite<2, 22, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_signed_chain<1, 26, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 26, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_wave2<2, 26, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 1, 0, true>(make_special_lite<2, 26, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    // 44.1 -> 16 kHz (16 slots; the speech-recognition front end's conversion) and 88.2 -> 48 / 44.1 -> 24 kHz (11 slots)

@@ -10,7 +10,7 @@ int specials_headline(void *table, int capacity)
 	    make_special<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 28, true, true, 0x12u>(),   // cfg 2 / cfg 5: stereo 44.1 -> 48 kHz, 3 lobes: the 64-bit chain in its mov-armed form (variant 28; 13 = the SDWA form is its fallback)
 	    with_chain<1, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 0x12u, 2>(make_special<1, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 28, true, true>()),   // mono upsampling, 3 lobes: two frames in flight per lane (79.9 -> 74.8 us on 20 minutes of mono)
 	    with_signed_chain<2, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3, true>(make_special<2, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>()),     // stereo mild downsampling, 3 lobes (+ the any-sign chain behind variants 28 / 29)
-	    make_special<1, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>(),     // mono mild downsampling, 3 lobes (the any-sign 64-bit chain measured slower here: 86.2 -> 89.5 us)
+	    with_signed_chain<1, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3, true, 2>(make_special<1, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 13, false, true>()),     // mono mild downsampling, 3 lobes: the any-sign chain with TWO frames in flight per lane (163.5 / 167.0 -> 160.5 / 161.0 us on 40 minutes of mono; with one frame in flight it measured slower than the SDWA form: 86.2 -> 89.5 us)
 	};
 	const int n = (int)(sizeof(mine) / sizeof(mine[0]));
 	if (table == nullptr)

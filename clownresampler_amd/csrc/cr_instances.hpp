@@ -128,15 +128,15 @@ special with_chain(special s)
 
 // The ANY-SIGN 64-bit chain (ASM mode 3: 3 instructions per tap and channel instead of the SDWA form's 4) behind variants 28 / 29 of a
 // downsampling instance with an even channel count, at geometry GEO; DEFAULT makes it the instance's default
-template <int CH, int TT, int MODE, int NORM, int GEO, bool DEFAULT = false>
+template <int CH, int TT, int MODE, int NORM, int GEO, bool DEFAULT = false, int U = 1>   // U: frames in flight per lane
 special with_signed_chain(special s)
 {
 	constexpr int T = GEOMETRY[GEO].threads, V = GEOMETRY[GEO].vecs;
-	s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, T, V, 3, 1, 0, 0, 0, 1>;
-	s.mad[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, T, V, 3, 1, 0, 0, 0, 0>;
-	s.mad16 = (poly_fn)k_poly<CH, TT, MODE, NORM, T, V, 3, 1, 0, 0, 1, 1>;
+	s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, T, V, 3, U, 0, 0, 0, 1>;
+	s.mad[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, T, V, 3, U, 0, 0, 0, 0>;
+	s.mad16 = (poly_fn)k_poly<CH, TT, MODE, NORM, T, V, 3, U, 0, 0, 1, 1>;
 	s.mad_any_sign = 1u;
-	s.mad_frames = 1;
+	s.mad_frames = U;
 	s.mad_geo = GEO;
 	if (s.lite)
 	{

@@ -315,6 +315,35 @@ def test_polyphase_shapes_of_baseline_configs():
     assert (info.slots, info.row_stride, info.row_mode, el) == (6, 8, 0, True)                                       # cfg 4: 5-6 taps, shifted windows
 
 
+def test_periodic_instance_constants_match_the_rows():
+    """k_int's periodic instances (csrc/cr_inst_int_d.hip) are compiled for the window starts, slot signs, 65536-weights and zero
+    slots of the reference table's rows at fraction 0; the library checks every launch against them, so a drift would silently
+    send those ratios back to the ordinary kernels.  Host-only: what ClownResamplerAMD_PeriodicShape derives from the rows must be
+    what stands in the instance table (and what tools/int_shapes.py printed when the instances were written)."""
+    src = open(os.path.join(os.path.dirname(cr.__file__), "csrc", "cr_inst_int_d.hip")).read()
+    table = set()
+    for m in re.finditer(r"make_per<\s*(\d+),\s*(\d+),\s*(\d+),\s*0x([0-9A-Fa-f]+)u,\s*(\d+),\s*(\d+),\s*0x([0-9A-Fa-f]+)ull,\s*0x([0-9A-Fa-f]+)ull(?:,\s*0x([0-9A-Fa-f]+)ull)?>\(\)", src):
+        ch, ratio, period, offs, slots, k, neg, safe, zero = m.groups()
+        table.add((int(ratio), int(period), int(offs, 16), int(slots), int(neg, 16), int(safe, 16), int(zero or "0", 16)))
+    assert len(table) >= 8
+    found = set()
+    for radius, rates in ((3, (48000, 32000)), (3, (24000, 48000)), (5, (48000, 32000)), (5, (24000, 48000)), (5, (12000, 48000)),
+                          (8, (48000, 32000)), (8, (24000, 48000)), (8, (12000, 48000))):
+        p = _product.Product(radius)
+        ok, st = p.low_init(1, rates[0], rates[1], min(rates))
+        sh = p.api.PeriodicShape(st.raw.lowest_level, p.pre, st.raw.increment)
+        assert sh is not None and sh["period"] in (2, 4) and sh["starts"][0] == 0
+        offs = sum(v << (8 * i) for i, v in enumerate(sh["starts"]))
+        key = (sh["ratio"], sh["period"], offs, sh["slots"], sh["negmask"], sh["safemask"], sh["zeromask"])
+        assert key in table, (radius, rates, sh)
+        found.add(key)
+    assert found == table, "an instance in cr_inst_int_d.hip that no tested ratio produces: %s" % (table - found)
+    # a ratio whose increment is truncated (1:3: floor(65536 / 3)) never repeats: no period
+    p = _product.Product(3)
+    ok, st = p.low_init(1, 16000, 48000, 16000)
+    assert p.api.PeriodicShape(st.raw.lowest_level, p.pre, st.raw.increment) is None
+
+
 def test_rejects_what_the_reference_cannot_run():
     p = _product.Product(3)
     ok, cfg = p.configure(2048, 1, 1)      # step underflows to 0: every tap reads table[0] == 0 -> weight sum 0 (SURVEY appendix A)

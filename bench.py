@@ -13,6 +13,11 @@ block, input halo replicated, no collective in the data path: STRONG scaling.  `
 10-minute shard of an N x 10-minute stream instead.  The final concatenate (north_star) is timed apart from the kernel:
 gather-to-root and all-gather over RCCL, reported as `gather` beside the kernel-only `value`.
 
+Every line carries its curve's N = 1 point: the default N = 1 line has `strong_curve_n1` (the hour of configs[4] as one launch on this
+GPU), every N > 1 line `efficiency_vs_n1` (each rank also runs the WHOLE stream alone on its own GPU, in the same process, after the
+timed region).  `parity_full_stream`: every sample of the last timed launch of every rank is compared with the all-core oracle.
+Ranks carry a wall-clock limit (--rank-timeout) and leave with status 124 when it passes.
+
 `python bench.py --gpus N` starts its own N workers (a child `python -m torch.distributed.run`, started before this
 process has touched the GPU); under an existing torch.distributed.run (RANK/WORLD_SIZE in the environment) it is a worker.
 
@@ -111,7 +116,7 @@ def free_port():
     return p
 
 
-def launch_workers(n):
+def launch_workers(n, timeout_s):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as children of THIS process, which has
     not initialised the GPU (no torch import, no HIP call - never an exec of a process that has), wait, pass on their status."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
@@ -119,7 +124,33 @@ def launch_workers(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.run(cmd, env=env).returncode
+    # the children are FRESH processes in their own group; a launcher that outlives its limit takes the whole group down and reports it
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=timeout_s + 60.0)
+    except subprocess.TimeoutExpired:
+        print("bench: the %d ranks did not finish within %.0f s - killing them" % (n, timeout_s + 60.0), file=sys.stderr)
+        try:
+            os.killpg(child.pid, 9)
+        except OSError:
+            pass
+        child.wait()
+        return 124
+
+
+def arm_watchdog(seconds, rank):
+    """Per-rank wall-clock limit: a rank stuck in a collective (a peer died, a link hung) must end the job with a non-zero status, not
+    sit in the driver's slot.  A daemon timer that leaves with os._exit - no exec, no signal to anything but this process."""
+    import threading
+
+    def fire():
+        print("bench: rank %d exceeded its wall-clock limit of %.0f s - exiting 124" % (rank, seconds), file=sys.stderr, flush=True)
+        os._exit(124)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def device_noise(n_samples, first_index, device):
@@ -285,6 +316,88 @@ def callback_api(api, pre, ch, rates, frames, pcm, expected, n_out):
             "equals_bulk_output": bool(np.array_equal(out[: n_out * ch], expected[: n_out * ch]))}
 
 
+def full_stream_check(radius, ch, rates, shard, d_pcm, d_out, s16):
+    """Every output sample of one launch against the oracle: the launch's input is copied back from the device, the all-core
+    oracle driver (oracle/cr_oracle.c, one state per host thread from the closed form) runs the shard from the shard's state,
+    and the whole output is compared.  Returns (ok, detail)."""
+    import numpy as np
+    import _checkers as ck
+    t0 = time.perf_counter()
+    o = ck.oracle(radius)
+    ok, ost = o.low_init(ch, *rates)
+    ost.pos_int, ost.pos_frac = int(shard.state.position_integer), int(shard.state.position_fractional)
+    host_in = d_pcm.cpu().numpy()
+    cores = os.cpu_count() or 1
+    want = o.low_resample_i32_mt(ost, host_in, int(shard.input_frames), cores)
+    n = int(shard.output_frames) * ch
+    if want.size < n:
+        return False, {"error": "the oracle produced %d samples, the launch %d" % (want.size, n)}
+    want = want[:n]    # (a shard is ended by its output capacity: clownresampler_amd.h, ClownResamplerAMD_Shard)
+    if s16:
+        want = np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16)
+    got = d_out[:n].cpu().numpy()
+    same = bool(np.array_equal(got, want))
+    detail = {"frames": int(shard.output_frames), "samples": n, "oracle_threads": cores, "seconds": time.perf_counter() - t0,
+              "stream_hash": "%016x" % ck.stream_hash(got.astype(np.int32))}
+    if not same:
+        bad = np.flatnonzero(got != want)
+        detail["first_difference_at_sample"] = int(bad[0])
+        detail["differing_samples"] = int(bad.size)
+    return same, detail
+
+
+def single_gpu_reference(api, pre, cr, name, device, stream, steps, warmup, check):
+    """The N = 1 point of a multi-GPU curve, measured in THIS process on THIS rank's GPU: the whole stream of workload `name`
+    device-resident, K launches between one event pair after W warm-up launches (the timed region's own method), and - check -
+    every sample of the last launch against the all-core oracle.  Buffers are rotated only when one set is smaller than a GiB
+    (a larger one cannot live in the 256 MiB Infinity Cache)."""
+    import torch
+    radius, ch, rates, frames = WORKLOADS[name]
+    whole = api.LowLevel_State()
+    assert api.LowLevel_Init(whole, ch, *rates)
+    R = whole.lowest_level.integer_stretched_kernel_radius
+    shard = api.PlanShard(whole, frames, 0, 1)
+    plan = api.PlanCreate(whole, pre)
+    set_bytes = (shard.input_frames + 2 * R) * ch * 2 + shard.output_frames * ch * 4
+    sets = []
+    for k in range(1 if set_bytes >= (1 << 30) else 3):
+        sets.append((stream_slice(-R, shard.input_frames + 2 * R, ch, frames, k * 7919, device),
+                     torch.empty(shard.output_frames * ch, dtype=torch.int32, device=device)))
+
+    def step(i):
+        pcm, out = sets[i % len(sets)]
+        st = cr.LowLevel_State.from_buffer_copy(shard.state)
+        n = api.ResampleDevice(plan, st, pcm.data_ptr(), shard.input_frames, out.data_ptr(), shard.output_frames, stream.cuda_stream)[0]
+        assert n == shard.output_frames
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        for i in range(max(1, warmup)):
+            step(i)
+        torch.cuda.synchronize(device)
+        ev0.record(stream)
+        for i in range(steps):
+            step(i)
+        ev1.record(stream)
+    torch.cuda.synchronize(device)
+    ms = ev0.elapsed_time(ev1) / steps
+    nbytes = shard.input_frames * ch * 2 + shard.output_frames * ch * 4
+    res = {"workload": name, "what": "the WHOLE stream (%d -> %d frames x %d ch) as one launch on this GPU, %d launches between one event pair after %d warm-up launches, %d buffer set(s)"
+                                     % (shard.input_frames, shard.output_frames, ch, steps, max(1, warmup), len(sets)),
+           "ms_per_step": ms, "value": shard.output_frames * ch / (ms * 1e-3) / 1e6, "unit": "Msamples/s",
+           "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes}
+    if check:
+        last = (steps - 1) % len(sets)
+        ok, detail = full_stream_check(radius, ch, rates, shard, sets[last][0], sets[last][1], False)
+        res["parity_full_stream"] = ok
+        res["parity_full_stream_detail"] = detail
+        if not ok:
+            raise SystemExit("bench: the single-GPU run of %s differs from the oracle (%s) - numbers void" % (name, detail))
+    del sets
+    torch.cuda.empty_cache()
+    return res
+
+
 def percentile(sorted_values, q):
     if not sorted_values:
         return None
@@ -301,6 +414,8 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: cfg2 at N=1, cfg5 (the 1-hour stream, sharded) at N>1")
     ap.add_argument("--scaling", default=None, choices=("strong", "weak"), help="N>1: strong = ONE stream of the workload's length split over the ranks (default); weak = every rank one stream-length shard of an N times longer stream")
     ap.add_argument("--sets", type=int, default=3, help="rotating buffer sets (defeats the 256 MiB Infinity Cache)")
+    ap.add_argument("--rank-timeout", type=float, default=900.0, help="wall-clock limit per rank in seconds: a rank still running then exits with status 124 (N > 1: so does the launcher, 60 s later, after killing its children)")
+    ap.add_argument("--no-n1-reference", action="store_true", help="N > 1: skip the same-process single-GPU run of the whole stream behind efficiency_vs_n1; N = 1: skip strong_curve_n1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
@@ -310,7 +425,7 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_workers(args.gpus))
+        sys.exit(launch_workers(args.gpus, args.rank_timeout))
 
     import numpy as np
     import torch
@@ -321,6 +436,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    watchdog = arm_watchdog(args.rank_timeout, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the GPU: the product has no CPU path")
     # Fewer GPUs than ranks (a 1-GPU box asked for --gpus 8), or CRA_BENCH_BACKEND=gloo: VALIDATION mode - the ranks share the
@@ -457,6 +573,8 @@ def main():
         launches_by_kernel = [args.steps] * 7
     dev_ms = max(ev0.elapsed_time(ev1), 0.0)
     mean_ms = dev_ms / args.steps
+    last_set = (args.steps - 1) % len(sets)
+    out_snapshot = None if args.no_check else sets[last_set][1].clone()   # what the LAST TIMED launch wrote (checked in full below)
 
     blocks, block_len = 10, 20   # fixed, whatever --steps is: with the driver's --steps 20 a K/10 rule gave 2-launch blocks (+-10 %)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(blocks + 1)]
@@ -528,19 +646,13 @@ def main():
         want, _, _ = o.low_resample_i32(ost, host_in, need - 2 * R, capacity=n_chk)
         return want
 
-    # correctness of what was just timed: EVERY rank checks the head and the tail of its shard against the oracle
-    check = None
+    # correctness of what was just timed: EVERY rank checks its WHOLE shard - every sample the last timed launch wrote (snapshot taken
+    # right behind the timed region, before the distribution region's launches) - against the all-core oracle run over the very input
+    # the launch read, copied back from the device.  Outside the timed region.
+    check, check_detail = None, None
     if not args.no_check:
-        last = (args.steps - 1) % len(sets)
-        out = sets[last][1]
-        ok_here = True
-        n_chk = min(100000, shard.output_frames)
-        for first in sorted({0, shard.output_frames - n_chk}):
-            want = oracle_window(shard.first_output_frame + first, n_chk, last * 7919)
-            got = out[first * ch: first * ch + want.size].cpu().numpy()
-            if args.s16:
-                want = np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16)
-            ok_here = ok_here and want.size == n_chk * ch and bool(np.array_equal(got, want))
+        ok_here, check_detail = full_stream_check(radius, ch, rates, shard, sets[last_set][0], out_snapshot, args.s16)
+        del out_snapshot
         if world > 1:
             t = torch.tensor([1 if ok_here else 0])
             tt = t.to(device) if backend == "nccl" else t
@@ -549,7 +661,21 @@ def main():
         else:
             check = ok_here
         if not check:
-            raise SystemExit("bench: device output differs from the oracle on rank %d (ok here: %s) - numbers void" % (rank, ok_here))
+            raise SystemExit("bench: device output differs from the oracle on rank %d (ok here: %s, %s) - numbers void" % (rank, ok_here, check_detail))
+
+    # The N = 1 point of the strong-scaling curve, self-contained in every line.  N = 1 (default workload): the hour of configs[4] as
+    # one launch beside the 10-minute headline.  N > 1: every rank runs the WHOLE stream of this job's workload alone on its own GPU
+    # (same process, after and outside the timed region), and efficiency_vs_n1 compares the job with the slowest of those.
+    n1_ref, strong_n1 = None, None
+    if not args.no_n1_reference and not args.s16:
+        if world == 1 and workload == "cfg2":
+            strong_n1 = single_gpu_reference(api, pre, cr, "cfg5", device, stream, 20, 5, not args.no_check)
+        elif world > 1:
+            del sets[1:]   # (the gather below reads set 0 only)
+            torch.cuda.empty_cache()
+            barrier()
+            n1_ref = single_gpu_reference(api, pre, cr, workload, device, stream, max(5, min(args.steps, 20)), 5, False)
+            barrier()
 
     # N > 1: the line proves what ran.  Every rank reports its GPU's identity and its own timing; the backend is asked to SUM a
     # one per rank (a collective that only comes out at N if N ranks took part in it).
@@ -560,6 +686,7 @@ def main():
                 "device": {"name": props.name, "uuid": str(getattr(props, "uuid", "")),
                            "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))},
                 "ms_per_step": mean_ms, "median_ms": median_ms, "output_frames": int(shard.output_frames), "input_frames": int(shard.input_frames),
+                "n1_ms_per_step": n1_ref["ms_per_step"] if n1_ref else None,
                 "first_output_frame": int(shard.first_output_frame), "kernel_launches_timed": [int(v) for v in launches_by_kernel]}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
@@ -642,8 +769,9 @@ def main():
             "roofline": roofline,
             "launch_mode": "hipGraph replay of the K steps" if graph is not None else "eager",
             "wall_ms_per_step": wall_ms / args.steps,
-            "parity_spot_check": check,
-            "parity_spot_check_is": "every rank: first and last 100,000 frames of its shard of the last timed launch == oracle; all ranks agree",
+            "parity_full_stream": check,
+            "parity_full_stream_is": "every rank: EVERY sample its last timed launch wrote == the all-core oracle over the input that launch read (copied back from the device); all ranks agree",
+            "parity_full_stream_detail": check_detail,
         }
         if roofline_valu:
             line["roofline_valu"] = roofline_valu
@@ -658,6 +786,16 @@ def main():
                                      "(%d output frames here); the N = 1 point of THIS curve is `--gpus 1 --workload cfg5` (the default N = 1 line is configs[1], 10 minutes); "
                                      "with the concatenate the curve is bound by the gather (SURVEY 8(e): bytes_per_rank over one xGMI link against a kernel of tens of microseconds)"
                                      % shard.output_frames) if workload == "cfg5" else None
+            if n1_ref:
+                # strong: N ranks share ONE stream, ideal time = t1 / N; weak: every rank has a stream of the N = 1 size, ideal = t1
+                t1 = max(r["n1_ms_per_step"] for r in per_rank)
+                ideal = t1 / world if scaling == "strong" else t1
+                line["efficiency_vs_n1"] = {"value": ideal / ms_per_step, "n1_ms_per_step": t1, "n1_value": n1_ref["value"] if scaling == "strong" else n1_ref["value"] * world,
+                                            "is": "(%s) / ms_per_step of this job; t1 = the slowest rank's own single-GPU run of %s, measured in this process after the timed region (kernel only, like `value`)"
+                                                  % ("t1 / N" if scaling == "strong" else "t1", n1_ref["what"]),
+                                            "n1_of_rank_0": n1_ref}
+        if strong_n1:
+            line["strong_curve_n1"] = strong_n1
         if gather:
             line["gather"] = gather
         if world == 1 and not args.no_host_paths and not args.s16:
@@ -675,6 +813,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    watchdog.cancel()
 
 
 if __name__ == "__main__":

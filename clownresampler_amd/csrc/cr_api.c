@@ -453,6 +453,17 @@ size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *r
 		}
 		use_table = cr_segments_mode() == 2 || (cr_segments_mode() == 0 && non_empty >= SEGMENT_TABLE_MIN_SEGMENTS
 		                                            && total_out / non_empty * probe.channels * taps < SEGMENT_TABLE_MAX_WORK);
+		/* Never on a stream that is recording into a hipGraph: the table travels through ONE pinned buffer and ONE device buffer
+		   per device that the next call overwrites, behind an event this call records - a graph would replay the copy of whatever the
+		   buffer holds by then, and the recorded event never "happens" for the host.  Launches per segment carry everything in their
+		   kernel arguments and own never-recycled ticket blocks under capture (cr_context.c, capture pool): they replay correctly. */
+		if (use_table)
+		{
+			int capturing = 0;
+
+			if (hip_stream != NULL && (crhip_stream_is_capturing(hip_stream, &capturing) != 0 || capturing))
+				use_table = 0;
+		}
 		if (use_table && non_empty != 0)
 		{
 			table = (crhip_segment *)malloc(non_empty * sizeof(crhip_segment));
@@ -602,7 +613,9 @@ static uint64_t replay_frames(ClownResampler_LowLevel_State *resampler, const in
 /* The consumer's callbacks run on the calling thread, one frame at a time, at 1-2 ns each: for a long call that - not the GPU -
    is where the time goes (10 minutes of stereo: ~45 ms of callbacks against ~5 ms of upload + kernel + download).  So once the
    batches have reached their full size, a helper thread computes batch k + 1 while the calling thread replays batch k (two
-   slots).  A consumer that stops early costs at most the batch in flight, as before. */
+   slots).  A consumer that stops early costs at most the batch in flight, as before.  The helper only computes: callbacks AND
+   error reports happen on the calling thread (a device failure over there is handed back and raised here).
+   CLOWNRESAMPLER_AMD_NO_REPLAY_THREAD=1 in the environment keeps the whole call on the calling thread. */
 typedef struct replay_ahead
 {
 	const ClownResamplerAMD_Plan *plan;
@@ -611,8 +624,10 @@ typedef struct replay_ahead
 	uint64_t first, available, batch;   /* output frames [first, available), `batch` at a time */
 	int32_t *slot[2];
 	uint64_t frames[2];
-	int state[2];                        /* 0: free, 1: filled, 2: the device failed (reported through the error handler) */
+	int state[2];                        /* 0: free, 1: filled, 2: the device failed (error_code / error_message: re-raised by the calling thread) */
 	int cancel;
+	int error_code;
+	char error_message[512];
 	pthread_mutex_t lock;
 	pthread_cond_t changed;
 } replay_ahead;
@@ -622,6 +637,9 @@ static void *replay_ahead_worker(void *argument)
 	replay_ahead *a = (replay_ahead *)argument;
 	uint64_t at = a->first;
 	unsigned k = 0;
+
+	/* failures on this thread are recorded, not reported: the client's error handler runs on the client's thread only */
+	cr_error_defer(1);
 
 	while (at < a->available)
 	{
@@ -643,6 +661,8 @@ static void *replay_ahead_worker(void *argument)
 		failed = cr_run_host(a->plan, a->input_buffer, a->padded_frames, pi, pf, n, a->slot[k], 0) != 0;
 
 		pthread_mutex_lock(&a->lock);
+		if (failed)
+			a->error_code = cr_error_take(a->error_message, sizeof(a->error_message));
 		a->frames[k] = n;
 		a->state[k] = failed ? 2 : 1;
 		pthread_cond_broadcast(&a->changed);
@@ -744,7 +764,7 @@ cc_bool ClownResampler_LowLevel_Resample(ClownResampler_LowLevel_State *resample
 		ahead.slot[1] = second;
 		pthread_mutex_init(&ahead.lock, NULL);
 		pthread_cond_init(&ahead.changed, NULL);
-		started = second != NULL && pthread_create(&worker, NULL, replay_ahead_worker, &ahead) == 0;
+		started = second != NULL && !cr_env_no_replay_thread() && pthread_create(&worker, NULL, replay_ahead_worker, &ahead) == 0;
 
 		while (started && done < available)
 		{
@@ -759,6 +779,8 @@ cc_bool ClownResampler_LowLevel_Resample(ClownResampler_LowLevel_State *resample
 			pthread_mutex_unlock(&ahead.lock);
 			if (state == 2)
 			{
+				/* the helper's failure, reported HERE: the calling thread's error state, the client's handler on the client's thread */
+				cr_fail(ahead.error_code != 0 ? ahead.error_code : CLOWNRESAMPLER_AMD_ERROR_HIP, "%s", ahead.error_message[0] != '\0' ? ahead.error_message : "the device failed in the compute-ahead thread");
 				failed = 1;
 				break;
 			}

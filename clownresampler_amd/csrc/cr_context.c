@@ -26,6 +26,26 @@ static void *g_handler_user = NULL;
 static __thread int t_last_code = 0;
 static __thread unsigned long t_error_serial = 0;
 static __thread char t_last_message[512];
+static __thread int t_deferred = 0;
+
+void cr_error_defer(int on)
+{
+	t_deferred = on;
+}
+
+int cr_error_take(char *message, size_t capacity)
+{
+	const int code = t_last_code;
+
+	if (capacity != 0)
+	{
+		strncpy(message, code != 0 ? t_last_message : "", capacity - 1);
+		message[capacity - 1] = '\0';
+	}
+	t_last_code = 0;
+	t_last_message[0] = '\0';
+	return code;
+}
 
 int cr_fail(int code, const char *format, ...)
 {
@@ -36,6 +56,12 @@ int cr_fail(int code, const char *format, ...)
 	va_end(ap);
 	t_last_code = code;
 	++t_error_serial;
+
+	/* a thread the LIBRARY created (the callback API's compute-ahead helper): the failure is recorded here and re-raised by the
+	   client's own thread (cr_error_take / cr_fail there) - the client's handler never runs on a thread it did not create, and
+	   ClownResamplerAMD_LastErrorCode on the calling thread tells the story */
+	if (t_deferred)
+		return code;
 
 	if (g_handler != NULL)
 	{
@@ -166,7 +192,10 @@ static unsigned long long *g_debug_stamps = NULL;
 static int g_variant = -1; /* -1: CLOWNRESAMPLER_AMD_VARIANT from the environment, else the default */
 /* launches enqueued so far, by kernel (numbered as ClownResamplerAMD_PlanInfo.kernel; 5 = k_int): what tests and bench.py
    assert "the kernel I mean is the one that ran" with (ClownResamplerAMD_DebugLaunchCount) */
-#define CR_KERNEL_IDS 7
+/* ... and [7]: how many of those launches drew their tiles as TICKETS (k_poly with dynamic_tiles on, k_int with ticket groups) -
+   the scheduler the long launches of cfg 2 / cfg 5 take and launches of fewer than eight tiles per workgroup do not */
+#define CR_KERNEL_IDS 8
+#define CR_COUNT_TICKETED 7
 static unsigned long long g_launch_count[CR_KERNEL_IDS];
 
 /* Where a plan WITHOUT a specialised instance runs the run-time-slot k_wave2 instead of the run-time-slot k_poly.  Measured on
@@ -204,6 +233,8 @@ static struct
 	int loaded;
 	int dynamic_tiles;          /* CLOWNRESAMPLER_AMD_DYNAMIC_TILES: -1 unset, else 0 / 1 */
 	int no_special, debug, no_occupancy_clamp, tile_groups, no_host_pipeline, no_small_call_path;
+	int no_replay_thread;       /* CLOWNRESAMPLER_AMD_NO_REPLAY_THREAD: the callback API never starts its compute-ahead helper thread */
+	int host_direct;            /* CLOWNRESAMPLER_AMD_HOST_DIRECT: -1 unset (the rule), 0 never, 1 input only, 2 input and output - see cr_run_host */
 	int wave2s_min_channels;    /* CLOWNRESAMPLER_AMD_WAVE2S_MIN_CHANNELS: frames from this many channels on take k_wave2s for long windows (99: never) */
 	int lane_map;               /* CLOWNRESAMPLER_AMD_LANE_MAP: 0 / 1 forces k_wave2's lane order (unset: the conflict model picks) */
 	int no_int_kernel;          /* CLOWNRESAMPLER_AMD_NO_INT_KERNEL: whole-number ratios take the plan's ordinary kernel (the A/B leg) */
@@ -226,6 +257,9 @@ static void load_env(void)
 	g_env.tile_groups = (e != NULL && atoi(e) > 0) ? atoi(e) : 0;
 	g_env.no_host_pipeline = getenv("CLOWNRESAMPLER_AMD_NO_HOST_PIPELINE") != NULL;
 	g_env.no_small_call_path = getenv("CLOWNRESAMPLER_AMD_NO_SMALL_CALL_PATH") != NULL;
+	g_env.no_replay_thread = getenv("CLOWNRESAMPLER_AMD_NO_REPLAY_THREAD") != NULL;
+	e = getenv("CLOWNRESAMPLER_AMD_HOST_DIRECT");
+	g_env.host_direct = (e != NULL && *e != '\0') ? atoi(e) : -1;
 	g_env.no_int_kernel = getenv("CLOWNRESAMPLER_AMD_NO_INT_KERNEL") != NULL;
 	e = getenv("CLOWNRESAMPLER_AMD_WAVE2S_MIN_CHANNELS");
 	g_env.wave2s_min_channels = (e != NULL && atoi(e) > 0) ? atoi(e) : CR_WAVE2S_MIN_CHANNELS;
@@ -1680,6 +1714,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 				}
 				e = crhip_launch_int(&il, stream);
 				ticket_block_enqueued(g_ctx[plan->device], ring);
+				__atomic_fetch_add(&g_launch_count[CR_COUNT_TICKETED], 1ull, __ATOMIC_RELAXED);
 				return cr_check_hip(e, "k_int launch");
 			}
 			return cr_check_hip(crhip_launch_int(&il, stream), "k_int launch");
@@ -1760,6 +1795,8 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			e = crhip_launch_poly(&l, stream);
 			ticket_block_enqueued(g_ctx[plan->device], ring);
 			__atomic_fetch_add(&g_launch_count[l.variant == CRHIP_VARIANT_RT_WAVE2S ? 6 : vecs >= 200u ? 3 : vecs >= 150u ? 4 : vecs >= 100u ? 2 : 1], 1ull, __ATOMIC_RELAXED);
+			if (vecs < 100u && l.dynamic_tiles != 0u)
+				__atomic_fetch_add(&g_launch_count[CR_COUNT_TICKETED], 1ull, __ATOMIC_RELAXED);
 			return cr_check_hip(e, "k_poly launch");
 		}
 	}
@@ -1974,6 +2011,7 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 	int have_thread = 0, bad = 0;
 	cr_workspace *ws;
 	cr_device_ctx *ctx;
+	void *alias_in = NULL, *alias_out = NULL;
 
 	if (n_out == 0)
 		return 0;
@@ -2015,6 +2053,36 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 			   || cr_check_hip(crhip_stream_sync(ws->stream), "hipStreamSynchronize") != 0;
 			if (!bad)
 				memcpy(host_out, ctx->small + out_at, out_bytes);
+			workspace_release(ctx);
+			return bad ? -1 : 0;
+		}
+	}
+
+	/* PAGE-LOCKED caller buffers (hipHostMalloc / hipHostRegister - a client that did the right thing): the device can address them,
+	   so nothing needs staging.  host_direct 2: ONE launch over the whole call, the LDS-DMA reading the caller's input across the bus
+	   and the stores writing the caller's output, both directions of the link busy at once, no copy calls, no helper thread.
+	   host_direct 1: only the input is read in place (no uploads); the output still goes through device staging and the download
+	   thread.  Which of the three a call takes is a measured rule (profiles/r04_host_paths.log); pageable memory always stages. */
+	if (g_env.host_direct != 0)
+	{
+		/* (everything from the call's first frame to the end of the caller's padded buffer: what the staged path may read as well) */
+		const uint64_t readable = pos_int < in_frames ? in_frames - pos_int : 0;
+
+		if (readable != 0 && crhip_host_alias(host_in + pos_int * plan->channels, (size_t)readable * frame_in, &alias_in) != 0)
+			alias_in = NULL;
+		if (alias_in != NULL && (g_env.host_direct == 2 || g_env.host_direct < 0)
+		 && crhip_host_alias(host_out, (size_t)n_out * frame_out, &alias_out) != 0)
+			alias_out = NULL;
+		if (g_env.host_direct < 0 && alias_out == NULL)
+			alias_in = NULL;   /* (the rule: all or nothing) */
+
+		if (alias_in != NULL && alias_out != NULL)
+		{
+			ws = workspace_acquire(ctx, 0, 0); /* (the lock and the stream) */
+			if (ws == NULL)
+				return -1;
+			bad = cr_plan_launch(plan, alias_in, readable * frame_in, alias_out, 0, pos_frac, n_out, ws->stream, out_s16) != 0
+			   || cr_check_hip(crhip_stream_sync(ws->stream), "hipStreamSynchronize") != 0;
 			workspace_release(ctx);
 			return bad ? -1 : 0;
 		}
@@ -2101,8 +2169,11 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 				break;
 		}
 
-		bad = cr_check_hip(crhip_memcpy_h2d(w->d_in, host_in + pi * plan->channels, (size_t)extent * frame_in, ws->stream), "hipMemcpyAsync(H2D)") != 0
-		   || cr_plan_launch(plan, w->d_in, extent * frame_in, w->d_out, 0, pf, n, ws->stream, out_s16) != 0;
+		if (alias_in != NULL)   /* the input is read where it lies (alias_in is the device's address of host_in + pos_int frames) */
+			bad = cr_plan_launch(plan, (const unsigned char *)alias_in + (size_t)(pi - pos_int) * frame_in, extent * frame_in, w->d_out, 0, pf, n, ws->stream, out_s16) != 0;
+		else
+			bad = cr_check_hip(crhip_memcpy_h2d(w->d_in, host_in + pi * plan->channels, (size_t)extent * frame_in, ws->stream), "hipMemcpyAsync(H2D)") != 0
+			   || cr_plan_launch(plan, w->d_in, extent * frame_in, w->d_out, 0, pf, n, ws->stream, out_s16) != 0;
 		if (have_thread && !bad)
 			bad = cr_check_hip(crhip_event_record(dl.slot[set].ready, ws->stream), "hipEventRecord") != 0;
 		if (bad)
@@ -2231,6 +2302,12 @@ void ClownResamplerAMD_PlanGetInfo(const ClownResamplerAMD_Plan *plan, ClownResa
 		info->brief_variant = plan->brief.variant;
 		info->brief_below = plan->brief.below;
 	}
+}
+
+int cr_env_no_replay_thread(void)
+{
+	env_ready();
+	return g_env.no_replay_thread;
 }
 
 static int g_segments_mode = 0;

@@ -20,6 +20,11 @@ extern "C" {
 int cr_fail(int code, const char *format, ...);
 /* Number of cr_fail calls made on this thread so far. */
 unsigned long cr_error_serial(void);
+/* For threads the library itself creates: with `on`, cr_fail on THIS thread only records (no handler call, no abort); the creating
+   thread then collects code and message with cr_error_take on the worker's behalf... */
+void cr_error_defer(int on);
+/* ... called ON the worker thread before it ends: returns the recorded code (0: none), copies the message, clears the record. */
+int cr_error_take(char *message, size_t capacity);
 /* cr_fail(CLOWNRESAMPLER_AMD_ERROR_HIP, ...) when hip_code != 0; returns hip_code. */
 int cr_check_hip(int hip_code, const char *what);
 
@@ -124,6 +129,8 @@ int cr_segments_run(const ClownResamplerAMD_Plan *plan, const void *d_in, void *
                     uint64_t n_out, int out_s16, void *stream);
 /* 0: the measured rule decides between one launch per segment and one launch for all, 1: always per segment, 2: always one launch */
 int cr_segments_mode(void);
+/* CLOWNRESAMPLER_AMD_NO_REPLAY_THREAD is set: ClownResampler_LowLevel_Resample stays on the calling thread for the whole call */
+int cr_env_no_replay_thread(void);
 
 /* cr_multi.c: the multi-device call behind ClownResamplerAMD_ResampleShardedDevice, and its part of Shutdown */
 struct ClownResampler_LowLevel_State;

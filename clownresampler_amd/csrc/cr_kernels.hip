@@ -242,6 +242,31 @@ int crhip_host_free(void *host_pointer)
 	return (int)hipHostFree(host_pointer);
 }
 
+// 0 and *device_alias when [host, host + bytes) lies in ONE block of page-locked host memory that the current device can address
+// (hipHostMalloc / hipHostRegister: what a client that "did the right thing" hands the host-pointer entry points); 1 for
+// ordinary pageable memory (not an error: the question was legitimate, the runtime's sticky error is cleared).
+int crhip_host_alias(const void *host, size_t bytes, void **device_alias)
+{
+	hipPointerAttribute_t at;
+	void *first = nullptr, *last = nullptr;
+
+	*device_alias = nullptr;
+	if (hipPointerGetAttributes(&at, host) != hipSuccess || at.type != hipMemoryTypeHost)
+	{
+		(void)hipGetLastError();
+		return 1;
+	}
+	if (hipHostGetDevicePointer(&first, const_cast<void *>(host), 0) != hipSuccess || first == nullptr
+	 || (bytes > 1 && (hipHostGetDevicePointer(&last, const_cast<char *>(static_cast<const char *>(host)) + bytes - 1, 0) != hipSuccess
+	                   || static_cast<char *>(last) - static_cast<char *>(first) != static_cast<ptrdiff_t>(bytes - 1))))
+	{
+		(void)hipGetLastError();
+		return 1;
+	}
+	*device_alias = first;
+	return 0;
+}
+
 int crhip_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
 {
 	return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);

@@ -173,6 +173,9 @@ int crhip_malloc(void **device_pointer, size_t bytes);
 int crhip_free(void *device_pointer);
 int crhip_host_alloc(void **host_pointer, size_t bytes);   /* pinned */
 int crhip_host_free(void *host_pointer);
+/* 0 and the address the current device reaches [host, host + bytes) under when that range is page-locked host memory (hipHostMalloc,
+   hipHostRegister); 1 for pageable memory (nothing is reported, no sticky error is left behind) */
+int crhip_host_alias(const void *host, size_t bytes, void **device_alias);
 int crhip_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);   /* async on stream */
 int crhip_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);   /* async on stream */
 int crhip_memset(void *dst, int value, size_t bytes, void *stream);

@@ -195,8 +195,9 @@ size_t ClownResamplerAMD_PlanCacheCount(void);
    gives its first frames to the ordinary kernel, which is what this function then names.  Ignores launch-length rules
    (brief_below). */
 uint32_t ClownResamplerAMD_PlanKernelAt(const ClownResamplerAMD_Plan *plan, uint32_t position_fractional);
-/* Launches enqueued by this process so far on `kernel` (0 ... 5, numbered as above): lets tests and benchmarks assert that the
-   kernel they mean is the one that ran. */
+/* Launches enqueued by this process so far on `kernel` (0 ... 6, numbered as above): lets tests and benchmarks assert that the
+   kernel they mean is the one that ran.  7 = how many of those launches drew their tiles as tickets (k_poly's and k_int's long
+   launches; a launch of fewer than eight tiles per workgroup is dealt round-robin instead). */
 unsigned long long ClownResamplerAMD_DebugLaunchCount(unsigned kernel);
 /* Test hook: whole-number ratios take the plan's ordinary kernel instead of k_int (the A/B leg; also CLOWNRESAMPLER_AMD_NO_INT_KERNEL
    in the environment at first use, which additionally skips k_int's one-time setup). */

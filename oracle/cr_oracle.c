@@ -535,8 +535,11 @@ size_t oracle_low_resample_i32_mt(const oracle_lowlevel *fresh, const int64_t *t
 	{
 		const uint64_t a = (uint64_t)frames * t / threads;
 		const uint64_t b = (uint64_t)frames * (t + 1) / threads;
-		const unsigned __int128 first_k = ((unsigned __int128)a * ORACLE_FRAC_ONE + fresh->increment - 1) / fresh->increment;
-		const unsigned __int128 first_p = first_k * fresh->increment;
+		/* (a state that is not fresh - a shard of a longer stream, a resumed call - starts its timeline at p0 instead of 0) */
+		const unsigned __int128 p0 = (unsigned __int128)fresh->pos_int * ORACLE_FRAC_ONE + fresh->pos_frac;
+		const unsigned __int128 a_pos = (unsigned __int128)a * ORACLE_FRAC_ONE;
+		const unsigned __int128 first_k = a_pos > p0 ? (a_pos - p0 + fresh->increment - 1) / fresh->increment : 0;
+		const unsigned __int128 first_p = p0 + first_k * fresh->increment;
 
 		jobs[t].st = *fresh;
 		jobs[t].st.pos_int = (uint64_t)(first_p / ORACLE_FRAC_ONE) - a;

@@ -320,6 +320,66 @@ def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch,
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("name,radius,ch,rates,frames,kernel,ticketed", [
+    ("cfg2", 3, 2, (44100, 48000, 44100), 26460000, 1, True),     # BASELINE configs[1]: THE launch bench.py times (7,032 tiles on 512 workgroups, tickets)
+    ("cfg3", 8, 2, (8000, 96000, 8000), 4800000, 3, None),         # configs[2]: k_up2, wave-tiles drawn from global counters throughout
+    ("cfg4", 3, 8, (48000, 44100, 44100), 28800000, 1, True),      # configs[3]: 8 channels, ticketed tiles
+    ("cfg5", 3, 2, (44100, 48000, 44100), 158760000, 1, True),     # configs[4]: the hour as ONE launch (42,188 tiles)
+    ("hq48", 8, 2, (44100, 48000, 44100), 26460000, 4, None),      # k_wave2: chunks of 4 wave-tiles (the 4 Mi batches of the host path get shorter ones)
+    ("hq44", 8, 2, (48000, 44100, 44100), 28800000, 4, None),
+    ("dn8", 3, 2, (44100, 8000, 8000), 26460000, 4, None),
+    ("dn6x", 3, 2, (48000, 8000, 8000), 57600000, 5, True),        # k_int, ticket groups of several tiles
+    ("dn32k", 3, 2, (48000, 32000, 32000), 28800000, 5, True),     # k_int, periodic ratio
+    ("mono", 3, 1, (44100, 48000, 44100), 52920000, 1, None),      # the mono instances
+    ("dn1", 3, 1, (48000, 44100, 44100), 57600000, 1, None),
+    ("hq48m", 8, 1, (44100, 48000, 44100), 52920000, 4, None),
+    ("dn8m", 3, 1, (44100, 8000, 8000), 52920000, None, None),
+    ("up12", 3, 12, (44100, 48000, 44100), 26460000, 1, True),     # two lanes per frame; tickets by the wide-frame rule (>= 48 tiles per workgroup)
+    ("ch11", 3, 11, (48000, 44100, 44100), 9600000, 1, None),      # odd wide frames (phantom channel)
+])
+def test_one_launch_full_size_bit_exact(products, name, radius, ch, rates, frames, kernel, ticketed):
+    """What bench.py times, verified in full: the WHOLE stream device-resident, ONE ClownResamplerAMD_ResampleDevice launch (reference
+    clownresampler.h:1058-1092 for the whole call), every output sample against the multi-threaded oracle.  The host-pointer entry
+    points the other full-size tests use cut a call into 4 Mi-frame batches, which never reach the launch shapes of a long
+    device-resident call - k_poly's ticket scheduler (at least eight tiles per workgroup), k_wave2's and k_int's longer chunks.
+    ticketed: whether the launch must have drawn its tiles as tickets (LaunchCount(7)); None = not asserted."""
+    p, o = products[radius], ck.oracle(radius)
+    api = p.api
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    R = int(ost.cfg.radius_frames)
+    padded = ck.pad_frames(ck.noise_pcm(frames * ch, 4242), ch, R)
+    want = o.low_resample_i32_mt(ost, padded, frames, threads=min(32, os.cpu_count() or 1))
+    total = want.size // ch
+    assert total == ck.count_output_frames(ost, frames)
+    d_in = api.DeviceAlloc(padded.nbytes + 64)
+    d_out = api.DeviceAlloc(want.nbytes + 64)
+    try:
+        api.CopyToDevice(d_in, padded)
+        del padded
+        plan = api.PlanCreate(st.raw, p.pre)
+        before = [api.LaunchCount(k) for k in range(8)]
+        n, left, ran_out = api.ResampleDevice(plan, st.raw, d_in, frames, d_out, total + 1)
+        api.StreamSynchronize()
+        after = [api.LaunchCount(k) for k in range(8)]
+        assert n == total and left == 0 and ran_out == 1
+        launched = [a - b for a, b in zip(after, before)]
+        assert sum(launched[:7]) == 1, ("the call must be ONE launch", launched)
+        if kernel is not None:
+            assert launched[kernel] == 1, (name, launched)
+        if ticketed is not None:
+            assert launched[7] == (1 if ticketed else 0), (name, "ticket scheduler", launched)
+        got = np.empty_like(want)
+        api.CopyFromDevice(got, d_out)
+        assert np.array_equal(got, want)
+        # the state the reference leaves when the input runs out (clownresampler.h:1065-1067): the overshoot into the next chunk
+        end = total * int(ost.increment)
+        assert (st.pos_int, st.pos_frac) == ((end >> 16) - frames, end & 0xFFFF)
+    finally:
+        api.DeviceFree(d_in)
+        api.DeviceFree(d_out)
+
+
 @pytest.mark.parametrize("ch", [1, 2])
 @pytest.mark.parametrize("radius,rates", [(3, (48000, 32000, 32000)), (3, (96000, 64000, 64000)), (3, (24000, 48000, 24000)), (8, (24000, 48000, 24000)), (8, (48000, 32000, 32000)),
                                           (5, (24000, 48000, 24000)), (5, (48000, 32000, 32000)), (8, (12000, 48000, 12000)), (5, (12000, 48000, 12000))])
@@ -727,6 +787,77 @@ def test_variable_rate_segments_on_device(products, radius, ch, s16, mode):
     assert np.array_equal(got[:len(want)], want) and not got[len(want):].any()
     assert (st.lowest_level.stretched_kernel_radius, st.position_integer, st.position_fractional, st.increment) == \
            (ost.cfg.stretched_radius, ost.pos_int, ost.pos_frac, ost.increment)
+
+
+def test_variable_rate_segments_captured_into_a_graph(products):
+    """many short segments take ONE launch with a segment table that travels through a reused pinned buffer behind
+    an event - state a hipGraph cannot own.  On a capturing stream the call must fall back to one launch per segment (everything in
+    the kernel arguments, capture-pool ticket blocks): the graph then replays correctly AFTER another segments call has reused the
+    table buffers, and the eager calls around it still take the table."""
+    import torch
+    p, o = products[3], ck.oracle(3)
+    api = p.api
+    dev = torch.device("cuda", 0)
+    ch, halo, first = 2, 20, (44100, 48000, 44100)
+    rng = np.random.default_rng(2024)
+
+    def make(n_seg):
+        return [(int(rng.integers(200, 3000)), int(rng.integers(30000, 96000)), int(rng.integers(30000, 96000)), int(rng.integers(30000, 96000))) for _ in range(n_seg)]
+
+    seg_a, seg_b = make(12), make(15)
+    runs = {}
+    for key, segments, seed in (("a", seg_a, 5), ("b", seg_b, 6)):
+        frames = sum(s[0] for s in segments)
+        pcm = ck.noise_pcm(frames * ch, seed)
+        want, counts, ost = _oracle_segments(o, ch, pcm, frames, halo, segments, first)
+        runs[key] = dict(segments=segments, want=want, d_in=torch.from_numpy(ck.pad_frames(pcm, ch, halo)).to(dev),
+                         d_out=torch.zeros(len(want) + 64, dtype=torch.int32, device=dev))
+
+    def call(key, stream=None):
+        r = runs[key]
+        st = api.LowLevel_State()
+        api.LowLevel_Init(st, ch, *first)
+        before = [api.LaunchCount(k) for k in range(7)]
+        n, _ = api.ResampleSegmentsDevice(st, p.pre, r["d_in"].data_ptr() + halo * ch * 2, halo, r["segments"], r["d_out"].data_ptr(), len(r["want"]) // ch,
+                                          hip_stream=stream)
+        assert n == len(r["want"]) // ch
+        return sum(api.LaunchCount(k) - before[k] for k in range(7))
+
+    # eager, rule's choice: ONE launch (and every plan the capture will need now exists: nothing allocates mid-capture)
+    api.DebugSegmentsMode(1)
+    call("a"); call("b")
+    api.DebugSegmentsMode(0)
+    assert call("a") == 1
+    torch.cuda.synchronize()
+    assert np.array_equal(runs["a"]["d_out"].cpu().numpy()[:len(runs["a"]["want"])], runs["a"]["want"])
+
+    api.ReserveCaptureLaunches(64)
+    cap_stream = torch.cuda.Stream(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(cap_stream):
+        with torch.cuda.graph(graph, stream=cap_stream):
+            launched = call("a", torch.cuda.current_stream(dev).cuda_stream)
+    assert launched == len(seg_a), "under capture: one launch per segment"
+    for rep in range(2):
+        # another eager call reuses the table buffers the first form of the code would have captured
+        assert call("b") == 1
+        torch.cuda.synchronize()
+        assert np.array_equal(runs["b"]["d_out"].cpu().numpy()[:len(runs["b"]["want"])], runs["b"]["want"])
+        runs["a"]["d_out"].zero_()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        got = runs["a"]["d_out"].cpu().numpy()
+        assert np.array_equal(got[:len(runs["a"]["want"])], runs["a"]["want"]) and not got[len(runs["a"]["want"]):].any(), rep
+    del graph
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    # the graph is gone: its ticket blocks go back to the pool (ClownResamplerAMD_ReleaseCapturedLaunches), and the library works on
+    assert api.ReleaseCapturedLaunches() == 0
+    assert call("a") == 1
+    torch.cuda.synchronize()
+    assert np.array_equal(runs["a"]["d_out"].cpu().numpy()[:len(runs["a"]["want"])], runs["a"]["want"])
 
 
 def test_variable_rate_segments_validate_before_launching(products):

@@ -433,3 +433,56 @@ def test_device_code_keeps_its_promises(tmp_path):
                 pending_checked += 1
             i = j
     assert draws >= 50 and pending_checked >= 2, (draws, pending_checked)   # every ticketed kernel; k_up2's two output forms
+
+
+REFERENCE = "/root/reference"
+
+
+def _symlink_tree(tmp_path, sub, names):
+    """<tmp>/clownresampler.h -> include/clownresampler.h (+ the generated radius list it includes), <tmp>/<sub>/<name> -> the
+    reference's own file.  Symlinks only: nothing of the reference is copied, nothing travels."""
+    tree = tmp_path / "tree"
+    (tree / sub).mkdir(parents=True)
+    for h in os.listdir(os.path.join(ROOT, "include")):
+        os.symlink(os.path.join(ROOT, "include", h), tree / h)
+    for n in names:
+        os.symlink(os.path.join(REFERENCE, sub, n), tree / sub / n)
+    return tree
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="container only: needs the reference's own client sources")
+@pytest.mark.parametrize("source", ["test-low-level.c", "test-high-level.c"])
+def test_reference_test_harnesses_build_against_the_drop_in(tmp_path, source):
+    """The source-level drop-in claim, pinned: the reference's UNMODIFIED harnesses (tests/test-low-level.c:25-28 and
+    tests/test-high-level.c:25-27 define CLOWNRESAMPLER_IMPLEMENTATION + _STATIC and include "../clownresampler.h") compile as
+    strict C89 against include/clownresampler.h and link against libclownresampler_amd.so the way tests/CMakeLists.txt:5-11 links
+    them (plus the library) - and every ClownResampler_* function they call is then an UNDEFINED symbol the library provides, i.e.
+    no reference implementation was compiled in."""
+    tree = _symlink_tree(tmp_path, "tests", [source, "dr_flac.h"])
+    exe = tmp_path / "harness"
+    cmd = ["gcc", "-std=c89", "-pedantic", "-Wall", "-O1", str(tree / "tests" / source), "-o", str(exe),
+           "-L", os.path.dirname(cr.LIB_PATH), "-Wl,-rpath," + os.path.dirname(cr.LIB_PATH), "-lclownresampler_amd", "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "clownresampler.h" not in r.stderr, r.stderr[-3000:]          # not one diagnostic from our header under -pedantic
+    undefined = set(re.findall(r"\bU (ClownResampler\w+)", subprocess.run(["nm", str(exe)], capture_output=True, text=True, check=True).stdout))
+    expect = {"ClownResampler_Precompute", "ClownResampler_LowLevel_Init", "ClownResampler_LowLevel_Resample"} if source == "test-low-level.c" else \
+             {"ClownResampler_Precompute", "ClownResampler_HighLevel_Init", "ClownResampler_HighLevel_Resample", "ClownResampler_HighLevel_ResampleEnd"}
+    assert undefined == expect, undefined
+    lib = C.CDLL(cr.LIB_PATH)
+    assert all(hasattr(lib, n) for n in undefined)
+    # and the usage message of the harness still comes out (no GPU is touched before the arguments are read)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode != 0 or out.stdout or out.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="container only: needs the reference's own client sources")
+@pytest.mark.parametrize("source", ["low-level.c", "high-level.c"])
+def test_reference_examples_compile_against_the_drop_in(tmp_path, source):
+    """examples/low-level.c:42-45 / examples/high-level.c:42-44: the players include the header the same way.  They need an audio
+    device and miniaudio's system libraries to LINK, so this is the compile half only (-fsyntax-only, strict C89 as the reference
+    builds them) - enough to pin that every declaration, struct field and macro they use exists with a compatible type."""
+    tree = _symlink_tree(tmp_path, "examples", [source, "libraries"])
+    r = subprocess.run(["gcc", "-std=c89", "-pedantic", "-fsyntax-only", str(tree / "examples" / source)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "clownresampler.h" not in r.stderr, r.stderr[-3000:]

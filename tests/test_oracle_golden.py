@@ -125,3 +125,21 @@ def test_multithreaded_baseline_equals_single_thread():
     for threads in (1, 2, 3, 8):
         ok, fresh = o.low_init(2, 44100, 48000, 44100)
         assert np.array_equal(o.low_resample_i32_mt(fresh, padded, frames, threads), one)
+
+
+def test_multithreaded_oracle_from_a_carried_state_equals_single_thread():
+    """bench.py checks every rank's WHOLE shard with the all-core driver; a shard's state is not fresh (position carried over from
+    the closed form, clownresampler.h:1076-1078), so the driver must start its timeline there."""
+    o = ck.oracle(3)
+    for ch, rates, pos in ((2, (44100, 48000, 44100), (0, 12345)), (1, (48000, 44100, 44100), (2, 65535)), (3, (44100, 8000, 8000), (7, 1)), (2, (8000, 44100, 8000), (0, 0))):
+        frames = 30011
+        ok, st = o.low_init(ch, *rates)
+        R = int(st.cfg.radius_frames)
+        padded = ck.pad_frames(ck.noise_pcm(frames * ch, 5), ch, R)
+        st.pos_int, st.pos_frac = pos
+        ok, carried = o.low_init(ch, *rates)
+        carried.pos_int, carried.pos_frac = pos
+        one, _, _ = o.low_resample_i32(st, padded, frames)
+        assert one.size == ck.count_output_frames(carried, frames) * ch
+        for threads in (1, 2, 5, 8):
+            assert np.array_equal(o.low_resample_i32_mt(carried, padded, frames, threads), one), (ch, rates, pos, threads)

@@ -11,7 +11,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS" \
            "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_COUNT" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc$i" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-check --no-host-paths "$@" > "$OUT/pmc$i.log" 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc$i" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-check --no-host-paths --no-n1-reference "$@" > "$OUT/pmc$i.log" 2>&1
   echo "pass $i ($grp): rc=$?"
 done
 python3 - "$OUT" "$GRAFT_REPO_ROOT" <<'PY'

@@ -600,7 +600,7 @@ def main():
     ran = api.PlanKernelAt(plan, shard_state.position_fractional)   # (5 = k_int: whole-number ratios, decided per launch by its fraction)
     if ran != 5:
         ran = info.brief_kernel if (info.kernel == 3 and shard.output_frames < info.brief_below) else info.kernel
-    kernel_name = {1: "k_poly<%d,%d>", 2: "k_wave<%d,%d>", 3: "k_up2<%d,%d>" if (info.variant in (27, 0xFFFF) and ch == 2) else "k_up<%d,%d>",   # (stereo: variant 27, the default, is k_up2; 26 and other channel counts k_up)
+    kernel_name = {1: "k_poly<%d,%d>", 2: "k_wave<%d,%d>", 3: "k_up2<%d,%d>" if ch == 2 else "k_up<%d,%d>",   # (stereo: k_up2 - variant 27, the default, with the FP32 round-toward-zero chain, 26 with the integer chain; other channel counts k_up)
                    4: "k_wave2<%d,%d>", 5: "k_int<%d,%d>", 6: "k_wave2s<%d,%d>"}[ran] % (ch, info.slots) if ran else "k_generic"
     if launches_by_kernel[ran] < args.steps:
         raise SystemExit("bench: expected the timed launches on kernel %d (%s); launch counters say %s" % (ran, kernel_name, launches_by_kernel))

@@ -218,6 +218,8 @@ static unsigned long long g_launch_count[CR_KERNEL_IDS];
    3 tiles 17.3 / 22.0, 16x: 1 tile 31.4 / 21.2, 2 tiles 31.9 / 35.5 */
 #define CR_BRIEF_HALF_TILES_LONG_WINDOWS 7
 #define CR_BRIEF_HALF_TILES 3
+/* bytes of slack k_up2 keeps on either side of a wave's staged frames (= UP2_SLACK, cr_kup.hpp) */
+#define CR_UP2_SLACK 144u
 /* k_up2 as an instance's default kernel: see plan_geometry */
 #define CR_UP_DEFAULT_MAX_INCREMENT (65536u / 8u)
 #define CR_UP_DEFAULT_MIN_INCREMENT (65536u / 13u)
@@ -987,14 +989,18 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 		{
 			cr_poly_slot_signs(&plan->poly, &pos_bits, &neg_bits);
 			ok = (neg_bits & ~negmask) == 0 && (pos_bits & negmask) == 0;
+			/* k_up2 stages every weight outside the two centre slots as |weight| << 15 (the mov-armed chain, cr_kup.hpp) */
+			if (ok && (cr_poly_slots_reaching(&plan->poly, 65536) & ~crhip_poly_mad_safemask(plan->poly.slots)) != 0)
+				ok = 0;
 		}
 
 		if (wave_tile > frames_multiple)
 			wave_tile = frames_multiple;
 		{
-			/* ... and no larger than the staging space one workgroup per CU leaves each wave */
+			/* ... and no larger than the staging space one workgroup per CU leaves each wave (k_up2: slack on either side of a wave's
+			   staged frames for the surplus frames of its unpredicated loop, UP2_SLACK in cr_kup.hpp) */
 			const uint32_t waves = plan->threads / 64u;
-			const uint32_t fixed = rows_bytes + 16u + waves * 2u * 1024u;
+			const uint32_t fixed = rows_bytes + 16u + waves * (2u * 1024u + 2u * CR_UP2_SLACK);
 			const uint32_t lds = (uint32_t)di->max_lds_per_block < 160u * 1024u ? (uint32_t)di->max_lds_per_block : 160u * 1024u;
 			const uint64_t room = lds > fixed ? ((lds - fixed) / waves & ~15u) / unit : 0;
 
@@ -1008,7 +1014,7 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 		{
 			const uint32_t stage_bytes = ((uint32_t)wave_tile * unit + 15u) & ~15u;
 
-			plan->lds_bytes = rows_bytes + (plan->threads / 64u) * (2u * 1024u + stage_bytes) + 16u;
+			plan->lds_bytes = rows_bytes + (plan->threads / 64u) * (2u * 1024u + stage_bytes + 2u * CR_UP2_SLACK) + 16u;
 			plan->tile_frames = (uint32_t)wave_tile * 4u;
 			per_cu = (160u * 1024u) / plan->lds_bytes;
 			if (per_cu > 2048u / plan->threads)

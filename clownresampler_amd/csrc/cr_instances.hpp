@@ -193,8 +193,11 @@ special make_special()
 		s.up[0] = (poly_fn)k_up<CH, TT, NORM, UPMASK, UP_WAVES, 0, 1, 0, 1>;   // round 1's form (64-bit chain, bias registers): kept for comparison
 		if constexpr (CH == 2)
 		{
-			s.up[1] = (poly_fn)k_up2<CH, TT, NORM, UPMASK, UP_WAVES, 0, 1>;
-			s.up16 = (poly_fn)k_up2<CH, TT, NORM, UPMASK, UP_WAVES, 1, 1>;
+			// stereo: variant 26 = k_up2 with the integer chain (v_mov_b32 + v_mad_i64_i32 per tap), variant 27 (the default where k_up
+			// is one) = k_up2 with the FP32 round-toward-zero chain (one v_pk_fma_f32 per tap)
+			s.up[0] = (poly_fn)k_up2<CH, TT, NORM, UPMASK, UP_WAVES, 0, 1, 0, 0>;
+			s.up[1] = (poly_fn)k_up2<CH, TT, NORM, UPMASK, UP_WAVES, 0, 1, 0, 1>;
+			s.up16 = (poly_fn)k_up2<CH, TT, NORM, UPMASK, UP_WAVES, 1, 1, 0, 1>;
 		}
 		else
 		{

@@ -421,23 +421,44 @@ __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 // and produces all of its output frames; results staged through LDS, coalesced stores; wave-autonomous), different arithmetic
 // and bookkeeping:
 //
-//   * The tap is  P = v_mad_i64_i32(S, W, P)  on a 64-bit accumulator pair P = {lo, hi} with
-//         S  = sample * 32768, negated for the slots whose weights are <= 0      (once per window, one multiply)
-//         W  = 2 * |weight|                                                      (once per workgroup, while the rows are staged)
-//         lo = S >> 31  (all ones where S < 0)                                   (once per window; one plain move per tap re-arms it)
-//     S * W = sample * weight * 65536 exactly (the two sign flips cancel), so the product's integer part lands in `hi` and its
-//     16 fraction bits in the top of `lo`.  With every W >= 0 the product is negative exactly where S is, and there the all-ones
-//     `lo` makes the carry into `hi` round the quotient up: hi += trunc(sample * weight / 65536), C's division
-//     (clownresampler.h:1020 via :625), for negative and positive products alike ((p << 16) + 0xFFFFFFFF carries iff the
-//     fraction bits of p are not all zero).  No per-sample sign work in the frame loop: a move and a multiply-add per tap and
-//     channel, against 4 VALU of the per-output-frame kernels.
-//   * The final (acc * reciprocal) / 32768 (clownresampler.h:1033) is one more 64-bit multiply-add and a funnel shift.
-//   * The frames of a lane run under a WAVE-UNIFORM trip count (floor(65536 / increment), plus one only for waves in which
-//     some position has the extra frame), with one predicate for the staging store - no per-lane loop control - and the
-//     lane's first frame is found once per wave-tile (its end is the next lane's start).
-//   * The copy-out of the staged frames runs on a wave-uniform base with one lane offset: no address arithmetic per vector.
+//   * The tap is  P = v_mad_i64_i32(X, W, P)  on a 64-bit accumulator pair P = {lo, hi}, in k_wave2's mov-armed form:
+//         X  = 2 * sample, negated for the slots whose weights are <= 0          (once per window: one SDWA multiply)
+//         W  = |weight| << 15                                                    (once per workgroup, while the rows are staged)
+//         lo = X                                                                 (ONE plain move per tap re-arms it)
+//     X * W = sample * weight * 65536 exactly (the two sign flips cancel), so the product's integer part lands in `hi` and its
+//     16 fraction bits in the top of `lo`.  With every W >= 0 the product is negative exactly where X is, and X ITSELF is a valid
+//     arm: the product is a multiple of 65536, so a `lo` in [2^32 - 65536, 2^32) carries into `hi` exactly when the fraction is not
+//     zero and a `lo` in [0, 65536] never does: hi += trunc(sample * weight / 65536), C's division (clownresampler.h:1020 via :625).
+//     |weight| << 15 needs |weight| < 65536: the two slots around the kernel's centre (mad_safemask<TT>(), weights up to 65536, never
+//     negative) keep the plain weight and take S = sample << 16 with the sign-shift arm B = S >> 31 - two registers per sample for
+//     those two slots only (round 2's form had S and B for all fifteen: 60 VALU per window and 60 registers; now 38 and 34).
+//   * A frame's FIRST tap adds to a pinned pair {X of slot 0, 0}: no zeroing of the accumulator, no arming move for that tap.
+//   * The final (acc * reciprocal) / 32768 (clownresampler.h:1033) is one more 64-bit multiply-add on a pinned pair {bias, 0}
+//     and a funnel shift.
+//   * Every lane runs the SAME number of frames: n_min = floor(65536 / increment) without any predicate - a lane clipped by the
+//     tile's end writes its surplus into slack behind the staged frames, lane 0 (whose position may have begun in the previous
+//     tile) runs end-aligned and writes its surplus into slack in front - plus ONE predicated frame in the waves where some
+//     position has n_min + 1.
+//   * The copy-out of the staged frames goes through a buffer descriptor of exactly the tile's bytes: wave-uniform base, one
+//     lane offset, no bounds arithmetic (stores beyond the tile are dropped by the range check).
 // ---------------------------------------------------------------------------------------------------------
-template <int CH, int TT, int NORM, unsigned NEGMASK, int WAVES, int OUT16, int NT, int ABL = 0>
+// bytes of slack on either side of a wave's staging buffer (16 surplus frames of 8 bytes, rounded up to 16 bytes)
+constexpr unsigned UP2_SLACK = 144u;
+//
+// FCHAIN = 1: the tap as ONE instruction, on the FLOAT pipe (round 4).  An FP32 accumulator that starts at 2^23 has an ulp of exactly 1,
+// and under round-toward-zero fma(|v|, |w| / 65536, acc) = acc + floor(|v| |w| / 65536): the product is exact inside the fused
+// operation (15 x 17 bits), the sum is rounded once, toward zero = downward for a positive sum - C's truncating division
+// (clownresampler.h:1020 via :625) of a non-negative product, accumulated, no arming, no 64-bit pair.  A negative product
+// truncates toward zero the same way on an accumulator that starts at -2^23.  Which of the two a tap feeds is the sign of
+// sample x weight - the weight's sign is the slot's (NEGMASK), the sample's is known once per window - so the window is
+// unpacked into pairs {max(v, 0), min(v, 0)} of v = +-sample as floats, the rows are staged as |weight| / 65536 (exact: at most
+// 17 bits), and v_pk_fma_f32 advances BOTH chains of a channel in one instruction (one of the two adds zero).  The frame's sum is
+// (bits of the positive chain) - (bits of the negative chain) + 2^31.  No slot is special (a weight of 65536 is 1.0f), nothing is
+// pinned.  |sum| < 2^23 is what the host proves for every 32-bit kernel; the chains' partial sums are bounded by the sum of
+// |weight| x 2^15 / 65536 < 2^19 for any table the 32-bit kernels accept.  tools/microbench/rtzchain.hip checks 2.7e8 random
+// 15-tap frames against the integer definition (0 differ) and tools/microbench/valurate.hip prices the instructions:
+// v_pk_fma_f32 2.0 ns per wave-instruction and SIMD at this occupancy against 2.95 for v_mov_b32 + v_mad_i64_i32.
+template <int CH, int TT, int NORM, unsigned NEGMASK, int WAVES, int OUT16, int NT, int ABL = 0, int FCHAIN = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 {
 	static_assert(CH == 2, "k_up2 is written for stereo (one packed dword per input frame, two accumulator pairs)");
@@ -495,17 +516,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 
 	const unsigned WT = a.tile_frames / 4u;        // output frames per wave-tile: at most 64 input positions
 	const unsigned stage_bytes = (WT * UNIT + 15u) & ~15u;
+	static_assert(17u * UNIT <= UP2_SLACK, "slack for a lane's surplus frames on either side of the staged tile");
 
+	// per wave: two window buffers, slack, the staged frames of a wave-tile, slack (the host sizes the workgroup's LDS for this:
+	// cr_context.c, plan_geometry)
 	const unsigned rows_bytes = a.plane_rows * a.row_stride * 4u;
-	unsigned char *my_buf = smem + rows_bytes + wave * (2u * BUF + stage_bytes);
-	unsigned char *my_stage = my_buf + 2u * BUF;
-	unsigned *waves_done = reinterpret_cast<unsigned *>(smem + rows_bytes + WAVES * (2u * BUF + stage_bytes));
+	unsigned char *my_buf = smem + rows_bytes + wave * (2u * BUF + stage_bytes + 2u * UP2_SLACK);
+	unsigned char *my_stage = my_buf + 2u * BUF + UP2_SLACK;
+	unsigned *waves_done = reinterpret_cast<unsigned *>(smem + rows_bytes + WAVES * (2u * BUF + stage_bytes + 2u * UP2_SLACK));
 
 	if (tid == 0)
 		*waves_done = 0;
 
-	// Stage the polyphase rows once per workgroup - as W = 2 * |weight|: plane q of the image holds int32 [4q, 4q + 4) of every
-	// row, i.e. slots 4q .. 4q + 3 (the reciprocal sits in slot TT and stays as it is).  The only barrier of the kernel.
+	// Stage the polyphase rows once per workgroup - as W = |weight| << 15 (mad_staged_weight): plane q of the image holds int32
+	// [4q, 4q + 4) of every row, i.e. slots 4q .. 4q + 3 (the reciprocal sits in slot TT).  The only barrier of the kernel.
 	{
 		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.d_rows);
 		u32x4 *dst = reinterpret_cast<u32x4 *>(smem);
@@ -535,8 +559,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 					for (int j = 0; j < 4; ++j)
 					{
 						const int slot = 4 * q + j;
-						if (slot < TT)
-							e[j] = ((NEGMASK >> slot) & 1u) ? -2 * e[j] : 2 * e[j];
+						if (slot < TT && FCHAIN)
+							e[j] = (int)__float_as_uint((float)(e[j] < 0 ? -e[j] : e[j]) * (1.0f / 65536.0f));   // |weight| / 65536 as a float: exact
+						else if (slot < TT)
+							e[j] = mad_staged_weight<TT, NEGMASK>(e[j], slot);   // |weight| << 15; the centre slots: the weight as it is
 						else if (slot == TT && NORM == CRHIP_NORM_U32)
 							e[j] = 2 * e[j];   // the reciprocal, doubled: see the normalisation in `one`
 					}
@@ -617,53 +643,110 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 	// smallest k with frac0 + k * increment >= l * 65536: the first frame (relative to the wave-tile) of input position l >= 1
 	auto first_frame_of = [&](unsigned l, unsigned frac0) -> unsigned {
 		const unsigned x = (l << 16) - frac0;                     // 1 .. 2^22
-		unsigned k = (unsigned)((float)x * inv_increment);        // within one of the quotient; made exact below
+		// x < 2^22 is exact as a float, the reciprocal and the product are good to 2^-22 of a quotient below 2^11: the truncated
+		// estimate is the answer or one off it, either way
+		unsigned k = (unsigned)((float)x * inv_increment);
 		k += (__umul24(k, a.increment) < x) ? 1u : 0u;
-		k += (__umul24(k, a.increment) < x) ? 1u : 0u;
-		k -= (k != 0 && __umul24(k - 1u, a.increment) >= x) ? 1u : 0u;
 		k -= (k != 0 && __umul24(k - 1u, a.increment) >= x) ? 1u : 0u;
 		return k;
 	};
 
 	// one wave-tile: n output frames from `first`, window at `base`; returns the number of store instructions issued
+	constexpr unsigned SAFEMASK = mad_safemask<TT>();
+	static_assert(TT > 1 && SAFEMASK != 0 && (SAFEMASK & NEGMASK) == 0 && !(SAFEMASK & 1u) && !(NEGMASK & 0u), "slot classes of the instance: slot 0 ordinary, the centre slots never negative");
 	auto wave_tile = [&](uint64_t first, unsigned n, const unsigned char *base) -> unsigned {
 		const uint64_t pos = a.pos0 + first * (uint64_t)a.increment;
 		const unsigned frac0 = (unsigned)(pos & 0xFFFFu);
 
 		// this lane's frames: [k0, k1) = [first frame of position `lane`, first frame of position `lane + 1`), clipped to the tile
-		unsigned k1 = first_frame_of(lane + 1u, frac0);
-		k1 = k1 < n ? k1 : n;
+		const unsigned k1_whole = first_frame_of(lane + 1u, frac0);   // (where the position ends in the stream, tile or no tile)
+		const unsigned k1 = k1_whole < n ? k1_whole : n;
 		unsigned k0 = (unsigned)__shfl_up((int)k1, 1);
 		k0 = lane == 0 ? 0u : k0;
 		const unsigned count = k1 - k0;
-		// wave-uniform trip count: n_min, or one more where some lane has its position's extra frame
-		const unsigned trips = ABL == 2 ? 0u : __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(count > n_min) != 0 ? n_min + 1u : n_min);
+		// Every lane runs n_min frames from `start` WITHOUT a predicate, all of them frames of ITS position (the running row index
+		// g only ever moves within one position: it does not survive the wrap of the fraction).  A position has n_min or n_min + 1
+		// frames in the stream.  A lane clipped by the tile's end keeps its start and writes its surplus at frame numbers >= n:
+		// slack behind the staged tile (nobody's frames).  Lane 0's position may have begun before the tile: it runs END-aligned
+		// on the position's last n_min frames, [k1_whole - n_min, k1_whole) - a start <= 0, the surplus at negative frame numbers:
+		// slack in front (and, where the tile ends before the position does, behind).  The one frame that would land on a
+		// neighbour's - the (n_min + 1)-th of a position that has only n_min - is the predicated extra trip.
+		const bool extra = count > n_min;
+		const int end_aligned = (int)k1_whole - (int)n_min;
+		const int start = (lane == 0 && !extra) ? (end_aligned < 0 ? end_aligned : 0) : (int)k0;
+		const bool any_extra = ABL != 2 && __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(extra) != 0);
+		const unsigned trips = ABL == 2 ? 0u : n_min;
 
-		// the window of this lane's input position: S = sample * +-32768, once
+		// the window of this lane's input position, once: X = +-2 * sample (operand AND arm of the ordinary slots); the centre
+		// slots: S = sample << 16 and its sign B
 		int f[TT];
 #pragma unroll
 		for (int s = 0; s < TT; ++s)
 			f[s] = *reinterpret_cast<const int *>(base + (lane + (unsigned)s) * FB);
-		int S[TT][CH], B[TT][CH];   // B = all ones where S < 0: the low dword a tap's accumulator pair starts from
-#pragma unroll
-		for (int s = 0; s < TT; ++s)
+		typedef float f32x2 __attribute__((ext_vector_type(2)));
+		f32x2 P[FCHAIN ? TT : 1][CH];   // FCHAIN: {max(v, 0), min(v, 0)} of v = +-sample
+		if constexpr (FCHAIN)
 		{
-			const int k = ((NEGMASK >> s) & 1u) ? -32768 : 32768;
-			S[s][0] = __mul24((int)(short)f[s], k);
-			S[s][1] = __mul24(f[s] >> 16, k);
-			B[s][0] = S[s][0] >> 31;
-			B[s][1] = S[s][1] >> 31;
-			asm volatile("" : "+v"(B[s][0]), "+v"(B[s][1]));   // keep them in registers: hipcc otherwise re-forms the shift in every frame
+#pragma unroll
+			for (int s = 0; s < TT; ++s)
+			{
+				float v0, v1;
+				asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(v0) : "v"(f[s]));
+				asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(v1) : "v"(f[s]));
+				if ((NEGMASK >> s) & 1u)
+				{
+					asm("v_max_f32_e64 %0, -%1, 0" : "=v"(P[s][0].x) : "v"(v0));
+					asm("v_min_f32_e64 %0, -%1, 0" : "=v"(P[s][0].y) : "v"(v0));
+					asm("v_max_f32_e64 %0, -%1, 0" : "=v"(P[s][1].x) : "v"(v1));
+					asm("v_min_f32_e64 %0, -%1, 0" : "=v"(P[s][1].y) : "v"(v1));
+				}
+				else
+				{
+					asm("v_max_f32_e64 %0, %1, 0" : "=v"(P[s][0].x) : "v"(v0));
+					asm("v_min_f32_e64 %0, %1, 0" : "=v"(P[s][0].y) : "v"(v0));
+					asm("v_max_f32_e64 %0, %1, 0" : "=v"(P[s][1].x) : "v"(v1));
+					asm("v_min_f32_e64 %0, %1, 0" : "=v"(P[s][1].y) : "v"(v1));
+				}
+			}
+		}
+		int X[TT][CH], B[TT][CH];
+		int plus_two = 2, minus_two = -2;
+#pragma unroll
+		for (int s = 0; s < (FCHAIN ? 0 : TT); ++s)
+		{
+			if ((SAFEMASK >> s) & 1u)
+			{
+				X[s][0] = (int)((unsigned)f[s] << 16);
+				X[s][1] = (int)((unsigned)f[s] & 0xFFFF0000u);
+				asm volatile("" : "+v"(X[s][0]), "+v"(X[s][1]));   // (registers: hipcc otherwise re-forms them in every frame)
+				B[s][0] = X[s][0] >> 31;
+				B[s][1] = X[s][1] >> 31;
+				asm volatile("" : "+v"(B[s][0]), "+v"(B[s][1]));
+			}
+			else
+			{
+				// one SDWA multiply per sample, straight from the packed frame (written out: for the factor + 2 hipcc prefers a shift
+				// pair per sample); the result is operand AND arm - B is the same register
+				const int k = ((NEGMASK >> s) & 1u) ? minus_two : plus_two;
+				asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(X[s][0]) : "v"(f[s]), "v"(k));
+				asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(X[s][1]) : "v"(f[s]), "v"(k));
+				B[s][0] = X[s][0];
+				B[s][1] = X[s][1];
+			}
 		}
 
 		// g = 65536 - fraction of the lane's current frame: the row is g >> 6 (pure-upsampling row index), 16 bytes per row and plane
-		unsigned g = 65536u - ((frac0 + __umul24(k0, a.increment)) & 0xFFFFu);
-		unsigned stage_at = k0 * UNIT;   // byte offset of the lane's current frame in the staging buffer
+		unsigned g = 65536u - ((unsigned)((int)frac0 + __mul24(start, (int)a.increment)) & 0xFFFFu);
+		unsigned stage_at = (unsigned)(start * (int)UNIT);   // byte offset of the lane's current frame from my_stage (lane 0: may be negative)
 
 		typedef __attribute__((address_space(3))) i32x4 lds_i32x4;
 		const unsigned smem_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)smem);
 		int thirty_one = 31;
 		asm volatile("" : "+v"(thirty_one));   // (a register: SDWA takes no literal shift amount)
+		// the high halves of the four pinned addend pairs: zeros the compiler must not know to be zeros (it would re-materialise a
+		// constant next to every use - four moves per frame - instead of keeping v113 / v115 / v117 / v119 set across the loop)
+		int zero_a = 0, zero_b = 0, zero_c = 0, zero_d = 0;
+		asm volatile("" : "+{v113}"(zero_a), "+{v115}"(zero_b), "+{v117}"(zero_c), "+{v119}"(zero_d));
 
 		auto read_row = [&](unsigned gg, int (&w)[RS]) {
 			// (a prefetch past the lane's last frame stays inside the image; bit-field extract + shift-add: one instruction fewer than
@@ -683,34 +766,94 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 			}
 		};
 
-		auto one = [&](const int (&w)[RS], bool mine) {
-			// accumulator pairs pinned to physical registers; the low dword is re-armed by a plain move of the slot's bias register
-			// (a v_ashrrev from S instead would save the bias registers but measured 30 % slower per frame at this occupancy:
-			// tools/microbench/chainbench.hip, profiles/r02_chainbench.log)
-			int lo0, hi0 = 0, lo1, hi1 = 0;
-			// How the statement is declared matters as much as what is in it: hipcc treats every asm statement as a possible
-			// forwarding hazard and pads with an s_nop whenever a register one statement DEFINES is touched - read or written - by
-			// the next instruction with nothing but other asm statements in between.  Declared with the low dword as an output and
-			// vcc as the carry-out of both chains, the frame loop carried 15 s_nop per frame beside its 73 VALU instructions
-			// (profiles/r03_kup2_nops.log).  So: (1) the two chains take their carry-out in different registers, vcc and
-			// s[94:95], and may sit back to back; (2) the low dword is declared as an INPUT only - the multiply-add leaves the
-			// product's fraction bits there, which nothing ever reads: the next tap's arming move overwrites it, and that move is
-			// hipcc's own instruction, free to follow the statement directly.  (What the compiler believes about v120 / v124 after
-			// a statement - "still the bias I put there" - is never used: every tap arms with a different register.)
-#define CRHIP_UP2_TAP(LO, HI, VLO, VHI, SAMPLE, WEIGHT, BIAS)                                                                       \
-	VLO = (BIAS);                                                                                                                  \
+		f32x2 chain_base;   // FCHAIN: where a frame's two chains start
+		chain_base.x = 8388608.0f;
+		chain_base.y = -8388608.0f;
+		asm volatile("" : "+v"(chain_base));
+		// PRED: the frame is stored only by the lanes with `extra`
+		auto one = [&](const int (&w)[RS], auto pred_tag) {
+			constexpr bool PRED = decltype(pred_tag)::value;
+			// Accumulator pairs pinned to physical registers: v[120:121] / v[124:125]; the first tap's addend pairs {X of slot 0, 0}:
+			// v[112:113] / v[114:115]; the normalisation's addend pairs {bias, 0}: v[116:117] / v[118:119], its products v[122:123] /
+			// v[126:127].  How a statement is DECLARED matters as much as what is in it: hipcc treats every asm statement as a
+			// possible forwarding hazard and pads with an s_nop whenever a register one statement DEFINES is touched - read or
+			// written - by the next instruction with nothing but other asm statements in between (15 s_nop per frame beside 73 VALU
+			// in round 3's first form, profiles/r03_kup2_nops.log).  So (1) the two chains take their carry-out in different
+			// registers, vcc and s[94:95], and may sit back to back; (2) a tap declares its low dword as an INPUT and a CLOBBER-free
+			// one: the multiply-add leaves the product's fraction bits there, which nothing ever reads - the next tap's arming move
+			// (hipcc's own instruction, free to follow the statement directly) overwrites it, and the last tap's is dead.  What
+			// the compiler may wrongly believe - "v120 still holds the arm I moved there" - it never uses: every tap arms with a
+			// different register (static_assert(TT > 1) above; tests/test_gpu_parity.py::test_input_stationary_* run every instance
+			// against the oracle).
+			int lo0, hi0, lo1, hi1;
+			if constexpr (FCHAIN)
+			{
+				// one v_pk_fma_f32 per tap and channel: {positive chain, negative chain} += {max(v, 0), min(v, 0)} * (|weight| / 65536),
+				// round toward zero (set around the frame loop); the weight is the low or the high half of a register pair of the row
+				// (Written as one or two asm statements, not one per tap: between asm statements that touch a common register hipcc pads
+				// with s_nop - 10 per frame here - while dependent VALU instructions inside a statement need none: the hardware
+				// interlocks them.  An asm statement takes at most 30 operands: 15 slots are two statements.)
+				f32x2 a0, a1;
+				auto wpair = [&](int k) {
+					f32x2 wp;
+					wp.x = __uint_as_float((unsigned)w[2 * k]);
+					wp.y = __uint_as_float((unsigned)w[2 * k + 1]);
+					return wp;
+				};
+#define CR_E(acc, p, wq) "v_pk_fma_f32 %" #acc ", %" #p ", %" #wq ", %" #acc " op_sel_hi:[1,0,1]\n\t"
+#define CR_O(acc, p, wq) "v_pk_fma_f32 %" #acc ", %" #p ", %" #wq ", %" #acc " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+#define CR_F(acc, p, wq, base) "v_pk_fma_f32 %" #acc ", %" #p ", %" #wq ", %" #base " op_sel_hi:[1,0,1]\n\t"
+				if constexpr (TT == 15)
+				{
+					asm volatile(CR_F(0, 2, 18, 22) CR_F(1, 10, 18, 22) CR_O(0, 3, 18) CR_O(1, 11, 18) CR_E(0, 4, 19) CR_E(1, 12, 19) CR_O(0, 5, 19) CR_O(1, 13, 19)
+					             CR_E(0, 6, 20) CR_E(1, 14, 20) CR_O(0, 7, 20) CR_O(1, 15, 20) CR_E(0, 8, 21) CR_E(1, 16, 21) CR_O(0, 9, 21) CR_O(1, 17, 21)
+					             : "=&v"(a0), "=&v"(a1)
+					             : "v"(P[0][0]), "v"(P[1][0]), "v"(P[2][0]), "v"(P[3][0]), "v"(P[4][0]), "v"(P[5][0]), "v"(P[6][0]), "v"(P[7][0]),
+					               "v"(P[0][1]), "v"(P[1][1]), "v"(P[2][1]), "v"(P[3][1]), "v"(P[4][1]), "v"(P[5][1]), "v"(P[6][1]), "v"(P[7][1]),
+					               "v"(wpair(0)), "v"(wpair(1)), "v"(wpair(2)), "v"(wpair(3)), "v"(chain_base));
+					asm volatile(CR_E(0, 2, 16) CR_E(1, 9, 16) CR_O(0, 3, 16) CR_O(1, 10, 16) CR_E(0, 4, 17) CR_E(1, 11, 17) CR_O(0, 5, 17) CR_O(1, 12, 17)
+					             CR_E(0, 6, 18) CR_E(1, 13, 18) CR_O(0, 7, 18) CR_O(1, 14, 18) CR_E(0, 8, 19) CR_E(1, 15, 19)
+					             : "+v"(a0), "+v"(a1)
+					             : "v"(P[8][0]), "v"(P[9][0]), "v"(P[10][0]), "v"(P[11][0]), "v"(P[12][0]), "v"(P[13][0]), "v"(P[14][0]),
+					               "v"(P[8][1]), "v"(P[9][1]), "v"(P[10][1]), "v"(P[11][1]), "v"(P[12][1]), "v"(P[13][1]), "v"(P[14][1]),
+					               "v"(wpair(4)), "v"(wpair(5)), "v"(wpair(6)), "v"(wpair(7)));
+				}
+				else
+				{
+					static_assert(TT == 5 || TT == 15, "k_up2's float chain is written out for 5 and 15 slots");
+					asm volatile(CR_F(0, 2, 12, 15) CR_F(1, 7, 12, 15) CR_O(0, 3, 12) CR_O(1, 8, 12) CR_E(0, 4, 13) CR_E(1, 9, 13) CR_O(0, 5, 13) CR_O(1, 10, 13)
+					             CR_E(0, 6, 14) CR_E(1, 11, 14)
+					             : "=&v"(a0), "=&v"(a1)
+					             : "v"(P[0][0]), "v"(P[1][0]), "v"(P[2][0]), "v"(P[3][0]), "v"(P[4][0]),
+					               "v"(P[0][1]), "v"(P[1][1]), "v"(P[2][1]), "v"(P[3][1]), "v"(P[4][1]),
+					               "v"(wpair(0)), "v"(wpair(1)), "v"(wpair(2)), "v"(chain_base));
+				}
+#undef CR_F
+#undef CR_O
+#undef CR_E
+				// positive chain = 2^23 + p (bits 0x4B000000 + p), negative chain = -(2^23 + q) (bits 0xCB000000 + q): p - q
+				hi0 = (int)(__float_as_uint(a0.x) - __float_as_uint(a0.y) + 0x80000000u);
+				hi1 = (int)(__float_as_uint(a1.x) - __float_as_uint(a1.y) + 0x80000000u);
+			}
+			else
+			{
+			asm("v_mad_i64_i32 v[120:121], vcc, %1, %2, v[112:113]" : "={v121}"(hi0) : "v"(X[0][0]), "v"(w[0]), "{v112}"(X[0][0]), "{v113}"(zero_a) : "vcc", "v120");
+			asm("v_mad_i64_i32 v[124:125], s[94:95], %1, %2, v[114:115]" : "={v125}"(hi1) : "v"(X[0][1]), "v"(w[0]), "{v114}"(X[0][1]), "{v115}"(zero_b) : "s94", "s95", "v124");
+#define CRHIP_UP2_TAP(LO, HI, VLO, VHI, SAMPLE, WEIGHT, ARM)                                                                        \
+	VLO = (ARM);                                                                                                                   \
 	asm("v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %1, %2, v[" #LO ":" #HI "]" : "+{v" #HI "}"(VHI) : "v"(SAMPLE), "v"(WEIGHT), "{v" #LO "}"(VLO) : "vcc")
-#define CRHIP_UP2_TAP_B(LO, HI, VLO, VHI, SAMPLE, WEIGHT, BIAS)                                                                     \
-	VLO = (BIAS);                                                                                                                  \
+#define CRHIP_UP2_TAP_B(LO, HI, VLO, VHI, SAMPLE, WEIGHT, ARM)                                                                      \
+	VLO = (ARM);                                                                                                                   \
 	asm("v_mad_i64_i32 v[" #LO ":" #HI "], s[94:95], %1, %2, v[" #LO ":" #HI "]" : "+{v" #HI "}"(VHI) : "v"(SAMPLE), "v"(WEIGHT), "{v" #LO "}"(VLO) : "s94", "s95")
 #pragma unroll
-			for (int s = 0; s < TT; ++s)
+			for (int s = 1; s < TT; ++s)
 			{
-				CRHIP_UP2_TAP(120, 121, lo0, hi0, S[s][0], w[s], B[s][0]);
-				CRHIP_UP2_TAP_B(124, 125, lo1, hi1, S[s][1], w[s], B[s][1]);
+				CRHIP_UP2_TAP(120, 121, lo0, hi0, X[s][0], w[s], B[s][0]);
+				CRHIP_UP2_TAP_B(124, 125, lo1, hi1, X[s][1], w[s], B[s][1]);
 			}
 #undef CRHIP_UP2_TAP_B
 #undef CRHIP_UP2_TAP
+			}
 			(void)lo0;
 			(void)lo1;
 
@@ -720,15 +863,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 				// (acc * reciprocal) / 32768 with C truncation (clownresampler.h:1033).  With p = acc * reciprocal that is
 				// floor((2p + (p < 0 ? 65535 : 0)) / 65536): for p = -32768 q - r (0 <= r < 32768) the numerator is -65536 q + (65535 - 2r)
 				// with 0 <= 65535 - 2r < 65536.  The rows carry 2 * reciprocal (staged so above), the 65535 is ONE instruction - the
-				// sign shift written to the low word of a zero-padded register - and the 64-bit multiply-add and a funnel shift finish:
-				// 3 VALU per channel (it was 4 with the 0x7FFF / shift-by-15 form).
-				unsigned b0, b1;
-				asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(b0) : "v"(thirty_one), "v"(hi0));
-				asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(b1) : "v"(thirty_one), "v"(hi1));
-				const long long v0 = (long long)hi0 * (long long)w[TT] + (long long)b0;
-				const long long v1 = (long long)hi1 * (long long)w[TT] + (long long)b1;
-				out0 = (int)(v0 >> 16);
-				out1 = (int)(v1 >> 16);
+				// sign shift written to the low word of a zero-padded register, which is the low half of a pinned pair {bias, 0} -
+				// and the 64-bit multiply-add and a funnel shift finish: 3 VALU per channel.  One statement for both channels: the
+				// two SDWA writes are each an instruction away from the multiply-add that reads them (dst-forwarding needs one).
+				asm("v_ashrrev_i32_sdwa v116, %4, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+				    "v_ashrrev_i32_sdwa v118, %4, %3 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+				    "v_mad_i64_i32 v[122:123], vcc, %2, %5, v[116:117]\n\t"
+				    "v_mad_i64_i32 v[126:127], vcc, %3, %5, v[118:119]\n\t"
+				    "v_alignbit_b32 %0, v123, v122, 16\n\t"
+				    "v_alignbit_b32 %1, v127, v126, 16"
+				    : "=&v"(out0), "=&v"(out1)
+				    : "v"(hi0), "v"(hi1), "v"(thirty_one), "v"(w[TT]), "{v117}"(zero_c), "{v119}"(zero_d)
+				    : "vcc", "v116", "v118", "v122", "v123", "v126", "v127");
 			}
 			else
 			{
@@ -736,21 +882,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 				out1 = normalise<NORM>(hi1, w[TT]);
 			}
 
-			if (mine)
+			if (!PRED || extra)
 			{
 				if constexpr (OUT16)
-					*reinterpret_cast<int *>(my_stage + stage_at) = (clamp_s16(out0) & 0xFFFF) | (clamp_s16(out1) << 16);
+					*reinterpret_cast<int *>(my_stage + (int)stage_at) = (clamp_s16(out0) & 0xFFFF) | (clamp_s16(out1) << 16);
 				else
 				{
 					i32x2 q;
 					q.x = out0;
 					q.y = out1;
-					*reinterpret_cast<i32x2 *>(my_stage + stage_at) = q;
+					*reinterpret_cast<i32x2 *>(my_stage + (int)stage_at) = q;
 				}
 			}
 		};
 
 		mark(0);
+		if constexpr (FCHAIN)
+			asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3");   // FP32 rounding: toward zero, for the chains of the frames
 		// the row of frame j + 1 is read before the arithmetic of frame j (two register sets, loop unrolled by two)
 		int wa[RS], wb[RS];
 		read_row(g, wa);
@@ -758,16 +906,26 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 		{
 			read_row(g - a.increment, wb);
 			__builtin_amdgcn_sched_barrier(0);
-			one(wa, j < count);
+			one(wa, std::false_type());
 			stage_at += UNIT;
+			g -= a.increment;
 			if (j + 1u >= trips)
+			{
+#pragma unroll
+				for (int i = 0; i < RS; ++i)
+					wa[i] = wb[i];
 				break;
-			read_row(g - 2u * a.increment, wa);
+			}
+			read_row(g - a.increment, wa);
 			__builtin_amdgcn_sched_barrier(0);
-			one(wb, j + 1u < count);
+			one(wb, std::false_type());
 			stage_at += UNIT;
-			g -= 2u * a.increment;
+			g -= a.increment;
 		}
+		if (any_extra)
+			one(wa, std::true_type());   // (its row was read as the prefetch of the last trip)
+		if constexpr (FCHAIN)
+			asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0");   // back to round-to-nearest-even
 
 		mark(1);
 		// the staged frames of the other lanes: same wave, LDS operations of a wave complete in order
@@ -775,42 +933,40 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-		// copy-out: wave-uniform base, one lane offset; four LDS reads in flight per trip
+		// copy-out: a buffer descriptor of exactly the tile's bytes (wave-uniform), one lane offset; four LDS reads in flight per
+		// trip; what a trip reads or would write beyond the tile is slack / dropped by the descriptor's range check
 		typedef typename std::conditional<VEC == 8, i32x2, int>::type vec_t;
 		const unsigned vectors = n * UNIT / VEC;
 		const vec_t *staged = reinterpret_cast<const vec_t *>(my_stage) + lane;
 		const uint64_t out_first = reinterpret_cast<uint64_t>(a.d_out) + first * UNIT;
 		const unsigned out_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)out_first);
 		const unsigned out_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(out_first >> 32));
-		// (a GLOBAL pointer by type: through a generic one these were flat stores, which go down the LDS path as well)
-		typedef __attribute__((address_space(1))) vec_t global_vec;
-		global_vec *dst = (global_vec *)(((uint64_t)out_hi << 32) | out_lo);
-		auto put = [&](global_vec *to, vec_t v) {
+		const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)out_hi << 32) | out_lo), 0,
+		                                                                          (int)__builtin_amdgcn_readfirstlane((int)(n * UNIT)), 0x00020000);
+		auto put = [&](unsigned at_vector, vec_t v) {   // at_vector: wave-uniform
 			if constexpr (ABL == 1)
 			{
 				asm volatile("" ::"v"(v));
 				return;
 			}
-			if constexpr (NT)
-				__builtin_nontemporal_store(v, to);
+			if constexpr (VEC == 8)
+				__builtin_amdgcn_raw_buffer_store_b64(v, out_rsrc, (int)(lane * VEC), (int)(at_vector * VEC), NT ? 2 : 0);
 			else
-				*to = v;
+				__builtin_amdgcn_raw_buffer_store_b32(v, out_rsrc, (int)(lane * VEC), (int)(at_vector * VEC), NT ? 2 : 0);
 		};
-		unsigned done = 0;   // wave-uniform
-		for (; done + 256u <= vectors; done += 256u)
+		unsigned stores = 0;   // wave-uniform
+		for (unsigned done = 0; done < vectors; done += 256u)
 		{
 			const vec_t v0 = staged[done], v1 = staged[done + 64u], v2 = staged[done + 128u], v3 = staged[done + 192u];
-			put(dst + done + lane, v0);
-			put(dst + done + 64u + lane, v1);
-			put(dst + done + 128u + lane, v2);
-			put(dst + done + 192u + lane, v3);
+			put(done, v0);
+			put(done + 64u, v1);
+			put(done + 128u, v2);
+			put(done + 192u, v3);
+			stores += 4u;
 		}
-		for (; done < vectors; done += 64u)
-			if (done + lane < vectors)
-				put(dst + done + lane, staged[done]);
 		__builtin_amdgcn_wave_barrier();
 		mark(2);
-		return ABL == 1 ? 0u : __builtin_amdgcn_readfirstlane((vectors + 63u) / 64u);
+		return ABL == 1 ? 0u : __builtin_amdgcn_readfirstlane(stores);
 	};
 
 	uint64_t tile = global_wave;

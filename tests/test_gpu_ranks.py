@@ -127,7 +127,7 @@ def test_bench_launches_its_own_ranks(gpus, extra):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     line = json.loads(lines[0])
-    assert line["n_gpus"] == gpus and line["parity_spot_check"] is True
+    assert line["n_gpus"] == gpus and line["parity_full_stream"] is True
     assert line["gather"]["seams_match_oracle"] is True
     assert line["value"] > 0
     # the line proves what ran: one entry per rank with its GPU's identity, its own time and its share; the backend summed N ones
@@ -156,7 +156,7 @@ def test_two_distinct_gpus_over_rccl():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert line["backend"].startswith("nccl") and line["world_size_seen_by_backend"]["all_reduce_sum_of_ones"] == 2
-    assert line["distinct_devices"] == 2 and line["parity_spot_check"] is True and line["gather"]["seams_match_oracle"] is True
+    assert line["distinct_devices"] == 2 and line["parity_full_stream"] is True and line["gather"]["seams_match_oracle"] is True
     exe = os.path.join(ROOT, "tools", "bin", "cr_multi")
     for mode in ("peer", "rccl"):
         c = subprocess.run([exe, "2", "2646000", mode], capture_output=True, text=True, timeout=600, env=env)

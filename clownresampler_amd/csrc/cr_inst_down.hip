@@ -16,7 +16,7 @@ int specials_down(void *table, int capacity)
 	    with_signed_chain<1, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_signed_chain<2, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<2, 8, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_signed_chain<1, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
-	    with_signed_chain<1, 33, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 33, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),   // mono 44.1 -> 8 kHz
+	    with_wave2<1, 33, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 2, 0, true>(with_signed_chain<1, 33, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 3>(make_special_lite<1, 33, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>())),   // mono 44.1 -> 8 kHz: k_wave2 by default (68.8 -> 66.7 us, profiles/r04_dn8m_kwave2_ab.log; 256-frame wave-tiles do not fit beside the rows)
 	    with_wave2<2, 33, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 1, 0, true>(make_special_lite<2, 33, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    with_wave2<2, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 16, 2, 2, 0, true>(make_special_lite<2, 18, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
 	    // high-rate material to CD / DAT rates: 176.4 -> 48 kHz (22 slots; also 44.1 -> 12 kHz), 192 -> 44.1 kHz (26 slots; 48 -> 11.025 kHz):

@@ -266,10 +266,12 @@ size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *r
  * devices while they compute.  Optionally the blocks are then concatenated on one device, each transfer enqueued behind
  * its shard's kernel on that shard's stream:
  *   CLOWNRESAMPLER_AMD_GATHER_PEER_COPY  one hipMemcpyPeerAsync per shard (point-to-point over xGMI; exact sizes)
- *   CLOWNRESAMPLER_AMD_GATHER_RCCL       grouped ncclSend / ncclRecv over a communicator set of the shards' devices, exact sizes
- *                                        like the copies (librccl.so is loaded on first use; every ordinal may appear only
- *                                        once - checked before anything is launched).  Has run with ONE rank only: the
- *                                        test pool has single-GPU boxes
+ *   CLOWNRESAMPLER_AMD_GATHER_RCCL       EXPERIMENTAL: grouped ncclSend / ncclRecv over a communicator set of the shards' devices, exact
+ *                                        sizes like the copies (librccl.so is loaded on first use; every ordinal may appear only
+ *                                        once - checked before anything is launched).  It has only ever run with ONE rank (the
+ *                                        test pool has single-GPU boxes), where no NCCL operation is issued at all: treat it as
+ *                                        unvalidated between distinct GPUs and prefer PEER_COPY until
+ *                                        tests/test_gpu_ranks.py::test_two_distinct_gpus_over_rccl has run on a multi-GPU node
  * Nothing is synchronised: use ClownResamplerAMD_ShardedSynchronize (or the streams) before reading.  Returns the total
  * number of output frames and leaves *resampler as ONE ClownResampler_LowLevel_Resample over the whole input would
  * (clownresampler.h:1065-1067); 0 after an error (reported through the handler).

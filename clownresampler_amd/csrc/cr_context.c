@@ -220,6 +220,7 @@ static unsigned long long g_launch_count[CR_KERNEL_IDS];
 #define CR_BRIEF_HALF_TILES 3
 /* bytes of slack k_up2 keeps on either side of a wave's staged frames (= UP2_SLACK, cr_kup.hpp) */
 #define CR_UP2_SLACK 144u
+#define CR_UP2_ENTRIES_BYTES 1280u
 /* k_up2 as an instance's default kernel: see plan_geometry */
 #define CR_UP_DEFAULT_MAX_INCREMENT (65536u / 8u)
 #define CR_UP_DEFAULT_MIN_INCREMENT (65536u / 13u)
@@ -1012,8 +1013,10 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 
 		if (ok)
 		{
-			const uint32_t stage_bytes = ((uint32_t)wave_tile * unit + 15u) & ~15u;
+			uint32_t stage_bytes = ((uint32_t)wave_tile * unit + 15u) & ~15u;
 
+			if (stage_bytes < CR_UP2_ENTRIES_BYTES)
+				stage_bytes = CR_UP2_ENTRIES_BYTES;   /* (k_up2 parks a wave-tile's converted window there first: UP2_ENTRIES_BYTES, cr_kup.hpp) */
 			plan->lds_bytes = rows_bytes + (plan->threads / 64u) * (2u * 1024u + stage_bytes + 2u * CR_UP2_SLACK) + 16u;
 			plan->tile_frames = (uint32_t)wave_tile * 4u;
 			per_cu = (160u * 1024u) / plan->lds_bytes;

@@ -444,6 +444,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_up(const crhip_poly_launch a)
 // ---------------------------------------------------------------------------------------------------------
 // bytes of slack on either side of a wave's staging buffer (16 surplus frames of 8 bytes, rounded up to 16 bytes)
 constexpr unsigned UP2_SLACK = 144u;
+// the least a wave's staging buffer holds: 80 converted input frames of 16 bytes (64 positions + a window of up to 16 slots)
+constexpr unsigned UP2_ENTRIES_BYTES = 1280u;
 //
 // FCHAIN = 1: the tap as ONE instruction, on the FLOAT pipe (round 4).  An FP32 accumulator that starts at 2^23 has an ulp of exactly 1,
 // and under round-toward-zero fma(|v|, |w| / 65536, acc) = acc + floor(|v| |w| / 65536): the product is exact inside the fused
@@ -515,8 +517,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 	};
 
 	const unsigned WT = a.tile_frames / 4u;        // output frames per wave-tile: at most 64 input positions
-	const unsigned stage_bytes = (WT * UNIT + 15u) & ~15u;
+	// (at least UP2_ENTRIES_BYTES: the float chain parks the wave-tile's converted input frames there before the first frame is staged)
+	const unsigned stage_bytes = ((WT * UNIT + 15u) & ~15u) > UP2_ENTRIES_BYTES ? ((WT * UNIT + 15u) & ~15u) : UP2_ENTRIES_BYTES;
 	static_assert(17u * UNIT <= UP2_SLACK, "slack for a lane's surplus frames on either side of the staged tile");
+	static_assert((64u + TT - 1u) * 16u <= UP2_ENTRIES_BYTES, "one 16-byte entry per input frame of a wave-tile's window");
 
 	// per wave: two window buffers, slack, the staged frames of a wave-tile, slack (the host sizes the workgroup's LDS for this:
 	// cr_context.c, plan_geometry)
@@ -679,35 +683,58 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 
 		// the window of this lane's input position, once: X = +-2 * sample (operand AND arm of the ordinary slots); the centre
 		// slots: S = sample << 16 and its sign B
-		int f[TT];
-#pragma unroll
-		for (int s = 0; s < TT; ++s)
-			f[s] = *reinterpret_cast<const int *>(base + (lane + (unsigned)s) * FB);
 		typedef float f32x2 __attribute__((ext_vector_type(2)));
-		f32x2 P[FCHAIN ? TT : 1][CH];   // FCHAIN: {max(v, 0), min(v, 0)} of v = +-sample
+		typedef float f32x4 __attribute__((ext_vector_type(4)));
+		f32x2 P[FCHAIN ? TT : 1][CH];   // FCHAIN: {max(v, 0), min(v, 0)} of v = the sample of window frame s, channel c
+		int f[FCHAIN ? 1 : TT];
 		if constexpr (FCHAIN)
 		{
+			// The windows of neighbouring lanes overlap in all but one frame, so every input frame of the wave-tile is converted ONCE -
+			// lane l converts frames l and 64 + l (the window of the last lane ends at frame 63 + TT - 1) - into {max(v, 0), min(v, 0)}
+			// per channel, 16 bytes, parked in the staging buffer (free until the first frame is staged: the LDS operations of a wave
+			// complete in order), and every lane then reads its TT entries back: 12 VALU per wave-tile where a lane converting its own
+			// window took 90.  A slot whose weights are negative takes the pair swapped and negated, which the multiply-add does for
+			// free (op_sel / neg_lo / neg_hi): {max(-v, 0), min(-v, 0)} = {-min(v, 0), -max(v, 0)}.
+			static_assert(64 + 63 < (int)(BUF / FB) && TT <= 64 && (2u * BUF + UP2_SLACK) % 16u == 0, "the second frame of every lane lies inside the window buffer; 16-byte entries");
+			auto convert = [&](int packed) {
+				float v0, v1;
+				f32x4 e;
+				asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(v0) : "v"(packed));
+				asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(v1) : "v"(packed));
+				asm("v_max_f32_e64 %0, %1, 0" : "=v"(e.x) : "v"(v0));
+				asm("v_min_f32_e64 %0, %1, 0" : "=v"(e.y) : "v"(v0));
+				asm("v_max_f32_e64 %0, %1, 0" : "=v"(e.z) : "v"(v1));
+				asm("v_min_f32_e64 %0, %1, 0" : "=v"(e.w) : "v"(v1));
+				return e;
+			};
+			f32x4 *entries = reinterpret_cast<f32x4 *>(my_stage);
+			const int own = *reinterpret_cast<const int *>(base + lane * FB);
+			const int beyond = *reinterpret_cast<const int *>(base + (64u + lane) * FB);   // (lanes from TT - 1 on: past the window, never read back)
+			entries[lane] = convert(own);
+			if (lane < (unsigned)TT - 1u)
+				entries[64u + lane] = convert(beyond);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
 			for (int s = 0; s < TT; ++s)
 			{
-				float v0, v1;
-				asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(v0) : "v"(f[s]));
-				asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(v1) : "v"(f[s]));
-				if ((NEGMASK >> s) & 1u)
-				{
-					asm("v_max_f32_e64 %0, -%1, 0" : "=v"(P[s][0].x) : "v"(v0));
-					asm("v_min_f32_e64 %0, -%1, 0" : "=v"(P[s][0].y) : "v"(v0));
-					asm("v_max_f32_e64 %0, -%1, 0" : "=v"(P[s][1].x) : "v"(v1));
-					asm("v_min_f32_e64 %0, -%1, 0" : "=v"(P[s][1].y) : "v"(v1));
-				}
-				else
-				{
-					asm("v_max_f32_e64 %0, %1, 0" : "=v"(P[s][0].x) : "v"(v0));
-					asm("v_min_f32_e64 %0, %1, 0" : "=v"(P[s][0].y) : "v"(v0));
-					asm("v_max_f32_e64 %0, %1, 0" : "=v"(P[s][1].x) : "v"(v1));
-					asm("v_min_f32_e64 %0, %1, 0" : "=v"(P[s][1].y) : "v"(v1));
-				}
+				const f32x4 e = entries[lane + (unsigned)s];
+				P[s][0].x = e.x;
+				P[s][0].y = e.y;
+				P[s][1].x = e.z;
+				P[s][1].y = e.w;
 			}
+			// (the frames' staging writes below come after these reads: same wave, in order)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		}
+		else
+		{
+#pragma unroll
+			for (int s = 0; s < TT; ++s)
+				f[s] = *reinterpret_cast<const int *>(base + (lane + (unsigned)s) * FB);
 		}
 		int X[TT][CH], B[TT][CH];
 		int plus_two = 2, minus_two = -2;
@@ -800,19 +827,30 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 					wp.y = __uint_as_float((unsigned)w[2 * k + 1]);
 					return wp;
 				};
-#define CR_E(acc, p, wq) "v_pk_fma_f32 %" #acc ", %" #p ", %" #wq ", %" #acc " op_sel_hi:[1,0,1]\n\t"
-#define CR_O(acc, p, wq) "v_pk_fma_f32 %" #acc ", %" #p ", %" #wq ", %" #acc " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-#define CR_F(acc, p, wq, base) "v_pk_fma_f32 %" #acc ", %" #p ", %" #wq ", %" #base " op_sel_hi:[1,0,1]\n\t"
+// E / O: the weight is the low / high half of its register pair; P / N: the slot's weights are >= 0 / <= 0 (N: the sample pair swapped
+// and negated); F: the first tap of a frame, which adds to the chains' base
+#define CR_SEL_EP " op_sel_hi:[1,0,1]\n\t"
+#define CR_SEL_OP " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+#define CR_SEL_EN " op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+#define CR_SEL_ON " op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+#define CR_T(acc, p, wq, SEL) "v_pk_fma_f32 %" #acc ", %" #p ", %" #wq ", %" #acc SEL
+#define CR_F(acc, p, wq, base, SEL) "v_pk_fma_f32 %" #acc ", %" #p ", %" #wq ", %" #base SEL
 				if constexpr (TT == 15)
 				{
-					asm volatile(CR_F(0, 2, 18, 22) CR_F(1, 10, 18, 22) CR_O(0, 3, 18) CR_O(1, 11, 18) CR_E(0, 4, 19) CR_E(1, 12, 19) CR_O(0, 5, 19) CR_O(1, 13, 19)
-					             CR_E(0, 6, 20) CR_E(1, 14, 20) CR_O(0, 7, 20) CR_O(1, 15, 20) CR_E(0, 8, 21) CR_E(1, 16, 21) CR_O(0, 9, 21) CR_O(1, 17, 21)
+					static_assert(NEGMASK == 0x2A55u, "slots 0, 2, 4, 6, 9, 11, 13 negative: the strings below are written for this mask");
+					asm volatile(CR_F(0, 2, 18, 22, CR_SEL_EN) CR_F(1, 10, 18, 22, CR_SEL_EN) CR_T(0, 3, 18, CR_SEL_OP) CR_T(1, 11, 18, CR_SEL_OP)
+					             CR_T(0, 4, 19, CR_SEL_EN) CR_T(1, 12, 19, CR_SEL_EN) CR_T(0, 5, 19, CR_SEL_OP) CR_T(1, 13, 19, CR_SEL_OP)
+					             CR_T(0, 6, 20, CR_SEL_EN) CR_T(1, 14, 20, CR_SEL_EN) CR_T(0, 7, 20, CR_SEL_OP) CR_T(1, 15, 20, CR_SEL_OP)
+					             CR_T(0, 8, 21, CR_SEL_EN) CR_T(1, 16, 21, CR_SEL_EN) CR_T(0, 9, 21, CR_SEL_OP) CR_T(1, 17, 21, CR_SEL_OP)
 					             : "=&v"(a0), "=&v"(a1)
 					             : "v"(P[0][0]), "v"(P[1][0]), "v"(P[2][0]), "v"(P[3][0]), "v"(P[4][0]), "v"(P[5][0]), "v"(P[6][0]), "v"(P[7][0]),
 					               "v"(P[0][1]), "v"(P[1][1]), "v"(P[2][1]), "v"(P[3][1]), "v"(P[4][1]), "v"(P[5][1]), "v"(P[6][1]), "v"(P[7][1]),
 					               "v"(wpair(0)), "v"(wpair(1)), "v"(wpair(2)), "v"(wpair(3)), "v"(chain_base));
-					asm volatile(CR_E(0, 2, 16) CR_E(1, 9, 16) CR_O(0, 3, 16) CR_O(1, 10, 16) CR_E(0, 4, 17) CR_E(1, 11, 17) CR_O(0, 5, 17) CR_O(1, 12, 17)
-					             CR_E(0, 6, 18) CR_E(1, 13, 18) CR_O(0, 7, 18) CR_O(1, 14, 18) CR_E(0, 8, 19) CR_E(1, 15, 19)
+					// slots 8 (+), 9 (-), 10 (+), 11 (-), 12 (+), 13 (-), 14 (+)
+					asm volatile(CR_T(0, 2, 16, CR_SEL_EP) CR_T(1, 9, 16, CR_SEL_EP) CR_T(0, 3, 16, CR_SEL_ON) CR_T(1, 10, 16, CR_SEL_ON)
+					             CR_T(0, 4, 17, CR_SEL_EP) CR_T(1, 11, 17, CR_SEL_EP) CR_T(0, 5, 17, CR_SEL_ON) CR_T(1, 12, 17, CR_SEL_ON)
+					             CR_T(0, 6, 18, CR_SEL_EP) CR_T(1, 13, 18, CR_SEL_EP) CR_T(0, 7, 18, CR_SEL_ON) CR_T(1, 14, 18, CR_SEL_ON)
+					             CR_T(0, 8, 19, CR_SEL_EP) CR_T(1, 15, 19, CR_SEL_EP)
 					             : "+v"(a0), "+v"(a1)
 					             : "v"(P[8][0]), "v"(P[9][0]), "v"(P[10][0]), "v"(P[11][0]), "v"(P[12][0]), "v"(P[13][0]), "v"(P[14][0]),
 					               "v"(P[8][1]), "v"(P[9][1]), "v"(P[10][1]), "v"(P[11][1]), "v"(P[12][1]), "v"(P[13][1]), "v"(P[14][1]),
@@ -820,17 +858,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 				}
 				else
 				{
-					static_assert(TT == 5 || TT == 15, "k_up2's float chain is written out for 5 and 15 slots");
-					asm volatile(CR_F(0, 2, 12, 15) CR_F(1, 7, 12, 15) CR_O(0, 3, 12) CR_O(1, 8, 12) CR_E(0, 4, 13) CR_E(1, 9, 13) CR_O(0, 5, 13) CR_O(1, 10, 13)
-					             CR_E(0, 6, 14) CR_E(1, 11, 14)
+					static_assert(TT == 5 && NEGMASK == 0x12u, "k_up2's float chain is written out for 15 slots (mask 0x2A55) and 5 slots (mask 0x12: slots 1 and 4 negative)");
+					asm volatile(CR_F(0, 2, 12, 15, CR_SEL_EP) CR_F(1, 7, 12, 15, CR_SEL_EP) CR_T(0, 3, 12, CR_SEL_ON) CR_T(1, 8, 12, CR_SEL_ON)
+					             CR_T(0, 4, 13, CR_SEL_EP) CR_T(1, 9, 13, CR_SEL_EP) CR_T(0, 5, 13, CR_SEL_OP) CR_T(1, 10, 13, CR_SEL_OP)
+					             CR_T(0, 6, 14, CR_SEL_EN) CR_T(1, 11, 14, CR_SEL_EN)
 					             : "=&v"(a0), "=&v"(a1)
 					             : "v"(P[0][0]), "v"(P[1][0]), "v"(P[2][0]), "v"(P[3][0]), "v"(P[4][0]),
 					               "v"(P[0][1]), "v"(P[1][1]), "v"(P[2][1]), "v"(P[3][1]), "v"(P[4][1]),
 					               "v"(wpair(0)), "v"(wpair(1)), "v"(wpair(2)), "v"(chain_base));
 				}
 #undef CR_F
-#undef CR_O
-#undef CR_E
+#undef CR_T
+#undef CR_SEL_ON
+#undef CR_SEL_EN
+#undef CR_SEL_OP
+#undef CR_SEL_EP
 				// positive chain = 2^23 + p (bits 0x4B000000 + p), negative chain = -(2^23 + q) (bits 0xCB000000 + q): p - q
 				hi0 = (int)(__float_as_uint(a0.x) - __float_as_uint(a0.y) + 0x80000000u);
 				hi1 = (int)(__float_as_uint(a1.x) - __float_as_uint(a1.y) + 0x80000000u);

@@ -217,7 +217,7 @@ def pmc_summary(workload, build_id):
     is quoted only when it is STAMPED with the source id of the library that is loaded now (tools/pmc_passes.sh writes
     ClownResamplerAMD_BuildId() into it): counters of another build say nothing about this one's kernels."""
     stale = None
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.txt" % (rnd, workload))
         if os.path.exists(path):
             vals, stamp = {}, None

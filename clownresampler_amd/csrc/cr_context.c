@@ -1262,7 +1262,9 @@ static uint32_t plan_pick_rotation(const ClownResamplerAMD_Plan *plan, double *p
 	if (form == 0)
 		return 0u;
 	rotation = cr_poly_pick_swizzle_mapped(&plan->poly, plan->increment, plan->lane_map, plain, best);
-	if (form == 2 && *plain - *best < g_env.rotate_min_gain)
+	/* (mono is the one shape whose LDS is busy enough for a smaller modelled gain to show: 44.1 -> 48 kHz models 12 -> 4 and measures
+	   77.6 -> 75.9 us rotated, profiles/r04_mono_rotated_rows_ab.log, where stereo and wider frames measure 0.5-1 % slower) */
+	if (form == 2 && *plain - *best < (plan->channels == 1u && g_env.rotate_min_gain == CR_ROTATE_MIN_GAIN ? 6.0 : g_env.rotate_min_gain))
 		rotation = 0u;
 	if (g_env.debug)
 		fprintf(stderr, "clownresampler_amd: plan variant %u, increment %llu: rows rotated by %u (modelled conflict cycles per row read %.2f -> %.2f)\n",

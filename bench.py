@@ -346,7 +346,7 @@ def full_stream_check(radius, ch, rates, shard, d_pcm, d_out, s16):
     return same, detail
 
 
-def single_gpu_reference(api, pre, cr, name, device, stream, steps, warmup, check):
+def single_gpu_reference(api, pre, cr, name, device, stream, steps, warmup, check, prewarm_ms=250.0):
     """The N = 1 point of a multi-GPU curve, measured in THIS process on THIS rank's GPU: the whole stream of workload `name`
     device-resident, K launches between one event pair after W warm-up launches (the timed region's own method), and - check -
     every sample of the last launch against the all-core oracle.  Buffers are rotated only when one set is smaller than a GiB
@@ -372,6 +372,13 @@ def single_gpu_reference(api, pre, cr, name, device, stream, steps, warmup, chec
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(stream):
+        # clock ramp, as for the timed region proper: the GPU has been idle while the host checked the main workload's output
+        t_pre, i_pre = time.perf_counter(), 0
+        while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:
+            for _ in range(4):
+                step(i_pre)
+                i_pre += 1
+            torch.cuda.synchronize(device)
         for i in range(max(1, warmup)):
             step(i)
         torch.cuda.synchronize(device)
@@ -382,8 +389,8 @@ def single_gpu_reference(api, pre, cr, name, device, stream, steps, warmup, chec
     torch.cuda.synchronize(device)
     ms = ev0.elapsed_time(ev1) / steps
     nbytes = shard.input_frames * ch * 2 + shard.output_frames * ch * 4
-    res = {"workload": name, "what": "the WHOLE stream (%d -> %d frames x %d ch) as one launch on this GPU, %d launches between one event pair after %d warm-up launches, %d buffer set(s)"
-                                     % (shard.input_frames, shard.output_frames, ch, steps, max(1, warmup), len(sets)),
+    res = {"workload": name, "what": "the WHOLE stream (%d -> %d frames x %d ch) as one launch on this GPU, %d launches between one event pair after %.0f ms of untimed launches and %d warm-up launches, %d buffer set(s)"
+                                     % (shard.input_frames, shard.output_frames, ch, steps, prewarm_ms, max(1, warmup), len(sets)),
            "ms_per_step": ms, "value": shard.output_frames * ch / (ms * 1e-3) / 1e6, "unit": "Msamples/s",
            "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes}
     if check:
@@ -669,12 +676,12 @@ def main():
     n1_ref, strong_n1 = None, None
     if not args.no_n1_reference and not args.s16:
         if world == 1 and workload == "cfg2":
-            strong_n1 = single_gpu_reference(api, pre, cr, "cfg5", device, stream, 20, 5, not args.no_check)
+            strong_n1 = single_gpu_reference(api, pre, cr, "cfg5", device, stream, 20, 5, not args.no_check, args.prewarm_ms)
         elif world > 1:
             del sets[1:]   # (the gather below reads set 0 only)
             torch.cuda.empty_cache()
             barrier()
-            n1_ref = single_gpu_reference(api, pre, cr, workload, device, stream, max(5, min(args.steps, 20)), 5, False)
+            n1_ref = single_gpu_reference(api, pre, cr, workload, device, stream, max(5, min(args.steps, 20)), 5, False, args.prewarm_ms)
             barrier()
 
     # N > 1: the line proves what ran.  Every rank reports its GPU's identity and its own timing; the backend is asked to SUM a

@@ -237,6 +237,7 @@ static struct
 	int dynamic_tiles;          /* CLOWNRESAMPLER_AMD_DYNAMIC_TILES: -1 unset, else 0 / 1 */
 	int no_special, debug, no_occupancy_clamp, tile_groups, no_host_pipeline, no_small_call_path;
 	int no_replay_thread;       /* CLOWNRESAMPLER_AMD_NO_REPLAY_THREAD: the callback API never starts its compute-ahead helper thread */
+	int no_dual_mono;           /* CLOWNRESAMPLER_AMD_NO_DUAL_MONO: long mono launches stay on the mono kernels (the A/B leg) */
 	int host_direct;            /* CLOWNRESAMPLER_AMD_HOST_DIRECT: -1 unset (the rule), 0 never, 1 input only, 2 input and output - see cr_run_host */
 	int wave2s_min_channels;    /* CLOWNRESAMPLER_AMD_WAVE2S_MIN_CHANNELS: frames from this many channels on take k_wave2s for long windows (99: never) */
 	int lane_map;               /* CLOWNRESAMPLER_AMD_LANE_MAP: 0 / 1 forces k_wave2's lane order (unset: the conflict model picks) */
@@ -261,6 +262,7 @@ static void load_env(void)
 	g_env.no_host_pipeline = getenv("CLOWNRESAMPLER_AMD_NO_HOST_PIPELINE") != NULL;
 	g_env.no_small_call_path = getenv("CLOWNRESAMPLER_AMD_NO_SMALL_CALL_PATH") != NULL;
 	g_env.no_replay_thread = getenv("CLOWNRESAMPLER_AMD_NO_REPLAY_THREAD") != NULL;
+	g_env.no_dual_mono = getenv("CLOWNRESAMPLER_AMD_NO_DUAL_MONO") != NULL;
 	e = getenv("CLOWNRESAMPLER_AMD_HOST_DIRECT");
 	g_env.host_direct = (e != NULL && *e != '\0') ? atoi(e) : -1;
 	g_env.no_int_kernel = getenv("CLOWNRESAMPLER_AMD_NO_INT_KERNEL") != NULL;
@@ -620,6 +622,18 @@ static void store_release(cr_plan_store *store, int device_usable)
 	free(store);
 }
 
+/* g_lock held.  A plan that has left the cache: its share of the rows, its private dual-mono partner, itself. */
+static void plan_free(ClownResamplerAMD_Plan *plan, int device_usable)
+{
+	if (plan->dual.partner != NULL)
+	{
+		store_release(plan->dual.partner->store, device_usable);
+		free(plan->dual.partner);
+	}
+	store_release(plan->store, device_usable);
+	free(plan);
+}
+
 /* g_lock held.  Frees what one device holds; fails (returns -1, nothing freed) while a call still holds one of its plans. */
 static int release_device_locked(cr_device_ctx *ctx)
 {
@@ -648,8 +662,7 @@ static int release_device_locked(cr_device_ctx *ctx)
 			continue;
 		}
 		*link = plan->next;
-		store_release(plan->store, ctx->ready);
-		free(plan);
+		plan_free(plan, ctx->ready);
 	}
 
 	if (ctx->ready)
@@ -1186,8 +1199,7 @@ static void evict_plans_locked(void)
 		{
 			ClownResamplerAMD_Plan *plan = *victim;
 			*victim = plan->next;
-			store_release(plan->store, g_ctx[plan->device] != NULL && g_ctx[plan->device]->ready);
-			free(plan);
+			plan_free(plan, g_ctx[plan->device] != NULL && g_ctx[plan->device]->ready);
 		}
 	}
 }
@@ -1317,6 +1329,67 @@ static int plan_prepare(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan, 
 		}
 	}
 	return 0;
+}
+
+/* DUAL MONO: a mono plan's private stereo partner over the mono plan's OWN rows (the image of a configuration's rows does not
+   depend on the channel count where both instances take the same layout), if the stereo instance of this configuration has a dual
+   form.  Nothing is reported when there is none: the mono kernels then do all the work, as before. */
+static void plan_dual_partner(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan)
+{
+	ClownResamplerAMD_Plan *partner;
+	crhip_poly_launch l;
+	uint64_t g = plan->increment, period = 65536u;
+	int per_cu = 0, vgprs = 0, static_lds = 0;
+
+	plan->dual.partner = NULL;
+	if (plan->channels != 1u || !plan->use_poly || g_env.no_dual_mono || g_force_generic)
+		return;
+	while (period > 1u && (g & 1u) == 0u)   /* 65536 / gcd(increment, 65536) */
+	{
+		g >>= 1;
+		period >>= 1;
+	}
+
+	partner = (ClownResamplerAMD_Plan *)calloc(1, sizeof(*partner));
+	if (partner == NULL)
+		return;
+	*partner = *plan;
+	partner->next = NULL;
+	partner->channels = 2u;
+	partner->variant = partner->key_variant;
+	memset(&partner->brief, 0, sizeof(partner->brief));
+	memset(&partner->intk, 0, sizeof(partner->intk));
+	memset(&partner->dual, 0, sizeof(partner->dual));
+	plan_geometry(partner);
+	partner->lane_map = 0u;
+	partner->lds_swizzle = plan_pick_rotation(partner, &partner->conflict_plain, &partner->conflict_best);
+	/* the stereo instance must be a specialised k_poly over the same image layout, with a dual form, whose two mono windows fit
+	   the halves of its DMA buffer (a stereo window of W frames fits the whole: W * 4 + 12 <= bytes; each mono one needs W * 2 + 14) */
+	fill_poly_launch(partner, &l);
+	l.dual = 1u;
+	if (!partner->use_poly || partner->vecs >= 100u || !partner->specialised || !plan->specialised
+	 || plan_image_stride(partner) != plan->device_row_stride || !crhip_poly_has_dual(&l)
+	 || ((((uint64_t)65535u + (uint64_t)(partner->tile_frames - 1u) * plan->increment) >> 16) + plan->poly.slots + plan->poly.window_extra) * 2u + 16u > (uint64_t)partner->vecs * 16u * partner->threads / 2u
+	 || crhip_poly_prepare(&l) != 0)
+	{
+		free(partner);
+		return;
+	}
+	partner->max_blocks_s16 = partner->max_blocks;
+	if (crhip_poly_occupancy(&l, &per_cu, &vgprs, &static_lds) == 0 && per_cu >= 1 && !g_env.no_occupancy_clamp)
+	{
+		const uint32_t resident = (uint32_t)per_cu * (uint32_t)(ctx->info.compute_units > 0 ? ctx->info.compute_units : 256);
+
+		if (resident < partner->max_blocks)
+			partner->max_blocks = resident;
+	}
+	if (g_env.debug)
+		fprintf(stderr, "clownresampler_amd: mono plan, increment %llu: dual-mono partner on the stereo instance (variant %u, tile %u frames, %u B LDS, grid cap %u, period %llu)\n",
+		        (unsigned long long)plan->increment, partner->variant, partner->tile_frames, partner->lds_bytes, partner->max_blocks, (unsigned long long)period);
+	plan->store->refs += 1;   /* (the partner's view of the rows) */
+	plan->dual.partner = partner;
+	plan->dual.period = period;
+	plan->dual.max_blocks = partner->max_blocks;
 }
 
 /* The shape of k_up's fallback kernel beside a k_up plan's own, for its brief launches (see the plan's `brief`). */
@@ -1600,6 +1673,7 @@ ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t t
 			goto fail_plan;
 		plan_brief_shape(ctx, plan);
 		plan_int_shape(ctx, plan);
+		plan_dual_partner(ctx, plan);
 	}
 
 	free(table);
@@ -1729,6 +1803,58 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 				return cr_check_hip(e, "k_int launch");
 			}
 			return cr_check_hip(crhip_launch_int(&il, stream), "k_int launch");
+		}
+	}
+
+	if (plan->dual.partner != NULL && !out_s16 && !g_force_generic && pos_int < (1ull << 47) && n_out < (1ull << 40))
+	{
+		/* DUAL MONO: a long mono launch on the stereo instance - output frames j and j + H as its two channels.  H = half the launch,
+		   rounded UP to a multiple of the period of the fraction (equal fractions: one row for both) and of the tile (no ragged tile):
+		   the second half is the shorter one, its missing frames are computed on zeros / neighbours and not stored - less than one part
+		   in sixteen of the launch by the rule below, 0.1 % for ten minutes of audio. */
+		const ClownResamplerAMD_Plan *partner = plan->dual.partner;
+		uint64_t ga = plan->dual.period, gb = partner->tile_frames, unit;   /* lcm(period, tile) */
+		while (gb != 0u)
+		{
+			const uint64_t t = ga % gb;
+			ga = gb;
+			gb = t;
+		}
+		unit = plan->dual.period / ga * partner->tile_frames;
+		const uint64_t half = ((n_out + 1u) / 2u + unit - 1u) / unit * unit;
+
+		if (n_out >= 16u * unit && half < n_out && half < (1ull << 30))
+		{
+			crhip_poly_launch l;
+			uint64_t blocks = half / partner->tile_frames;
+			int ring, e;
+
+			fill_poly_launch(partner, &l);
+			l.d_in = d_in;
+			l.in_valid_bytes = in_valid_bytes;
+			l.d_out = d_out;
+			l.pos0 = (pos_int << 16) + pos_frac;
+			l.n_out = half;
+			l.dual = 1u;
+			l.dual_out_frames = half;
+			l.dual_valid_frames = n_out - half;
+			l.dual_in_bytes = ((half * plan->increment) >> 16) * 2u;   /* (half * increment is a multiple of 65536) */
+			if (blocks > plan->dual.max_blocks)
+				blocks = plan->dual.max_blocks;
+			l.blocks = (uint32_t)blocks;
+			l.dynamic_tiles = g_env.dynamic_tiles >= 0 ? (uint32_t)g_env.dynamic_tiles
+			                                           : (uint32_t)crhip_poly_dynamic_default(2u, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode);
+			if (g_env.dynamic_tiles < 0 && half / partner->tile_frames < 8ull * blocks)
+				l.dynamic_tiles = 0u;
+			l.d_tickets = ticket_block_for(g_ctx[plan->device], stream, &ring);
+			if (l.d_tickets == NULL)
+				return -1;
+			e = crhip_launch_poly(&l, stream);
+			ticket_block_enqueued(g_ctx[plan->device], ring);
+			__atomic_fetch_add(&g_launch_count[1], 1ull, __ATOMIC_RELAXED);
+			if (l.dynamic_tiles != 0u)
+				__atomic_fetch_add(&g_launch_count[CR_COUNT_TICKETED], 1ull, __ATOMIC_RELAXED);
+			return cr_check_hip(e, "k_poly launch (dual mono)");
 		}
 	}
 

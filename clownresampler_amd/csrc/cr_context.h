@@ -100,6 +100,16 @@ typedef struct ClownResamplerAMD_Plan
 		crhip_int_shape shape;
 		uint32_t max_blocks, max_blocks_s16;
 	} intk;
+	/* DUAL MONO (mono plans; crhip_poly_launch.dual, cr_kpoly.hpp): long launches run on the STEREO instance of the same
+	   configuration, output frames j and j + H as its two channels (H * increment a multiple of 65536: equal fractions, one row for
+	   both).  `partner` is a private stereo plan over this plan's own rows (not in the cache; freed with this plan); `period` =
+	   65536 / gcd(increment, 65536): H must be a multiple of it. */
+	struct
+	{
+		struct ClownResamplerAMD_Plan *partner;
+		uint64_t period;
+		uint32_t max_blocks;
+	} dual;
 } ClownResamplerAMD_Plan;
 
 /* Cache lookup by (hash of the caller's raw table bytes, radius, configuration, channels, increment); on a miss

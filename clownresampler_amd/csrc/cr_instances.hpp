@@ -80,6 +80,7 @@ struct special
 	poly_fn fn_rotated, fn16_rotated;        // lite instances (pure upsampling, short windows): their one k_poly with rotated rows, likewise
 	uint32_t mad_geo;                        // geometry (index into GEOMETRY) of the chain in mad[] where it is not the usual one (0: geometry 3 / the lite variant's)
 	uint32_t mad_any_sign;                   // 1: the chain in mad[] is the any-sign form (ASM mode 3): no slot-sign precondition for the host to check
+	poly_fn mad_dual, mad_dual_rotated;      // stereo instances: mad[0] built with DUAL (a mono stream as two phase-aligned "channels", crhip_poly_launch.dual); nullptr if none
 };
 
 constexpr uint32_t MAD_VARIANT = 28;    // variant ids 28, 29
@@ -135,6 +136,8 @@ special with_signed_chain(special s)
 	s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, T, V, 3, U, 0, 0, 0, 1>;
 	s.mad[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, T, V, 3, U, 0, 0, 0, 0>;
 	s.mad16 = (poly_fn)k_poly<CH, TT, MODE, NORM, T, V, 3, U, 0, 0, 1, 1>;
+	if constexpr (CH == 2 && TT <= 8 && U == 1)
+		s.mad_dual = (poly_fn)k_poly<CH, TT, MODE, NORM, T, V, 3, U, 0, 0, 0, 1, 1, 0, 1>;
 	s.mad_any_sign = 1u;
 	s.mad_frames = U;
 	s.mad_geo = GEO;
@@ -186,6 +189,11 @@ special make_special()
 		s.mad_rotated[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 1, 0, 0, 0>;
 		s.mad16 = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 1, 1>;
 		s.mad16_rotated = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 1, 0, 1, 1>;
+		if constexpr (CH == 2 && TT <= 8)
+		{
+			s.mad_dual = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 1, 1, 0, 1>;
+			s.mad_dual_rotated = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 1, 0, 0, 1, 1, 0, 1>;
+		}
 	}
 	if constexpr (UPMASK != 0)
 	{

@@ -385,6 +385,14 @@ int crhip_get_device(int *ordinal)
 	return (int)hipGetDevice(ordinal);
 }
 
+static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo);
+
+int crhip_poly_has_dual(const crhip_poly_launch *launch)
+{
+	uint32_t geo;
+	return launch->dual && launch->channels == 2u && launch->specialised && select_poly(launch, &geo) != nullptr && geo < 100u ? 1 : 0;
+}
+
 int crhip_poly_has_instance(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
 {
 	return find_special(channels, slots, row_mode, norm_mode) != nullptr ? 1 : 0;
@@ -624,6 +632,15 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 	const special *sp = launch->specialised ? find_special(launch->channels, launch->slots, launch->row_mode, launch->norm_mode) : nullptr;
 	const uint32_t v = resolve_variant(sp, launch->variant, launch->out_s16);
 	poly_fn fn;
+
+	if (launch->dual)
+	{
+		// a MONO stream on this stereo instance (crhip_poly_launch.dual): only the chain form of k_poly has it; nullptr otherwise
+		if (sp == nullptr || v != MAD_VARIANT || launch->out_s16 || launch->channels != 2u)
+			return nullptr;
+		*geo = sp->mad_any_sign ? sp->mad_geo : (sp->lite ? sp->lite_variant % 5u : 3u);
+		return launch->swizzle != 0 ? sp->mad_dual_rotated : sp->mad_dual;
+	}
 
 	if (sp != nullptr && v == WAVE2_VARIANT)
 	{

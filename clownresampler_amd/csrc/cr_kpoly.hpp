@@ -27,9 +27,17 @@ namespace
 //           frames as two lanes of 4: every store instruction of a wave is one contiguous 1 KiB)
 // PH        1 = the frame has CH * SPLIT - 1 channels (odd totals above 8, SPLIT == 2): the second lane's last channel is a
 //           PHANTOM - it multiplies whatever follows the frame in the window and its result is never stored
-template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0, int OUT16 = 0, int NT = 0, int SPLIT = 1, int PH = 0>
+// DUAL      1 = DUAL MONO (round 4): a stereo instance run on a MONO stream.  Output frames j and j + H of one stream have the same
+//           fractional position whenever H * increment is a multiple of 65536 - hence the same row - so they can be the two
+//           "channels" of one lane: one row index, one row read, one reciprocal for two frames, and the frame body is the stereo
+//           instance's, unchanged.  Per tile the two mono input windows (H * increment / 65536 input frames apart) are fetched by
+//           the two halves of the workgroup into the two halves of the DMA buffer, interleaved into a stereo tile by an LDS -> LDS
+//           pass (two funnel shifts and two byte permutes per pair of frames), and the results leave as two 4-byte stores H frames
+//           apart.  crhip_poly_launch.dual* carry H, how many second frames exist, and the input offset; n_out counts pairs.
+template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0, int OUT16 = 0, int NT = 0, int SPLIT = 1, int PH = 0, int DUAL = 0>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR_BUDGET))) void k_poly(const crhip_poly_launch a)
 {
+	static_assert(!DUAL || (CH == 2 && SPLIT == 1 && PH == 0 && OUT16 == 0 && TT > 0 && ABL == 0 && (NTHREADS / 2) % 64 == 0), "dual mono: a stereo instance, int32 output");
 	constexpr unsigned CHT = CH * SPLIT - PH;             // channels of a frame
 	constexpr unsigned FB = CHT * 2;                      // bytes per input frame (all channels)
 	constexpr unsigned FBL = CH * 2;                      // bytes of one lane's share of a frame
@@ -82,6 +90,44 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 	const unsigned wave_first = __builtin_amdgcn_readfirstlane(tid & ~63u);
 	auto fetch = [&](uint64_t jt, unsigned n, unsigned char *tile) -> unsigned {
 		const uint64_t pos = a.pos0 + jt * (uint64_t)a.increment;
+		if constexpr (DUAL)
+		{
+			// two MONO windows: 16-byte vector c of the tile buffer belongs to the first window while c * 16 < TILE_BYTES / 2, to the
+			// second (dual_in_bytes further on in the input) from there on - wave-uniform either way.  Returns both shifts.
+			constexpr unsigned HALF = TILE_BYTES / 2u;
+			const unsigned last_rel = (unsigned)(((pos & 0xFFFFu) + (uint64_t)(n - 1) * a.increment) >> 16);
+			unsigned shifts = 0;
+#pragma unroll
+			for (int h = 0; h < 2; ++h)
+			{
+				const uint64_t first_byte = in_base + ((pos >> 16) + a.first_slot) * 2u + (h ? a.dual_in_bytes : 0ull);
+				const uint64_t aligned = first_byte & ~(uint64_t)15;
+				const unsigned shift = (unsigned)(first_byte - aligned);
+				uint64_t want = (uint64_t)shift + (uint64_t)(last_rel + T) * 2u;
+				const uint64_t avail = in_end > aligned ? in_end - aligned : 0;
+				if (want > avail)
+					want = avail;
+				want = (want + 3u) & ~(uint64_t)3u;
+				if (want > HALF)
+					want = HALF;   // (the host sizes dual launches so that a window fits its half; never reached)
+				shifts |= shift << (8 * h);
+				const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)aligned);
+				const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(aligned >> 32));
+				const unsigned rec = __builtin_amdgcn_readfirstlane((unsigned)want);
+				const __amdgpu_buffer_rsrc_t rsrc =
+				    __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)rec, 0x00020000);
+#pragma unroll
+				for (int v = 0; v < NV; ++v)
+				{
+					// which half this wave's vector lies in is wave-uniform (NV == 1: by thread number; NV == 2: by v)
+					const bool second = NV == 1 ? (wave_first >= NTHREADS / 2u) : (v >= NV / 2);
+					if (second == (h == 1))
+						__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(tile + (v * NTHREADS + wave_first) * 16u), 16,
+						                                         (int)((v * NTHREADS + tid) * 16u - (h ? HALF : 0u)), 0, 0, 0);
+				}
+			}
+			return shifts;
+		}
 		const uint64_t first_byte = in_base + ((pos >> 16) + a.first_slot) * FB;
 		const uint64_t aligned = first_byte & ~(uint64_t)15;
 		const unsigned shift = (unsigned)(first_byte - aligned);
@@ -117,7 +163,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 	constexpr unsigned GROUP = NTHREADS * U;
 	constexpr int ADJ = 0;   // a lane's U frames are NTHREADS apart: every store instruction is coalesced across the wave
 	// (a LOWER bound of the store instructions per group: see min_stores_of_bytes; a phantom lane-frame leaves as at least one)
-	constexpr int STORES_PER_GROUP = PH ? U : U * min_stores_of_bytes(CH * (OUT16 ? 2 : 4));
+	constexpr int STORES_PER_GROUP = PH ? U : (DUAL ? 2 * U : U * min_stores_of_bytes(CH * (OUT16 ? 2 : 4)));
 
 	// Tickets.  One global counter would serialise: a single word sustains ~88 atomic draws per microsecond on this
 	// chip (MI355X_MICROARCH.md, "dequeue") and a 10-minute stereo launch draws 7,000 of them - measured 92 us instead
@@ -263,17 +309,45 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 
 	for (unsigned it = 0;; ++it)
 	{
-		const unsigned char *tile = tiles + (it & 1u) * TILE_BYTES;
+		// (dual mono: the DMA always lands in the first buffer, the second holds the interleaved tile the frames read)
+		const unsigned char *tile = DUAL ? tiles + TILE_BYTES : tiles + (it & 1u) * TILE_BYTES;
 		const bool more = next_index < n_tiles;
 		const uint64_t jn = next_index * NT64;
 		unsigned n_next = 0, shift_next = 0;
 		unsigned ticket = 0;
 
+		if constexpr (DUAL)
+		{
+			// The tile's two mono windows have landed in the two halves of the first buffer (the barrier behind us): interleave them
+			// into a stereo tile, frame f = {first window's frame f, second window's frame f}.  A thread takes PAIRS of frames: the
+			// aligned dwords around each window's pair, a funnel shift where the window starts in the middle of a dword
+			// (wave-uniform), two byte permutes, one 8-byte write.  Then a second barrier: the interleaved tile is complete and the
+			// DMA buffer free for the next tile's windows.
+			const uint64_t pos_t = a.pos0 + jt * (uint64_t)a.increment;
+			const unsigned frames = (unsigned)(((pos_t & 0xFFFFu) + (uint64_t)(n - 1) * a.increment) >> 16) + T;
+			const unsigned sa = shift & 0xFFu, sb = shift >> 8;
+			const unsigned *wa = reinterpret_cast<const unsigned *>(tiles + (sa & ~3u));
+			const unsigned *wb = reinterpret_cast<const unsigned *>(tiles + TILE_BYTES / 2u + (sb & ~3u));
+			const unsigned ra = (sa & 2u) * 8u, rb = (sb & 2u) * 8u;
+			i32x2 *inter = reinterpret_cast<i32x2 *>(tiles + TILE_BYTES);
+			for (unsigned p = tid; p < (frames + 1u) / 2u; p += NTHREADS)
+			{
+				const unsigned ap = __builtin_amdgcn_alignbit(wa[p + 1u], wa[p], ra);
+				const unsigned bp = __builtin_amdgcn_alignbit(wb[p + 1u], wb[p], rb);
+				i32x2 f;
+				f.x = (int)__builtin_amdgcn_perm(bp, ap, 0x05040100u);   // {a.lo, b.lo}
+				f.y = (int)__builtin_amdgcn_perm(bp, ap, 0x07060302u);   // {a.hi, b.hi}
+				inter[p] = f;
+			}
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+		}
+
 		if (more)
 		{
 			// the other buffer was last read in the previous iteration, which every wave has left (barrier below)
 			n_next = (unsigned)((a.n_out - jn < NT64) ? (a.n_out - jn) : NT64);
-			shift_next = fetch(jn, n_next, tiles + ((it + 1u) & 1u) * TILE_BYTES);
+			shift_next = fetch(jn, n_next, DUAL ? tiles : tiles + ((it + 1u) & 1u) * TILE_BYTES);
 			if (dynamic && wave0)
 				ticket = draw();   // for the tile after the next one; posted below, just before the barrier
 		}
@@ -309,8 +383,32 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 					out_tile[at + CH - 1] = v[CH - 1];
 			}
 		};
-		const unsigned char *base = tile + shift + (tid % SPLIT) * FBL;
-
+		const unsigned char *base = DUAL ? tile : tile + shift + (tid % SPLIT) * FBL;
+		// dual mono: where this tile's first frames go, and how many of its SECOND frames exist (the second half of the stream may be
+		// the shorter one)
+		int *out_mono = reinterpret_cast<int *>(a.d_out) + jt;
+		const unsigned dual_valid = !DUAL ? 0u : (a.dual_valid_frames > jt ? (unsigned)((a.dual_valid_frames - jt < NT64) ? (a.dual_valid_frames - jt) : NT64) : 0u);
+		// Stores through ONE buffer descriptor from the tile's first frames to the end of its second frames, with a wave-uniform frame
+		// offset (scalar: + H frames for the second) and one constant lane offset: no address arithmetic and no predicate per frame -
+		// a second frame that does not exist lies beyond the descriptor's range and the store is dropped.  (H < 2^30 frames: the host.)
+		const uint64_t lo_base = reinterpret_cast<uint64_t>(out_mono);
+		const unsigned second_bytes = (unsigned)a.dual_out_frames * 4u;   // wave-uniform
+		const unsigned valid_here = dual_valid < n ? dual_valid : n;
+		const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+		    reinterpret_cast<void *>(((uint64_t)__builtin_amdgcn_readfirstlane((int)(unsigned)(lo_base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)lo_base)), 0,
+		    (int)__builtin_amdgcn_readfirstlane((int)(!DUAL ? 0u : (valid_here != 0u ? second_bytes + valid_here * 4u : n * 4u))), 0x00020000);
+		const unsigned lane_bytes = tid * 4u;
+		auto store_dual = [&](unsigned first, const int *v) {   // first: wave-uniform (the frame of lane 0 of the workgroup)
+			unsigned at = first * 4u;
+			asm volatile("" : "+s"(at));   // (the instruction's scalar offset: as a compile-time constant hipcc adds it to the lane offset, one VALU per store)
+			__builtin_amdgcn_raw_buffer_store_b32(v[0], rs_out, (int)lane_bytes, (int)at, NT ? 2 : 0);
+			__builtin_amdgcn_raw_buffer_store_b32(v[1], rs_out, (int)lane_bytes, (int)(at + second_bytes), NT ? 2 : 0);
+		};
+		auto store_dual_lane = [&](unsigned frame, const int *v) {   // frame: per lane (ragged tiles)
+			out_mono[frame] = v[0];
+			if (frame < dual_valid)
+				out_mono[a.dual_out_frames + frame] = v[1];
+		};
 		// One group = NTHREADS * U frames: U independent frames per lane, no bounds checks.
 		// Positions are formed as (lane part, once per tile) + (group part, wave-uniform, scalar unit): one VALU add per
 		// frame instead of a 24-bit multiply-add; same for the output address, which goes out as SGPR base + lane offset.
@@ -344,6 +442,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 				if constexpr (PH)
 				{
 					store_phantom(g + u * NTHREADS + tid, outv + u * CH);
+				}
+				else if constexpr (DUAL)
+				{
+					store_dual(g + u * NTHREADS, outv + u * CH);
 				}
 				else if constexpr (OUT16)
 				{
@@ -383,7 +485,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 					__builtin_amdgcn_sched_barrier(0);   // keep the reads above the arithmetic below
 					compute_frame<CH, TT, NORM, ASM>(d[i & 1], outv);
 
-					if constexpr (OUT16)
+					if constexpr (DUAL)
+						store_dual(first, outv);
+					else if constexpr (OUT16)
 						store_shorts<CH, NT>(out_tile16 + (size_t)first * CH + tid * CH, outv);
 					else
 						store_ints<CH, NT>(out_tile + (size_t)first * CH + tid * CH, outv);
@@ -424,6 +528,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 				one_frame<CH, TT, MODE, NORM, ASM, SWZ, SPLIT, PH>(a, rows, base, __umul24(jl / SPLIT, a.increment) + frac0, outv);
 				if constexpr (PH)
 					store_phantom(jl, outv);
+				else if constexpr (DUAL)
+					store_dual_lane(jl, outv);
 				else if constexpr (OUT16)
 					store_shorts<CH, NT>(out_tile16 + (size_t)jl * CH, outv);
 				else

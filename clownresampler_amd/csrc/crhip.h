@@ -64,6 +64,12 @@ typedef struct crhip_poly_launch
 	uint32_t out_s16;           /* 1: d_out is int16, samples clamped to +-0x7FFF (extension); 0: int32 unclamped (reference) */
 	uint32_t wave_tile;         /* k_wave2s: output frames per wave-tile (a multiple of the frames one wave-instruction covers, 64 / ceil(channels / 2)) */
 	uint32_t lane_map;          /* k_wave2: 0 = lane l takes frame l of its 64, 1 = lanes 0-31 the even frames, 32-63 the odd ones (LDS bank conflicts of the window reads) */
+	/* DUAL MONO (k_poly stereo instances built with DUAL): a MONO stream run as two "channels" - output frame j and output frame
+	   j + dual_out_frames, whose fractional positions are equal (dual_out_frames * increment is a multiple of 65536) and which
+	   therefore share their row; the second one's window lies dual_in_bytes further on in d_in.  channels is 2, n_out counts
+	   PAIRS, d_out is the mono output (int32): pair j writes d_out[j] and - while j < dual_valid_frames - d_out[j + dual_out_frames]. */
+	uint32_t dual;
+	uint64_t dual_out_frames, dual_valid_frames, dual_in_bytes;
 } crhip_poly_launch;
 
 /* One launch of the generic kernel: the reference arithmetic restated with 64-bit integers, one thread per
@@ -206,6 +212,8 @@ int crhip_poly_occupancy(const crhip_poly_launch *launch, int *workgroups_per_cu
 int crhip_launch_poly(const crhip_poly_launch *launch, void *stream);
 int crhip_launch_generic(const crhip_generic_launch *launch, void *stream);
 
+/* 1 when the instance a launch with these parameters selects (launch->dual set) has a dual-mono form */
+int crhip_poly_has_dual(const crhip_poly_launch *launch);
 /* 1 when a specialised (channels, slots, row mode, norm mode) template instance exists for the polyphase kernel. */
 int crhip_poly_has_instance(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode);
 /* 1 when the instance a launch with these parameters selects applies the row swizzle. */

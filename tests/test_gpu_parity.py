@@ -380,6 +380,66 @@ def test_one_launch_full_size_bit_exact(products, name, radius, ch, rates, frame
         api.DeviceFree(d_out)
 
 
+@pytest.mark.parametrize("rates,frames,start", [
+    ((44100, 48000, 44100), 3_000_000, (0, 0)),          # odd increment: the fraction repeats after 65,536 frames; ~3.3 M output frames -> H = 1,638,400
+    ((44100, 48000, 44100), 1_234_567, (0, 0)),          # H rounded up past half: the second half is the shorter one
+    ((44100, 48000, 44100), 2_000_001, (5, 40001)),      # a resumed stream: overshoot and fraction carried in
+    ((48000, 44100, 44100), 2_500_000, (0, 0)),          # mild downsampling: the any-sign chain of the stereo instance
+    ((48000, 44100, 44100), 1_100_000, (0, 12345)),
+    ((8000, 44100, 8000), 400_000, (0, 0)),              # 5.5x upsampling (increment 11888 = 2^4 x 743: period 4,096)
+    ((22050, 44100, 22050), 1_500_000, (0, 0)),          # exactly 2x (increment 32768: period 2 - the tile decides H)
+    ((44100, 48000, 44100), 600_000, (0, 0)),            # too short for the rule: the mono kernel does all of it
+])
+def test_dual_mono_long_launches_bit_exact(products, rates, frames, start):
+    """DUAL MONO (round 4): a long MONO launch runs on the STEREO instance - output frames j and j + H, whose fractions are equal
+    (H x increment a multiple of 65536), as its two channels, the two input windows interleaved in LDS per tile.  Device-resident,
+    ONE call, every sample against the oracle; also with a capacity stop in the second half and the rest as a second call (the
+    resumed state starts mid-stream), and with the dual form switched off (the same stream on the mono kernel)."""
+    p, o = products[3], ck.oracle(3)
+    api = p.api
+    ch = 1
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    st.raw.position_integer, st.raw.position_fractional = start
+    ost.pos_int, ost.pos_frac = start
+    R = int(ost.cfg.radius_frames)
+    padded = ck.pad_frames(ck.noise_pcm((frames + 8) * ch, 777), ch, R)   # (a few frames of slack for the carried-in overshoot)
+    carried = ck.LowLevel.from_buffer_copy(ost)
+    want = o.low_resample_i32_mt(carried, padded, frames, threads=min(32, os.cpu_count() or 1))
+    total = want.size
+    assert total == ck.count_output_frames(ost, frames)
+    d_in = api.DeviceAlloc(padded.nbytes + 64)
+    d_out = api.DeviceAlloc(want.nbytes + 64)
+    try:
+        api.CopyToDevice(d_in, padded)
+        plan = api.PlanCreate(st.raw, p.pre)
+        got = np.zeros_like(want)
+        # (a) one call
+        first = cr.LowLevel_State.from_buffer_copy(st.raw)
+        before = [api.LaunchCount(k) for k in range(8)]
+        n, left, ran_out = api.ResampleDevice(plan, first, d_in, frames, d_out, total + 1)
+        api.StreamSynchronize()
+        launched = [api.LaunchCount(k) - b for k, b in zip(range(8), before)]
+        assert n == total and left == 0 and ran_out == 1 and sum(launched[:7]) == 1 and launched[1] + launched[5] == 1   # (exactly 2x: the periodic k_int instance)
+        api.CopyFromDevice(got, d_out)
+        assert np.array_equal(got, want)
+        # (b) stopped by its capacity at 70 % of the stream, the rest as a second call from the state the first one left
+        cut = total * 7 // 10
+        two = cr.LowLevel_State.from_buffer_copy(st.raw)
+        got[:] = 0
+        api.CopyToDevice(d_out, got)
+        n1, left1, ran1 = api.ResampleDevice(plan, two, d_in, frames, d_out, cut)
+        assert n1 == cut and ran1 == 0
+        n2, left2, ran2 = api.ResampleDevice(plan, two, d_in + (frames - left1) * ch * 2, left1, d_out + cut * ch * 4, total - cut + 1)
+        api.StreamSynchronize()
+        assert n1 + n2 == total and left2 == 0 and ran2 == 1
+        api.CopyFromDevice(got, d_out)
+        assert np.array_equal(got, want)
+    finally:
+        api.DeviceFree(d_in)
+        api.DeviceFree(d_out)
+
+
 @pytest.mark.parametrize("ch", [1, 2])
 @pytest.mark.parametrize("radius,rates", [(3, (48000, 32000, 32000)), (3, (96000, 64000, 64000)), (3, (24000, 48000, 24000)), (8, (24000, 48000, 24000)), (8, (48000, 32000, 32000)),
                                           (5, (24000, 48000, 24000)), (5, (48000, 32000, 32000)), (8, (12000, 48000, 12000)), (5, (12000, 48000, 12000))])

@@ -22,10 +22,9 @@ def line(w):
 
 
 def stats(w):
-    rows = open(os.path.join(P, "r04_kernel_stats_%s.csv" % w)).read().split("\n")
-    head = [h.strip('"') for h in rows[0].split(",")]
-    f = [x.strip('"') for x in rows[1].split(",")]
-    d = dict(zip(head, f))
+    import csv
+    rows = list(csv.reader(open(os.path.join(P, "r04_kernel_stats_%s.csv" % w))))
+    d = dict(zip(rows[0], rows[1]))   # (the first data row: the workload's kernel, by total duration)
     return int(d["Calls"]), float(d["AverageNs"]) / 1e3
 
 

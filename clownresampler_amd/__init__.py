@@ -202,6 +202,7 @@ class Api:
         self._LaunchCount = fn("ClownResamplerAMD_DebugLaunchCount", C.c_ulonglong, [C.c_uint], False)
         self._BuildId = fn("ClownResamplerAMD_BuildId", C.c_char_p, [], False)
         self._DisableInt = fn("ClownResamplerAMD_DebugDisableIntKernel", None, [C.c_int], False)
+        self._DisableDual = fn("ClownResamplerAMD_DebugDisableDualMono", None, [C.c_int], False)
         self._SegmentsMode = fn("ClownResamplerAMD_DebugSegmentsMode", None, [C.c_int], False)
         self._HighRelease = fn("ClownResamplerAMD_HighLevel_Release", None, [P(HighLevel_State)], False)
         self._WindowCount = fn("ClownResamplerAMD_StreamingWindowCount", C.c_size_t, [], False)
@@ -434,6 +435,9 @@ class Api:
     def DebugSegmentsMode(self, mode):
         """0: the rule picks, 1: one launch per segment, 2: one launch for all segments (segment table)"""
         self._SegmentsMode(mode)
+
+    def DebugDisableDualMono(self, on):
+        self._DisableDual(1 if on else 0)
 
     def DebugDisableIntKernel(self, on):
         self._DisableInt(1 if on else 0)

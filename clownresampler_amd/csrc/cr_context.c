@@ -188,6 +188,7 @@ static uint64_t g_plan_clock = 0;
 static size_t g_plan_limit = 64;   /* unpinned plans kept; ClownResamplerAMD_SetPlanCacheLimit */
 static int g_force_generic = 0;
 static int g_no_int_kernel = 0;   /* ClownResamplerAMD_DebugDisableIntKernel */
+static int g_no_dual_mono = 0;    /* ClownResamplerAMD_DebugDisableDualMono */
 static unsigned long long *g_debug_stamps = NULL;
 static int g_variant = -1; /* -1: CLOWNRESAMPLER_AMD_VARIANT from the environment, else the default */
 /* launches enqueued so far, by kernel (numbered as ClownResamplerAMD_PlanInfo.kernel; 5 = k_int): what tests and bench.py
@@ -1361,19 +1362,28 @@ static void plan_dual_partner(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *
 	memset(&partner->intk, 0, sizeof(partner->intk));
 	memset(&partner->dual, 0, sizeof(partner->dual));
 	plan_geometry(partner);
-	partner->lane_map = 0u;
+	partner->lane_map = plan_pick_lane_map(partner);
 	partner->lds_swizzle = plan_pick_rotation(partner, &partner->conflict_plain, &partner->conflict_best);
 	/* the stereo instance must be a specialised k_poly over the same image layout, with a dual form, whose two mono windows fit
 	   the halves of its DMA buffer (a stereo window of W frames fits the whole: W * 4 + 12 <= bytes; each mono one needs W * 2 + 14) */
 	fill_poly_launch(partner, &l);
 	l.dual = 1u;
-	if (!partner->use_poly || partner->vecs >= 100u || !partner->specialised || !plan->specialised
-	 || plan_image_stride(partner) != plan->device_row_stride || !crhip_poly_has_dual(&l)
-	 || ((((uint64_t)65535u + (uint64_t)(partner->tile_frames - 1u) * plan->increment) >> 16) + plan->poly.slots + plan->poly.window_extra) * 2u + 16u > (uint64_t)partner->vecs * 16u * partner->threads / 2u
-	 || crhip_poly_prepare(&l) != 0)
 	{
-		free(partner);
-		return;
+		/* frames of the longest tile's window, and the bytes ONE mono window may take: half of the stereo instance's DMA buffer
+		   (k_poly: vecs * 16 bytes per thread; k_wave2: vecs - 150 KiB per wave-tile of 64 * ITER frames = tile_frames / 4) */
+		const int wave2 = partner->vecs >= 150u && partner->vecs < 200u;
+		const uint64_t tile = wave2 ? partner->tile_frames / 4u : partner->tile_frames;
+		const uint64_t window = (((uint64_t)65535u + (tile - 1u) * plan->increment) >> 16) + plan->poly.slots + plan->poly.window_extra;
+		const uint64_t half_bytes = wave2 ? (uint64_t)(partner->vecs - 150u) * 1024u / 2u : (uint64_t)partner->vecs * 16u * partner->threads / 2u;
+
+		if (!partner->use_poly || (partner->vecs >= 100u && !wave2) || !partner->specialised || !plan->specialised
+		 || plan_image_stride(partner) != plan->device_row_stride || !crhip_poly_has_dual(&l)
+		 || window * 2u + 4u > half_bytes   /* (the dual fetches start at the 4-byte word of a window's first sample) */
+		 || crhip_poly_prepare(&l) != 0)
+		{
+			free(partner);
+			return;
+		}
 	}
 	partner->max_blocks_s16 = partner->max_blocks;
 	if (crhip_poly_occupancy(&l, &per_cu, &vgprs, &static_lds) == 0 && per_cu >= 1 && !g_env.no_occupancy_clamp)
@@ -1806,7 +1816,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		}
 	}
 
-	if (plan->dual.partner != NULL && !out_s16 && !g_force_generic && pos_int < (1ull << 47) && n_out < (1ull << 40))
+	if (plan->dual.partner != NULL && !out_s16 && !g_force_generic && !g_no_dual_mono && pos_int < (1ull << 47) && n_out < (1ull << 40))
 	{
 		/* DUAL MONO: a long mono launch on the stereo instance - output frames j and j + H as its two channels.  H = half the launch,
 		   rounded UP to a multiple of the period of the fraction (equal fractions: one row for both) and of the tile (no ragged tile):
@@ -1826,10 +1836,23 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		if (n_out >= 16u * unit && half < n_out && half < (1ull << 30))
 		{
 			crhip_poly_launch l;
-			uint64_t blocks = half / partner->tile_frames;
+			uint64_t blocks;
+			const int wave2 = partner->vecs >= 150u;
 			int ring, e;
 
 			fill_poly_launch(partner, &l);
+			if (wave2)
+			{
+				/* (k_wave2's chunks: see the ordinary launch below) */
+				const uint32_t wave_tile = partner->tile_frames / 4u;
+				const uint64_t waves = (uint64_t)plan->dual.max_blocks * (partner->threads / 64u);
+
+				while (l.tile_frames > wave_tile && half / l.tile_frames < 8u * waves)
+					l.tile_frames /= 2u;
+				blocks = (half / l.tile_frames + partner->threads / 64u - 1u) / (partner->threads / 64u);
+			}
+			else
+				blocks = half / partner->tile_frames;
 			l.d_in = d_in;
 			l.in_valid_bytes = in_valid_bytes;
 			l.d_out = d_out;
@@ -1851,8 +1874,8 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 				return -1;
 			e = crhip_launch_poly(&l, stream);
 			ticket_block_enqueued(g_ctx[plan->device], ring);
-			__atomic_fetch_add(&g_launch_count[1], 1ull, __ATOMIC_RELAXED);
-			if (l.dynamic_tiles != 0u)
+			__atomic_fetch_add(&g_launch_count[wave2 ? 4 : 1], 1ull, __ATOMIC_RELAXED);
+			if (!wave2 && l.dynamic_tiles != 0u)
 				__atomic_fetch_add(&g_launch_count[CR_COUNT_TICKETED], 1ull, __ATOMIC_RELAXED);
 			return cr_check_hip(e, "k_poly launch (dual mono)");
 		}
@@ -2457,6 +2480,11 @@ int cr_segments_mode(void)
 void ClownResamplerAMD_DebugSegmentsMode(int mode)
 {
 	g_segments_mode = (mode >= 0 && mode <= 2) ? mode : 0;
+}
+
+void ClownResamplerAMD_DebugDisableDualMono(int on)
+{
+	g_no_dual_mono = on != 0;
 }
 
 void ClownResamplerAMD_DebugDisableIntKernel(int on)

@@ -81,6 +81,7 @@ struct special
 	uint32_t mad_geo;                        // geometry (index into GEOMETRY) of the chain in mad[] where it is not the usual one (0: geometry 3 / the lite variant's)
 	uint32_t mad_any_sign;                   // 1: the chain in mad[] is the any-sign form (ASM mode 3): no slot-sign precondition for the host to check
 	poly_fn mad_dual, mad_dual_rotated;      // stereo instances: mad[0] built with DUAL (a mono stream as two phase-aligned "channels", crhip_poly_launch.dual); nullptr if none
+	poly_fn wave2_dual;                      // ... and k_wave2 built with DUAL
 };
 
 constexpr uint32_t MAD_VARIANT = 28;    // variant ids 28, 29
@@ -97,6 +98,8 @@ void add_wave2(special &s)
 	constexpr unsigned SAFEMASK = (!SIGNED && TT == 15) ? 0x180u : 0u;
 	s.wave2 = (poly_fn)k_wave2<CH, TT, MODE, NORM, WAVES, NVW, ITER, 0, 1, NEGMASK, SIGNED, SAFEMASK>;
 	s.wave2_16 = (poly_fn)k_wave2<CH, TT, MODE, NORM, WAVES, NVW, ITER, 1, 1, NEGMASK, SIGNED, SAFEMASK>;
+	if constexpr (CH == 2)
+		s.wave2_dual = (poly_fn)k_wave2<CH, TT, MODE, NORM, WAVES, NVW, ITER, 0, 1, NEGMASK, SIGNED, SAFEMASK, 1>;   // a mono stream as two phase-aligned channels
 	s.wave2_safemask = SAFEMASK;
 	s.wave2_waves = WAVES;
 	s.wave2_nvw = NVW;

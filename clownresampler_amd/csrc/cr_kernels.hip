@@ -390,7 +390,7 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo);
 int crhip_poly_has_dual(const crhip_poly_launch *launch)
 {
 	uint32_t geo;
-	return launch->dual && launch->channels == 2u && launch->specialised && select_poly(launch, &geo) != nullptr && geo < 100u ? 1 : 0;
+	return launch->dual && launch->channels == 2u && launch->specialised && select_poly(launch, &geo) != nullptr && (geo < 100u || geo == 150u) ? 1 : 0;
 }
 
 int crhip_poly_has_instance(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode)
@@ -636,7 +636,14 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 	if (launch->dual)
 	{
 		// a MONO stream on this stereo instance (crhip_poly_launch.dual): only the chain form of k_poly has it; nullptr otherwise
-		if (sp == nullptr || v != MAD_VARIANT || launch->out_s16 || launch->channels != 2u)
+		if (sp == nullptr || launch->out_s16 || launch->channels != 2u)
+			return nullptr;
+		if (v == WAVE2_VARIANT)
+		{
+			*geo = 150u;
+			return sp->wave2_dual;
+		}
+		if (v != MAD_VARIANT)
 			return nullptr;
 		*geo = sp->mad_any_sign ? sp->mad_geo : (sp->lite ? sp->lite_variant % 5u : 3u);
 		return launch->swizzle != 0 ? sp->mad_dual_rotated : sp->mad_dual;

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 			for (int h = 0; h < 2; ++h)
 			{
 				const uint64_t first_byte = in_base + ((pos >> 16) + a.first_slot) * 2u + (h ? a.dual_in_bytes : 0ull);
-				const uint64_t aligned = first_byte & ~(uint64_t)15;
+				const uint64_t aligned = first_byte & ~(uint64_t)3;   // (any alignment will do for the DMA: the window starts at the word of its first sample)
 				const unsigned shift = (unsigned)(first_byte - aligned);
 				uint64_t want = (uint64_t)shift + (uint64_t)(last_rel + T) * 2u;
 				const uint64_t avail = in_end > aligned ? in_end - aligned : 0;

@@ -45,10 +45,16 @@ constexpr int wave2_reads_ahead(bool with_rows, int reads_per_slot, int tt, int 
 	return later;
 }
 
-template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, int OUT16, int NT, unsigned NEGMASK, int SIGNED, unsigned SAFEMASK = 0>
+// DUAL = 1: DUAL MONO (see k_poly): a stereo instance run on a MONO stream - output frames j and j + H, whose fractions are equal,
+// as its two channels.  The wave-tile's two mono windows are fetched into the two halves of the packed buffer by ONE descriptor
+// (the second window's lanes add its distance to their offsets), the expansion pass writes them interleaved - X of the first
+// window's sample p into dword 0 of entry p + 1, of the second window's into dword 1 - and the frames leave as two 4-byte stores
+// through one descriptor that ends where the second half of the stream does.
+template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, int OUT16, int NT, unsigned NEGMASK, int SIGNED, unsigned SAFEMASK = 0, int DUAL = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 {
 	static_assert(CH >= 1 && CH <= 8, "one lane per frame");
+	static_assert(!DUAL || (CH == 2 && TT > 0 && OUT16 == 0), "dual mono: a stereo instance with a compile-time slot count, int32 output");
 	// SAFEMASK != 0 (fixed signs only): the MOV-ARMED form.  Of all the one-instruction ways to arm `lo`, a plain v_mov_b32 is the
 	// only one that costs next to nothing beside the multiply-add (tools/microbench/chainbench.hip: 231 cycles per wave-frame for
 	// the multiply-adds alone, 258 with a v_mov_b32 each, 313-348 with v_and / v_ashrrev / v_not / v_mov_sdwa / v_xor_sdwa / v_bfe).
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	const unsigned PER_WAVE = 2u * BUF + XBUF;
 	constexpr int RS = (TT + 1 + 3) & ~3;          // (specialised form) int32 per row: the slots, the reciprocal, padding
 	const unsigned planes_total = RT ? a.row_stride / 4u : (unsigned)(RS / 4);
-	constexpr int STORES_PER_FRAME = min_stores_of_bytes(CH * (OUT16 ? 2 : 4));   // a lower bound: see cr_device.hpp
+	constexpr int STORES_PER_FRAME = DUAL ? 2 : min_stores_of_bytes(CH * (OUT16 ? 2 : 4));   // a lower bound: see cr_device.hpp
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -146,6 +152,39 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	// offset of the window's first frame inside the buffer in the low 16 bits and the window's frame count above them.  Not waited for.
 	auto fetch = [&](uint64_t first, unsigned n, unsigned char *buf) -> unsigned {
 		const uint64_t pos = a.pos0 + first * (uint64_t)a.increment;
+		if constexpr (DUAL)
+		{
+			// returns shift of the first window | shift of the second << 8 | frames << 16
+			const uint64_t byte_a = in_base + ((pos >> 16) + a.first_slot) * 2u, byte_b = byte_a + a.dual_in_bytes;
+			// (the DMA takes a source of any alignment - tools/microbench/dmaalign.hip - so a window starts at the 4-byte word of its
+			// first sample: a shift of 0 or 2 bytes, and a mono window of the longest tile fits half the stereo instance's buffer)
+			const uint64_t aligned_a = byte_a & ~(uint64_t)3, aligned_b = byte_b & ~(uint64_t)3;
+			const unsigned shift_a = (unsigned)(byte_a - aligned_a), shift_b = (unsigned)(byte_b - aligned_b);
+			const unsigned last_rel = (unsigned)(((pos & 0xFFFFu) + (uint64_t)(n - 1) * a.increment) >> 16);
+			const unsigned frames = last_rel + slots + a.window_extra;
+			// one descriptor from the first window's start to the end of the caller's buffer (whole dwords: see k_poly); what a lane of
+			// either window reads beyond it comes back as zeros
+			uint64_t avail = in_end > aligned_a ? in_end - aligned_a : 0;
+			avail = (avail + 3u) & ~(uint64_t)3u;
+			if (avail > 0xFFFFFFFCull)
+				avail = 0xFFFFFFFCull;
+			const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)aligned_a);
+			const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(aligned_a >> 32));
+			const unsigned rec = __builtin_amdgcn_readfirstlane((unsigned)avail);
+			const unsigned delta = __builtin_amdgcn_readfirstlane((unsigned)(aligned_b - aligned_a));   // (< 2^32: the host)
+			const __amdgpu_buffer_rsrc_t rsrc =
+			    __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)rec, 0x00020000);
+			const unsigned half = BUF / 2u;
+#pragma unroll
+			for (int v = 0; v < NVW; ++v)
+			{
+				// buffer byte q belongs to the first window while q < half, to the second from there on
+				const unsigned q = (unsigned)v * 1024u + lane * 16u;
+				const unsigned from = q < half ? q : delta + (q - half);
+				__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + v * 1024u), 16, (int)from, 0, 0, 0);
+			}
+			return (unsigned)__builtin_amdgcn_readfirstlane((int)(shift_a | (shift_b << 8) | (frames << 16)));
+		}
 		const uint64_t first_byte = in_base + ((pos >> 16) + a.first_slot) * FB;
 		const uint64_t aligned = first_byte & ~(uint64_t)15;
 		const unsigned shift = (unsigned)(first_byte - aligned);
@@ -243,6 +282,54 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	// as zeros).  The window is converted dword by dword from the aligned dword its first sample sits in: for an odd channel
 	// count that sample may be the dword's HIGH half, and sample j of the window is then X[1 + j] (returned: 0 or 1).
 	auto expand = [&](const unsigned char *buf, unsigned shift_frames) -> unsigned {
+		if constexpr (DUAL)
+		{
+			// two packed mono windows -> interleaved entries {X of the first window's sample p, X of the second's}: entry p + 1 (a
+			// window that starts in the high half of its first dword has a "sample -1" in front).  A lane converts dword k of each
+			// window: two samples each, two entries each, written as a pair of dwords two apart.
+			const unsigned shift_a = shift_frames & 0xFFu, shift_b = (shift_frames >> 8) & 0xFFu, frames = shift_frames >> 16;
+			const unsigned odd_a = (shift_a >> 1) & 1u, odd_b = (shift_b >> 1) & 1u;
+			const unsigned dwords = (1u + frames + 1u) / 2u;   // wave-uniform: enough for either window
+			const int *from_a = reinterpret_cast<const int *>(buf + (shift_a & ~3u)) + lane;
+			const int *from_b = reinterpret_cast<const int *>(buf + BUF / 2u + (shift_b & ~3u)) + lane;
+			int *x = reinterpret_cast<int *>(my_x);
+#pragma unroll
+			for (unsigned k = 0; k < (unsigned)NVW * 2u; ++k)   // (a window is half a buffer: NVW * 2 trips of 64 dwords)
+			{
+				if (k * 64u >= dwords)
+					break;
+				const unsigned d = k * 64u + lane;
+				if (d < dwords)
+				{
+					const int fa = from_a[k * 64u], fb = from_b[k * 64u];
+					int a0, a1, b0, b1;
+					if constexpr (MOVARM)
+					{
+						a0 = (int)((unsigned)fa << 16) >> 15;
+						a1 = (fa >> 16) * 2;
+						b0 = (int)((unsigned)fb << 16) >> 15;
+						b1 = (fb >> 16) * 2;
+					}
+					else
+					{
+						a0 = (int)((unsigned)fa << 16);
+						a1 = (int)((unsigned)fa & 0xFFFF0000u);
+						b0 = (int)((unsigned)fb << 16);
+						b1 = (int)((unsigned)fb & 0xFFFF0000u);
+					}
+					// sample p = 2 d - odd (and p + 1) -> entries p + 1, p + 2: dwords 2 (p + 1) [+ 1 for the second window], two further on
+					int *ea = x + 2u * (2u * d - odd_a + 1u), *eb = x + 2u * (2u * d - odd_b + 1u) + 1u;
+					ea[0] = a0;
+					ea[2] = a1;
+					eb[0] = b0;
+					eb[2] = b1;
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			return 2u;   // (entry p + 1: one entry - two dwords - in front, whatever the windows' alignment)
+		}
 		const unsigned shift = shift_frames & 0xFFFFu, frames = shift_frames >> 16;
 		const unsigned odd = (shift >> 1) & 1u;
 		const unsigned dwords = (odd + frames * CH + 1u) / 2u;   // wave-uniform
@@ -658,7 +745,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 		});
 	};
 
+	// dual mono: one descriptor over the mono output, from its first frame to the end of the second half of the stream (H + the second
+	// half's frames): frame j goes to [j], its partner to [j + H] - beyond the range where it does not exist, and the store is dropped
+	const uint64_t dual_base = reinterpret_cast<uint64_t>(a.d_out);
+	const uint64_t dual_bytes = (a.dual_out_frames + a.dual_valid_frames) * 4u;
+	const __amdgpu_buffer_rsrc_t dual_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+	    reinterpret_cast<void *>(((uint64_t)__builtin_amdgcn_readfirstlane((int)(unsigned)(dual_base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)dual_base)), 0,
+	    (int)__builtin_amdgcn_readfirstlane((int)(unsigned)(!DUAL ? 0u : (dual_bytes > 0xFFFFFFFCull ? 0xFFFFFFFCull : dual_bytes))), 0x00020000);
+	const unsigned dual_second = __builtin_amdgcn_readfirstlane((unsigned)a.dual_out_frames * 4u);
 	auto store_frame = [&](uint64_t frame, const int *out) {
+		if constexpr (DUAL)
+		{
+			const unsigned at = (unsigned)frame * 4u;   // (frame < H < 2^30: the host)
+			__builtin_amdgcn_raw_buffer_store_b32(out[0], dual_rsrc, (int)at, 0, NT ? 2 : 0);
+			__builtin_amdgcn_raw_buffer_store_b32(out[1], dual_rsrc, (int)at, (int)dual_second, NT ? 2 : 0);
+			return;
+		}
 		if constexpr (OUT16)
 			store_shorts<CH, NT>(reinterpret_cast<short *>(a.d_out) + frame * CH, out);
 		else

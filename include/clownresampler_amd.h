@@ -202,6 +202,9 @@ unsigned long long ClownResamplerAMD_DebugLaunchCount(unsigned kernel);
 /* Test hook: whole-number ratios take the plan's ordinary kernel instead of k_int (the A/B leg; also CLOWNRESAMPLER_AMD_NO_INT_KERNEL
    in the environment at first use, which additionally skips k_int's one-time setup). */
 void ClownResamplerAMD_DebugDisableIntKernel(int on);
+/* Test hook: long MONO launches stay on the plan's mono kernel instead of running as two phase-aligned "channels" of the stereo
+   instance (dual mono; also CLOWNRESAMPLER_AMD_NO_DUAL_MONO in the environment at first use). */
+void ClownResamplerAMD_DebugDisableDualMono(int on);
 /* Test hook for ClownResamplerAMD_ResampleSegmentsDevice: 0 = the measured rule picks (default), 1 = always one launch per segment
    (the polyphase kernels), 2 = always ONE launch for all segments (the generic kernel with a segment table). */
 void ClownResamplerAMD_DebugSegmentsMode(int mode);

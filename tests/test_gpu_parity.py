@@ -291,7 +291,7 @@ def test_baseline_configs_full_size_bit_exact(products, name, radius, ch, rates,
     ("dn32k", 3, 2, (48000, 32000, 32000), 28800000, 5),    # a periodic ratio on k_int: 3:2 (two rows in the kernel arguments) ...
     ("dn32km", 3, 1, (48000, 32000, 32000), 57600000, 5),   # ... mono
     ("dn16", 3, 2, (44100, 16000, 16000), 26460000, 4),     # 44.1 -> 16 kHz: 16-slot k_wave2 instance
-    ("dn16m", 3, 1, (44100, 16000, 16000), 26460000, 1),    # ... mono: specialised k_poly, any-sign chain on the packed mono window
+    ("dn16m", 3, 1, (44100, 16000, 16000), 26460000, 1),    # ... mono: specialised k_poly, any-sign chain on the packed mono window (dual mono off: this row is about the mono kernel)
     ("dn11", 3, 2, (88200, 48000, 48000), 26460000, 4),     # 88.2 -> 48 kHz: 11-slot k_wave2 instance
     ("dn26", 3, 2, (192000, 44100, 44100), 57600000, 4),    # 192 -> 44.1 kHz: 26-slot k_wave2 instance
     ("dn22", 3, 2, (176400, 48000, 48000), 52920000, 4),    # 176.4 -> 48 kHz: 22-slot k_wave2 instance
@@ -306,6 +306,7 @@ def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch,
     plan = p.api.PlanCreate(st.raw, p.pre)
     info = p.api.PlanGetInfo(plan)
     p.api.DebugDisableIntKernel(kernel != 5)
+    p.api.DebugDisableDualMono(True)   # (mono rows name the MONO kernel; the dual form has its own tests)
     try:
         assert p.api.PlanKernelAt(plan, 0) == kernel, (name, info.kernel, p.api.PlanKernelAt(plan, 0))
         R = int(ost.cfg.radius_frames)
@@ -316,6 +317,7 @@ def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch,
         assert p.api.LaunchCount(kernel) > before, "the kernel this row names is not the one that ran"
     finally:
         p.api.DebugDisableIntKernel(False)
+        p.api.DebugDisableDualMono(False)
     assert got.size == want.size == ck.count_output_frames(ost, frames) * ch and ran_out == 1 and left == 0
     assert np.array_equal(got, want)
 
@@ -380,22 +382,29 @@ def test_one_launch_full_size_bit_exact(products, name, radius, ch, rates, frame
         api.DeviceFree(d_out)
 
 
-@pytest.mark.parametrize("rates,frames,start", [
-    ((44100, 48000, 44100), 3_000_000, (0, 0)),          # odd increment: the fraction repeats after 65,536 frames; ~3.3 M output frames -> H = 1,638,400
-    ((44100, 48000, 44100), 1_234_567, (0, 0)),          # H rounded up past half: the second half is the shorter one
-    ((44100, 48000, 44100), 2_000_001, (5, 40001)),      # a resumed stream: overshoot and fraction carried in
-    ((48000, 44100, 44100), 2_500_000, (0, 0)),          # mild downsampling: the any-sign chain of the stereo instance
-    ((48000, 44100, 44100), 1_100_000, (0, 12345)),
-    ((8000, 44100, 8000), 400_000, (0, 0)),              # 5.5x upsampling (increment 11888 = 2^4 x 743: period 4,096)
-    ((22050, 44100, 22050), 1_500_000, (0, 0)),          # exactly 2x (increment 32768: period 2 - the tile decides H)
-    ((44100, 48000, 44100), 600_000, (0, 0)),            # too short for the rule: the mono kernel does all of it
+@pytest.mark.parametrize("radius,rates,frames,start", [
+    (3, (44100, 48000, 44100), 3_000_000, (0, 0)),          # odd increment: the fraction repeats after 65,536 frames; ~3.3 M output frames -> H = 1,638,400
+    (3, (44100, 48000, 44100), 1_234_567, (0, 0)),          # H rounded up past half: the second half is the shorter one
+    (3, (44100, 48000, 44100), 2_000_001, (5, 40001)),      # a resumed stream: overshoot and fraction carried in
+    (3, (48000, 44100, 44100), 2_500_000, (0, 0)),          # mild downsampling: the any-sign chain of the stereo instance
+    (3, (48000, 44100, 44100), 1_100_000, (0, 12345)),
+    (3, (8000, 44100, 8000), 400_000, (0, 0)),              # 5.5x upsampling (increment 11888 = 2^4 x 743: period 4,096)
+    (3, (22050, 44100, 22050), 1_500_000, (0, 0)),          # exactly 2x (increment 32768: period 2 - the tile decides H)
+    (3, (44100, 48000, 44100), 600_000, (0, 0)),            # too short for the rule: the mono kernel does all of it
+    (8, (44100, 48000, 44100), 3_000_000, (0, 0)),          # the stereo partner is k_wave2 (mov-armed, 15 slots) ...
+    (8, (44100, 48000, 44100), 1_700_001, (3, 65535)),
+    (8, (48000, 44100, 44100), 3_000_000, (0, 0)),          # ... k_wave2, any-sign, 17 slots
+    (3, (44100, 8000, 8000), 12_000_000, (0, 0)),           # ... 33 slots (2.2 M output frames)
+    (3, (44100, 8000, 8000), 9_000_001, (17, 999)),
+    (3, (96000, 44100, 44100), 5_000_000, (0, 0)),          # the mono kernel is k_poly<1,13>, its stereo partner k_wave2<2,13>
+    (3, (44100, 16000, 16000), 6_000_000, (0, 7)),          # k_poly<1,16> / k_wave2<2,16>
 ])
-def test_dual_mono_long_launches_bit_exact(products, rates, frames, start):
+def test_dual_mono_long_launches_bit_exact(products, radius, rates, frames, start):
     """DUAL MONO (round 4): a long MONO launch runs on the STEREO instance - output frames j and j + H, whose fractions are equal
     (H x increment a multiple of 65536), as its two channels, the two input windows interleaved in LDS per tile.  Device-resident,
     ONE call, every sample against the oracle; also with a capacity stop in the second half and the rest as a second call (the
-    resumed state starts mid-stream), and with the dual form switched off (the same stream on the mono kernel)."""
-    p, o = products[3], ck.oracle(3)
+    resumed state starts mid-stream)."""
+    p, o = products[radius], ck.oracle(radius)
     api = p.api
     ch = 1
     ok, st = p.low_init(ch, *rates)
@@ -420,7 +429,7 @@ def test_dual_mono_long_launches_bit_exact(products, rates, frames, start):
         n, left, ran_out = api.ResampleDevice(plan, first, d_in, frames, d_out, total + 1)
         api.StreamSynchronize()
         launched = [api.LaunchCount(k) - b for k, b in zip(range(8), before)]
-        assert n == total and left == 0 and ran_out == 1 and sum(launched[:7]) == 1 and launched[1] + launched[5] == 1   # (exactly 2x: the periodic k_int instance)
+        assert n == total and left == 0 and ran_out == 1 and sum(launched[:7]) == 1 and launched[1] + launched[4] + launched[5] == 1   # (5: exactly 2x is the periodic k_int instance's)
         api.CopyFromDevice(got, d_out)
         assert np.array_equal(got, want)
         # (b) stopped by its capacity at 70 % of the stream, the rest as a second call from the state the first one left

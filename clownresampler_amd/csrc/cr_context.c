@@ -1135,7 +1135,7 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 		tile = ((1ull << 32) - 65536u) / plan->increment;
 	if (tile > (1u << 24) - 1u)
 		tile = (1u << 24) - 1u;
-	/* whole groups of threads * frames-in-flight; 4, 2 or 1 groups per tile run as straight-line code in the kernel */
+	/* whole groups of threads * frames-in-flight; 4, 3, 2 or 1 groups per tile run as straight-line code in the kernel */
 	{
 		const int tile_groups = g_env.tile_groups; /* tuning hook (CLOWNRESAMPLER_AMD_TILE_GROUPS): cap the groups per tile */
 		/* 13 and 15 channels (7-8 channels per lane plus the phantom channel): one group per tile.  With four groups - strong
@@ -1148,6 +1148,10 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 	}
 	if (tile >= 4u * frames_multiple)
 		tile = 4u * frames_multiple;
+	else if (tile >= 3u * frames_multiple && plan->channels <= 2u)
+		tile = 3u * frames_multiple;   /* (round 4: 48 -> 44.1 kHz fits three groups, not four: 2,048 -> 3,072-frame tiles; stereo + 4 %, and the
+		                                  dual-mono launches on the stereo instance + 13 %; 4 and 8 channels measured 1-3 % SLOWER with three groups
+		                                  and keep two: profiles/r04_three_group_tiles_ab.log) */
 	else if (tile >= 2u * frames_multiple)
 		tile = 2u * frames_multiple;
 	else if (tile >= frames_multiple)

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 			}
 		};
 
-		// Full tiles of 4, 2 or 1 groups as straight-line code (see the vmcnt note above).  Specialised instances
+		// Full tiles of 4, 3, 2 or 1 groups as straight-line code (see the vmcnt note above).  Specialised instances
 		// (TT > 0) run the frames of a tile as a software pipeline: the LDS reads of frame i+1 are issued before the
 		// arithmetic of frame i.
 		auto run_groups = [&](auto groups_tag) {
@@ -511,6 +511,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 
 		if (nl == 4u * GROUP)
 			run_groups(std::integral_constant<int, 4>());
+		else if (nl == 3u * GROUP)
+			run_groups(std::integral_constant<int, 3>());
 		else if (nl == 2u * GROUP)
 			run_groups(std::integral_constant<int, 2>());
 		else if (nl == GROUP)

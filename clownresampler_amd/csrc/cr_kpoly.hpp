@@ -310,7 +310,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 	for (unsigned it = 0;; ++it)
 	{
 		// (dual mono: the DMA always lands in the first buffer, the second holds the interleaved tile the frames read)
-		const unsigned char *tile = DUAL ? tiles + TILE_BYTES : tiles + (it & 1u) * TILE_BYTES;
+		// (its distance as a VALUE, not a constant: hipcc otherwise adds it to the address of every window read that has no room for
+		// it in its offset field - two VALU per frame)
+		unsigned dual_at = TILE_BYTES;
+		asm volatile("" : "+s"(dual_at));
+		const unsigned char *tile = DUAL ? tiles + dual_at : tiles + (it & 1u) * TILE_BYTES;
 		const bool more = next_index < n_tiles;
 		const uint64_t jn = next_index * NT64;
 		unsigned n_next = 0, shift_next = 0;

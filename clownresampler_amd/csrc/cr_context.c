@@ -1837,7 +1837,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		unit = plan->dual.period / ga * partner->tile_frames;
 		const uint64_t half = ((n_out + 1u) / 2u + unit - 1u) / unit * unit;
 
-		if (n_out >= 16u * unit && half < n_out && half < (1ull << 30))
+		if (n_out >= 16u * unit && half < n_out && half < (1ull << 30) && ((half * plan->increment) >> 16) < (1ull << 31))
 		{
 			crhip_poly_launch l;
 			uint64_t blocks;
@@ -1863,9 +1863,9 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			l.pos0 = (pos_int << 16) + pos_frac;
 			l.n_out = half;
 			l.dual = 1u;
-			l.dual_out_frames = half;
-			l.dual_valid_frames = n_out - half;
-			l.dual_in_bytes = ((half * plan->increment) >> 16) * 2u;   /* (half * increment is a multiple of 65536) */
+			l.dual_out_frames = (uint32_t)half;
+			l.dual_valid_frames = (uint32_t)(n_out - half);
+			l.dual_in_bytes = (uint32_t)(((half * plan->increment) >> 16) * 2u);   /* (half * increment is a multiple of 65536; < 2^32: checked above) */
 			if (blocks > plan->dual.max_blocks)
 				blocks = plan->dual.max_blocks;
 			l.blocks = (uint32_t)blocks;

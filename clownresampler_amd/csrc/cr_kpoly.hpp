@@ -391,12 +391,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 		// dual mono: where this tile's first frames go, and how many of its SECOND frames exist (the second half of the stream may be
 		// the shorter one)
 		int *out_mono = reinterpret_cast<int *>(a.d_out) + jt;
-		const unsigned dual_valid = !DUAL ? 0u : (a.dual_valid_frames > jt ? (unsigned)((a.dual_valid_frames - jt < NT64) ? (a.dual_valid_frames - jt) : NT64) : 0u);
+		const unsigned jt32 = (unsigned)jt;   // (dual mono: fewer than 2^30 pairs)
+		const unsigned dual_valid = !DUAL ? 0u : (a.dual_valid_frames > jt32 ? ((a.dual_valid_frames - jt32 < (unsigned)NT64) ? (a.dual_valid_frames - jt32) : (unsigned)NT64) : 0u);
 		// Stores through ONE buffer descriptor from the tile's first frames to the end of its second frames, with a wave-uniform frame
 		// offset (scalar: + H frames for the second) and one constant lane offset: no address arithmetic and no predicate per frame -
 		// a second frame that does not exist lies beyond the descriptor's range and the store is dropped.  (H < 2^30 frames: the host.)
 		const uint64_t lo_base = reinterpret_cast<uint64_t>(out_mono);
-		const unsigned second_bytes = (unsigned)a.dual_out_frames * 4u;   // wave-uniform
+		const unsigned second_bytes = a.dual_out_frames * 4u;   // wave-uniform
 		const unsigned valid_here = dual_valid < n ? dual_valid : n;
 		const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
 		    reinterpret_cast<void *>(((uint64_t)__builtin_amdgcn_readfirstlane((int)(unsigned)(lo_base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)lo_base)), 0,

@@ -748,11 +748,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	// dual mono: one descriptor over the mono output, from its first frame to the end of the second half of the stream (H + the second
 	// half's frames): frame j goes to [j], its partner to [j + H] - beyond the range where it does not exist, and the store is dropped
 	const uint64_t dual_base = reinterpret_cast<uint64_t>(a.d_out);
-	const uint64_t dual_bytes = (a.dual_out_frames + a.dual_valid_frames) * 4u;
+	const uint64_t dual_bytes = ((uint64_t)a.dual_out_frames + a.dual_valid_frames) * 4u;
 	const __amdgpu_buffer_rsrc_t dual_rsrc = __builtin_amdgcn_make_buffer_rsrc(
 	    reinterpret_cast<void *>(((uint64_t)__builtin_amdgcn_readfirstlane((int)(unsigned)(dual_base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)dual_base)), 0,
 	    (int)__builtin_amdgcn_readfirstlane((int)(unsigned)(!DUAL ? 0u : (dual_bytes > 0xFFFFFFFCull ? 0xFFFFFFFCull : dual_bytes))), 0x00020000);
-	const unsigned dual_second = __builtin_amdgcn_readfirstlane((unsigned)a.dual_out_frames * 4u);
+	const unsigned dual_second = __builtin_amdgcn_readfirstlane(a.dual_out_frames * 4u);
 	auto store_frame = [&](uint64_t frame, const int *out) {
 		if constexpr (DUAL)
 		{

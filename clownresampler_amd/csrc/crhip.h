@@ -69,7 +69,7 @@ typedef struct crhip_poly_launch
 	   therefore share their row; the second one's window lies dual_in_bytes further on in d_in.  channels is 2, n_out counts
 	   PAIRS, d_out is the mono output (int32): pair j writes d_out[j] and - while j < dual_valid_frames - d_out[j + dual_out_frames]. */
 	uint32_t dual;
-	uint64_t dual_out_frames, dual_valid_frames, dual_in_bytes;
+	uint32_t dual_out_frames, dual_valid_frames, dual_in_bytes;   /* (all below 2^32: the host launches at most 2^30 pairs) */
 } crhip_poly_launch;
 
 /* One launch of the generic kernel: the reference arithmetic restated with 64-bit integers, one thread per

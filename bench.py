@@ -609,6 +609,11 @@ def main():
         ran = info.brief_kernel if (info.kernel == 3 and shard.output_frames < info.brief_below) else info.kernel
     kernel_name = {1: "k_poly<%d,%d>", 2: "k_wave<%d,%d>", 3: "k_up2<%d,%d>" if ch == 2 else "k_up<%d,%d>",   # (stereo: k_up2 - variant 27, the default, with the FP32 round-toward-zero chain, 26 with the integer chain; other channel counts k_up)
                    4: "k_wave2<%d,%d>", 5: "k_int<%d,%d>", 6: "k_wave2s<%d,%d>"}[ran] % (ch, info.slots) if ran else "k_generic"
+    # a long mono launch runs on the STEREO instance of its configuration (dual mono: frames j and j + H as the two channels)
+    dual = api.PlanDualMonoKernel(plan) if (ch == 1 and not args.s16 and ran != 5 and os.environ.get("CLOWNRESAMPLER_AMD_NO_DUAL_MONO") is None) else 0
+    if dual and launches_by_kernel[dual] >= args.steps:
+        kernel_name = "%s<2,%d> as dual mono (mono plan: %s)" % ({1: "k_poly", 4: "k_wave2"}[dual], info.slots, kernel_name)
+        ran = dual
     if launches_by_kernel[ran] < args.steps:
         raise SystemExit("bench: expected the timed launches on kernel %d (%s); launch counters say %s" % (ran, kernel_name, launches_by_kernel))
     pmc, pmc_file, traffic_note = pmc_summary(workload, api.BuildId()) if (world == 1 and not args.s16) else (None, None, "N > 1 / int16 output: no PMC summary applies")

@@ -203,6 +203,7 @@ class Api:
         self._BuildId = fn("ClownResamplerAMD_BuildId", C.c_char_p, [], False)
         self._DisableInt = fn("ClownResamplerAMD_DebugDisableIntKernel", None, [C.c_int], False)
         self._DisableDual = fn("ClownResamplerAMD_DebugDisableDualMono", None, [C.c_int], False)
+        self._PlanDualMono = fn("ClownResamplerAMD_PlanDualMonoKernel", C.c_uint32, [C.c_void_p], False)
         self._SegmentsMode = fn("ClownResamplerAMD_DebugSegmentsMode", None, [C.c_int], False)
         self._HighRelease = fn("ClownResamplerAMD_HighLevel_Release", None, [P(HighLevel_State)], False)
         self._WindowCount = fn("ClownResamplerAMD_StreamingWindowCount", C.c_size_t, [], False)
@@ -435,6 +436,10 @@ class Api:
     def DebugSegmentsMode(self, mode):
         """0: the rule picks, 1: one launch per segment, 2: one launch for all segments (segment table)"""
         self._SegmentsMode(mode)
+
+    def PlanDualMonoKernel(self, plan):
+        """0, or the kernel id of the stereo instance long launches of this mono plan run on (dual mono)"""
+        return int(self._PlanDualMono(plan))
 
     def DebugDisableDualMono(self, on):
         self._DisableDual(1 if on else 0)

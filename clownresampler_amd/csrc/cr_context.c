@@ -2486,6 +2486,15 @@ void ClownResamplerAMD_DebugSegmentsMode(int mode)
 	g_segments_mode = (mode >= 0 && mode <= 2) ? mode : 0;
 }
 
+uint32_t ClownResamplerAMD_PlanDualMonoKernel(const ClownResamplerAMD_Plan *plan)
+{
+	const ClownResamplerAMD_Plan *partner = plan != NULL ? plan->dual.partner : NULL;
+
+	if (partner == NULL || g_no_dual_mono)
+		return 0u;
+	return partner->vecs >= 150u ? 4u : 1u;
+}
+
 void ClownResamplerAMD_DebugDisableDualMono(int on)
 {
 	g_no_dual_mono = on != 0;

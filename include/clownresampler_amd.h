@@ -202,6 +202,9 @@ unsigned long long ClownResamplerAMD_DebugLaunchCount(unsigned kernel);
 /* Test hook: whole-number ratios take the plan's ordinary kernel instead of k_int (the A/B leg; also CLOWNRESAMPLER_AMD_NO_INT_KERNEL
    in the environment at first use, which additionally skips k_int's one-time setup). */
 void ClownResamplerAMD_DebugDisableIntKernel(int on);
+/* 0, or the kernel (numbered as ClownResamplerAMD_PlanInfo.kernel: 1 = k_poly, 4 = k_wave2) of the STEREO instance that long launches
+   of this MONO plan run on as "dual mono": output frames j and j + H, whose fractional positions are equal, as its two channels. */
+uint32_t ClownResamplerAMD_PlanDualMonoKernel(const ClownResamplerAMD_Plan *plan);
 /* Test hook: long MONO launches stay on the plan's mono kernel instead of running as two phase-aligned "channels" of the stereo
    instance (dual mono; also CLOWNRESAMPLER_AMD_NO_DUAL_MONO in the environment at first use). */
 void ClownResamplerAMD_DebugDisableDualMono(int on);

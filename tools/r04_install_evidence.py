@@ -74,4 +74,9 @@ else:
     s = re.sub(r"<!-- MEASUREMENTS BEGIN.*?<!-- MEASUREMENTS END -->", lambda m: "<!-- MEASUREMENTS BEGIN (tools/r04_install_evidence.py) -->\n" + table + "\n<!-- MEASUREMENTS END -->", s, flags=re.S)
 open(p, "w").write(s)
 print(table)
+# README headline: this round's evidence box
+p = os.path.join(ROOT, "README.md")
+s = open(p).read()
+s = re.sub(r"this round's evidence box: [^,]+,\s*[^ ]+ Msamples/s", "this round's evidence box: %.3f,\n%s Msamples/s" % (c2["roofline"]["frac"], "{:,.0f}".format(c2["value"])), s)
+open(p, "w").write(s)
 print("\ncfg2: %.1f us, frac %.3f, value %.0f" % (c2["ms_per_step"] * 1e3, c2["roofline"]["frac"], c2["value"]))

@@ -418,11 +418,14 @@ def test_dual_mono_long_launches_bit_exact(products, radius, rates, frames, star
     total = want.size
     assert total == ck.count_output_frames(ost, frames)
     d_in = api.DeviceAlloc(padded.nbytes + 64)
-    d_out = api.DeviceAlloc(want.nbytes + 64)
+    GUARD = 1 << 18   # frames behind the output that no launch may touch (the last stream of a dual launch is the shorter one: its missing frames are computed and must be DROPPED)
+    d_out = api.DeviceAlloc(want.nbytes + GUARD * 4)
     try:
         api.CopyToDevice(d_in, padded)
         plan = api.PlanCreate(st.raw, p.pre)
-        got = np.zeros_like(want)
+        got = np.zeros(total + GUARD, dtype=want.dtype)
+        got[:] = 0x5A5A5A5A
+        api.CopyToDevice(d_out, got)
         # (a) one call
         first = cr.LowLevel_State.from_buffer_copy(st.raw)
         before = [api.LaunchCount(k) for k in range(8)]
@@ -431,7 +434,8 @@ def test_dual_mono_long_launches_bit_exact(products, radius, rates, frames, star
         launched = [api.LaunchCount(k) - b for k, b in zip(range(8), before)]
         assert n == total and left == 0 and ran_out == 1 and sum(launched[:7]) == 1 and launched[1] + launched[4] + launched[5] == 1   # (5: exactly 2x is the periodic k_int instance's)
         api.CopyFromDevice(got, d_out)
-        assert np.array_equal(got, want)
+        assert np.array_equal(got[:total], want)
+        assert np.all(got[total:] == 0x5A5A5A5A), "the launch wrote behind its last output frame"
         # (b) stopped by its capacity at 70 % of the stream, the rest as a second call from the state the first one left
         cut = total * 7 // 10
         two = cr.LowLevel_State.from_buffer_copy(st.raw)
@@ -439,11 +443,14 @@ def test_dual_mono_long_launches_bit_exact(products, radius, rates, frames, star
         api.CopyToDevice(d_out, got)
         n1, left1, ran1 = api.ResampleDevice(plan, two, d_in, frames, d_out, cut)
         assert n1 == cut and ran1 == 0
+        api.StreamSynchronize()
+        api.CopyFromDevice(got, d_out)
+        assert np.array_equal(got[:cut], want[:cut]) and not got[cut:].any(), "the capacity-stopped launch wrote behind its last output frame"
         n2, left2, ran2 = api.ResampleDevice(plan, two, d_in + (frames - left1) * ch * 2, left1, d_out + cut * ch * 4, total - cut + 1)
         api.StreamSynchronize()
         assert n1 + n2 == total and left2 == 0 and ran2 == 1
         api.CopyFromDevice(got, d_out)
-        assert np.array_equal(got, want)
+        assert np.array_equal(got[:total], want) and not got[total:].any()
     finally:
         api.DeviceFree(d_in)
         api.DeviceFree(d_out)

@@ -595,10 +595,11 @@ struct FrameData
 
 // SPLIT > 1: a frame of CH * SPLIT channels is shared by SPLIT neighbouring lanes, each taking CH of them (`base` then
 // already points at the lane's share of the first frame); FS is the distance between consecutive frames.
-template <int CH, int TT, int MODE, int SWZ, int SPLIT = 1>
+// PH: the frame has CH * SPLIT - 1 channels (k_poly's phantom channel): a lane's share then starts on any 2-byte boundary.
+template <int CH, int TT, int MODE, int SWZ, int SPLIT = 1, int PH = 0>
 __device__ __forceinline__ void fetch_frame(const crhip_poly_launch &a, const int *rows, const unsigned char *base, unsigned rel, FrameData<CH, TT> &d)
 {
-	constexpr unsigned FB = CH * 2 * SPLIT;
+	constexpr unsigned FB = (CH * SPLIT - PH) * 2;
 	unsigned shift;
 	const unsigned row = row_of<MODE>(a, rel & 0xFFFFu, shift);
 	const unsigned phys = SWZ ? ((row & ~15u) | ((__umul24(row >> 4, a.swizzle) + row) & 15u)) : row;
@@ -634,7 +635,12 @@ __device__ __forceinline__ void fetch_frame(const crhip_poly_launch &a, const in
 	{
 #pragma unroll
 		for (int s = 0; s < TT; ++s)
-			d.f[s].load(src + s * FB);
+		{
+			if constexpr (PH)
+				d.f[s].load_any(src + s * FB);
+			else
+				d.f[s].load(src + s * FB);
+		}
 	}
 }
 
@@ -944,13 +950,13 @@ __device__ __forceinline__ void compute_frame(const FrameData<CH, TT> &d, int *o
 template <int CH, int TT, int MODE, int NORM, int ASM, int SWZ, int SPLIT = 1, int PH = 0>
 __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int *rows, const unsigned char *base, unsigned rel, int *out)
 {
-	static_assert(PH == 0 || (TT == 0 && SPLIT == 2), "the phantom channel exists for run-time-slot instances with two lanes per frame");
+	static_assert(PH == 0 || SPLIT == 2, "the phantom channel exists for instances with two lanes per frame");
 	if constexpr ((ASM & 0xFF) == 2 || ((ASM & 0xFF) == 3 && TT > 0))
 	{
 		// (the rows are staged for the 64-bit chain: every path of such an instance goes through it - and so does the any-sign chain
 		// of a specialised instance)
 		FrameData<CH, TT> d;
-		fetch_frame<CH, TT, MODE, SWZ, SPLIT>(a, rows, base, rel, d);
+		fetch_frame<CH, TT, MODE, SWZ, SPLIT, PH>(a, rows, base, rel, d);
 		compute_frame<CH, TT, NORM, ASM>(d, out);
 		return;
 	}
@@ -1020,6 +1026,8 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 			Frame<CH> f;
 			if constexpr (CH % 2 == 1 && SPLIT == 1)
 				OddWindow<CH, (int)FB>(src).load(f, s);
+			else if constexpr (PH)
+				f.load_any(src + s * FB);
 			else
 				f.load(src + s * FB);
 			if (s == 0)

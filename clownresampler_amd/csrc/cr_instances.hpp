@@ -293,6 +293,20 @@ special make_special_lite_split()
 	return s;
 }
 
+// ... the same for an ODD total above 8: the second lane's last channel is k_poly's phantom (PH)
+template <int CHT, int TT, int MODE, int NORM>
+special make_special_lite_split_odd()
+{
+	static_assert(CHT % 2 == 1 && CHT > 8, "odd channel counts above 8");
+	constexpr int DV = 14;
+	constexpr int T = GEOMETRY[DV % 5].threads, V = GEOMETRY[DV % 5].vecs;
+	special s = {CHT, TT, MODE, NORM, DV, {}, nullptr, {nullptr, nullptr}, nullptr, false, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr}, nullptr, true, 2u, 0u, {nullptr, nullptr}, nullptr, nullptr, 0u, 0u, 0u, 13u, 0u, 0u, nullptr, 13u, 1u};
+	const poly_fn fn = (poly_fn)k_poly<(CHT + 1) / 2, TT, MODE, NORM, T, V, CRA_SPLIT_LITE_ASM, 1, 0, 0, 0, 1, 2, 1>;
+	for (int v = 0; v < VARIANTS; ++v)
+		s.fn[v] = fn;
+	s.fn16 = (poly_fn)k_poly<(CHT + 1) / 2, TT, MODE, NORM, T, V, CRA_SPLIT_LITE_ASM, 1, 0, 0, 1, 1, 2, 1>;
+	return s;
+}
 
 // run-time slot count: every channel count 1..8 and the even counts 10..16 (the reference's maximum,
 // CLOWNRESAMPLER_MAXIMUM_CHANNELS, clownresampler.h:462), both row modes, both normalisations, both output forms.  One
@@ -353,6 +367,7 @@ int specials_long(void *table, int capacity);       // cr_inst_long.hip: the 8-l
 int specials_long_b(void *table, int capacity);     // cr_inst_long_b.hip: the same for 3 to 6 channels
 int specials_multi_a(void *table, int capacity);    // cr_inst_multi_a.hip: 8 channels 48 -> 44.1 kHz with every tuning variant, BASELINE configs[3]
 int specials_multi_b(void *table, int capacity);    // cr_inst_multi_b.hip: 3 to 16 channels at 44.1 <-> 48 kHz, one instance each
+int specials_multi_c(void *table, int capacity);    // cr_inst_multi_c.hip: the odd channel counts above 8 at 44.1 <-> 48 kHz
 int specials_down(void *table, int capacity);       // cr_inst_down.hip: mono / stereo at the usual downsampling ratios
 void *ablation_instance(int abl);                   // cr_inst_headline.hip / cr_inst_long.hip (abl 8)
 void *ablation_instance_long(int abl);

@@ -141,7 +141,7 @@ const special *specials(int *count)
 	static std::vector<special> table;
 	static std::once_flag once;
 	std::call_once(once, [] {
-		int (*const providers[])(void *, int) = {crk::specials_headline, crk::specials_long, crk::specials_long_b, crk::specials_multi_a, crk::specials_multi_b, crk::specials_down};
+		int (*const providers[])(void *, int) = {crk::specials_headline, crk::specials_long, crk::specials_long_b, crk::specials_multi_a, crk::specials_multi_b, crk::specials_multi_c, crk::specials_down};
 		size_t total = 0;
 		for (auto provider : providers)
 			total += (size_t)provider(nullptr, 0);

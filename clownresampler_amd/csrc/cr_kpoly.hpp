@@ -475,7 +475,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 			if constexpr (TT > 0 && (ABL == 0 || ABL == 6))
 			{
 				FrameData<CH, TT> d[2];
-				fetch_frame<CH, TT, MODE, SWZ, SPLIT>(a, rows, base, lane_rel, d[0]);
+				fetch_frame<CH, TT, MODE, SWZ, SPLIT, PH>(a, rows, base, lane_rel, d[0]);
 #pragma unroll
 				for (int i = 0; i < N; ++i)
 				{
@@ -485,13 +485,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 					if (i + 1 < N)
 					{
 						const unsigned next_first = (unsigned)((i + 1) / U) * GROUP + (unsigned)((i + 1) % U) * NTHREADS;
-						fetch_frame<CH, TT, MODE, SWZ, SPLIT>(a, rows, base, lane_rel + (next_first / SPLIT) * a.increment, d[(i + 1) & 1]);
+						fetch_frame<CH, TT, MODE, SWZ, SPLIT, PH>(a, rows, base, lane_rel + (next_first / SPLIT) * a.increment, d[(i + 1) & 1]);
 					}
 					__builtin_amdgcn_sched_barrier(0);   // keep the reads above the arithmetic below
 					compute_frame<CH, TT, NORM, ASM>(d[i & 1], outv);
 
 					if constexpr (DUAL)
 						store_dual(first, outv);
+					else if constexpr (PH)
+						store_phantom(first + tid, outv);
 					else if constexpr (OUT16)
 						store_shorts<CH, NT>(out_tile16 + (size_t)first * CH + tid * CH, outv);
 					else

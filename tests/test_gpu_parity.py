@@ -562,6 +562,42 @@ def test_whole_number_ratio_kernel_wide_frames(products, ch):
     assert np.array_equal(got16, np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16))
 
 
+@pytest.mark.parametrize("ch", [9, 11, 13, 15])
+@pytest.mark.parametrize("rates,slots", [((44100, 48000, 44100), 5), ((48000, 44100, 44100), 6)])
+def test_odd_wide_frames_specialised(products, ch, rates, slots):
+    """9, 11, 13 and 15 channels at 44.1 <-> 48 kHz: specialised instances with two lanes per frame, the last channel of the second
+    lane a phantom (cr_inst_multi_c.hip) - lengths around the tile, pieces with capacity stops, int16 output, against the oracle."""
+    p, o = products[3], ck.oracle(3)
+    ok, probe = p.low_init(ch, *rates)
+    info = p.api.PlanGetInfo(p.api.PlanCreate(probe.raw, p.pre))
+    assert info.kernel == 1 and info.specialised == 1 and info.slots == slots, info.asdict()
+    T = int(info.tile_frames)
+    for frames in (1, 2, T - 1, T + 1, 3 * T + 17, 40 * T + 5, 150001):
+        ok, st = p.low_init(ch, *rates)
+        ok, ost = o.low_init(ch, *rates)
+        R = int(ost.cfg.radius_frames)
+        padded = ck.pad_frames(ck.noise_pcm(frames * ch, 9 + frames), ch, R)
+        got, left, ran = p.low_resample_i32(st, padded, frames)
+        want, oleft, oran = o.low_resample_i32(ost, padded, frames)
+        assert (left, ran) == (oleft, oran) and np.array_equal(got, want) and st.astuple() == ost.astuple(), (ch, frames)
+    frames = 60000
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    padded = ck.pad_frames(ck.noise_pcm(frames * ch, 47), ch, R)
+    at = 0
+    for piece, cap in ((2471, None), (5, None), (20001, 333), (19900, None), (17956, None)):
+        view = padded[at * ch:(at + piece + 2 * R) * ch]
+        g, gl, gr = p.low_resample_i32(st, view, piece, capacity=cap)
+        w, wl, wr = o.low_resample_i32(ost, view, piece, capacity=cap)
+        assert (gl, gr) == (wl, wr) and np.array_equal(g, w) and st.astuple() == ost.astuple(), (ch, piece, cap)
+        at += piece - gl
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    got16, _, _ = p.api.LowLevel_ResampleBulkS16(st.raw, p.pre, padded, frames)
+    want, _, _ = o.low_resample_i32(ost, padded, frames)
+    assert np.array_equal(got16, np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16))
+
+
 @pytest.mark.parametrize("ch", [1, 2])
 @pytest.mark.parametrize("radius,ratio", [(5, 2), (5, 3), (5, 4), (8, 2), (8, 3)])
 def test_whole_number_ratio_kernel_long_windows(products, radius, ratio, ch):

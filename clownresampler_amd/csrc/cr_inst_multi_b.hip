@@ -17,7 +17,7 @@ int specials_multi_b(void *table, int capacity)
 	    with_signed_chain<5, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 4>(make_special_lite<5, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>()),
 	    with_signed_chain<7, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 4>(make_special_lite<7, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>()),
 	    with_signed_chain<7, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, 4>(make_special_lite<7, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>()),
-	    make_special_lite_split<12, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),        // 7.1.4 and 16 channels (the reference's maximum) at 44.1 <-> 48 kHz; (16,5) measured SLOWER than the run-time instance
+	    make_special_lite_split<12, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),        // 7.1.4 and 16 channels (the reference's maximum) at 44.1 <-> 48 kHz; (16,5), slower than the run-time instance with SDWA taps, came with the chain: cr_inst_multi_c.hip
 	    make_special_lite_split<12, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
 	    make_special_lite_split<16, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
 	};

@@ -1,4 +1,5 @@
-// cr_inst_multi_c.hip - instance unit: the odd channel counts above 8 at 44.1 <-> 48 kHz (two lanes per frame, the last channel of the second a phantom)  (see cr_instances.hpp)
+// cr_inst_multi_c.hip - instance unit: 9 to 16 channels at 44.1 <-> 48 kHz, two lanes per frame (odd counts: the last channel of the second lane a phantom);
+// 12 channels and (16, 6) are in cr_inst_multi_b.hip  (see cr_instances.hpp)
 #include "cr_instances.hpp"
 
 namespace crk
@@ -19,6 +20,7 @@ int specials_multi_c(void *table, int capacity)
 	    make_special_lite_split<10, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
 	    make_special_lite_split<14, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),
 	    make_special_lite_split<14, 6, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31>(),
+	    make_special_lite_split<16, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31>(),
 	};
 	const int n = (int)(sizeof(mine) / sizeof(mine[0]));
 	if (table == nullptr)

@@ -277,8 +277,10 @@ special make_special_lite_chain()
 }
 
 // ... and with two lanes per frame (CHT channels in all, CHT / 2 per lane), at the geometry of the run-time instances above 8 channels
+// Tap arithmetic: 3 = the any-sign 64-bit chain (3 VALU per tap and channel), 1 = the SDWA form (4).  One box, 9 to 16 channels at
+// 44.1 <-> 48 kHz: the chain 1-8 % faster on every row but one (profiles/r04_odd_wide_frames_ab.log).
 #ifndef CRA_SPLIT_LITE_ASM
- #define CRA_SPLIT_LITE_ASM 1
+ #define CRA_SPLIT_LITE_ASM 3
 #endif
 template <int CHT, int TT, int MODE, int NORM>
 special make_special_lite_split()

@@ -325,23 +325,28 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 			// The tile's two mono windows have landed in the two halves of the first buffer (the barrier behind us): interleave them
 			// into a stereo tile, frame f = {first window's frame f, second window's frame f}.  A thread takes PAIRS of frames: the
 			// aligned dwords around each window's pair, a funnel shift where the window starts in the middle of a dword
-			// (wave-uniform), two byte permutes, one 8-byte write.  Then a second barrier: the interleaved tile is complete and the
+			// (wave-uniform), byte permutes, one wide write.  Then a second barrier: the interleaved tile is complete and the
 			// DMA buffer free for the next tile's windows.
 			const uint64_t pos_t = a.pos0 + jt * (uint64_t)a.increment;
 			const unsigned frames = (unsigned)(((pos_t & 0xFFFFu) + (uint64_t)(n - 1) * a.increment) >> 16) + T;
-			const unsigned sa = shift & 0xFFu, sb = shift >> 8;
-			const unsigned *wa = reinterpret_cast<const unsigned *>(tiles + (sa & ~3u));
-			const unsigned *wb = reinterpret_cast<const unsigned *>(tiles + TILE_BYTES / 2u + (sb & ~3u));
-			const unsigned ra = (sa & 2u) * 8u, rb = (sb & 2u) * 8u;
-			i32x2 *inter = reinterpret_cast<i32x2 *>(tiles + TILE_BYTES);
-			for (unsigned p = tid; p < (frames + 1u) / 2u; p += NTHREADS)
+			// (the dual fetches start at the dword of a window's first sample: the shifts are 0 or 2, both halves 16-byte aligned)
+			const unsigned ra = (shift & 2u) * 8u, rb = ((shift >> 8) & 2u) * 8u;
+			const unsigned *wa = reinterpret_cast<const unsigned *>(tiles);
+			const unsigned *wb = reinterpret_cast<const unsigned *>(tiles + TILE_BYTES / 2u);
+			i32x4 *inter = reinterpret_cast<i32x4 *>(tiles + TILE_BYTES);
+			// FOUR frames per thread (one pass for a 16 KiB tile: at most 1024 quads): 8 + 4 bytes of each window, an 16-byte write
+			for (unsigned q = tid; q < (frames + 3u) / 4u; q += NTHREADS)
 			{
-				const unsigned ap = __builtin_amdgcn_alignbit(wa[p + 1u], wa[p], ra);
-				const unsigned bp = __builtin_amdgcn_alignbit(wb[p + 1u], wb[p], rb);
-				i32x2 f;
-				f.x = (int)__builtin_amdgcn_perm(bp, ap, 0x05040100u);   // {a.lo, b.lo}
-				f.y = (int)__builtin_amdgcn_perm(bp, ap, 0x07060302u);   // {a.hi, b.hi}
-				inter[p] = f;
+				const i32x2 a01 = *reinterpret_cast<const i32x2 *>(wa + 2u * q), b01 = *reinterpret_cast<const i32x2 *>(wb + 2u * q);
+				const unsigned a2 = wa[2u * q + 2u], b2 = wb[2u * q + 2u];
+				const unsigned ap0 = __builtin_amdgcn_alignbit((unsigned)a01.y, (unsigned)a01.x, ra), ap1 = __builtin_amdgcn_alignbit(a2, (unsigned)a01.y, ra);
+				const unsigned bp0 = __builtin_amdgcn_alignbit((unsigned)b01.y, (unsigned)b01.x, rb), bp1 = __builtin_amdgcn_alignbit(b2, (unsigned)b01.y, rb);
+				i32x4 f;
+				f.x = (int)__builtin_amdgcn_perm(bp0, ap0, 0x05040100u);   // {a.lo, b.lo}
+				f.y = (int)__builtin_amdgcn_perm(bp0, ap0, 0x07060302u);   // {a.hi, b.hi}
+				f.z = (int)__builtin_amdgcn_perm(bp1, ap1, 0x05040100u);
+				f.w = (int)__builtin_amdgcn_perm(bp1, ap1, 0x07060302u);
+				inter[q] = f;
 			}
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 			__builtin_amdgcn_s_barrier();

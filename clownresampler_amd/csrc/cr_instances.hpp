@@ -170,7 +170,8 @@ special with_wave2(special s)
 }
 
 constexpr uint32_t UP_VARIANT = 26;     // variant ids 26, 27 select k_up where the instance has one and the plan qualifies
-constexpr int UP_WAVES = 12;
+constexpr int UP_WAVES = 12;          // (16 - four waves per SIMD, which k_up2's 128 VGPRs allow - leaves each wave 3.5 KB of staging beside the 66 KB of rows: wave-tiles of 36 positions
+                                      //  instead of 60, cfg 3 179 against 132 us: profiles/r04_kup2_ab.log)
 constexpr uint32_t UP_MAX_WAVE_TILE = 1024;   // output frames per wave-tile (LDS staging)
 
 constexpr uint32_t SPLIT_VARIANT = 22;   // variant ids 22..25

@@ -30,6 +30,8 @@ python3 bench.py --workload cfg2 --s16 --no-cpu-baseline > $O/bench_cfg2_s16.jso
 bash tools/all_workloads.sh > $O/all_workloads.log 2>&1
 for n in 2 8; do python3 bench.py --gpus $n > $O/bench_n${n}_sharedgpu_gloo.json 2> $O/bench_n$n.err; done
 python3 tools/pinned_paths.py > $O/host_paths_pinned.log 2>&1
+# k_up2 on cfg 3: the default (27, FP32 chain), the integer chain (26), and the timing-only ablations (1008 clock stamps, 1009 no stores, 1010 no frames)
+python3 tools/sweep_variants.py --workload cfg3 --variants 27,26,1008,1009,1010 > $O/kup2_ablations.log 2>&1
 (python3 tools/channel_table.py 3
  python3 tools/channel_table.py 8 44100:48000 48000:44100 8000:96000) > $O/channel_table.log 2>&1
 ls -la $O

@@ -12,7 +12,7 @@ for w in ("cfg2", "cfg3", "cfg4"):
     shutil.copy(os.path.join(O, "kernel_trace_head_%s.csv" % w), os.path.join(P, "r04_kernel_trace_head_%s.csv" % w))
 for w in ("cfg2", "cfg3", "cfg4", "cfg5", "hq48", "cfg2_s16", "n2_sharedgpu_gloo", "n8_sharedgpu_gloo"):
     shutil.copy(os.path.join(O, "bench_%s.json" % w), os.path.join(P, "r04_bench_%s.json" % w))
-for f in ("all_workloads", "channel_table", "host_paths_pinned", "gpu_tests"):
+for f in ("all_workloads", "channel_table", "host_paths_pinned", "gpu_tests", "kup2_ablations"):
     text = [l for l in open(os.path.join(O, f + ".log")) if "amdgpu.ids" not in l]
     open(os.path.join(P, "r04_%s.log" % f), "w").writelines(text)
 

@@ -204,6 +204,7 @@ class Api:
         self._DisableInt = fn("ClownResamplerAMD_DebugDisableIntKernel", None, [C.c_int], False)
         self._DisableDual = fn("ClownResamplerAMD_DebugDisableDualMono", None, [C.c_int], False)
         self._PlanDualMono = fn("ClownResamplerAMD_PlanDualMonoKernel", C.c_uint32, [C.c_void_p], False)
+        self._PlanPadded = fn("ClownResamplerAMD_PlanPaddedTiles", C.c_uint32, [C.c_void_p], False)
         self._SegmentsMode = fn("ClownResamplerAMD_DebugSegmentsMode", None, [C.c_int], False)
         self._HighRelease = fn("ClownResamplerAMD_HighLevel_Release", None, [P(HighLevel_State)], False)
         self._WindowCount = fn("ClownResamplerAMD_StreamingWindowCount", C.c_size_t, [], False)
@@ -440,6 +441,10 @@ class Api:
     def PlanDualMonoKernel(self, plan):
         """0, or the kernel id of the stereo instance long launches of this mono plan run on (dual mono)"""
         return int(self._PlanDualMono(plan))
+
+    def PlanPaddedTiles(self, plan):
+        """1 when the plan's k_poly instance repacks its tiles to 32-byte frames (9-11, 13-15 channels, no specialised instance, up to 2:1)"""
+        return int(self._PlanPadded(plan))
 
     def DebugDisableDualMono(self, on):
         self._DisableDual(1 if on else 0)

@@ -220,6 +220,9 @@ static unsigned long long g_launch_count[CR_KERNEL_IDS];
 #define CR_BRIEF_HALF_TILES_LONG_WINDOWS 7
 #define CR_BRIEF_HALF_TILES 3
 /* bytes of slack k_up2 keeps on either side of a wave's staged frames (= UP2_SLACK, cr_kup.hpp) */
+/* k_poly's padded tiles (9-11, 13-15 channels without a specialised instance): up to 2:1 downsampling.  One box, 8 lobes: 44.1 -> 48
+   kHz + 14-19 %, 48 -> 44.1 kHz + 3-17 %; at 44.1 -> 8 kHz, where 32-byte frames halve the tile, - 11 to + 13 % (profiles/r04_padded_tiles_ab.log) */
+#define CR_PADDED_MAX_INCREMENT (2u << 16)
 #define CR_UP2_SLACK 144u
 #define CR_UP2_ENTRIES_BYTES 1280u
 /* k_up2 as an instance's default kernel: see plan_geometry */
@@ -239,6 +242,7 @@ static struct
 	int no_special, debug, no_occupancy_clamp, tile_groups, no_host_pipeline, no_small_call_path;
 	int no_replay_thread;       /* CLOWNRESAMPLER_AMD_NO_REPLAY_THREAD: the callback API never starts its compute-ahead helper thread */
 	int no_dual_mono;           /* CLOWNRESAMPLER_AMD_NO_DUAL_MONO: long mono launches stay on the mono kernels (the A/B leg) */
+	int no_padded_tiles;        /* CLOWNRESAMPLER_AMD_NO_PADDED_TILES: 9-11 / 13-15 channels compute from the tiles as the DMA leaves them (the A/B leg) */
 	int host_direct;            /* CLOWNRESAMPLER_AMD_HOST_DIRECT: -1 unset (the rule), 0 never, 1 input only, 2 input and output - see cr_run_host */
 	int wave2s_min_channels;    /* CLOWNRESAMPLER_AMD_WAVE2S_MIN_CHANNELS: frames from this many channels on take k_wave2s for long windows (99: never) */
 	int lane_map;               /* CLOWNRESAMPLER_AMD_LANE_MAP: 0 / 1 forces k_wave2's lane order (unset: the conflict model picks) */
@@ -264,6 +268,7 @@ static void load_env(void)
 	g_env.no_small_call_path = getenv("CLOWNRESAMPLER_AMD_NO_SMALL_CALL_PATH") != NULL;
 	g_env.no_replay_thread = getenv("CLOWNRESAMPLER_AMD_NO_REPLAY_THREAD") != NULL;
 	g_env.no_dual_mono = getenv("CLOWNRESAMPLER_AMD_NO_DUAL_MONO") != NULL;
+	g_env.no_padded_tiles = getenv("CLOWNRESAMPLER_AMD_NO_PADDED_TILES") != NULL;
 	e = getenv("CLOWNRESAMPLER_AMD_HOST_DIRECT");
 	g_env.host_direct = (e != NULL && *e != '\0') ? atoi(e) : -1;
 	g_env.no_int_kernel = getenv("CLOWNRESAMPLER_AMD_NO_INT_KERNEL") != NULL;
@@ -846,7 +851,7 @@ static uint32_t plan_image_stride(const ClownResamplerAMD_Plan *plan)
 /* Launch geometry of k_poly for this plan on the current device. */
 static void plan_geometry(ClownResamplerAMD_Plan *plan)
 {
-	const uint32_t frame_bytes = plan->channels * 2u;
+	uint32_t frame_bytes = plan->channels * 2u;   /* (k_poly's run-time-slot instances of 13-15 channels: 32 in their LDS tiles, below) */
 	/* int32 per row of the device image: see cr_poly_device_image */
 	const uint32_t image_stride = plan_image_stride(plan);
 	const uint32_t rows_bytes = cr_poly_plane_rows(&plan->poly) * image_stride * 4u;
@@ -1117,7 +1122,15 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 		return;
 	}
 
-	/* frames the tile image can hold after the (< 16 byte) alignment shift */
+	/* frames the tile image can hold after the (< 16 byte) alignment shift; 13 to 15 channels without a specialised instance repack
+	   their tiles to frames of 32 bytes (the second buffer; the DMA buffer holds them as they are) */
+	plan->padded = 0u;
+	if (!plan->specialised && plan->vecs < 100u && crhip_poly_runtime_padded_frame_bytes(plan->channels) != 0u && plan->increment <= CR_PADDED_MAX_INCREMENT
+	 && !g_env.no_padded_tiles)
+	{
+		plan->padded = 1u;
+		frame_bytes = crhip_poly_runtime_padded_frame_bytes(plan->channels);
+	}
 	cap_frames = (tile_bytes - 16u) / frame_bytes;
 
 	if (cap_frames <= window_slots)
@@ -1738,6 +1751,7 @@ static void fill_poly_launch(const ClownResamplerAMD_Plan *plan, crhip_poly_laun
 	l->variant = plan->variant;
 	l->plane_rows = plan->plane_rows;
 	l->swizzle = plan->lds_swizzle;
+	l->padded = plan->padded;
 	l->lane_map = plan->lane_map;
 	l->wave_tile = plan->wave_tile;
 	l->debug_stamps = g_debug_stamps;
@@ -2493,6 +2507,11 @@ uint32_t ClownResamplerAMD_PlanDualMonoKernel(const ClownResamplerAMD_Plan *plan
 	if (partner == NULL || g_no_dual_mono)
 		return 0u;
 	return partner->vecs >= 150u ? 4u : 1u;
+}
+
+uint32_t ClownResamplerAMD_PlanPaddedTiles(const ClownResamplerAMD_Plan *plan)
+{
+	return plan != NULL && plan->use_poly ? plan->padded : 0u;
 }
 
 void ClownResamplerAMD_DebugDisableDualMono(int on)

@@ -100,6 +100,7 @@ typedef struct ClownResamplerAMD_Plan
 		crhip_int_shape shape;
 		uint32_t max_blocks, max_blocks_s16;
 	} intk;
+	uint32_t padded;   /* 1: k_poly's run-time-slot instance computes from padded tiles (crhip_poly_launch.padded) */
 	/* DUAL MONO (mono plans; crhip_poly_launch.dual, cr_kpoly.hpp): long launches run on the STEREO instance of the same
 	   configuration, output frames j and j + H as its two channels (H * increment a multiple of 65536: equal fractions, one row for
 	   both).  `partner` is a private stereo plan over this plan's own rows (not in the cache; freed with this plan); `period` =

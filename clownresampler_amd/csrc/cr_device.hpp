@@ -260,6 +260,17 @@ struct Frame
 		}
 	}
 
+	// a lane's share in a PADDED tile (padded_frames below): 16 bytes at a 16-byte boundary, the first CH channels its own
+	__device__ __forceinline__ void load_padded(const unsigned char *p)
+	{
+		static_assert(WORDS <= 4, "a lane's share of a padded frame is 16 bytes");
+		const i32x4 d = *reinterpret_cast<const i32x4 *>(p);
+		const int w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+		for (int k = 0; k < WORDS; ++k)
+			v[k] = w[k];
+	}
+
 	// the same for a frame that may start on ANY 2-byte boundary whatever its channel count (frames of an odd total channel
 	// count shared by two lanes): aligned dwords + funnel shift, as above
 	__device__ __forceinline__ void load_any(const unsigned char *p)
@@ -592,6 +603,17 @@ struct FrameData
 	int w[RS];
 	Frame<CH> f[TT];
 };
+
+// PADDED tiles: run-time-slot instances with two lanes per frame where a lane's share does not start on a dword - 9, 10, 11, 13, 14
+// and 15 channels (frames of 18 to 30 bytes).  Read where they lie, every tap costs a lane five dword reads
+// and four funnel shifts; with long windows a frame is read by 15 to 33 taps of every output frame near it.  So k_poly repacks such
+// a tile ONCE after its DMA has landed, LDS -> LDS: lane-share L = 2 * frame + half goes to L * 16 - frames of 32 bytes, every
+// share one aligned ds_read_b128, its tail (the first samples of what follows) meeting the phantom channel or nothing.
+template <int CH, int TT, int SPLIT, int PH>
+constexpr bool padded_frames()
+{
+	return TT == 0 && SPLIT == 2 && CH >= 5 && (PH == 1 || CH % 2 == 1);   // (9, 10, 11, 13, 14, 15 channels)
+}
 
 // SPLIT > 1: a frame of CH * SPLIT channels is shared by SPLIT neighbouring lanes, each taking CH of them (`base` then
 // already points at the lane's share of the first frame); FS is the distance between consecutive frames.
@@ -947,7 +969,7 @@ __device__ __forceinline__ void compute_frame(const FrameData<CH, TT> &d, int *o
 // One output frame: CH normalised int32 into out[0..CH).
 //   rel   16.16 position relative to the tile's first integer position
 //   base  LDS address of the tile's first window frame (tile + shift)
-template <int CH, int TT, int MODE, int NORM, int ASM, int SWZ, int SPLIT = 1, int PH = 0>
+template <int CH, int TT, int MODE, int NORM, int ASM, int SWZ, int SPLIT = 1, int PH = 0, int PADT = 0>
 __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int *rows, const unsigned char *base, unsigned rel, int *out)
 {
 	static_assert(PH == 0 || SPLIT == 2, "the phantom channel exists for instances with two lanes per frame");
@@ -960,7 +982,8 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 		compute_frame<CH, TT, NORM, ASM>(d, out);
 		return;
 	}
-	constexpr unsigned FB = (CH * SPLIT - PH) * 2;
+	constexpr bool PAD = PADT != 0;   // (k_poly's padded tiles: frames of 32 bytes, a lane's share 16)
+	constexpr unsigned FB = PAD ? 32u : (CH * SPLIT - PH) * 2;
 	constexpr int RS_CT = (TT + 1 + 3) & ~3;
 
 	const unsigned frac = rel & 0xFFFFu;
@@ -1090,7 +1113,9 @@ __device__ __forceinline__ void one_frame(const crhip_poly_launch &a, const int 
 #pragma unroll
 					for (int k = 0; k < N; ++k)
 					{
-						if constexpr (PH)
+						if constexpr (PAD)
+							f[k].load_padded(src + (4u * q + (unsigned)k) * FB);
+						else if constexpr (PH)
 							f[k].load_any(src + (4u * q + (unsigned)k) * FB);
 						else
 							f[k].load(src + (4u * q + (unsigned)k) * FB);

@@ -331,6 +331,12 @@ constexpr int RUNTIME_SWZ = 0;
  #define CRA_RUNTIME_ASM 3
 #endif
 constexpr int RUNTIME_ASM = CRA_RUNTIME_ASM;
+// bytes a frame of the run-time-slot instance of CHT channels takes in the LDS tiles it computes from, where k_poly repacks them (0: as they come)
+template <int CHT>
+constexpr uint32_t runtime_padded_bytes()
+{
+	return padded_frames<(CHT + 1) / 2, 0, 2, CHT % 2>() ? 32u : 0u;
+}
 constexpr int runtime_split(int channels)
 {
 	return channels > 8 ? 2 : 1;
@@ -348,15 +354,20 @@ poly_fn pick_runtime(uint32_t mode, uint32_t norm)
 }
 
 // two lanes per frame, HALF channels each (run-time slot count, geometry 4); PH = 1: 2 * HALF - 1 channels (see k_poly)
-template <int HALF, int OUT16, int PH = 0>
-poly_fn pick_runtime_split(uint32_t mode, uint32_t norm)
+template <int HALF, int OUT16, int PH = 0, int PADT = 0>
+poly_fn pick_runtime_split(uint32_t mode, uint32_t norm, uint32_t padded = 0)
 {
 	constexpr int T = GEOMETRY[runtime_geo(16)].threads, V = GEOMETRY[runtime_geo(16)].vecs;
+	if constexpr (PADT == 0 && padded_frames<HALF, 0, 2, PH>())
+	{
+		if (padded)
+			return pick_runtime_split<HALF, OUT16, PH, 1>(mode, norm);   // the same instance computing from padded tiles (k_poly PADT)
+	}
 	if (norm == CRHIP_NORM_S31)
-		return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, T, V, RUNTIME_ASM, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>
-		                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, T, V, RUNTIME_ASM, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>;
-	return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, T, V, RUNTIME_ASM, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>
-	                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, T, V, RUNTIME_ASM, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH>;
+		return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, T, V, RUNTIME_ASM, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH, 0, PADT>
+		                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_S31, T, V, RUNTIME_ASM, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH, 0, PADT>;
+	return mode == CRHIP_ROWMODE_UPSAMPLE ? (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_U32, T, V, RUNTIME_ASM, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH, 0, PADT>
+	                                      : (poly_fn)k_poly<HALF, 0, CRHIP_ROWMODE_AFFINE, CRHIP_NORM_U32, T, V, RUNTIME_ASM, 1, RUNTIME_SWZ, 0, OUT16, 1, 2, PH, 0, PADT>;
 }
 
 
@@ -376,7 +387,7 @@ void *ablation_instance(int abl);                   // cr_inst_headline.hip / cr
 void *ablation_instance_long(int abl);
 void *runtime_instance_1_4(uint32_t channels, uint32_t mode, uint32_t norm, int out16);     // cr_inst_runtime_a.hip
 void *runtime_instance_5_8(uint32_t channels, uint32_t mode, uint32_t norm, int out16);     // cr_inst_runtime_b.hip
-void *runtime_instance_9_16(uint32_t channels, uint32_t mode, uint32_t norm, int out16);    // cr_inst_runtime_c.hip
+void *runtime_instance_9_16(uint32_t channels, uint32_t mode, uint32_t norm, int out16, uint32_t padded);    // cr_inst_runtime_c.hip (padded: k_poly's PADT form, where the channel count has one)
 void *runtime_wave2s_instance(uint32_t channels, int out16);                                   // cr_inst_runtime_w.hip: k_wave2s, a lane per channel pair
 void *runtime_wave2_instance(uint32_t channels, uint32_t mode, int out16);                  // cr_inst_runtime_w.hip: k_wave2, run-time slot count
 }

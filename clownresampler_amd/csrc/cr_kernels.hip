@@ -171,13 +171,13 @@ const special *find_special(uint32_t channels, uint32_t slots, uint32_t mode, ui
 
 
 template <int OUT16>
-poly_fn pick_runtime_channels(uint32_t channels, uint32_t mode, uint32_t norm)
+poly_fn pick_runtime_channels(uint32_t channels, uint32_t mode, uint32_t norm, uint32_t padded)
 {
 	if (channels >= 1 && channels <= 4)
 		return (poly_fn)crk::runtime_instance_1_4(channels, mode, norm, OUT16);
 	if (channels <= 8)
 		return (poly_fn)crk::runtime_instance_5_8(channels, mode, norm, OUT16);
-	return (poly_fn)crk::runtime_instance_9_16(channels, mode, norm, OUT16);
+	return (poly_fn)crk::runtime_instance_9_16(channels, mode, norm, OUT16, padded);
 }
 
 } // namespace
@@ -386,6 +386,22 @@ int crhip_get_device(int *ordinal)
 }
 
 static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo);
+
+uint32_t crhip_poly_runtime_padded_frame_bytes(uint32_t channels)
+{
+	switch (channels)
+	{
+		case 9: return runtime_padded_bytes<9>();
+		case 10: return runtime_padded_bytes<10>();
+		case 11: return runtime_padded_bytes<11>();
+		case 12: return runtime_padded_bytes<12>();
+		case 13: return runtime_padded_bytes<13>();
+		case 14: return runtime_padded_bytes<14>();
+		case 15: return runtime_padded_bytes<15>();
+		case 16: return runtime_padded_bytes<16>();
+		default: return 0u;
+	}
+}
 
 int crhip_poly_has_dual(const crhip_poly_launch *launch)
 {
@@ -699,9 +715,9 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 	}
 
 	if (launch->out_s16)
-		fn = sp != nullptr ? sp->fn16 : pick_runtime_channels<1>(launch->channels, launch->row_mode, launch->norm_mode);
+		fn = sp != nullptr ? sp->fn16 : pick_runtime_channels<1>(launch->channels, launch->row_mode, launch->norm_mode, launch->padded);
 	else
-		fn = sp != nullptr ? sp->fn[v] : pick_runtime_channels<0>(launch->channels, launch->row_mode, launch->norm_mode);
+		fn = sp != nullptr ? sp->fn[v] : pick_runtime_channels<0>(launch->channels, launch->row_mode, launch->norm_mode, launch->padded);
 	if (sp != nullptr && sp->lite && sp->fn_rotated != nullptr && launch->swizzle != 0)
 		fn = launch->out_s16 ? sp->fn16_rotated : sp->fn_rotated;
 

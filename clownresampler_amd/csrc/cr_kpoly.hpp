@@ -34,7 +34,7 @@ namespace
 //           the two halves of the workgroup into the two halves of the DMA buffer, interleaved into a stereo tile by an LDS -> LDS
 //           pass (two funnel shifts and two byte permutes per pair of frames), and the results leave as two 4-byte stores H frames
 //           apart.  crhip_poly_launch.dual* carry H, how many second frames exist, and the input offset; n_out counts pairs.
-template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0, int OUT16 = 0, int NT = 0, int SPLIT = 1, int PH = 0, int DUAL = 0>
+template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0, int OUT16 = 0, int NT = 0, int SPLIT = 1, int PH = 0, int DUAL = 0, int PADT = 0>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR_BUDGET))) void k_poly(const crhip_poly_launch a)
 {
 	static_assert(!DUAL || (CH == 2 && SPLIT == 1 && PH == 0 && OUT16 == 0 && TT > 0 && ABL == 0 && (NTHREADS / 2) % 64 == 0), "dual mono: a stereo instance, int32 output");
@@ -42,6 +42,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 	constexpr unsigned FB = CHT * 2;                      // bytes per input frame (all channels)
 	constexpr unsigned FBL = CH * 2;                      // bytes of one lane's share of a frame
 	constexpr unsigned TILE_BYTES = NV * 16u * NTHREADS;
+	// PADDED tiles (cr_device.hpp padded_frames: 13, 14, 15 channels on the run-time-slot instances): the DMA always lands in the first
+	// buffer, an LDS -> LDS pass repacks it into the second - lane-share L at L * 16 - and the frames read that
+	// (PADT: chosen per plan - crhip_poly_launch.padded - where the shorter tiles it leaves are worth it)
+	constexpr bool PADL = PADT != 0;
+	static_assert(!PADL || (padded_frames<CH, TT, SPLIT, PH>() && !DUAL && ABL == 0), "padded tiles: the run-time-slot instances of 9-11 and 13-15 channels");
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 		// it in its offset field - two VALU per frame)
 		unsigned dual_at = TILE_BYTES;
 		asm volatile("" : "+s"(dual_at));
-		const unsigned char *tile = DUAL ? tiles + dual_at : tiles + (it & 1u) * TILE_BYTES;
+		const unsigned char *tile = (DUAL || PADL) ? tiles + dual_at : tiles + (it & 1u) * TILE_BYTES;
 		const bool more = next_index < n_tiles;
 		const uint64_t jn = next_index * NT64;
 		unsigned n_next = 0, shift_next = 0;
@@ -352,11 +357,45 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 			__builtin_amdgcn_s_barrier();
 		}
 
+		if constexpr (PADL)
+		{
+			// The tile's window has landed in the first buffer (the barrier behind us).  Lane-share L = 2 * frame + half: CH * 2 bytes
+			// from byte shift + frame * FB + half * FBL - any 2-byte boundary - as the aligned dwords that cover it, funnel-shifted, one
+			// 16-byte write to L * 16 of the second buffer.  Then a second barrier: the padded tile is complete and the first buffer
+			// free for the next tile's DMA.  (The host sizes these tiles for 32 bytes per frame: plan_geometry.)
+			const uint64_t pos_t = a.pos0 + jt * (uint64_t)a.increment;
+			const unsigned shares = 2u * ((unsigned)(((pos_t & 0xFFFFu) + (uint64_t)(n - 1) * a.increment) >> 16) + T);
+			constexpr int WORDS = (CH + 1) / 2;
+			i32x4 *padded = reinterpret_cast<i32x4 *>(tiles + TILE_BYTES);
+			for (unsigned L = tid; L < shares; L += NTHREADS)
+			{
+				const unsigned at = shift + (L >> 1) * FB + (L & 1u) * FBL;
+				const unsigned *q = reinterpret_cast<const unsigned *>(tiles + (at & ~3u));
+				const unsigned r = (at & 2u) * 8u;
+				unsigned d[WORDS + 1];
+#pragma unroll
+				for (int k = 0; k < WORDS + 1; ++k)
+					d[k] = q[k];
+				int v[4] = {0, 0, 0, 0};
+#pragma unroll
+				for (int k = 0; k < WORDS; ++k)
+					v[k] = (int)__builtin_amdgcn_alignbit(d[k + 1], d[k], r);
+				i32x4 e;
+				e.x = v[0];
+				e.y = v[1];
+				e.z = v[2];
+				e.w = v[3];
+				padded[L] = e;
+			}
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+		}
+
 		if (more)
 		{
 			// the other buffer was last read in the previous iteration, which every wave has left (barrier below)
 			n_next = (unsigned)((a.n_out - jn < NT64) ? (a.n_out - jn) : NT64);
-			shift_next = fetch(jn, n_next, DUAL ? tiles : tiles + ((it + 1u) & 1u) * TILE_BYTES);
+			shift_next = fetch(jn, n_next, (DUAL || PADL) ? tiles : tiles + ((it + 1u) & 1u) * TILE_BYTES);
 			if (dynamic && wave0)
 				ticket = draw();   // for the tile after the next one; posted below, just before the barrier
 		}
@@ -392,7 +431,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 					out_tile[at + CH - 1] = v[CH - 1];
 			}
 		};
-		const unsigned char *base = DUAL ? tile : tile + shift + (tid % SPLIT) * FBL;
+		const unsigned char *base = DUAL ? tile : (PADL ? tile + (tid % SPLIT) * 16u : tile + shift + (tid % SPLIT) * FBL);
 		// dual mono: where this tile's first frames go, and how many of its SECOND frames exist (the second half of the stream may be
 		// the shorter one)
 		int *out_mono = reinterpret_cast<int *>(a.d_out) + jt;
@@ -436,7 +475,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 						outv[u * CH + c] = (int)(first + tid);
 				}
 				else
-					one_frame<CH, TT, MODE, NORM, ASM, SWZ, SPLIT, PH>(a, rows, base, lane_rel + (first / SPLIT) * a.increment, outv + u * CH);
+					one_frame<CH, TT, MODE, NORM, ASM, SWZ, SPLIT, PH, PADT>(a, rows, base, lane_rel + (first / SPLIT) * a.increment, outv + u * CH);
 			}
 			if constexpr (ABL == 1 || ABL == 3)
 			{
@@ -539,7 +578,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 			for (unsigned jl = g + tid; jl < nl; jl += NTHREADS)
 			{
 				int outv[CH];
-				one_frame<CH, TT, MODE, NORM, ASM, SWZ, SPLIT, PH>(a, rows, base, __umul24(jl / SPLIT, a.increment) + frac0, outv);
+				one_frame<CH, TT, MODE, NORM, ASM, SWZ, SPLIT, PH, PADT>(a, rows, base, __umul24(jl / SPLIT, a.increment) + frac0, outv);
 				if constexpr (PH)
 					store_phantom(jl, outv);
 				else if constexpr (DUAL)

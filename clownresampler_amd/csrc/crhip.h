@@ -68,6 +68,9 @@ typedef struct crhip_poly_launch
 	   j + dual_out_frames, whose fractional positions are equal (dual_out_frames * increment is a multiple of 65536) and which
 	   therefore share their row; the second one's window lies dual_in_bytes further on in d_in.  channels is 2, n_out counts
 	   PAIRS, d_out is the mono output (int32): pair j writes d_out[j] and - while j < dual_valid_frames - d_out[j + dual_out_frames]. */
+	/* 1: the run-time-slot instance computes from PADDED tiles (cr_device.hpp padded_frames; crhip_poly_runtime_padded_frame_bytes says
+	   which channel counts have the form): tile_frames is sized for 32-byte frames */
+	uint32_t padded;
 	uint32_t dual;
 	uint32_t dual_out_frames, dual_valid_frames, dual_in_bytes;   /* (all below 2^32: the host launches at most 2^30 pairs) */
 } crhip_poly_launch;
@@ -212,6 +215,9 @@ int crhip_poly_occupancy(const crhip_poly_launch *launch, int *workgroups_per_cu
 int crhip_launch_poly(const crhip_poly_launch *launch, void *stream);
 int crhip_launch_generic(const crhip_generic_launch *launch, void *stream);
 
+/* 0, or the bytes a frame takes in the LDS tiles of the PADDED form of the run-time-slot k_poly instance of this channel count (9-11,
+   13-15 channels: 32; cr_device.hpp padded_frames) - a launch with `padded` set has its tiles sized with it. */
+uint32_t crhip_poly_runtime_padded_frame_bytes(uint32_t channels);
 /* 1 when the instance a launch with these parameters selects (launch->dual set) has a dual-mono form */
 int crhip_poly_has_dual(const crhip_poly_launch *launch);
 /* 1 when a specialised (channels, slots, row mode, norm mode) template instance exists for the polyphase kernel. */

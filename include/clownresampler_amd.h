@@ -205,6 +205,11 @@ void ClownResamplerAMD_DebugDisableIntKernel(int on);
 /* 0, or the kernel (numbered as ClownResamplerAMD_PlanInfo.kernel: 1 = k_poly, 4 = k_wave2) of the STEREO instance that long launches
    of this MONO plan run on as "dual mono": output frames j and j + H, whose fractional positions are equal, as its two channels. */
 uint32_t ClownResamplerAMD_PlanDualMonoKernel(const ClownResamplerAMD_Plan *plan);
+/* 1 when the plan's k_poly instance computes from PADDED tiles: 9-11 and 13-15 channels without a specialised instance, up to 2:1
+   downsampling - a frame of 18 to 30 bytes leaves a lane's share of it on any 2-byte boundary, so every tile is repacked once,
+   LDS -> LDS, to frames of 32 bytes whose shares are one aligned 16-byte read per tap (CLOWNRESAMPLER_AMD_NO_PADDED_TILES in the
+   environment at first use: never). */
+uint32_t ClownResamplerAMD_PlanPaddedTiles(const ClownResamplerAMD_Plan *plan);
 /* Test hook: long MONO launches stay on the plan's mono kernel instead of running as two phase-aligned "channels" of the stereo
    instance (dual mono; also CLOWNRESAMPLER_AMD_NO_DUAL_MONO in the environment at first use). */
 void ClownResamplerAMD_DebugDisableDualMono(int on);

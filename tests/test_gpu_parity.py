@@ -598,6 +598,57 @@ def test_odd_wide_frames_specialised(products, ch, rates, slots):
     assert np.array_equal(got16, np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16))
 
 
+@pytest.mark.parametrize("ch", [9, 10, 11, 13, 14, 15])
+@pytest.mark.parametrize("radius,rates", [(8, (44100, 48000, 44100)), (8, (48000, 44100, 44100)), (3, (48000, 32000, 32000)), (5, (44100, 48000, 44100)), (3, (48000, 25000, 25000))])
+def test_padded_tiles_wide_frames(products, ch, radius, rates):
+    """9-11 and 13-15 channels on the run-time-slot instances, up to 2:1 downsampling: every tile repacked LDS -> LDS to frames of 32
+    bytes (a lane's share one aligned 16-byte read per tap).  Device pointers of minimal alignment (frames on every 2-byte phase of
+    the tile), lengths around the tile, pieces with a capacity stop, int16 output - against the oracle."""
+    p, o = products[radius], ck.oracle(radius)
+    api = p.api
+    ok, probe = p.low_init(ch, *rates)
+    plan = api.PlanCreate(probe.raw, p.pre)
+    info = api.PlanGetInfo(plan)
+    assert info.kernel == 1 and info.specialised == 0 and api.PlanPaddedTiles(plan) == 1, info.asdict()
+    T = int(info.tile_frames)
+    for frames, in_off, out_off in ((1, 2, 4), (T - 1, 6, 12), (T + 1, 14, 8), (5 * T + 33, 2, 0), (30011, 10, 4)):
+        ok, st = p.low_init(ch, *rates)
+        ok, ost = o.low_init(ch, *rates)
+        R = int(ost.cfg.radius_frames)
+        padded = ck.pad_frames(ck.noise_pcm(frames * ch, 77 + frames), ch, R)
+        want, _, _ = o.low_resample_i32(ost, padded, frames)
+        total = want.size // ch
+        d_in = api.DeviceAlloc(padded.nbytes + 256)
+        d_out = api.DeviceAlloc(want.nbytes + 256)
+        try:
+            api.CopyToDevice(d_in + in_off, padded)
+            n, left, ran_out = api.ResampleDevice(plan, st.raw, d_in + in_off, frames, d_out + out_off, total + 8)
+            api.StreamSynchronize()
+            assert (n, left, ran_out) == (total, 0, 1)
+            got = np.empty_like(want)
+            api.CopyFromDevice(got, d_out + out_off)
+            assert np.array_equal(got, want), (ch, rates, frames)
+        finally:
+            api.DeviceFree(d_in)
+            api.DeviceFree(d_out)
+    frames = 40000
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    padded = ck.pad_frames(ck.noise_pcm(frames * ch, 51), ch, R)
+    at = 0
+    for piece, cap in ((1471, None), (5, None), (15001, 333), (14900, None), (10000, None)):
+        view = padded[at * ch:(at + piece + 2 * R) * ch]
+        g, gl, gr = p.low_resample_i32(st, view, piece, capacity=cap)
+        w, wl, wr = o.low_resample_i32(ost, view, piece, capacity=cap)
+        assert (gl, gr) == (wl, wr) and np.array_equal(g, w) and st.astuple() == ost.astuple(), (ch, piece, cap)
+        at += piece - gl
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    got16, _, _ = api.LowLevel_ResampleBulkS16(st.raw, p.pre, padded, frames)
+    want, _, _ = o.low_resample_i32(ost, padded, frames)
+    assert np.array_equal(got16, np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16))
+
+
 @pytest.mark.parametrize("ch", [1, 2])
 @pytest.mark.parametrize("radius,ratio", [(5, 2), (5, 3), (5, 4), (8, 2), (8, 3)])
 def test_whole_number_ratio_kernel_long_windows(products, radius, ratio, ch):

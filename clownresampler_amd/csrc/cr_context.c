@@ -851,7 +851,7 @@ static uint32_t plan_image_stride(const ClownResamplerAMD_Plan *plan)
 /* Launch geometry of k_poly for this plan on the current device. */
 static void plan_geometry(ClownResamplerAMD_Plan *plan)
 {
-	uint32_t frame_bytes = plan->channels * 2u;   /* (k_poly's run-time-slot instances of 13-15 channels: 32 in their LDS tiles, below) */
+	uint32_t frame_bytes = plan->channels * 2u;   /* (k_poly's padded tiles - 9-11, 13-15 channels without a specialised instance: 32 in the LDS tiles, below) */
 	/* int32 per row of the device image: see cr_poly_device_image */
 	const uint32_t image_stride = plan_image_stride(plan);
 	const uint32_t rows_bytes = cr_poly_plane_rows(&plan->poly) * image_stride * 4u;
@@ -1122,7 +1122,7 @@ static void plan_geometry(ClownResamplerAMD_Plan *plan)
 		return;
 	}
 
-	/* frames the tile image can hold after the (< 16 byte) alignment shift; 13 to 15 channels without a specialised instance repack
+	/* frames the tile image can hold after the (< 16 byte) alignment shift; 9-11 and 13-15 channels without a specialised instance repack
 	   their tiles to frames of 32 bytes (the second buffer; the DMA buffer holds them as they are) */
 	plan->padded = 0u;
 	if (!plan->specialised && plan->vecs < 100u && crhip_poly_runtime_padded_frame_bytes(plan->channels) != 0u && plan->increment <= CR_PADDED_MAX_INCREMENT

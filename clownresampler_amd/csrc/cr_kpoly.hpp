@@ -32,7 +32,7 @@ namespace
 //           "channels" of one lane: one row index, one row read, one reciprocal for two frames, and the frame body is the stereo
 //           instance's, unchanged.  Per tile the two mono input windows (H * increment / 65536 input frames apart) are fetched by
 //           the two halves of the workgroup into the two halves of the DMA buffer, interleaved into a stereo tile by an LDS -> LDS
-//           pass (two funnel shifts and two byte permutes per pair of frames), and the results leave as two 4-byte stores H frames
+//           pass (four frames per thread: four funnel shifts, four byte permutes, one 16-byte write), and the results leave as two 4-byte stores H frames
 //           apart.  crhip_poly_launch.dual* carry H, how many second frames exist, and the input offset; n_out counts pairs.
 template <int CH, int TT, int MODE, int NORM, int NTHREADS, int NV, int ASM, int U, int SWZ, int ABL = 0, int OUT16 = 0, int NT = 0, int SPLIT = 1, int PH = 0, int DUAL = 0, int PADT = 0>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR_BUDGET))) void k_poly(const crhip_poly_launch a)
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 	constexpr unsigned FB = CHT * 2;                      // bytes per input frame (all channels)
 	constexpr unsigned FBL = CH * 2;                      // bytes of one lane's share of a frame
 	constexpr unsigned TILE_BYTES = NV * 16u * NTHREADS;
-	// PADDED tiles (cr_device.hpp padded_frames: 13, 14, 15 channels on the run-time-slot instances): the DMA always lands in the first
+	// PADDED tiles (cr_device.hpp padded_frames: 9-11 and 13-15 channels on the run-time-slot instances, where the plan asks): the DMA always lands in the first
 	// buffer, an LDS -> LDS pass repacks it into the second - lane-share L at L * 16 - and the frames read that
 	// (PADT: chosen per plan - crhip_poly_launch.padded - where the shorter tiles it leaves are worth it)
 	constexpr bool PADL = PADT != 0;

@@ -570,10 +570,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 	asm("v_ashrrev_i32_e32 v118, 31, %2\n\t"                                                                                     \
 	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[118:119]"                                                               \
 	    : "=&{v" #LO "}"(VLO), "=&{v" #HI "}"(VHI) : "v"(X), "v"(W), "{v119}"(zero119) : "vcc", "v118")
+// (the arming move is the COMPILER's instruction: between two asm statements that touch a common pinned register hipcc pads with an
+// s_nop unless an instruction of its own stands in between - 28 s_nop per 15-slot stereo frame with the move inside the statement, 7 so)
 #define CRHIP_W2_TAP_MOV(LO, HI, VLO, VHI, X, W)                                                                                   \
-	asm("v_mov_b32_e32 v" #LO ", %2\n\t"                                                                                         \
-	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
-	    : "=&{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc")
+	VLO = (X);                                                                                                                     \
+	asm("v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
+	    : "+{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc")
 #define CRHIP_W2_TAP_MOV_SAFE(LO, HI, VLO, VHI, X, W)                                                                              \
 	asm("v_lshlrev_b32_e32 v118, 15, %2\n\t"                                                                                     \
 	    "v_mov_b32_e32 v" #LO ", %2\n\t"                                                                                         \

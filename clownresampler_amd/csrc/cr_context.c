@@ -1379,6 +1379,13 @@ static void plan_dual_partner(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *
 	memset(&partner->intk, 0, sizeof(partner->intk));
 	memset(&partner->dual, 0, sizeof(partner->dual));
 	plan_geometry(partner);
+	if (partner->use_poly && partner->vecs >= 200u && partner->key_variant == (uint32_t)CR_DEFAULT_VARIANT)
+	{
+		/* the stereo instance's kernel at this ratio is k_up2 (8x - 13x upsampling with 8 lobes: the mono version of cfg 3), which has no
+		   dual form: the partner takes the instance's other kernel (k_wave2), as the plan's own brief launches do */
+		partner->variant = crhip_poly_up_fallback_variant(partner->channels, partner->poly.slots, partner->poly.row_mode, partner->poly.norm_mode);
+		plan_geometry(partner);
+	}
 	partner->lane_map = plan_pick_lane_map(partner);
 	partner->lds_swizzle = plan_pick_rotation(partner, &partner->conflict_plain, &partner->conflict_best);
 	/* the stereo instance must be a specialised k_poly over the same image layout, with a dual form, whose two mono windows fit

@@ -398,6 +398,8 @@ def test_one_launch_full_size_bit_exact(products, name, radius, ch, rates, frame
     (3, (44100, 8000, 8000), 9_000_001, (17, 999)),
     (3, (96000, 44100, 44100), 5_000_000, (0, 0)),          # the mono kernel is k_poly<1,13>, its stereo partner k_wave2<2,13>
     (3, (44100, 16000, 16000), 6_000_000, (0, 7)),          # k_poly<1,16> / k_wave2<2,16>
+    (8, (8000, 96000, 8000), 400_000, (0, 0)),              # the mono version of cfg 3: the stereo instance's kernel here is k_up2, which has no dual form - its k_wave2 takes the pairs
+    (8, (8000, 96000, 8000), 250_001, (1, 4097)),
 ])
 def test_dual_mono_long_launches_bit_exact(products, radius, rates, frames, start):
     """DUAL MONO (round 4): a long MONO launch runs on the STEREO instance - output frames j and j + H, whose fractions are equal

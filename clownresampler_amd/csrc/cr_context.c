@@ -1844,21 +1844,16 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 	if (plan->dual.partner != NULL && !out_s16 && !g_force_generic && !g_no_dual_mono && pos_int < (1ull << 47) && n_out < (1ull << 40))
 	{
 		/* DUAL MONO: a long mono launch on the stereo instance - output frames j and j + H as its two channels.  H = half the launch,
-		   rounded UP to a multiple of the period of the fraction (equal fractions: one row for both) and of the tile (no ragged tile):
+		   rounded UP to a multiple of the period of the fraction (equal fractions: one row for both):
 		   the second half is the shorter one, its missing frames are computed on zeros / neighbours and not stored - less than one part
 		   in sixteen of the launch by the rule below, 0.1 % for ten minutes of audio. */
 		const ClownResamplerAMD_Plan *partner = plan->dual.partner;
-		uint64_t ga = plan->dual.period, gb = partner->tile_frames, unit;   /* lcm(period, tile) */
-		while (gb != 0u)
-		{
-			const uint64_t t = ga % gb;
-			ga = gb;
-			gb = t;
-		}
-		unit = plan->dual.period / ga * partner->tile_frames;
+		/* (H a multiple of the period only: the last tile of the pairs may be a ragged one - round 4's first form rounded H to whole
+		   tiles too, lcm(65536, 3072) = 196,608 frames for the 3-lobe instances, and took launches from 3.1 M output frames on) */
+		const uint64_t unit = plan->dual.period;
 		const uint64_t half = ((n_out + 1u) / 2u + unit - 1u) / unit * unit;
 
-		if (n_out >= 16u * unit && half < n_out && half < (1ull << 30) && ((half * plan->increment) >> 16) < (1ull << 31))
+		if (n_out >= 16u * unit && half >= 8ull * partner->tile_frames && half < n_out && half < (1ull << 30) && ((half * plan->increment) >> 16) < (1ull << 31))
 		{
 			crhip_poly_launch l;
 			uint64_t blocks;
@@ -1877,7 +1872,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 				blocks = (half / l.tile_frames + partner->threads / 64u - 1u) / (partner->threads / 64u);
 			}
 			else
-				blocks = half / partner->tile_frames;
+				blocks = (half + partner->tile_frames - 1u) / partner->tile_frames;
 			l.d_in = d_in;
 			l.in_valid_bytes = in_valid_bytes;
 			l.d_out = d_out;

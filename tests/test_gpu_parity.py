@@ -400,6 +400,8 @@ def test_one_launch_full_size_bit_exact(products, name, radius, ch, rates, frame
     (3, (44100, 16000, 16000), 6_000_000, (0, 7)),          # k_poly<1,16> / k_wave2<2,16>
     (8, (8000, 96000, 8000), 400_000, (0, 0)),              # the mono version of cfg 3: the stereo instance's kernel here is k_up2, which has no dual form - its k_wave2 takes the pairs
     (8, (8000, 96000, 8000), 250_001, (1, 4097)),
+    (3, (48000, 44100, 44100), 1_300_000, (0, 0)),          # 1.19 M output frames: H = 10 periods = 655,360 pairs, 213.3 tiles of 3,072 - a ragged last tile
+    (3, (44100, 48000, 44100), 1_000_003, (0, 3)),          # just above the rule (16 periods)
 ])
 def test_dual_mono_long_launches_bit_exact(products, radius, rates, frames, start):
     """DUAL MONO (round 4): a long MONO launch runs on the STEREO instance - output frames j and j + H, whose fractions are equal

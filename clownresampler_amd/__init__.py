@@ -46,34 +46,65 @@ def build_native(verbose=False):
         raise RuntimeError("build did not produce " + LIB_PATH)
 
 
-# ---- the reference's POD structs, default (C89) integer types on LP64 (reference clownresampler.h:546-560, :627-659) ----
-cc_s16l, cc_s32l, cc_s32f, cc_u32f, cc_u8f, cc_bool = C.c_short, C.c_long, C.c_long, C.c_ulong, C.c_uint, C.c_ubyte
+# ---- the reference's POD structs, per integer ABI on LP64 (reference clownresampler.h:483-501 / :546-560, :627-659) ----
+# "c89": the reference's default types (8-byte `long` table entries, `unsigned int` channel counts) - libclownresampler_amd.so
+# "c99": CC_USE_C99_INTEGERS (int_least32_t table entries = 4 bytes, uint_fast8_t channel counts = 1 byte on glibc x86-64;
+#        int_fast32_t / uint_fast32_t stay 8 bytes) - libclownresampler_amd_c99.so
+ABIS = ("c89", "c99")
 
 
-class LowestLevel_Configuration(C.Structure):
-    _fields_ = [("stretched_kernel_radius", C.c_size_t), ("integer_stretched_kernel_radius", C.c_size_t),
-                ("stretched_kernel_radius_delta", C.c_size_t), ("kernel_step_size", C.c_size_t)]
+class _Types:
+    pass
 
 
-class LowLevel_State(C.Structure):
-    _fields_ = [("lowest_level", LowestLevel_Configuration), ("channels", cc_u8f), ("position_integer", C.c_size_t),
-                ("position_fractional", cc_u32f), ("increment", cc_u32f)]
+def _make_types(abi):
+    T = _Types()
+    T.abi = abi
+    T.cc_s16l, T.cc_s32f, T.cc_u32f, T.cc_bool = C.c_short, C.c_long, C.c_ulong, C.c_ubyte
+    if abi == "c89":
+        T.cc_s32l, T.cc_u8f = C.c_long, C.c_uint
+    elif abi == "c99":
+        T.cc_s32l, T.cc_u8f = C.c_int32, C.c_uint8
+    else:
+        raise ValueError("abi is one of %s" % (ABIS,))
 
-    def astuple(self):
-        ll = self.lowest_level
-        return (ll.stretched_kernel_radius, ll.integer_stretched_kernel_radius, ll.stretched_kernel_radius_delta, ll.kernel_step_size,
-                self.channels, self.position_integer, self.position_fractional, self.increment)
+    class LowestLevel_Configuration(C.Structure):
+        _fields_ = [("stretched_kernel_radius", C.c_size_t), ("integer_stretched_kernel_radius", C.c_size_t),
+                    ("stretched_kernel_radius_delta", C.c_size_t), ("kernel_step_size", C.c_size_t)]
+
+    class LowLevel_State(C.Structure):
+        _fields_ = [("lowest_level", LowestLevel_Configuration), ("channels", T.cc_u8f), ("position_integer", C.c_size_t),
+                    ("position_fractional", T.cc_u32f), ("increment", T.cc_u32f)]
+
+        def astuple(self):
+            ll = self.lowest_level
+            return (ll.stretched_kernel_radius, ll.integer_stretched_kernel_radius, ll.stretched_kernel_radius_delta, ll.kernel_step_size,
+                    self.channels, self.position_integer, self.position_fractional, self.increment)
+
+    class HighLevel_State(C.Structure):
+        _fields_ = [("low_level", LowLevel_State), ("input_buffer", T.cc_s16l * 0x1000), ("input_buffer_start", C.c_void_p),
+                    ("input_buffer_end", C.c_void_p), ("maximum_integer_stretched_kernel_radius", C.c_size_t),
+                    ("leading_padding_frames_needed", C.c_size_t), ("trailing_padding_frames_remaining", C.c_size_t)]
+
+    class Shard(C.Structure):  # ClownResamplerAMD_Shard
+        _fields_ = [("first_output_frame", C.c_size_t), ("output_frames", C.c_size_t), ("first_input_frame", C.c_size_t),
+                    ("input_frames", C.c_size_t), ("halo_frames", C.c_size_t), ("state", LowLevel_State)]
+
+    class Segment(C.Structure):  # ClownResamplerAMD_Segment
+        _fields_ = [("input_frames", C.c_size_t), ("input_sample_rate", T.cc_u32f), ("output_sample_rate", T.cc_u32f), ("low_pass_filter_sample_rate", T.cc_u32f)]
+
+    T.LowestLevel_Configuration, T.LowLevel_State, T.HighLevel_State, T.Shard, T.Segment = LowestLevel_Configuration, LowLevel_State, HighLevel_State, Shard, Segment
+    T.InputCallback = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(T.cc_s16l), C.c_size_t)             # reference clownresampler.h:661
+    T.OutputCallback = C.CFUNCTYPE(T.cc_bool, C.c_void_p, C.POINTER(T.cc_s32f), T.cc_u8f)                # reference clownresampler.h:662
+    return T
 
 
-class HighLevel_State(C.Structure):
-    _fields_ = [("low_level", LowLevel_State), ("input_buffer", cc_s16l * 0x1000), ("input_buffer_start", C.c_void_p),
-                ("input_buffer_end", C.c_void_p), ("maximum_integer_stretched_kernel_radius", C.c_size_t),
-                ("leading_padding_frames_needed", C.c_size_t), ("trailing_padding_frames_remaining", C.c_size_t)]
-
-
-class Shard(C.Structure):  # ClownResamplerAMD_Shard
-    _fields_ = [("first_output_frame", C.c_size_t), ("output_frames", C.c_size_t), ("first_input_frame", C.c_size_t),
-                ("input_frames", C.c_size_t), ("halo_frames", C.c_size_t), ("state", LowLevel_State)]
+_TYPES = {abi: _make_types(abi) for abi in ABIS}
+# the default ABI's types under their plain names (what every client of the default library uses)
+_T89 = _TYPES["c89"]
+cc_s16l, cc_s32l, cc_s32f, cc_u32f, cc_u8f, cc_bool = _T89.cc_s16l, _T89.cc_s32l, _T89.cc_s32f, _T89.cc_u32f, _T89.cc_u8f, _T89.cc_bool
+LowestLevel_Configuration, LowLevel_State, HighLevel_State = _T89.LowestLevel_Configuration, _T89.LowLevel_State, _T89.HighLevel_State
+Shard, Segment, InputCallback, OutputCallback = _T89.Shard, _T89.Segment, _T89.InputCallback, _T89.OutputCallback
 
 
 class DeviceShard(C.Structure):  # ClownResamplerAMD_DeviceShard
@@ -81,10 +112,6 @@ class DeviceShard(C.Structure):  # ClownResamplerAMD_DeviceShard
 
 
 GATHER_NONE, GATHER_PEER_COPY, GATHER_RCCL = 0, 1, 2
-
-
-class Segment(C.Structure):  # ClownResamplerAMD_Segment
-    _fields_ = [("input_frames", C.c_size_t), ("input_sample_rate", cc_u32f), ("output_sample_rate", cc_u32f), ("low_pass_filter_sample_rate", cc_u32f)]
 
 
 class PlanInfo(C.Structure):  # ClownResamplerAMD_PlanInfo
@@ -96,33 +123,32 @@ class PlanInfo(C.Structure):  # ClownResamplerAMD_PlanInfo
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-InputCallback = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(cc_s16l), C.c_size_t)             # reference clownresampler.h:661
-OutputCallback = C.CFUNCTYPE(cc_bool, C.c_void_p, C.POINTER(cc_s32f), cc_u8f)                    # reference clownresampler.h:662
 ErrorHandler = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
 
-_lib = None
-_handler_keepalive = None
+LIB_PATH_C99 = os.environ.get("CLOWNRESAMPLER_AMD_LIBRARY_C99") or os.path.join(_HERE, "libclownresampler_amd_c99.so")
+_libs = {}
+_handler_keepalive = {}
 
 
-def _load_library():
-    global _lib, _handler_keepalive
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _load_library(abi="c89"):
+    if abi in _libs:
+        return _libs[abi]
+    path = LIB_PATH if abi == "c89" else LIB_PATH_C99
+    if not os.path.exists(path):
         raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
-                          "There is no fallback implementation." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+                          "There is no fallback implementation." % path)
+    lib = C.CDLL(path)
 
     # Errors surface as Python exceptions instead of abort(): the handler records, the wrappers raise.
     def _on_error(code, message, _user):
         pass  # the code/message are kept per thread by the library; wrappers poll them
 
-    _handler_keepalive = ErrorHandler(_on_error)
+    _handler_keepalive[abi] = ErrorHandler(_on_error)
     lib.ClownResamplerAMD_SetErrorHandler.argtypes = [ErrorHandler, C.c_void_p]
-    lib.ClownResamplerAMD_SetErrorHandler(_handler_keepalive, None)
+    lib.ClownResamplerAMD_SetErrorHandler(_handler_keepalive[abi], None)
     lib.ClownResamplerAMD_LastErrorCode.restype = C.c_int
     lib.ClownResamplerAMD_LastErrorMessage.restype = C.c_char_p
-    _lib = lib
+    _libs[abi] = lib
     return lib
 
 
@@ -140,14 +166,20 @@ def _as_i16(a):
 
 
 class Api:
-    """The API instance for one CLOWNRESAMPLER_KERNEL_RADIUS (symbols ..._R<radius> for radius != 3)."""
+    """The API instance for one CLOWNRESAMPLER_KERNEL_RADIUS (symbols ..._R<radius> for radius != 3) of one integer ABI
+    ("c89": libclownresampler_amd.so, "c99": the CC_USE_C99_INTEGERS build, libclownresampler_amd_c99.so)."""
 
-    def __init__(self, radius=3):
+    def __init__(self, radius=3, abi="c89"):
         if radius not in SUPPORTED_RADII:
             raise ValueError("library built for radii %s" % (SUPPORTED_RADII,))
         self.radius = radius
-        self.lib = lib = _load_library()
+        self.abi = abi
+        self.T = T = _TYPES[abi]
+        self.lib = lib = _load_library(abi)
         self.table_len = radius * 2 * KERNEL_RESOLUTION
+        cc_s16l, cc_s32l, cc_s32f, cc_u32f, cc_u8f, cc_bool = T.cc_s16l, T.cc_s32l, T.cc_s32f, T.cc_u32f, T.cc_u8f, T.cc_bool
+        LowestLevel_Configuration, LowLevel_State, HighLevel_State = T.LowestLevel_Configuration, T.LowLevel_State, T.HighLevel_State
+        Shard, Segment, InputCallback, OutputCallback = T.Shard, T.Segment, T.InputCallback, T.OutputCallback
 
         class Precomputed(C.Structure):  # reference clownresampler.h:627-630
             _fields_ = [("lanczos_kernel_table", cc_s32l * self.table_len)]
@@ -240,7 +272,7 @@ class Api:
 
     def LowestLevel_Resample(self, configuration, precomputed, output_frame, channels, input_buffer, position_integer, position_fractional):
         """output_frame: sequence of `channels` ints, accumulated into (reference clownresampler.h:1020,1033). Returns the new frame."""
-        frame = (cc_s32f * channels)(*[int(v) for v in output_frame])
+        frame = (self.T.cc_s32f * channels)(*[int(v) for v in output_frame])
         keep, ptr = _as_i16(input_buffer)
         self._LowestResample(C.byref(configuration), C.byref(precomputed), frame, channels, ptr, position_integer, position_fractional)
         _raise_if_failed(self.lib)
@@ -260,7 +292,7 @@ class Api:
             return 1 if output_callback([frame[i] for i in range(n)]) else 0
 
         left = C.c_size_t(total_input_frames)
-        r = self._LowResample(C.byref(resampler), C.byref(precomputed), ptr, C.byref(left), OutputCallback(tramp), None)
+        r = self._LowResample(C.byref(resampler), C.byref(precomputed), ptr, C.byref(left), self.T.OutputCallback(tramp), None)
         _raise_if_failed(self.lib)
         return bool(r), left.value
 
@@ -282,7 +314,7 @@ class Api:
         def tramp_out(_user, frame, n):
             return 1 if output_callback([frame[i] for i in range(n)]) else 0
 
-        r = self._HighResample(C.byref(resampler), C.byref(precomputed), InputCallback(tramp_in), OutputCallback(tramp_out), None)
+        r = self._HighResample(C.byref(resampler), C.byref(precomputed), self.T.InputCallback(tramp_in), self.T.OutputCallback(tramp_out), None)
         _raise_if_failed(self.lib)
         return bool(r)
 
@@ -290,7 +322,7 @@ class Api:
         def tramp_out(_user, frame, n):
             return 1 if output_callback([frame[i] for i in range(n)]) else 0
 
-        r = self._HighEnd(C.byref(resampler), C.byref(precomputed), OutputCallback(tramp_out), None)
+        r = self._HighEnd(C.byref(resampler), C.byref(precomputed), self.T.OutputCallback(tramp_out), None)
         _raise_if_failed(self.lib)
         return bool(r)
 
@@ -331,7 +363,7 @@ class Api:
         self._Advance(C.byref(state), frames)
 
     def PlanShard(self, state, total_input_frames, shard, shard_count):
-        s = Shard()
+        s = self.T.Shard()
         if self._PlanShard(C.byref(state), total_input_frames, shard, shard_count, C.byref(s)) != 0:
             raise ValueError("bad shard index")
         return s
@@ -395,7 +427,7 @@ class Api:
     def ResampleSegmentsDevice(self, resampler, precomputed, device_timeline, halo_frames, segments, device_output, output_capacity_frames, hip_stream=None, s16=False):
         """Variable rate on the device (ClownResamplerAMD_ResampleSegmentsDevice).  segments: [(input_frames, in_rate, out_rate, low_pass), ...];
         device_timeline: device address of input frame 0.  Returns (total_frames, [frames per segment]); not synchronised."""
-        array = (Segment * max(1, len(segments)))(*[Segment(*seg) for seg in segments])
+        array = (self.T.Segment * max(1, len(segments)))(*[self.T.Segment(*seg) for seg in segments])
         counts = (C.c_size_t * max(1, len(segments)))()
         n = self._ResampleSegmentsDevice(C.byref(resampler), C.byref(precomputed), C.c_void_p(device_timeline), halo_frames, array, len(segments),
                                          C.c_void_p(device_output), output_capacity_frames, 1 if s16 else 0, counts, C.c_void_p(hip_stream or 0))
@@ -526,7 +558,7 @@ class Api:
 _apis = {}
 
 
-def load(radius=3):
-    if radius not in _apis:
-        _apis[radius] = Api(radius)
-    return _apis[radius]
+def load(radius=3, abi="c89"):
+    if (radius, abi) not in _apis:
+        _apis[(radius, abi)] = Api(radius, abi)
+    return _apis[(radius, abi)]

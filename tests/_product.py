@@ -45,9 +45,11 @@ class HighView:
 
 
 class Product:
-    def __init__(self, radius=3):
-        self.api = cr.load(radius)
+    def __init__(self, radius=3, abi="c89"):
+        # abi "c99": libclownresampler_amd_c99.so, the CC_USE_C99_INTEGERS build (reference clownresampler.h:483-501)
+        self.api = cr.load(radius, abi)
         self.radius = radius
+        self.abi = abi
         self.pre = self.api.precomputed()
 
     def table(self):
@@ -89,6 +91,12 @@ class Product:
     def low_resample_cb(self, st, padded, frames, emit):
         r, left = self.api.LowLevel_Resample(st.raw, self.pre, padded, frames, emit)
         return int(r), left
+
+    def high_resample_cb(self, st, pull, emit):
+        return self.api.HighLevel_Resample(st.raw, self.pre, pull, emit)
+
+    def high_end_cb(self, st, emit):
+        return self.api.HighLevel_ResampleEnd(st.raw, self.pre, emit)
 
     def high_run_i32(self, st, pcm, pull_chunk=0, capacity=None):
         """tests/test-high-level.c:126-127 through the callback ABI: Resample until the input dries up, then ResampleEnd."""

@@ -1286,6 +1286,53 @@ def test_highlevel_random_streams(products):
         products[3].api.SetStreamingWindow(1 << 18)
 
 
+@pytest.mark.parametrize("window", [0, 5000, 1 << 18])
+def test_highlevel_adjust_mid_stream(products, window):
+    """ClownResampler_HighLevel_Adjust (clownresampler.h:1183-1209) on a stream in flight: random scripted sessions
+    (tests/_scripts.py - the scripts that pin the oracle to the compiled reference in tests/test_oracle_vs_ref.py) of
+    ClownResampler_HighLevel_Resample calls stopped by the output callback after 1 ... 4,000 frames, Adjusts to triples that are
+    accepted (radius kept or SMALLER than at Init, :1165), rejected for a wider kernel (:1195) or by ClownResampler_LowLevel_Adjust
+    itself, ResampleEnd in pieces with Adjusts in between.  With the reference's one pull per GPU call (window 0), a 5,000-frame
+    and the default 262,144-frame read-ahead window: return values, every emitted frame and the state's scalars after every step
+    equal the oracle's."""
+    import _scripts
+    done = accepted = rejected = shrunk = 0
+    seed = 0
+    products[3].api.SetStreamingWindow(window)
+    try:
+        while done < 36:
+            seed += 1
+            radius = (3, 8, 3, 5)[seed % 4]
+            p, o = products[radius], ck.oracle(radius)
+            script = _scripts.make_script(50000 + 1000 * radius + seed, radius)
+            if not _scripts.usable(script, o):
+                continue
+            a, b = _scripts.play(p, script), _scripts.play(o, script)
+            assert _scripts.first_difference(a, b) is None, (window, script["seed"], script["channels"], script["first"], _scripts.first_difference(a, b))
+            done += 1
+            for step in b:
+                if step[0] == "adjust":
+                    accepted += step[2]
+                    rejected += 1 - step[2]
+                    shrunk += step[2] and step[3][1] < b[0][1][8]
+    finally:
+        products[3].api.SetStreamingWindow(1 << 18)
+    assert accepted > 30 and rejected > 15 and shrunk > 8, (accepted, rejected, shrunk)
+
+
+def test_highlevel_adjust_staging_rule_leaves_the_state_alone(products):
+    """:1202 - a radius whose two halos would not fit the reference's 0x1000-sample staging buffer is refused and the state restored
+    (only reachable from an Init that was itself too wide for that buffer; nothing is resampled here, the reference could not)."""
+    p, o = products[3], ck.oracle(3)
+    for ch, first, then in [(16, (48000, 48000, 1100), (48000, 48000, 1110)), (16, (48000, 48000, 1100), (48000, 48000, 48000)), (8, (44100, 44100, 500), (44100, 22050, 510))]:
+        ok_a, a = p.high_init(ch, *first)
+        ok_b, b = o.high_init(ch, *first)
+        assert ok_a == ok_b == 1
+        assert bool(p.high_adjust(a, *then)) == bool(o.high_adjust(b, *then))
+        assert a.low.astuple() == tuple(int(v) for v in b.low.astuple()) and a.max_radius_frames == b.max_radius_frames
+        p.api.HighLevel_Release(a.raw)
+
+
 def test_highlevel_reinit_reuses_window(products):
     """The side window is registered under the state's ADDRESS: re-initialising a state (or a new state where a discarded one
     lived) takes the window over, Release frees it, and a byte copy of a state elsewhere does not share it - like the

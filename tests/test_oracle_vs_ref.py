@@ -161,3 +161,30 @@ def test_python_callback_path_early_stop_state():
     ra = o.low_resample_cb(a, padded, 1000, lambda f: (got_a.append(f), len(got_a) < 100)[1])
     rb = r.low_resample_cb(b, padded, 1000, lambda f: (got_b.append(f), len(got_b) < 100)[1])
     assert ra == rb and got_a == got_b and len(got_a) == 100 and a.astuple() == b.astuple()
+
+
+@pytest.mark.parametrize("radius", [3, 8])
+def test_highlevel_adjust_mid_stream_scripts(radius):
+    """ClownResampler_HighLevel_Adjust BETWEEN ClownResampler_HighLevel_Resample / ResampleEnd calls (clownresampler.h:1183-1209 on a
+    stream in flight: radius kept, shrunk :1165, or the change rejected :1195): the oracle's restatement against the compiled
+    reference over random scripted sessions - return values, every emitted frame, the state after every step.  The same scripts
+    (tests/_scripts.py) hold the GPU path to the oracle in tests/test_gpu_parity.py."""
+    import _scripts
+    o, r = ck.oracle(radius), ck.reference(radius)
+    done = accepted = rejected = shrunk = 0
+    seed = 0
+    while done < 40:
+        seed += 1
+        script = _scripts.make_script(1000 * radius + seed, radius)
+        if not _scripts.usable(script, o):
+            continue
+        a, b = _scripts.play(o, script), _scripts.play(r, script)
+        assert _scripts.first_difference(a, b) is None, (script["seed"], _scripts.first_difference(a, b))
+        done += 1
+        max_radius = a[0][1][8]
+        for step in a:
+            if step[0] == "adjust":
+                accepted += step[2]
+                rejected += 1 - step[2]
+                shrunk += step[2] and step[3][1] < max_radius
+    assert accepted > 40 and rejected > 20 and shrunk > 10, (accepted, rejected, shrunk)

@@ -1020,6 +1020,7 @@ cc_bool ClownResampler_HighLevel_Resample(ClownResampler_HighLevel_State *resamp
 			}
 
 			stream->start = halo_samples;
+			stream->pull_count = 0;
 
 			while (have + one_pull <= limit || have == 0)
 			{
@@ -1029,6 +1030,12 @@ cc_bool ClownResampler_HighLevel_Resample(ClownResampler_HighLevel_State *resamp
 
 				if (got == 0)
 					break;
+
+				if (cr_stream_note_pull(stream, stream->start + have * channels) != 0)
+				{
+					cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
+					return cc_true;
+				}
 			}
 
 			stream->end = stream->start + have * channels;
@@ -1044,6 +1051,32 @@ cc_bool ClownResampler_HighLevel_Resample(ClownResampler_HighLevel_State *resamp
 			const unsigned long errors_before = cr_error_serial();
 
 			consumer_stopped = !ClownResampler_LowLevel_Resample(&resampler->low_level, precomputed, stream->window + stream->start - current_halo, &frames, output_callback, user_data);
+
+			if (consumer_stopped && stream->pull_count > 1 && cr_error_serial() == errors_before)
+			{
+				/* The window holds several of the reference's windows (one per pull), and what the reference's state says after a
+				   consumer's stop depends on which of them it was in: it consumes whole frames up to the next frame's position
+				   but never beyond the END OF THAT WINDOW (:1085-1088, delta = min(position, frames of the window)), the rest of
+				   the way staying in position_integer.  ClownResampler_LowLevel_Resample above has applied that rule to the whole
+				   big window; redo it with the pull's end, so that the caller-visible state (and the frame the next
+				   ClownResampler_HighLevel_Adjust takes effect at - the same either way) is the reference's for any window. */
+				const size_t old_start = stream->start;
+				const size_t consumed = (stream->end - old_start) / channels - frames;
+				const size_t next_position = consumed + resampler->low_level.position_integer;   /* of the next frame, from old_start */
+				/* the frame the consumer stopped at: one increment back (16.16; :1076-1078) */
+				const uint64_t next_fixed = ((uint64_t)next_position << 16) + (uint64_t)resampler->low_level.position_fractional;
+				const size_t stopped_at = (size_t)((next_fixed - (uint64_t)resampler->low_level.increment) >> 16);
+				size_t k = 0, window_end, take;
+
+				while (k + 1 < stream->pull_count && stream->pull_ends[k] <= old_start + stopped_at * channels)
+					++k;
+
+				window_end = (stream->pull_ends[k] - old_start) / channels;   /* frames from old_start to the end of that pull */
+				take = next_position < window_end ? next_position : window_end;
+				resampler->low_level.position_integer = next_position - take;
+				frames = (stream->end - old_start) / channels - take;
+			}
+
 			stream->start = stream->end - frames * channels; /* :1171 */
 
 			/* a device failure was reported and the (non-default) error handler returned: the window was not

@@ -766,6 +766,7 @@ void ClownResamplerAMD_Shutdown(void)
 		{
 			cr_stream *next = g_streams->next;
 			free(g_streams->window);
+			free(g_streams->pull_ends);
 			free(g_streams);
 			g_streams = next;
 		}
@@ -829,7 +830,7 @@ static uint32_t current_variant(void)
 	{
 		const char *e = getenv("CLOWNRESAMPLER_AMD_VARIANT");
 		g_variant = (e != NULL && *e != '\0') ? atoi(e) : CR_DEFAULT_VARIANT;
-		if (g_variant < 0 || (g_variant >= crhip_poly_variants() && !(g_variant >= 1000 && g_variant <= 1010)))
+		if (g_variant < 0 || (g_variant >= crhip_poly_variants() && !(g_variant >= 1000 && g_variant <= 1013)))
 			g_variant = CR_DEFAULT_VARIANT;
 	}
 	return (uint32_t)g_variant;
@@ -2555,7 +2556,7 @@ uint32_t ClownResamplerAMD_PlanRowOf(const ClownResamplerAMD_Plan *plan, uint32_
 
 void ClownResamplerAMD_DebugSetVariant(int variant)
 {
-	g_variant = ((variant >= 0 && variant < crhip_poly_variants()) || (variant >= 1000 && variant <= 1010)) ? variant : CR_DEFAULT_VARIANT;
+	g_variant = ((variant >= 0 && variant < crhip_poly_variants()) || (variant >= 1000 && variant <= 1013)) ? variant : CR_DEFAULT_VARIANT;
 }
 
 void ClownResamplerAMD_DebugForceGenericKernel(int on)
@@ -2591,6 +2592,7 @@ cr_stream *cr_stream_claim(const void *owner)
 	if (stream != NULL)
 	{
 		stream->id = ++g_stream_serial ^ 0x434C4F574E5253ull; /* never 0; a new id per claim: keys of the address's past lives die */
+		stream->pull_count = 0;
 		/* an idle window does not keep its largest size for ever */
 		if (stream->window_samples > (size_t)1 << 16)
 		{
@@ -2645,6 +2647,7 @@ void cr_stream_drop(const void *owner)
 	if (stream != NULL)
 	{
 		free(stream->window);
+		free(stream->pull_ends);
 		free(stream);
 	}
 }
@@ -2663,6 +2666,24 @@ int cr_stream_reserve(cr_stream *stream, size_t samples)
 	memset(grown + stream->window_samples, 0, (samples - stream->window_samples) * sizeof(int16_t));
 	stream->window = grown;
 	stream->window_samples = samples;
+	return 0;
+}
+
+int cr_stream_note_pull(cr_stream *stream, size_t end_sample)
+{
+	if (stream->pull_count == stream->pull_capacity)
+	{
+		const size_t capacity = stream->pull_capacity != 0 ? 2 * stream->pull_capacity : 64;
+		size_t *grown = (size_t *)realloc(stream->pull_ends, capacity * sizeof(size_t));
+
+		if (grown == NULL)
+			return -1;
+
+		stream->pull_ends = grown;
+		stream->pull_capacity = capacity;
+	}
+
+	stream->pull_ends[stream->pull_count++] = end_sample;
 	return 0;
 }
 

@@ -181,12 +181,17 @@ typedef struct cr_stream
 	size_t window_samples;  /* allocated */
 	size_t start, end;      /* sample indices into window: the frames not yet resampled (input_buffer_start / _end) */
 	size_t target_frames;   /* payload frames to collect per refill; grows while the consumer keeps draining whole windows */
+	/* where each of the refill's pulls ended (sample indices into window, ascending, the last one == end): the windows the
+	   REFERENCE would have resampled one by one - what its state says after a consumer's stop depends on them (cr_api.c) */
+	size_t *pull_ends;
+	size_t pull_count, pull_capacity;
 } cr_stream;
 
 cr_stream *cr_stream_claim(const void *owner);  /* the window of the state at this address (new id; made if there is none) */
 cr_stream *cr_stream_lookup(uint64_t id, const void *owner);
 void cr_stream_drop(const void *owner);
 int cr_stream_reserve(cr_stream *stream, size_t samples);   /* grows window keeping its contents; 0 on success */
+int cr_stream_note_pull(cr_stream *stream, size_t end_sample);   /* appends to pull_ends; 0 on success */
 size_t cr_stream_max_frames(void);             /* ClownResamplerAMD_SetStreamingWindow */
 
 #ifdef __cplusplus

@@ -33,7 +33,7 @@ void *ablation_instance(int abl)
 		case 5: return (void *)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 4, 0, 1>;   // as 4, non-temporal stores
 		case 6: return (void *)k_poly<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, 1024, 1, 1, 1, 0, 6, 0, 1>;   // the real kernel (variant 13) + clock stamps
 		case 7: return (void *)k_wave<2, 5, CRHIP_ROWMODE_UPSAMPLE, CRHIP_NORM_S31, WAVE_WAVES, WAVE_NVW, WAVE_ITER, 0, 1, 6>;   // k_wave + stamps
-		case 8: case 9: case 10: return ablation_instance_long(abl);
+		case 8: case 9: case 10: case 11: case 12: case 13: return ablation_instance_long(abl);
 		default: return nullptr;
 	}
 }

@@ -28,6 +28,9 @@ void *ablation_instance_long(int abl)
 		case 8: return (void *)k_up2<2, 15, CRHIP_NORM_U32, 0x2A55u, UP_WAVES, 0, 1, 6, 1>;    // k_up2 of the 8-lobe stereo instance + clock stamps
 		case 9: return (void *)k_up2<2, 15, CRHIP_NORM_U32, 0x2A55u, UP_WAVES, 0, 1, 1, 1>;    // timing only: no global stores
 		case 10: return (void *)k_up2<2, 15, CRHIP_NORM_U32, 0x2A55u, UP_WAVES, 0, 1, 2, 1>;   // timing only: no frames (window unpack + copy-out)
+		case 11: return (void *)k_up2<2, 15, CRHIP_NORM_U32, 0x2A55u, UP_WAVES, 0, 1, 3, 1>;   // timing only: one row read per wave-tile instead of per frame
+		case 12: return (void *)k_up2<2, 15, CRHIP_NORM_U32, 0x2A55u, UP_WAVES, 0, 1, 4, 1>;   // timing only: staging writes free of bank conflicts
+		case 13: return (void *)k_up2<2, 15, CRHIP_NORM_U32, 0x2A55u, UP_WAVES, 0, 1, 5, 1>;   // timing only: both
 		default: return nullptr;
 	}
 }

@@ -435,7 +435,7 @@ static uint32_t resolve_variant(const special *sp, uint32_t variant, uint32_t ou
 	}
 	if (sp->lite)
 		return sp->default_variant != WAVE2_VARIANT ? sp->default_variant : sp->wave2_fallback;
-	if (variant >= 1008u && variant <= 1010u)
+	if (variant >= 1008u && variant <= 1013u)
 		return sp->up[0] != nullptr ? UP_VARIANT : (sp->wave[0] != nullptr ? WAVE_VARIANT : 13u);   // diagnostic k_up instance
 	if (variant == 1007u && sp->wave[0] != nullptr)
 		return WAVE_VARIANT;                                  // diagnostic k_wave instance: k_wave geometry
@@ -694,7 +694,7 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 	if (sp != nullptr && v >= UP_VARIANT)
 	{
 		*geo = 200u;
-		if (launch->variant >= 1008u && launch->variant <= 1010u && !launch->out_s16 && launch->channels == 2 && launch->slots == 15)
+		if (launch->variant >= 1008u && launch->variant <= 1013u && !launch->out_s16 && launch->channels == 2 && launch->slots == 15)
 			return ablation_instance((int)(launch->variant - 1000u));
 		return launch->out_s16 ? sp->up16 : sp->up[v - UP_VARIANT];
 	}

@@ -765,6 +765,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 		// g = 65536 - fraction of the lane's current frame: the row is g >> 6 (pure-upsampling row index), 16 bytes per row and plane
 		unsigned g = 65536u - ((unsigned)((int)frac0 + __mul24(start, (int)a.increment)) & 0xFFFFu);
 		unsigned stage_at = (unsigned)(start * (int)UNIT);   // byte offset of the lane's current frame from my_stage (lane 0: may be negative)
+		// (timing-only ablations 4 / 5: every step's 64 frames side by side - the staging writes free of bank conflicts, results WRONG)
+		constexpr unsigned STAGE_STEP = (ABL == 4 || ABL == 5) ? 56u * UNIT : UNIT;
+		if constexpr (ABL == 4 || ABL == 5)
+			stage_at = lane * UNIT;
 
 		typedef __attribute__((address_space(3))) i32x4 lds_i32x4;
 		const unsigned smem_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)smem);
@@ -944,12 +948,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 		// the row of frame j + 1 is read before the arithmetic of frame j (two register sets, loop unrolled by two)
 		int wa[RS], wb[RS];
 		read_row(g, wa);
+		// (timing-only ablations 3 / 5: the row of the lane's first frame serves all of its frames - no row reads in the loop, results WRONG)
+		constexpr bool ROWS_ONCE = ABL == 3 || ABL == 5;
+		if constexpr (ROWS_ONCE)
+		{
+#pragma unroll
+			for (int i = 0; i < RS; ++i)
+				wb[i] = wa[i];
+		}
 		for (unsigned j = 0; j < trips; j += 2u)
 		{
-			read_row(g - a.increment, wb);
+			if constexpr (!ROWS_ONCE)
+				read_row(g - a.increment, wb);
 			__builtin_amdgcn_sched_barrier(0);
 			one(wa, std::false_type());
-			stage_at += UNIT;
+			stage_at += STAGE_STEP;
 			g -= a.increment;
 			if (j + 1u >= trips)
 			{
@@ -958,10 +971,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 					wa[i] = wb[i];
 				break;
 			}
-			read_row(g - a.increment, wa);
+			if constexpr (!ROWS_ONCE)
+				read_row(g - a.increment, wa);
 			__builtin_amdgcn_sched_barrier(0);
 			one(wb, std::false_type());
-			stage_at += UNIT;
+			stage_at += STAGE_STEP;
 			g -= a.increment;
 		}
 		if (any_extra)

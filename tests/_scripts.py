@@ -62,7 +62,8 @@ def make_script(seed, radius, max_out_frames=30000):
         if budget_left <= 0:
             break
     # drain: whatever is left comes out in big bites, with one more Adjust on the way
-    steps += [("run", 1 << 30), ("adjust", rng.choice([first, (i, o, i)])), ("run", 1 << 30), ("end", 3), ("end", 1 << 30), ("end", 1 << 30)]
+    steps += [("run", 1 << 30), ("adjust", rng.choice([first, (i, o, i)])), ("run", 1 << 30), ("end", 1), ("adjust", (rng.choice(RATES), rng.choice(RATES), rng.choice(RATES))),
+              ("end", 3), ("adjust", rng.choice([first, (i, o, i), (o, i, o)])), ("end", 1 << 30), ("end", 1 << 30)]
     return dict(seed=seed, radius=radius, channels=ch, first=first, frames=frames, pull_chunk=pull_chunk, steps=steps)
 
 
@@ -79,7 +80,11 @@ def usable(script, oracle):
     return script["frames"] * worst_ratio <= 400000
 
 
-def play(engine, script):
+def play(engine, script, early_end=True):
+    """early_end=False: an "end" step BEFORE the source has run dry (no ClownResampler_HighLevel_Resample call has returned true yet) is
+    played as a "run" step instead.  Flushing while the source still has frames is where a read-ahead window shows: the reference then
+    pads behind the frames of ITS 0x1000-sample buffer, the product behind everything it has already pulled
+    from the caller - up to its streaming window - so the two agree on such a session only with the reference's own window (0)."""
     ch = script["channels"]
     pcm = ck.noise_pcm(script["frames"] * ch, 7000 + script["seed"])
     ok, st = engine.high_init(ch, *script["first"])
@@ -95,7 +100,10 @@ def play(engine, script):
         pos[0] += k
         return a
 
+    dry = False
     for kind, arg in script["steps"]:
+        if kind == "end" and not dry and not early_end:
+            kind = "run"
         if kind == "adjust":
             r = engine.high_adjust(st, *arg)
             trace.append(("adjust", arg, int(bool(r)), _state_of(st)))
@@ -109,6 +117,7 @@ def play(engine, script):
             return budget[0] > 0
 
         r = engine.high_resample_cb(st, pull, emit) if kind == "run" else engine.high_end_cb(st, emit)
+        dry = dry or (kind == "run" and bool(r))
         # (which input frame the source stands at is NOT compared: the product reads ahead)
         trace.append((kind, arg, int(bool(r)), len(out), hash(tuple(out)), out[:2], out[-2:], _state_of(st)))
     return trace

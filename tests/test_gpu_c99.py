@@ -119,6 +119,6 @@ def test_c99_highlevel_adjust_mid_stream(products99):
         script = _scripts.make_script(90000 + seed, radius)
         if not _scripts.usable(script, o):
             continue
-        a, b = _scripts.play(p, script), _scripts.play(o, script)
+        a, b = _scripts.play(p, script, early_end=False), _scripts.play(o, script, early_end=False)
         assert _scripts.first_difference(a, b) is None, (script["seed"], _scripts.first_difference(a, b))
         done += 1

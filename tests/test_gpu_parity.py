@@ -1307,7 +1307,8 @@ def test_highlevel_adjust_mid_stream(products, window):
             script = _scripts.make_script(50000 + 1000 * radius + seed, radius)
             if not _scripts.usable(script, o):
                 continue
-            a, b = _scripts.play(p, script), _scripts.play(o, script)
+            # (a flush while the source still has frames only with the reference's own window: _scripts.play)
+            a, b = _scripts.play(p, script, early_end=window == 0), _scripts.play(o, script, early_end=window == 0)
             assert _scripts.first_difference(a, b) is None, (window, script["seed"], script["channels"], script["first"], _scripts.first_difference(a, b))
             done += 1
             for step in b:

@@ -110,7 +110,7 @@ def main():
                     m = st[:, 3] == x
                     if m.any():
                         extra += "\n   XCC %d: %3d workgroups, end time median %.1f max %.1f us" % (x, m.sum(), _np.median(endt[m]), endt[m].max())
-            print("ablation %d (timing only%s): %7.1f us median %7.1f min%s" % (v - 1000, "" if v in (1006, 1007, 1008) else ", results wrong by design" + {1009: "; k_up2 without global stores", 1010: "; k_up2 without the frames"}.get(v, ""), med, mn, extra))
+            print("ablation %d (timing only%s): %7.1f us median %7.1f min%s" % (v - 1000, "" if v in (1006, 1007, 1008) else ", results wrong by design" + {1009: "; k_up2 without global stores", 1010: "; k_up2 without the frames", 1011: "; k_up2 with one row read per wave-tile", 1012: "; k_up2 with conflict-free staging writes", 1013: "; k_up2 with both"}.get(v, ""), med, mn, extra))
             continue
         if v >= 22 and v < 26:
             print("%3d  2 lanes/frame geo %s nt=%d %5d %6d %4d | %7.1f %7.1f | %7.0f  %.3f %s" % (v, [(1024, 2), (512, 2)][(v - 22) % 2], 1 - (v - 22) // 2, i.tile_frames, i.lds_bytes, i.max_blocks, med, mn, nbytes / med / 1e3, nbytes / med / 1e3 / 8000, "MISMATCH" if v in bad else ""))

@@ -235,6 +235,7 @@ class Api:
         self._BuildId = fn("ClownResamplerAMD_BuildId", C.c_char_p, [], False)
         self._DisableInt = fn("ClownResamplerAMD_DebugDisableIntKernel", None, [C.c_int], False)
         self._DisableDual = fn("ClownResamplerAMD_DebugDisableDualMono", None, [C.c_int], False)
+        self._SegKernel = fn("ClownResamplerAMD_DebugSegKernel", None, [C.c_int], False)
         self._PlanDualMono = fn("ClownResamplerAMD_PlanDualMonoKernel", C.c_uint32, [C.c_void_p], False)
         self._PlanPadded = fn("ClownResamplerAMD_PlanPaddedTiles", C.c_uint32, [C.c_void_p], False)
         self._SegmentsMode = fn("ClownResamplerAMD_DebugSegmentsMode", None, [C.c_int], False)
@@ -477,6 +478,10 @@ class Api:
     def PlanPaddedTiles(self, plan):
         """1 when the plan's k_poly instance repacks its tiles to 32-byte frames (9-11, 13-15 channels, no specialised instance, up to 2:1)"""
         return int(self._PlanPadded(plan))
+
+    def DebugSegKernel(self, mode):
+        """0: the rule, 1: k_seg for every launch it can take, 2: never (kernel 8 of LaunchCount counts its launches)"""
+        self._SegKernel(mode)
 
     def DebugDisableDualMono(self, on):
         self._DisableDual(1 if on else 0)

@@ -189,14 +189,16 @@ static size_t g_plan_limit = 64;   /* unpinned plans kept; ClownResamplerAMD_Set
 static int g_force_generic = 0;
 static int g_no_int_kernel = 0;   /* ClownResamplerAMD_DebugDisableIntKernel */
 static int g_no_dual_mono = 0;    /* ClownResamplerAMD_DebugDisableDualMono */
+static int g_seg_mode = 0;        /* ClownResamplerAMD_DebugSegKernel: 0 the rule, 1 whenever the launch can take it, 2 never */
 static unsigned long long *g_debug_stamps = NULL;
 static int g_variant = -1; /* -1: CLOWNRESAMPLER_AMD_VARIANT from the environment, else the default */
 /* launches enqueued so far, by kernel (numbered as ClownResamplerAMD_PlanInfo.kernel; 5 = k_int): what tests and bench.py
    assert "the kernel I mean is the one that ran" with (ClownResamplerAMD_DebugLaunchCount) */
 /* ... and [7]: how many of those launches drew their tiles as TICKETS (k_poly with dynamic_tiles on, k_int with ticket groups) -
    the scheduler the long launches of cfg 2 / cfg 5 take and launches of fewer than eight tiles per workgroup do not */
-#define CR_KERNEL_IDS 8
+#define CR_KERNEL_IDS 9
 #define CR_COUNT_TICKETED 7
+#define CR_COUNT_SEG 8            /* k_seg launches */
 static unsigned long long g_launch_count[CR_KERNEL_IDS];
 
 /* Where a plan WITHOUT a specialised instance runs the run-time-slot k_wave2 instead of the run-time-slot k_poly.  Measured on
@@ -228,6 +230,12 @@ static unsigned long long g_launch_count[CR_KERNEL_IDS];
 /* k_up2 as an instance's default kernel: see plan_geometry */
 #define CR_UP_DEFAULT_MAX_INCREMENT (65536u / 8u)
 #define CR_UP_DEFAULT_MIN_INCREMENT (65536u / 13u)
+/* k_seg (cr_kseg.hpp): the ratios it is built for (a tile of CR_SEG_MIN_TILE frames advances over at most 12 input frames), the tile
+   sizes, and how much of a launch its last, partial super-block may waste in idle lanes before the launch stays with k_up2 */
+#define CR_SEG_MIN_INCREMENT 4096u
+#define CR_SEG_MIN_TILE 64u
+#define CR_SEG_MAX_TILE 256u
+#define CR_SEG_MAX_WASTE 0.06
 /* a launch of a periodic ratio that starts mid-period is split (a few frames on the ordinary kernel, the rest on k_int) from this
    many output frames on: below, the second launch costs more than k_int saves */
 #define CR_INT_SPLIT_MIN_FRAMES 8192u
@@ -249,6 +257,9 @@ static struct
 	int no_int_kernel;          /* CLOWNRESAMPLER_AMD_NO_INT_KERNEL: whole-number ratios take the plan's ordinary kernel (the A/B leg) */
 	int rt_wave2_min_slots;     /* CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS: windows from this many slots on take the run-time-slot k_wave2 */
 	double rotate_min_gain;     /* CLOWNRESAMPLER_AMD_ROTATE_MIN_GAIN: see plan_pick_rotation */
+	int no_seg;                 /* CLOWNRESAMPLER_AMD_NO_SEG: long k_up2-shaped launches stay with k_up2 (the A/B leg) */
+	int seg_form;               /* CLOWNRESAMPLER_AMD_SEG_FORM: diagnostic instance of k_seg (crhip_seg_launch.debug_form) */
+	int seg_tile;               /* CLOWNRESAMPLER_AMD_SEG_TILE: k_seg's frames per lane and tile (a multiple of 16; unset: the rule) */
 	int brief_half_tiles;       /* CLOWNRESAMPLER_AMD_BRIEF_HALF_TILES: k_up launches of fewer half wave-tiles per wave take the plan's other kernel (0: none do; unset: per instance) */
 } g_env;
 static pthread_once_t g_env_once = PTHREAD_ONCE_INIT;
@@ -260,6 +271,11 @@ static void load_env(void)
 	e = getenv("CLOWNRESAMPLER_AMD_DYNAMIC_TILES");
 	g_env.dynamic_tiles = (e != NULL && *e != '\0') ? (atoi(e) != 0) : -1;
 	g_env.no_special = getenv("CLOWNRESAMPLER_AMD_NO_SPECIAL") != NULL;
+	g_env.no_seg = getenv("CLOWNRESAMPLER_AMD_NO_SEG") != NULL;
+	e = getenv("CLOWNRESAMPLER_AMD_SEG_FORM");
+	g_env.seg_form = (e != NULL && *e != '\0') ? atoi(e) : 0;
+	e = getenv("CLOWNRESAMPLER_AMD_SEG_TILE");
+	g_env.seg_tile = (e != NULL && *e != '\0') ? atoi(e) : 0;
 	g_env.debug = getenv("CLOWNRESAMPLER_AMD_DEBUG") != NULL;
 	g_env.no_occupancy_clamp = getenv("CLOWNRESAMPLER_AMD_NO_OCCUPANCY_CLAMP") != NULL;
 	e = getenv("CLOWNRESAMPLER_AMD_TILE_GROUPS");
@@ -623,6 +639,7 @@ static void store_release(cr_plan_store *store, int device_usable)
 		/* hipFree waits for the device: a launch that was enqueued with these rows has finished by the time they go */
 		crhip_free(store->d_table);
 		crhip_free(store->d_rows);
+		crhip_free(store->d_rows_seg);
 	}
 	cr_poly_free(&store->poly);
 	free(store);
@@ -1462,6 +1479,72 @@ static void plan_brief_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *p
 }
 
 /* k_int beside the plan's ordinary kernel: see the plan's `intk`. */
+/* k_seg for this plan?  The shape k_up2 is the kernel of (the instance's slot signs hold for every row), at the ratios where a tile's
+   window fits its registers and LDS entries; the float image of the rows is made once per store.  0 on success (available or not). */
+static int plan_seg_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan)
+{
+	uint32_t negmask = 0, pos_bits = 0, neg_bits = 0, threads = 0, lds = 0;
+	cr_plan_store *store = plan->store;
+	int per_cu = 0;
+	uint64_t g;
+
+	(void)ctx;
+	plan->seg.available = 0;
+	if (g_env.no_seg || !plan->use_poly || plan->poly.row_mode != CRHIP_ROWMODE_UPSAMPLE || plan->poly.window_extra != 0
+	 || !crhip_seg_instance(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, &negmask, &threads, &lds))
+		return 0;
+	cr_poly_slot_signs(&plan->poly, &pos_bits, &neg_bits);
+	if ((neg_bits & ~negmask) != 0 || (pos_bits & negmask) != 0 || cr_poly_slots_reaching(&plan->poly, 65537) != 0 || plan->poly.rows > 1025u)
+		return 0;
+	/* a tile of at least CR_SEG_MIN_TILE frames must not advance over more input frames than the kernel keeps for it (SEG_FUTURE = 12) */
+	if (plan->increment < CR_SEG_MIN_INCREMENT || ((65535u + (uint64_t)(CR_SEG_MIN_TILE - 1u) * plan->increment) >> 16) > 12u)
+		return 0;
+
+	if (store->d_rows_seg == NULL)
+	{
+		const size_t bytes = (size_t)plan->poly.rows * 64u;
+		uint32_t *image = (uint32_t *)malloc(bytes);
+		uint32_t r, s;
+		int failed;
+
+		if (image == NULL)
+			return cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
+		for (r = 0; r < plan->poly.rows; ++r)
+		{
+			const int32_t *row = plan->poly.weights + (size_t)r * plan->poly.row_stride;
+
+			for (s = 0; s < 15u; ++s)
+			{
+				/* |weight| <= 65536: exact as a float, and so is the division by 2^16 */
+				const float f = (float)(row[s] < 0 ? -(int64_t)row[s] : (int64_t)row[s]) * (1.0f / 65536.0f);
+				memcpy(&image[r * 16u + s], &f, sizeof(f));
+			}
+			image[r * 16u + 15u] = 2u * (uint32_t)row[plan->poly.slots];   /* the reciprocal, doubled: k_up2's normalisation (cr_kup.hpp) */
+		}
+		failed = cr_check_hip(crhip_malloc(&store->d_rows_seg, bytes), "hipMalloc(rows, k_seg)") != 0
+		      || cr_check_hip(crhip_memcpy_h2d(store->d_rows_seg, image, bytes, NULL), "hipMemcpy(rows, k_seg)") != 0
+		      || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0;
+		free(image);
+		if (failed)
+			return -1;
+	}
+
+	if (cr_check_hip(crhip_seg_prepare(plan->channels, plan->poly.slots, &per_cu), "k_seg setup") != 0)
+		return -1;
+	if (per_cu < 1)
+		return 0;
+	/* 65536 / gcd(increment, 65536) */
+	for (g = 65536u; g > 1u && (plan->increment & (65536u / g * 2u - 1u)) == 0; g >>= 1)
+		;
+	plan->seg.period = g;
+	plan->seg.threads = threads;
+	plan->seg.lds_bytes = lds;
+	plan->seg.max_blocks = (uint32_t)per_cu * (uint32_t)(g_ctx[plan->device]->info.compute_units > 0 ? g_ctx[plan->device]->info.compute_units : 256);
+	plan->seg.d_rows = store->d_rows_seg;
+	plan->seg.available = 1;
+	return 0;
+}
+
 static void plan_int_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan)
 {
 	int per_cu = 0, per_cu_s16 = 0;
@@ -1709,6 +1792,8 @@ ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t t
 		plan_brief_shape(ctx, plan);
 		plan_int_shape(ctx, plan);
 		plan_dual_partner(ctx, plan);
+		if (plan_seg_shape(ctx, plan) != 0)
+			goto fail_plan;
 	}
 
 	free(table);
@@ -1763,6 +1848,29 @@ static void fill_poly_launch(const ClownResamplerAMD_Plan *plan, crhip_poly_laun
 	l->lane_map = plan->lane_map;
 	l->wave_tile = plan->wave_tile;
 	l->debug_stamps = g_debug_stamps;
+}
+
+/* Whether a dual-mono launch of n_out mono frames, split at `half`, stays inside the 32-bit arithmetic of the kernels' buffer descriptors:
+   the dual forms of k_poly / k_wave2 store both halves through ONE descriptor over the mono output (4 bytes per frame, clamped to
+   0xFFFFFFFC bytes) with 32-bit byte offsets that run up to a tile past the last frame, and fetch both windows through ONE descriptor from the
+   first window's start to the end of the caller's buffer (also clamped).  Beyond that a store would be dropped or an offset would wrap - the
+   ordinary mono kernels (64-bit pointers) take such launches. */
+int cr_dual_mono_fits(uint64_t n_out, uint64_t half, uint64_t tile_frames, uint64_t increment, uint64_t in_valid_bytes)
+{
+	const uint64_t limit = 0xFFFFFFFCull;
+
+	if (half >= (1ull << 30) || ((half * increment) >> 16) >= (1ull << 31))
+		return 0;
+	if (n_out * 4u + 4u * tile_frames * 4u > limit)   /* the output, plus the ragged last tile's offsets */
+		return 0;
+	if (in_valid_bytes > limit)                        /* the input: both windows inside one descriptor */
+		return 0;
+	return 1;
+}
+
+int ClownResamplerAMD_DebugDualMonoFits(uint64_t n_out, uint64_t half, uint64_t tile_frames, uint64_t increment, uint64_t in_valid_bytes)
+{
+	return cr_dual_mono_fits(n_out, half, tile_frames, increment, in_valid_bytes);
 }
 
 int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_t in_valid_bytes, void *d_out,
@@ -1842,6 +1950,61 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		}
 	}
 
+	if (plan->seg.available && !out_s16 && !g_force_generic && g_seg_mode != 2 && pos_int < (1ull << 40) && n_out < (1ull << 40) && in_valid_bytes < 0xFFFFFFFCull
+	 && (g_variant < 0 || g_variant == CR_DEFAULT_VARIANT))
+	{
+		/* k_seg: the lanes of a wave S output frames apart, S a multiple of the fraction's period (equal fractions: one row per wave and
+		   step, in scalar registers).  S is the smallest such multiple of 1,024 frames or more (segments of a few tiles), a super-block 64 S; the lanes of
+		   the last super-block that lie beyond the launch idle, and a launch that would waste more than CR_SEG_MAX_WASTE of its
+		   lane-steps that way stays with k_up2 (cfg 3, odd increment: S = 65536, 13.7 super-blocks in ten minutes, 1.9 %). */
+		const uint64_t period = plan->seg.period;
+		const uint64_t seg = period >= 1024u ? period : 1024u;   /* (both powers of two) */
+		const uint64_t blocks64 = (n_out + 64u * seg - 1u) / (64u * seg);
+		const double waste = 1.0 - (double)n_out / ((double)blocks64 * 64.0 * (double)seg);
+		/* frames per lane and tile: a power of two from 64 to 256 (it divides S), as large as the tile's advances (at most 12) and the
+		   balance (four tiles per wave or more) allow */
+		uint64_t tile = CR_SEG_MAX_TILE;
+		const uint64_t waves = (uint64_t)plan->seg.max_blocks * (plan->seg.threads / 64u);
+
+		while (tile > CR_SEG_MIN_TILE && (((65535u + (tile - 1u) * plan->increment) >> 16) > 12u || blocks64 * (seg / tile) < 4u * waves))
+			tile /= 2u;
+		if (g_env.seg_tile >= 16 && (g_env.seg_tile & (g_env.seg_tile - 1)) == 0 && (uint64_t)g_env.seg_tile <= seg)
+			tile = (uint64_t)g_env.seg_tile;
+		if (((65535u + (tile - 1u) * plan->increment) >> 16) <= 12u && seg * 512u < (1ull << 32) && ((seg * plan->increment) >> 16) * 256u < (1ull << 32)
+		 && (g_seg_mode == 1 || (waste <= CR_SEG_MAX_WASTE && blocks64 * (seg / tile) >= 2u * waves)))
+		{
+			crhip_seg_launch sl;
+			int ring, e;
+			uint64_t grid;
+
+			memset(&sl, 0, sizeof(sl));
+			sl.d_in = d_in;
+			sl.in_valid_bytes = in_valid_bytes;
+			sl.d_out = d_out;
+			sl.d_rows = plan->seg.d_rows;
+			sl.pos0 = (pos_int << 16) + pos_frac;
+			sl.n_out = n_out;
+			sl.seg_frames = seg;
+			sl.seg_in_frames = (seg * plan->increment) >> 16;   /* (exact: seg is a multiple of the period) */
+			sl.increment = (uint32_t)plan->increment;
+			sl.first_slot = plan->poly.first_slot;
+			sl.slots = plan->poly.slots;
+			sl.tile_frames = (uint32_t)tile;
+			sl.tiles_per_seg = (uint32_t)(seg / tile);
+			sl.n_tiles = blocks64 * sl.tiles_per_seg;
+			sl.debug_form = (uint32_t)g_env.seg_form;
+			grid = (sl.n_tiles + plan->seg.threads / 64u - 1u) / (plan->seg.threads / 64u);
+			sl.blocks = (uint32_t)(grid > plan->seg.max_blocks ? plan->seg.max_blocks : grid);
+			sl.d_tickets = ticket_block_for(g_ctx[plan->device], stream, &ring);
+			if (sl.d_tickets == NULL)
+				return -1;
+			e = crhip_launch_seg(&sl, stream);
+			ticket_block_enqueued(g_ctx[plan->device], ring);
+			__atomic_fetch_add(&g_launch_count[CR_COUNT_SEG], 1ull, __ATOMIC_RELAXED);
+			return cr_check_hip(e, "k_seg launch");
+		}
+	}
+
 	if (plan->dual.partner != NULL && !out_s16 && !g_force_generic && !g_no_dual_mono && pos_int < (1ull << 47) && n_out < (1ull << 40))
 	{
 		/* DUAL MONO: a long mono launch on the stereo instance - output frames j and j + H as its two channels.  H = half the launch,
@@ -1854,7 +2017,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		const uint64_t unit = plan->dual.period;
 		const uint64_t half = ((n_out + 1u) / 2u + unit - 1u) / unit * unit;
 
-		if (n_out >= 16u * unit && half >= 8ull * partner->tile_frames && half < n_out && half < (1ull << 30) && ((half * plan->increment) >> 16) < (1ull << 31))
+		if (n_out >= 16u * unit && half >= 8ull * partner->tile_frames && half < n_out && cr_dual_mono_fits(n_out, half, partner->tile_frames, plan->increment, in_valid_bytes))
 		{
 			crhip_poly_launch l;
 			uint64_t blocks;
@@ -2515,6 +2678,11 @@ uint32_t ClownResamplerAMD_PlanDualMonoKernel(const ClownResamplerAMD_Plan *plan
 uint32_t ClownResamplerAMD_PlanPaddedTiles(const ClownResamplerAMD_Plan *plan)
 {
 	return plan != NULL && plan->use_poly ? plan->padded : 0u;
+}
+
+void ClownResamplerAMD_DebugSegKernel(int mode)
+{
+	g_seg_mode = mode;
 }
 
 void ClownResamplerAMD_DebugDisableDualMono(int on)

@@ -45,6 +45,7 @@ typedef struct cr_plan_store
 	int32_t *d_table;       /* caller's table as int32 (generic kernel) */
 	cr_poly poly;           /* host copy of the rows + row-index form (owns its arrays) */
 	int32_t *d_rows;        /* device image of the rows, NULL until a plan needs it */
+	void *d_rows_seg;       /* k_seg's image of the same rows (64 bytes per row: 15 x |weight| / 65536 as float, 2 * reciprocal), NULL until a plan needs it */
 	int rows_layout;        /* CR_IMAGE_* of d_rows */
 	uint32_t plane_rows, swizzle, device_row_stride;
 } cr_plan_store;
@@ -100,6 +101,15 @@ typedef struct ClownResamplerAMD_Plan
 		crhip_int_shape shape;
 		uint32_t max_blocks, max_blocks_s16;
 	} intk;
+	/* k_seg (cr_kseg.hpp): long launches of a k_up2 shape (stereo, 15 slots, fixed slot signs) with the lanes of a wave on frames of equal
+	   fraction, `period` = 65536 / gcd(increment, 65536) output frames apart (or a multiple), the row in scalar registers */
+	struct
+	{
+		int available;
+		uint64_t period;
+		uint32_t threads, lds_bytes, max_blocks;
+		const void *d_rows;
+	} seg;
 	uint32_t padded;   /* 1: k_poly's run-time-slot instance computes from padded tiles (crhip_poly_launch.padded) */
 	/* DUAL MONO (mono plans; crhip_poly_launch.dual, cr_kpoly.hpp): long launches run on the STEREO instance of the same
 	   configuration, output frames j and j + H as its two channels (H * increment a multiple of 65536: equal fractions, one row for
@@ -132,6 +142,9 @@ int cr_ensure_device_of(const ClownResamplerAMD_Plan *plan);
 /* Enqueues the computation of output frames [0, n_out) starting at (pos_int, pos_frac) on `stream`. 0 on success. */
 int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_t in_valid_bytes, void *d_out,
                    uint64_t pos_int, uint64_t pos_frac, uint64_t n_out, void *stream, int out_s16);
+
+/* the 32-bit descriptor arithmetic of the dual-mono kernels holds for this launch (cr_context.c) */
+int cr_dual_mono_fits(uint64_t n_out, uint64_t half, uint64_t tile_frames, uint64_t increment, uint64_t in_valid_bytes);
 
 /* Variable rate in one launch: `count` non-empty segments (first_out ascending) of one timeline at d_in, n_out frames in all, through
    the generic kernel with a segment table (any configuration per segment; `plan` supplies the device, the table and the channel

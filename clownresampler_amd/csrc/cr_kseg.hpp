@@ -1,0 +1,403 @@
+// cr_kseg.hpp - k_seg: a lane per stream SEGMENT, the 64 lanes of a wave on frames of EQUAL fraction; the polyphase row in scalar registers.
+#ifndef CR_KSEG_HPP
+#define CR_KSEG_HPP
+
+#include "cr_device.hpp"
+
+namespace
+{
+
+// ---------------------------------------------------------------------------------------------------------
+// k_seg - long upsampling launches (cfg 3: stereo 8 -> 96 kHz, 8 lobes), round 5
+// ---------------------------------------------------------------------------------------------------------
+// Where k_up2's time goes (profiles/r05_kup2_lds_ablations.log, timing-only builds): the row a lane reads for every frame - four
+// ds_read_b128, 64 bytes, 16 of a wave-step's ~34 LDS cycles, three VALU of addressing - is 18 % of the launch, and 64 lanes read
+// only four or five DIFFERENT rows per step.  The reference's position is j * increment in 16.16 (clownresampler.h:1076-1078), so
+// output frames j and j + S have the SAME fraction whenever S * increment is a multiple of 65536 (dual mono's observation, round 4):
+// the same row, windows exactly D = S * increment / 65536 input frames apart.  Here the 64 lanes of a wave take the frames
+// j, j + S, ..., j + 63 S - lane l walks segment l of a "super-block" of 64 S output frames - so at every step the whole wave needs
+// ONE row, and:
+//   * the row arrives by s_load_dwordx16 (from a 64-byte-per-row float image in global memory: L2 / scalar cache), a frame ahead,
+//     and the taps take their weights as SCALAR operands of v_pk_fma_f32 (k_up2's FP32 round-toward-zero chain, cr_kup.hpp):
+//     no row in LDS (66 KB free), no row address arithmetic in the vector unit, the fraction walk (g -= increment, wrap) is SALU;
+//   * every lane is at the same place in its window: "the position advances" is a scalar branch, the window a register ring -
+//     the frame body exists in TT rotations of the register names, so nothing is ever moved - fed one input frame per advance;
+//   * no lane is ever idle inside a tile (k_up2: 60 of 64 positions per wave-tile), no predicated frames, no per-position
+//     bookkeeping (first_frame_of, start / count / extra);
+//   * a lane's frames are consecutive in ITS segment: they are staged 16 at a time (one 128-byte line per lane, rows 136 bytes
+//     apart: ds_write_b64 free of bank conflicts - k_up2's staging writes were 4-way conflicted at 12 frames per position) and
+//     leave as 16 buffer stores of four whole lines each.
+// What it needs: S a multiple of 65536 / gcd(increment, 65536) (65536 frames for an odd increment such as cfg 3's 5461), a launch
+// of many super-blocks (the lanes of the last, partial one idle: the host takes k_seg when that waste is small), fixed slot signs
+// (NEGMASK, as k_up2), a stream below 4 GiB either side of a super-block (32-bit buffer offsets).
+// A tile = K consecutive frames (a multiple of 16) of each of the 64 segments of one super-block; tiles are drawn as tickets.
+// ---------------------------------------------------------------------------------------------------------
+constexpr unsigned SEG_CHUNK = 16u;          // frames a lane stages before the wave copies them out: 128 bytes, one line, per lane
+constexpr unsigned SEG_LANE_STRIDE = 136u;   // bytes between the lanes' staging rows (34 dwords: 16 neighbouring lanes on 32 different banks)
+constexpr unsigned SEG_FUTURE = 12u;         // input frames beyond its first window that a tile may advance onto (kept in LDS, [entry][lane])
+constexpr unsigned SEG_WAVE_BYTES = 64u * SEG_LANE_STRIDE + SEG_FUTURE * 256u;
+
+// ABL (timing-only diagnostic instances, results WRONG): 1 = one row per tile (no scalar loads in the frame loop), 2 = no global stores,
+// 3 = both.  PF: frames the scalar row loads run ahead (1 or 2).
+template <int TT, unsigned NEGMASK, int WAVES, int NT, int ABL = 0, int PF = 1>
+__global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
+{
+	static_assert(TT == 15 && NEGMASK == 0x2A55u, "the frame body is written out for 15 slots, slots 0, 2, 4, 6, 9, 11, 13 negative");
+	typedef float f32x2 __attribute__((ext_vector_type(2)));
+	typedef float f32x4 __attribute__((ext_vector_type(4)));
+	typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+	const unsigned lane = threadIdx.x & 63u;
+	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	unsigned char *my_stage = smem + wave * SEG_WAVE_BYTES;
+	unsigned char *my_future = my_stage + 64u * SEG_LANE_STRIDE;
+	unsigned *waves_done = reinterpret_cast<unsigned *>(smem + WAVES * SEG_WAVE_BYTES);
+
+	if (threadIdx.x == 0)
+		*waves_done = 0;
+	__syncthreads();
+
+	// ---- tiles as tickets (k_up2's scheme: the first by global wave number, the rest from 32 counter lanes) ----
+	const uint64_t n_tiles = a.n_tiles;
+	const uint64_t global_wave = (uint64_t)wave * gridDim.x + blockIdx.x;
+	const uint64_t global_waves = (uint64_t)gridDim.x * WAVES;
+	const unsigned LANES = global_waves < 32u ? (unsigned)global_waves : 32u;
+	const unsigned lane_id = (unsigned)(global_wave % LANES);
+	const uint64_t lane_tiles = n_tiles > lane_id ? (n_tiles - lane_id + LANES - 1u) / LANES : 0;
+	const unsigned lane_waves = (unsigned)((global_waves - lane_id + LANES - 1u) / LANES);
+	unsigned *lane_counter = a.d_tickets + lane_id * 32u;
+	auto draw_resolve = [&](unsigned got) -> uint64_t {
+		const uint64_t k = (uint64_t)lane_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+		return k < lane_tiles ? lane_id + (uint64_t)LANES * k : ~0ull;
+	};
+	auto retire = [&]() {
+		if (lane == 0 && __hip_atomic_fetch_add(waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == WAVES - 1u)
+		{
+			unsigned *finished = a.d_tickets + 32u * 32u;
+			if (__hip_atomic_fetch_add(finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u)
+			{
+				for (unsigned c = 0; c < 32u; ++c)
+					__hip_atomic_store(a.d_tickets + c * 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	};
+
+	// ---- launch constants (wave-uniform) ----
+	const unsigned increment = __builtin_amdgcn_readfirstlane(a.increment);
+	const unsigned K = __builtin_amdgcn_readfirstlane(a.tile_frames);
+	const uint64_t S = a.seg_frames;
+	const unsigned tiles_per_seg = __builtin_amdgcn_readfirstlane(a.tiles_per_seg);
+	const unsigned tiles_shift = (unsigned)__builtin_ctz(tiles_per_seg);
+	// (constant address space: a uniform load from it is an s_load whatever the kernel stores elsewhere)
+	const __attribute__((address_space(4))) f32x16 *rows = (const __attribute__((address_space(4))) f32x16 *)(uintptr_t)a.d_rows;
+	const uint64_t in_base = reinterpret_cast<uint64_t>(a.d_in);
+	const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+	    reinterpret_cast<void *>(((uint64_t)__builtin_amdgcn_readfirstlane((int)(unsigned)(in_base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)in_base)), 0,
+	    (int)__builtin_amdgcn_readfirstlane((int)(unsigned)(a.in_valid_bytes > 0xFFFFFFFCull ? 0xFFFFFFFCull : a.in_valid_bytes)), 0x00020000);
+	// lane l's window lies l * D input frames behind lane 0's (4 bytes per stereo frame; the host keeps everything below 2^32)
+	const unsigned lane_in_bytes = lane * (unsigned)a.seg_in_frames * 4u;
+
+	// {max(v, 0), min(v, 0)} of both channels of a packed input frame, as floats (k_up2's `convert`)
+	auto convert = [&](int packed, f32x2 &left, f32x2 &right) {
+		float v0, v1;
+		asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(v0) : "v"(packed));
+		asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(v1) : "v"(packed));
+		asm("v_max_f32_e64 %0, %1, 0" : "=v"(left.x) : "v"(v0));
+		asm("v_min_f32_e64 %0, %1, 0" : "=v"(left.y) : "v"(v0));
+		asm("v_max_f32_e64 %0, %1, 0" : "=v"(right.x) : "v"(v1));
+		asm("v_min_f32_e64 %0, %1, 0" : "=v"(right.y) : "v"(v1));
+	};
+
+	f32x2 chain_base;   // where a frame's two chains start: +-2^23, ulp 1 (cr_kup.hpp, FCHAIN)
+	chain_base.x = 8388608.0f;
+	chain_base.y = -8388608.0f;
+	asm volatile("" : "+v"(chain_base));
+	int thirty_one = 31;
+	asm volatile("" : "+v"(thirty_one));
+	int zero_c = 0, zero_d = 0;
+	asm volatile("" : "+{v117}"(zero_c), "+{v119}"(zero_d));   // the high halves of the normalisation's pinned addend pairs (see k_up2)
+
+	// staging: this lane's row, and where it reads for the copy-out (store i of a chunk: segments 4 i ... 4 i + 3, 16 lanes each)
+	const unsigned stage_row = (unsigned)(uintptr_t)my_stage + lane * SEG_LANE_STRIDE;
+	const unsigned copy_from = (unsigned)(uintptr_t)my_stage + (lane >> 4) * SEG_LANE_STRIDE + (lane & 15u) * 8u;
+	const unsigned future_at = (unsigned)(uintptr_t)my_future + lane * 4u;
+
+	uint64_t tile = global_wave;
+	if (tile >= n_tiles)
+	{
+		retire();
+		return;
+	}
+
+	for (;;)
+	{
+		// the ticket for the tile after this one: its round trip runs under the tile
+		// (the counter's address rebuilt from scalar halves: with this kernel's scalar register pressure hipcc otherwise parks the pointer in a VGPR pair,
+		// which the scalar atomic cannot take)
+		const uint64_t counter_bits = reinterpret_cast<uint64_t>(lane_counter);
+		unsigned *const counter = reinterpret_cast<unsigned *>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(counter_bits >> 32)) << 32)
+		                                                       | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)counter_bits));
+		const unsigned ticket = draw_ticket_begin(counter);
+
+		// ---- where the tile is ----
+		// (tiles_per_seg is a power of two - S and K are - and everything below is wave-uniform by construction: say so, or hipcc
+		// carries the tile's 64-bit bookkeeping through the vector unit and wraps every store in a waterfall loop)
+		const unsigned tile_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tile), tile_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(tile >> 32));
+		const uint64_t tile_u = ((uint64_t)tile_hi << 32) | tile_lo;
+		const uint64_t block = tile_u >> tiles_shift;
+		const unsigned t = tile_lo & (tiles_per_seg - 1u);
+		const uint64_t first = block * 64u * S + (uint64_t)t * K;           // lane 0's first frame; lane l's: first + l * S
+		const uint64_t pos = a.pos0 + first * (uint64_t)increment;           // 16.16
+		const uint64_t position = (pos >> 16) + a.first_slot;                // input frame that slot 0 of lane 0's first frame multiplies
+		int g = 65536 - (int)(unsigned)(pos & 0xFFFFu);                      // 65536 - fraction: the row is g >> 6
+
+		// ---- the first window (TT frames) and the frames the tile will advance onto, per lane: TT + SEG_FUTURE dwords from the
+		//      lane's own place in the stream (beyond the caller's buffer: zeros) ----
+		const unsigned in_at = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(position * 4u)) + lane_in_bytes;
+		int raw[28];
+#pragma unroll
+		for (int q = 0; q < 7; ++q)
+		{
+			const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)(in_at + 16u * q), 0, 0);
+			raw[4 * q] = v.x;
+			raw[4 * q + 1] = v.y;
+			raw[4 * q + 2] = v.z;
+			raw[4 * q + 3] = v.w;
+		}
+		static_assert(TT + SEG_FUTURE <= 28, "seven 16-byte loads per lane");
+		f32x2 P[TT][2];   // slot s of rotation R is P[(s + R) % TT]
+#pragma unroll
+		for (int s = 0; s < TT; ++s)
+			convert(raw[s], P[s][0], P[s][1]);
+		// (the previous tile's reads of these entries are long done: same wave, LDS operations in order)
+#pragma unroll
+		for (int e = 0; e < (int)SEG_FUTURE; ++e)
+			*reinterpret_cast<__attribute__((address_space(3))) int *>((uintptr_t)(future_at + 256u * e)) = raw[TT + e];
+
+		// ---- the output side of the tile: 16 descriptors, one per store of a chunk (segments 4 i ... 4 i + 3), re-based per chunk ----
+		const uint64_t out_first = reinterpret_cast<uint64_t>(a.d_out) + first * 8u;
+		const uint64_t out_end = reinterpret_cast<uint64_t>(a.d_out) + a.n_out * 8u;
+		const unsigned store_at = (unsigned)((lane >> 4) * S * 8u) + (lane & 15u) * 8u;   // (< 2^32: the host)
+
+		unsigned frames_left = K;
+		{
+			const uint64_t seg_left = S - (uint64_t)t * K;   // (the last tile of a segment may be shorter: a multiple of 16 all the same)
+			if (seg_left < frames_left)
+				frames_left = (unsigned)seg_left;
+		}
+		frames_left = __builtin_amdgcn_readfirstlane(frames_left);
+		unsigned staged = 0;        // frames of the current chunk staged so far (wave-uniform)
+		unsigned chunk = 0;         // chunks copied out
+		unsigned stage_at = stage_row;
+		unsigned advance = 0;       // input frames advanced onto so far
+		int next_frame = 0;         // the frame the next advance brings in (read from LDS a position ahead)
+
+		// the row of the first frame, then always PF frames ahead
+		f32x16 w = rows[(unsigned)g >> 6];
+		int g1 = g - (int)increment;
+		g1 += g1 <= 0 ? 65536 : 0;
+		f32x16 w1 = rows[(unsigned)g1 >> 6];   // (PF == 2: the row of the frame after this one)
+
+		// bytes from the tile's first frame (segment 0) to the end of the stream, as far as 32 bits see (the host keeps a whole
+		// super-block - 64 S frames of 8 bytes - below 2^32, so whatever is clamped away here lies beyond every store of the tile)
+		const uint64_t room64 = out_end > out_first ? out_end - out_first : 0;
+		const unsigned room = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(room64 > 0xFFFFFFFCull ? 0xFFFFFFFCull : room64));
+		const unsigned seg4_bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(S * 32u));   // four segments further on
+
+		// A frame's result is written to its staging slot DURING THE NEXT frame (between that frame's two blocks of taps): the wait for the
+		// scalar row load at the head of every frame is lgkmcnt(0) - scalar loads return out of order, nothing less will do - and it would
+		// otherwise sit out the LDS write issued just in front of it, every frame.  `pending` is the frame waiting to be written; before
+		// the first frame of a tile (and after a copy-out) it is a dummy aimed at the 8 bytes of padding behind the lane's 128.
+		i32x2 pending;
+		pending.x = 0;
+		pending.y = 0;
+		unsigned pending_at = stage_row + SEG_CHUNK * 8u;
+		auto write_pending = [&]() {
+			asm volatile("ds_write_b64 %0, %1" ::"v"(pending_at), "v"(pending) : "memory");
+		};
+
+		auto copy_out = [&]() {
+			write_pending();   // the chunk's last frame
+			pending_at = stage_row + SEG_CHUNK * 8u;
+			// the staged frames of the other lanes: same wave, LDS operations complete in order
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			// every read first, then the stores (one wait for the LDS instead of sixteen)
+			i32x2 v[16];
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				v[i] = *reinterpret_cast<const __attribute__((address_space(3))) i32x2 *>((uintptr_t)(copy_from + (unsigned)i * 4u * SEG_LANE_STRIDE));
+			unsigned off = chunk * (SEG_CHUNK * 8u);   // of segment 4 i's line of this chunk from out_first
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+			{
+				// one descriptor per store: it starts at segment 4 i's line and ends with the stream (a line, or a segment, beyond the
+				// stream's end: dropped by the range check) - scalar arithmetic, 32 bits
+				const uint64_t at = out_first + off;
+				// (room - off, 0 if that borrows - as two scalar instructions: written in C++ hipcc forms a saturating subtract, which only the
+				// vector unit has, and then feeds the store its descriptor through a waterfall loop)
+				unsigned left;
+				asm("s_sub_u32 %0, %1, %2\n\ts_cselect_b32 %0, 0, %0" : "=&s"(left) : "s"(room), "s"(off) : "scc");
+				const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+				    reinterpret_cast<void *>(((uint64_t)__builtin_amdgcn_readfirstlane((int)(unsigned)(at >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)at)), 0,
+				    (int)left, 0x00020000);
+				if constexpr (ABL == 2 || ABL == 3)
+					asm volatile("" ::"v"(v[i]), "s"(rsrc));
+				else
+					__builtin_amdgcn_raw_buffer_store_b64(v[i], rsrc, (int)store_at, 0, NT ? 2 : 0);
+				off += seg4_bytes;
+			}
+			__builtin_amdgcn_wave_barrier();
+			++chunk;
+			staged = 0;
+			stage_at = stage_row;
+		};
+
+		// one frame of every lane with the window in rotation R; the weights: the scalar row `w`
+		auto frame = [&](auto r_tag) {
+			constexpr int R = decltype(r_tag)::value;
+			auto wpair = [&](int k) {
+				f32x2 wp;
+				wp.x = w[2 * k];
+				wp.y = w[2 * k + 1];
+				return wp;
+			};
+#define CR_SEL_EP " op_sel_hi:[1,0,1]\n\t"
+#define CR_SEL_OP " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+#define CR_SEL_EN " op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+#define CR_SEL_ON " op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+#define CR_T(acc, p, wq, SEL) "v_pk_fma_f32 %" #acc ", %" #p ", %" #wq ", %" #acc SEL
+#define CR_F(acc, p, wq, base, SEL) "v_pk_fma_f32 %" #acc ", %" #p ", %" #wq ", %" #base SEL
+#define CR_P(s, c) P[((s) + R) % TT][c]
+			f32x2 a0, a1;
+			// slots 0 (-), 1 (+), 2 (-), 3 (+), 4 (-), 5 (+), 6 (-), 7 (+): cr_kup.hpp, the same strings with scalar weight pairs
+			asm volatile(CR_F(0, 2, 18, 22, CR_SEL_EN) CR_F(1, 10, 18, 22, CR_SEL_EN) CR_T(0, 3, 18, CR_SEL_OP) CR_T(1, 11, 18, CR_SEL_OP)
+			             CR_T(0, 4, 19, CR_SEL_EN) CR_T(1, 12, 19, CR_SEL_EN) CR_T(0, 5, 19, CR_SEL_OP) CR_T(1, 13, 19, CR_SEL_OP)
+			             CR_T(0, 6, 20, CR_SEL_EN) CR_T(1, 14, 20, CR_SEL_EN) CR_T(0, 7, 20, CR_SEL_OP) CR_T(1, 15, 20, CR_SEL_OP)
+			             CR_T(0, 8, 21, CR_SEL_EN) CR_T(1, 16, 21, CR_SEL_EN) CR_T(0, 9, 21, CR_SEL_OP) CR_T(1, 17, 21, CR_SEL_OP)
+			             : "=&v"(a0), "=&v"(a1)
+			             : "v"(CR_P(0, 0)), "v"(CR_P(1, 0)), "v"(CR_P(2, 0)), "v"(CR_P(3, 0)), "v"(CR_P(4, 0)), "v"(CR_P(5, 0)), "v"(CR_P(6, 0)), "v"(CR_P(7, 0)),
+			               "v"(CR_P(0, 1)), "v"(CR_P(1, 1)), "v"(CR_P(2, 1)), "v"(CR_P(3, 1)), "v"(CR_P(4, 1)), "v"(CR_P(5, 1)), "v"(CR_P(6, 1)), "v"(CR_P(7, 1)),
+			               "s"(wpair(0)), "s"(wpair(1)), "s"(wpair(2)), "s"(wpair(3)), "v"(chain_base));
+			if constexpr (ABL == 4)
+			{
+				// diagnostic: ten more scalar instructions per frame (what does a scalar instruction cost this kernel?)
+				unsigned junk = staged;
+				asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\t"
+				             "s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1" : "+s"(junk) : : "scc");
+			}
+			write_pending();   // the previous frame's result: its LDS write has the rest of this frame to complete
+			// slots 8 (+), 9 (-), 10 (+), 11 (-), 12 (+), 13 (-), 14 (+)
+			asm volatile(CR_T(0, 2, 16, CR_SEL_EP) CR_T(1, 9, 16, CR_SEL_EP) CR_T(0, 3, 16, CR_SEL_ON) CR_T(1, 10, 16, CR_SEL_ON)
+			             CR_T(0, 4, 17, CR_SEL_EP) CR_T(1, 11, 17, CR_SEL_EP) CR_T(0, 5, 17, CR_SEL_ON) CR_T(1, 12, 17, CR_SEL_ON)
+			             CR_T(0, 6, 18, CR_SEL_EP) CR_T(1, 13, 18, CR_SEL_EP) CR_T(0, 7, 18, CR_SEL_ON) CR_T(1, 14, 18, CR_SEL_ON)
+			             CR_T(0, 8, 19, CR_SEL_EP) CR_T(1, 15, 19, CR_SEL_EP)
+			             : "+v"(a0), "+v"(a1)
+			             : "v"(CR_P(8, 0)), "v"(CR_P(9, 0)), "v"(CR_P(10, 0)), "v"(CR_P(11, 0)), "v"(CR_P(12, 0)), "v"(CR_P(13, 0)), "v"(CR_P(14, 0)),
+			               "v"(CR_P(8, 1)), "v"(CR_P(9, 1)), "v"(CR_P(10, 1)), "v"(CR_P(11, 1)), "v"(CR_P(12, 1)), "v"(CR_P(13, 1)), "v"(CR_P(14, 1)),
+			               "s"(wpair(4)), "s"(wpair(5)), "s"(wpair(6)), "s"(wpair(7)));
+#undef CR_P
+#undef CR_F
+#undef CR_T
+#undef CR_SEL_ON
+#undef CR_SEL_EN
+#undef CR_SEL_OP
+#undef CR_SEL_EP
+			// positive chain = 2^23 + p, negative chain = -(2^23 + q): the frame's sum is p - q
+			const int hi0 = (int)(__float_as_uint(a0.x) - __float_as_uint(a0.y) + 0x80000000u);
+			const int hi1 = (int)(__float_as_uint(a1.x) - __float_as_uint(a1.y) + 0x80000000u);
+			// (acc * reciprocal) / 32768 toward zero (clownresampler.h:1033), the row's last entry being 2 * reciprocal: k_up2's form
+			int out0, out1;
+			const int reciprocal2 = (int)__float_as_uint(w[TT]);
+			asm("v_ashrrev_i32_sdwa v116, %4, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+			    "v_ashrrev_i32_sdwa v118, %4, %3 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+			    "v_mad_i64_i32 v[122:123], vcc, %2, %5, v[116:117]\n\t"
+			    "v_mad_i64_i32 v[126:127], vcc, %3, %5, v[118:119]\n\t"
+			    "v_alignbit_b32 %0, v123, v122, 16\n\t"
+			    "v_alignbit_b32 %1, v127, v126, 16"
+			    : "=&v"(out0), "=&v"(out1)
+			    : "v"(hi0), "v"(hi1), "v"(thirty_one), "s"(reciprocal2), "{v117}"(zero_c), "{v119}"(zero_d)
+			    : "vcc", "v116", "v118", "v122", "v123", "v126", "v127");
+			pending.x = out0;
+			pending.y = out1;
+			pending_at = stage_at;
+		};
+
+		asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3");   // FP32 rounding: toward zero, for the chains (restored below)
+
+		// the frame the first advance brings in
+		next_frame = *reinterpret_cast<const __attribute__((address_space(3))) int *>((uintptr_t)future_at);
+
+		bool done = false;
+		while (!done)
+		{
+			static_for<TT>([&](auto r_tag) {
+				constexpr int R = decltype(r_tag)::value;
+				if (done)
+					return;
+				// the frames at this position: until the fraction wraps (or the tile ends)
+				for (;;)
+				{
+					// the row of the frame PF frames on, requested before this frame's arithmetic
+					const bool wraps = g - (int)increment <= 0;
+					if constexpr (PF == 1)
+					{
+						int g_next = g - (int)increment;
+						g_next += wraps ? 65536 : 0;
+						f32x16 w_next = w;
+						if constexpr (ABL != 1 && ABL != 3)
+							w_next = rows[(unsigned)g_next >> 6];
+						frame(r_tag);
+						w = w_next;
+						g = g_next;
+					}
+					else
+					{
+						int g2 = g1 - (int)increment;
+						g2 += g2 <= 0 ? 65536 : 0;
+						f32x16 w2 = w1;
+						if constexpr (ABL != 1 && ABL != 3)
+							w2 = rows[(unsigned)g2 >> 6];
+						frame(r_tag);
+						w = w1;
+						w1 = w2;
+						g = g1;
+						g1 = g2;
+					}
+					stage_at += 8u;
+					--frames_left;
+					if (++staged == SEG_CHUNK)
+						copy_out();
+					if (frames_left == 0)
+					{
+						done = true;
+						return;
+					}
+					if (wraps)
+						break;
+				}
+				// the position advances: the oldest slot's registers take the new frame, the names rotate by one
+				convert(next_frame, P[R % TT][0], P[R % TT][1]);
+				++advance;
+				next_frame = *reinterpret_cast<const __attribute__((address_space(3))) int *>((uintptr_t)(future_at + 256u * (advance < SEG_FUTURE ? advance : SEG_FUTURE - 1u)));
+			});
+		}
+
+		asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0");   // back to round-to-nearest-even
+
+		const uint64_t next = draw_resolve(draw_ticket_end(ticket));
+		if (next == ~0ull)
+			break;
+		tile = next;
+	}
+
+	retire();
+}
+
+} // namespace
+
+#endif // CR_KSEG_HPP

@@ -134,6 +134,37 @@ int crhip_int_instance(uint32_t channels, uint32_t ratio, uint32_t period, uint3
 int crhip_int_prepare(uint32_t channels, uint32_t ratio, uint32_t period, uint32_t slots, int *per_cu, int *per_cu_s16);
 int crhip_launch_int(const crhip_int_launch *launch, void *stream);
 
+/* One launch of k_seg (cr_kseg.hpp): long pure-upsampling launches with fixed slot signs (cfg 3's shape).  The 64 lanes of a wave take
+   output frames seg_frames apart - seg_frames * increment is a multiple of 65536, so they share their fraction, hence their row,
+   which travels in scalar registers.  Lane l of super-block b walks output frames [b * 64 S + l S, + S) (S = seg_frames), K at a
+   time (a tile: K frames of each of the 64 segments; tile index = b * tiles_per_seg + t). */
+typedef struct crhip_seg_launch
+{
+	const void *d_in;           /* interleaved int16, stereo */
+	uint64_t in_valid_bytes;    /* < 2^32 */
+	void *d_out;                /* int32, n_out * 2 */
+	const void *d_rows;         /* the FLOAT row image: 16 dwords per row, row-major - |weight| / 65536 as float for the 15 slots, then
+	                               2 * reciprocal as int32 (clownresampler.h:1025, :1033) */
+	uint64_t pos0;              /* 16.16, of output frame 0 relative to frame 0 of d_in */
+	uint64_t n_out;
+	uint64_t seg_frames;        /* S: a multiple of 65536 / gcd(increment, 65536) and of tile_frames; 512 S < 2^32 */
+	uint64_t seg_in_frames;     /* D = S * increment / 65536; 256 D < 2^32 */
+	uint64_t n_tiles;           /* ceil(n_out / (64 S)) * tiles_per_seg */
+	uint32_t increment;         /* 16.16; (65535 + (tile_frames - 1) * increment) >> 16 <= 12 */
+	uint32_t first_slot;
+	uint32_t slots;             /* 15 */
+	uint32_t tile_frames;       /* K: a multiple of 16 */
+	uint32_t tiles_per_seg;     /* S / K */
+	uint32_t blocks;
+	uint32_t *d_tickets;        /* CRHIP_TICKET_WORDS zeroed counters (as crhip_poly_launch.d_tickets) */
+	uint32_t debug_form;        /* 0; diagnostic instances: 1-3 timing-only ablations (results wrong), 4 = row loads two frames ahead */
+} crhip_seg_launch;
+
+/* 1 and the slot signs the instance is built for (as crhip_poly_up_negmask) when there is a k_seg instance for the shape */
+int crhip_seg_instance(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t *negmask, uint32_t *threads, uint32_t *lds_bytes);
+int crhip_seg_prepare(uint32_t channels, uint32_t slots, int *per_cu);   /* one-time setup (dynamic LDS limit); not legal inside a capture */
+int crhip_launch_seg(const crhip_seg_launch *launch, void *stream);
+
 /* Many short constant-rate segments of ONE timeline in ONE launch (variable rate: ClownResamplerAMD_ResampleSegmentsDevice): the
    generic kernel's per-frame arithmetic with the segment's parameters looked up in a table - every lane finds its segment by
    bisection over the segments' first output frames. */

@@ -195,7 +195,7 @@ size_t ClownResamplerAMD_PlanCacheCount(void);
    gives its first frames to the ordinary kernel, which is what this function then names.  Ignores launch-length rules
    (brief_below). */
 uint32_t ClownResamplerAMD_PlanKernelAt(const ClownResamplerAMD_Plan *plan, uint32_t position_fractional);
-/* Launches enqueued by this process so far on `kernel` (0 ... 6, numbered as above): lets tests and benchmarks assert that the
+/* Launches enqueued by this process so far on `kernel` (0 ... 6, numbered as above; 8 = k_seg): lets tests and benchmarks assert that the
    kernel they mean is the one that ran.  7 = how many of those launches drew their tiles as tickets (k_poly's and k_int's long
    launches; a launch of fewer than eight tiles per workgroup is dealt round-robin instead). */
 unsigned long long ClownResamplerAMD_DebugLaunchCount(unsigned kernel);
@@ -210,6 +210,13 @@ uint32_t ClownResamplerAMD_PlanDualMonoKernel(const ClownResamplerAMD_Plan *plan
    LDS -> LDS, to frames of 32 bytes whose shares are one aligned 16-byte read per tap (CLOWNRESAMPLER_AMD_NO_PADDED_TILES in the
    environment at first use: never). */
 uint32_t ClownResamplerAMD_PlanPaddedTiles(const ClownResamplerAMD_Plan *plan);
+/* Test hook for k_seg (long stereo launches of 8x - 13x upsampling with 8 lobes: the lanes of a wave on output frames of equal fraction,
+   the polyphase row in scalar registers): 0 = the rule (launches whose last, partial block of 64 segments wastes little), 1 = every
+   launch the kernel can take, 2 = never (also CLOWNRESAMPLER_AMD_NO_SEG in the environment at first use).  Kernel 8 of
+   ClownResamplerAMD_DebugLaunchCount counts its launches. */
+void ClownResamplerAMD_DebugSegKernel(int mode);
+/* Test hook (host only, no device needed): the predicate that keeps dual-mono launches inside their kernels' 32-bit buffer-descriptor arithmetic. */
+int ClownResamplerAMD_DebugDualMonoFits(uint64_t n_out, uint64_t half, uint64_t tile_frames, uint64_t increment, uint64_t in_valid_bytes);
 /* Test hook: long MONO launches stay on the plan's mono kernel instead of running as two phase-aligned "channels" of the stereo
    instance (dual mono; also CLOWNRESAMPLER_AMD_NO_DUAL_MONO in the environment at first use). */
 void ClownResamplerAMD_DebugDisableDualMono(int on);

@@ -324,7 +324,8 @@ def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch,
 
 @pytest.mark.parametrize("name,radius,ch,rates,frames,kernel,ticketed", [
     ("cfg2", 3, 2, (44100, 48000, 44100), 26460000, 1, True),     # BASELINE configs[1]: THE launch bench.py times (7,032 tiles on 512 workgroups, tickets)
-    ("cfg3", 8, 2, (8000, 96000, 8000), 4800000, 3, None),         # configs[2]: k_up2, wave-tiles drawn from global counters throughout
+    ("cfg3", 8, 2, (8000, 96000, 8000), 4800000, 8, None),         # configs[2]: k_seg (13.7 blocks of 64 segments: the lanes of a wave 65,536 frames apart)
+    ("cfg3m", 8, 2, (8000, 96000, 8000), 1200000, 3, None),        # 2.5 minutes of it: 3.4 such blocks, 14 % of the lane-steps of four idle - k_up2, wave-tiles drawn from global counters throughout
     ("cfg4", 3, 8, (48000, 44100, 44100), 28800000, 1, True),      # configs[3]: 8 channels, ticketed tiles
     ("cfg5", 3, 2, (44100, 48000, 44100), 158760000, 1, True),     # configs[4]: the hour as ONE launch (42,188 tiles)
     ("hq48", 8, 2, (44100, 48000, 44100), 26460000, 4, None),      # k_wave2: chunks of 4 wave-tiles (the 4 Mi batches of the host path get shorter ones)
@@ -360,13 +361,13 @@ def test_one_launch_full_size_bit_exact(products, name, radius, ch, rates, frame
         api.CopyToDevice(d_in, padded)
         del padded
         plan = api.PlanCreate(st.raw, p.pre)
-        before = [api.LaunchCount(k) for k in range(8)]
+        before = [api.LaunchCount(k) for k in range(9)]
         n, left, ran_out = api.ResampleDevice(plan, st.raw, d_in, frames, d_out, total + 1)
         api.StreamSynchronize()
-        after = [api.LaunchCount(k) for k in range(8)]
+        after = [api.LaunchCount(k) for k in range(9)]
         assert n == total and left == 0 and ran_out == 1
         launched = [a - b for a, b in zip(after, before)]
-        assert sum(launched[:7]) == 1, ("the call must be ONE launch", launched)
+        assert sum(launched[:7]) + launched[8] == 1, ("the call must be ONE launch", launched)
         if kernel is not None:
             assert launched[kernel] == 1, (name, launched)
         if ticketed is not None:
@@ -378,6 +379,67 @@ def test_one_launch_full_size_bit_exact(products, name, radius, ch, rates, frame
         end = total * int(ost.increment)
         assert (st.pos_int, st.pos_frac) == ((end >> 16) - frames, end & 0xFFFF)
     finally:
+        api.DeviceFree(d_in)
+        api.DeviceFree(d_out)
+
+
+@pytest.mark.parametrize("rates,frames,forced", [
+    ((8000, 64000, 8000), 70000, True),      # 8x: increment 8192, the fraction repeats every 8 frames - segments of 1,024 frames, 8.5 blocks of 64
+    ((6000, 72000, 6000), 9000, True),       # 12x at another rate pair: increment 5461 (odd) - segments of 65,536 frames, one partial block, forced
+    ((8000, 96000, 8000), 130000, True),     # cfg 3's ratio: 1.56 M frames = 24 of the 64 segments of one block
+    ((8000, 88000, 8000), 100000, True),     # 11x (increment 5957)
+    ((8000, 72000, 8000), 120000, True),     # 9x (increment 7281)
+    ((9000, 96000, 9000), 60000, True),      # 10.67x: increment 6144 = 3 * 2048, the fraction repeats every 32 frames
+    ((8000, 104000, 8000), 50000, True),     # 13x
+    ((12000, 96000, 12000), 1500, True),     # a launch shorter than one tile per segment (96 frames of segment 0 ... 11)
+])
+def test_segment_kernel_bit_exact(products, rates, frames, forced):
+    """k_seg (cr_kseg.hpp): the lanes of a wave S output frames apart, S * increment a multiple of 65536 - equal fractions, one polyphase
+    row per wave and step (reference clownresampler.h:993-1001: the taps of a frame are a function of its fractional position only),
+    taken from scalar registers.  Fresh and carried-in states, a launch stopped by the output capacity, launches of a partial block
+    of segments, of less than a tile: every sample against the oracle, through ONE k_seg launch each (kernel 8 of LaunchCount)."""
+    p, o = products[8], ck.oracle(8)
+    api = p.api
+    ch = 2
+    ok, st = p.low_init(ch, *rates)
+    ok, ost = o.low_init(ch, *rates)
+    plan = api.PlanCreate(st.raw, p.pre)
+    R = int(ost.cfg.radius_frames)
+    padded = ck.pad_frames(ck.noise_pcm(frames * ch, 77 + frames), ch, R)
+    total = int(ck.count_output_frames(ost, frames))
+    d_in = api.DeviceAlloc(padded.nbytes + 64)
+    d_out = api.DeviceAlloc((total + 1) * ch * 4 + 4096)
+    api.DebugSegKernel(1 if forced else 0)
+    try:
+        api.CopyToDevice(d_in, padded)
+        guard = np.full(1024, 0x5A5A5A5A, dtype=np.int32)
+        # two calls: the first stopped by its capacity somewhere in the stream (an odd count: the second starts at any fraction)
+        first = total // 3 + 1
+        got = np.empty(total * ch, dtype=np.int32)
+        want = np.empty(total * ch, dtype=np.int32)
+        pos_in, done = 0, 0
+        for cap in (first, total - first + 5):
+            left_before = frames - pos_in
+            before = [api.LaunchCount(k) for k in range(9)]
+            api.CopyToDevice(d_out + (done + min(cap, total - done)) * ch * 4, guard)
+            n, left, ran_out = api.ResampleDevice(plan, st.raw, d_in + pos_in * ch * 2, left_before, d_out + done * ch * 4, cap)
+            api.StreamSynchronize()
+            launched = [a - b for a, b in zip([api.LaunchCount(k) for k in range(9)], before)]
+            assert launched[8] == 1 and sum(launched[:7]) == 0, (rates, "k_seg must be the one launch", launched)
+            w, wl, wr = o.low_resample_i32(ost, padded[pos_in * ch:], left_before, capacity=cap)
+            assert (n, left, ran_out) == (w.size // ch, wl, wr) and st.astuple() == tuple(int(v) for v in ost.astuple())
+            want[done * ch:(done + n) * ch] = w
+            tail = np.empty(guard.size, dtype=np.int32)
+            api.CopyFromDevice(tail, d_out + (done + n) * ch * 4)
+            assert np.array_equal(tail, guard), "frames behind the launch's last one were written"
+            pos_in += left_before - left
+            done += n
+        assert done == total
+        api.CopyFromDevice(got, d_out)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (rates, "%d samples differ, first at frame %d: got %d want %d" % (bad.size, bad[0] // ch, got[bad[0]], want[bad[0]]))
+    finally:
+        api.DebugSegKernel(0)
         api.DeviceFree(d_in)
         api.DeviceFree(d_out)
 

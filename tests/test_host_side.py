@@ -486,3 +486,23 @@ def test_reference_examples_compile_against_the_drop_in(tmp_path, source):
     r = subprocess.run(["gcc", "-std=c89", "-pedantic", "-fsyntax-only", str(tree / "examples" / source)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "clownresampler.h" not in r.stderr, r.stderr[-3000:]
+
+
+def test_dual_mono_guard_keeps_launches_inside_32_bit_descriptors():
+    """the dual-mono kernels store both halves of a mono launch through ONE buffer descriptor of n_out * 4 bytes
+    (clamped to 0xFFFFFFFC) with 32-bit byte offsets, and fetch both windows through one descriptor to the end of the caller's buffer:
+    a launch whose output or input does not fit - with a tile of headroom for the ragged last tile's offsets - must stay on the mono
+    kernels (64-bit pointers).  The predicate cr_plan_launch consults, on its own (host only)."""
+    lib = C.CDLL(cr.LIB_PATH)
+    f = lib.ClownResamplerAMD_DebugDualMonoFits
+    f.restype, f.argtypes = C.c_int, [C.c_uint64] * 5
+    inc = 60211                       # 44.1 -> 48 kHz
+    tile = 4096
+    ok = lambda n, in_bytes=1 << 30, t=tile, i=inc: f(n, (n + 1) // 2, t, i, in_bytes)
+    assert ok(52_920_000) == 1                                  # ten minutes of mono: what the path is for
+    assert ok((1 << 30) - 4 * tile - 1) == 1                    # the largest output that still leaves a tile of headroom ...
+    assert ok((1 << 30) - 4 * tile) == 0                        # ... and the first that does not: n_out * 4 + 4 tiles * 4 > 0xFFFFFFFC
+    assert ok(1 << 30) == 0 and ok((1 << 31) + 5) == 0          # 4 GiB of output and beyond: the second half would be silently dropped
+    assert ok(52_920_000, in_bytes=0xFFFFFFFC) == 1 and ok(52_920_000, in_bytes=0xFFFFFFFD) == 0   # the input side: one descriptor over both windows
+    assert f(1 << 31, 1 << 30, tile, inc, 1 << 30) == 0          # half itself
+    assert f(100_000_000, 50_000_000, tile, 3000 << 16, 1 << 30) == 0   # the second window's distance (half * increment >> 16) beyond 2^31 frames

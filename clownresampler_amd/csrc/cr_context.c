@@ -1962,11 +1962,12 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		const uint64_t blocks64 = (n_out + 64u * seg - 1u) / (64u * seg);
 		const double waste = 1.0 - (double)n_out / ((double)blocks64 * 64.0 * (double)seg);
 		/* frames per lane and tile: a power of two from 64 to 256 (it divides S), as large as the tile's advances (at most 12) and the
-		   balance (four tiles per wave or more) allow */
+		   balance (two tiles per wave or more) allow - cfg 3: 128 frames, 2.3 tiles per wave, 115 us where 64-frame tiles take 121
+		   (profiles/r05_kseg_ab.log: a tile's first window is 7 scattered loads and 90 conversions per lane) */
 		uint64_t tile = CR_SEG_MAX_TILE;
 		const uint64_t waves = (uint64_t)plan->seg.max_blocks * (plan->seg.threads / 64u);
 
-		while (tile > CR_SEG_MIN_TILE && (((65535u + (tile - 1u) * plan->increment) >> 16) > 12u || blocks64 * (seg / tile) < 4u * waves))
+		while (tile > CR_SEG_MIN_TILE && (((65535u + (tile - 1u) * plan->increment) >> 16) > 12u || blocks64 * (seg / tile) < 2u * waves))
 			tile /= 2u;
 		if (g_env.seg_tile >= 16 && (g_env.seg_tile & (g_env.seg_tile - 1)) == 0 && (uint64_t)g_env.seg_tile <= seg)
 			tile = (uint64_t)g_env.seg_tile;
@@ -1993,6 +1994,13 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			sl.tiles_per_seg = (uint32_t)(seg / tile);
 			sl.n_tiles = blocks64 * sl.tiles_per_seg;
 			sl.debug_form = (uint32_t)g_env.seg_form;
+			if (sl.debug_form == 6u)
+			{
+				/* (diagnostic: four waves per SIMD, four future entries: tiles of 32 frames) */
+				sl.tile_frames = 32u;
+				sl.tiles_per_seg = (uint32_t)(seg / 32u);
+				sl.n_tiles = blocks64 * sl.tiles_per_seg;
+			}
 			grid = (sl.n_tiles + plan->seg.threads / 64u - 1u) / (plan->seg.threads / 64u);
 			sl.blocks = (uint32_t)(grid > plan->seg.max_blocks ? plan->seg.max_blocks : grid);
 			sl.d_tickets = ticket_block_for(g_ctx[plan->device], stream, &ring);

@@ -11,9 +11,11 @@ constexpr int SEG_WAVES = 12;
 constexpr unsigned SEG_LDS = SEG_WAVES * SEG_WAVE_BYTES + 16u;
 typedef void (*seg_fn)(const crhip_seg_launch);
 const seg_fn seg_2_15 = k_seg<15, 0x2A55u, SEG_WAVES, 1>;
-// diagnostic instances (crhip_seg_launch.debug_form): 1-3 timing-only ablations (results wrong), 4 = the row loads two frames ahead
-const seg_fn seg_2_15_forms[6] = {seg_2_15, k_seg<15, 0x2A55u, SEG_WAVES, 1, 1>, k_seg<15, 0x2A55u, SEG_WAVES, 1, 2>, k_seg<15, 0x2A55u, SEG_WAVES, 1, 3>,
-                                  k_seg<15, 0x2A55u, SEG_WAVES, 1, 0, 2>, k_seg<15, 0x2A55u, SEG_WAVES, 1, 4>};
+// diagnostic instances (crhip_seg_launch.debug_form): 1-3 timing-only ablations (results wrong), 5 = ten more scalar instructions per frame
+const seg_fn seg_2_15_forms[7] = {seg_2_15, k_seg<15, 0x2A55u, SEG_WAVES, 1, 1>, k_seg<15, 0x2A55u, SEG_WAVES, 1, 2>, k_seg<15, 0x2A55u, SEG_WAVES, 1, 3>,
+                                  seg_2_15, k_seg<15, 0x2A55u, SEG_WAVES, 1, 4>, k_seg<15, 0x2A55u, 16, 1, 0, 4u>};
+// (form 6: sixteen waves - four per SIMD - with four future entries per tile: tiles of 32 frames at 12x)
+constexpr unsigned SEG_LDS_16 = 16u * seg_wave_bytes(4u) + 16u;
 }
 
 extern "C" {
@@ -33,8 +35,8 @@ int crhip_seg_prepare(uint32_t channels, uint32_t slots, int *per_cu)
 	if (channels != 2u || slots != 15u)
 		return (int)hipErrorInvalidValue;
 	hipError_t e = hipSuccess;
-	for (int f = 0; f < 6 && e == hipSuccess; ++f)
-		e = hipFuncSetAttribute((const void *)seg_2_15_forms[f], hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEG_LDS);
+	for (int f = 0; f < 7 && e == hipSuccess; ++f)
+		e = hipFuncSetAttribute((const void *)seg_2_15_forms[f], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(f == 6 ? SEG_LDS_16 : SEG_LDS));
 	if (e != hipSuccess)
 		return (int)e;
 	return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, (const void *)seg_2_15, SEG_WAVES * 64, SEG_LDS);
@@ -47,7 +49,8 @@ int crhip_launch_seg(const crhip_seg_launch *launch, void *stream)
 		return (int)hipErrorInvalidValue;
 	if (launch->n_out == 0)
 		return 0;
-	hipLaunchKernelGGL(seg_2_15_forms[launch->debug_form < 6u ? launch->debug_form : 0u], dim3(launch->blocks), dim3(SEG_WAVES * 64), SEG_LDS, (hipStream_t)stream, *launch);
+	const unsigned form = launch->debug_form < 7u ? launch->debug_form : 0u;
+	hipLaunchKernelGGL(seg_2_15_forms[form], dim3(launch->blocks), dim3(form == 6u ? 1024 : SEG_WAVES * 64), form == 6u ? SEG_LDS_16 : SEG_LDS, (hipStream_t)stream, *launch);
 	return (int)hipGetLastError();
 }
 

@@ -35,13 +35,16 @@ namespace
 constexpr unsigned SEG_CHUNK = 16u;          // frames a lane stages before the wave copies them out: 128 bytes, one line, per lane
 constexpr unsigned SEG_LANE_STRIDE = 136u;   // bytes between the lanes' staging rows (34 dwords: 16 neighbouring lanes on 32 different banks)
 constexpr unsigned SEG_FUTURE = 12u;         // input frames beyond its first window that a tile may advance onto (kept in LDS, [entry][lane])
-constexpr unsigned SEG_WAVE_BYTES = 64u * SEG_LANE_STRIDE + SEG_FUTURE * 256u;
+constexpr unsigned seg_wave_bytes(unsigned future) { return 64u * SEG_LANE_STRIDE + future * 256u; }
+constexpr unsigned SEG_WAVE_BYTES = seg_wave_bytes(SEG_FUTURE);
 
 // ABL (timing-only diagnostic instances, results WRONG): 1 = one row per tile (no scalar loads in the frame loop), 2 = no global stores,
-// 3 = both.  PF: frames the scalar row loads run ahead (1 or 2).
-template <int TT, unsigned NEGMASK, int WAVES, int NT, int ABL = 0, int PF = 1>
+// 3 = both, 4 = ten more scalar instructions per frame.
+template <int TT, unsigned NEGMASK, int WAVES, int NT, int ABL = 0, unsigned FUT = SEG_FUTURE>
 __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 {
+	constexpr unsigned SEG_FUTURE = FUT;                        // (a diagnostic instance trades entries for a fourth wave per SIMD)
+	constexpr unsigned SEG_WAVE_BYTES = seg_wave_bytes(FUT);
 	static_assert(TT == 15 && NEGMASK == 0x2A55u, "the frame body is written out for 15 slots, slots 0, 2, 4, 6, 9, 11, 13 negative");
 	typedef float f32x2 __attribute__((ext_vector_type(2)));
 	typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -152,7 +155,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 		const uint64_t first = block * 64u * S + (uint64_t)t * K;           // lane 0's first frame; lane l's: first + l * S
 		const uint64_t pos = a.pos0 + first * (uint64_t)increment;           // 16.16
 		const uint64_t position = (pos >> 16) + a.first_slot;                // input frame that slot 0 of lane 0's first frame multiplies
-		int g = 65536 - (int)(unsigned)(pos & 0xFFFFu);                      // 65536 - fraction: the row is g >> 6
+		// the fraction of the wave's current frame in the TOP half of a register: adding the increment (shifted likewise) carries exactly
+		// when the position advances, and nothing has to be wrapped back (scalar: 2 instructions per frame)
+		unsigned F = (unsigned)(pos & 0xFFFFu) << 16;
+		const unsigned INC = increment << 16;                                // (increment < 65536: upsampling)
 
 		// ---- the first window (TT frames) and the frames the tile will advance onto, per lane: TT + SEG_FUTURE dwords from the
 		//      lane's own place in the stream (beyond the caller's buffer: zeros) ----
@@ -189,17 +195,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 				frames_left = (unsigned)seg_left;
 		}
 		frames_left = __builtin_amdgcn_readfirstlane(frames_left);
-		unsigned staged = 0;        // frames of the current chunk staged so far (wave-uniform)
+		unsigned in_chunk = SEG_CHUNK;   // frames until the chunk is copied out (wave-uniform)
 		unsigned chunk = 0;         // chunks copied out
 		unsigned stage_at = stage_row;
 		unsigned advance = 0;       // input frames advanced onto so far
 		int next_frame = 0;         // the frame the next advance brings in (read from LDS a position ahead)
 
-		// the row of the first frame, then always PF frames ahead
-		f32x16 w = rows[(unsigned)g >> 6];
-		int g1 = g - (int)increment;
-		g1 += g1 <= 0 ? 65536 : 0;
-		f32x16 w1 = rows[(unsigned)g1 >> 6];   // (PF == 2: the row of the frame after this one)
+		// The row of a frame: (65536 - fraction) >> 6 (pure-upsampling row index), 64 bytes per row: s_load_dwordx16, a frame ahead.
+		auto load_row = [&](unsigned fraction_hi) -> f32x16 {
+			const unsigned off = (0x10000u - (fraction_hi >> 16)) & 0x1FFC0u;
+			return *reinterpret_cast<const __attribute__((address_space(4))) f32x16 *>(reinterpret_cast<const __attribute__((address_space(4))) unsigned char *>(rows) + off);
+		};
+		f32x16 w_a = load_row(F);
 
 		// bytes from the tile's first frame (segment 0) to the end of the stream, as far as 32 bits see (the host keeps a whole
 		// super-block - 64 S frames of 8 bytes - below 2^32, so whatever is clamped away here lies beyond every store of the tile)
@@ -231,34 +238,34 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 #pragma unroll
 			for (int i = 0; i < 16; ++i)
 				v[i] = *reinterpret_cast<const __attribute__((address_space(3))) i32x2 *>((uintptr_t)(copy_from + (unsigned)i * 4u * SEG_LANE_STRIDE));
-			unsigned off = chunk * (SEG_CHUNK * 8u);   // of segment 4 i's line of this chunk from out_first
+			// ONE descriptor per chunk: from segment 0's line of this chunk to the end of the stream; store i goes four segments further
+			// on each time through its SCALAR offset, which the range check of a raw buffer on gfx9 / gfx950 takes into account (a line,
+			// or a segment, beyond the stream's end is dropped: tests/test_gpu_parity.py::test_segment_kernel_bit_exact holds a guard
+			// over a whole block of segments behind the output)
+			const unsigned chunk_off = chunk * (SEG_CHUNK * 8u);
+			const uint64_t at = out_first + chunk_off;
+			unsigned left;
+			asm("s_sub_u32 %0, %1, %2\n\ts_cselect_b32 %0, 0, %0" : "=&s"(left) : "s"(room), "s"(chunk_off) : "scc");
+			const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+			    reinterpret_cast<void *>(((uint64_t)__builtin_amdgcn_readfirstlane((int)(unsigned)(at >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)at)), 0,
+			    (int)left, 0x00020000);
+			unsigned soff = 0;
 #pragma unroll
 			for (int i = 0; i < 16; ++i)
 			{
-				// one descriptor per store: it starts at segment 4 i's line and ends with the stream (a line, or a segment, beyond the
-				// stream's end: dropped by the range check) - scalar arithmetic, 32 bits
-				const uint64_t at = out_first + off;
-				// (room - off, 0 if that borrows - as two scalar instructions: written in C++ hipcc forms a saturating subtract, which only the
-				// vector unit has, and then feeds the store its descriptor through a waterfall loop)
-				unsigned left;
-				asm("s_sub_u32 %0, %1, %2\n\ts_cselect_b32 %0, 0, %0" : "=&s"(left) : "s"(room), "s"(off) : "scc");
-				const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-				    reinterpret_cast<void *>(((uint64_t)__builtin_amdgcn_readfirstlane((int)(unsigned)(at >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)at)), 0,
-				    (int)left, 0x00020000);
 				if constexpr (ABL == 2 || ABL == 3)
-					asm volatile("" ::"v"(v[i]), "s"(rsrc));
+					asm volatile("" ::"v"(v[i]), "s"(soff));
 				else
-					__builtin_amdgcn_raw_buffer_store_b64(v[i], rsrc, (int)store_at, 0, NT ? 2 : 0);
-				off += seg4_bytes;
+					__builtin_amdgcn_raw_buffer_store_b64(v[i], rsrc, (int)store_at, (int)soff, NT ? 2 : 0);
+				soff += seg4_bytes;
 			}
 			__builtin_amdgcn_wave_barrier();
 			++chunk;
-			staged = 0;
 			stage_at = stage_row;
 		};
 
 		// one frame of every lane with the window in rotation R; the weights: the scalar row `w`
-		auto frame = [&](auto r_tag) {
+		auto frame = [&](auto r_tag, const f32x16 &w) {
 			constexpr int R = decltype(r_tag)::value;
 			auto wpair = [&](int k) {
 				f32x2 wp;
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 			if constexpr (ABL == 4)
 			{
 				// diagnostic: ten more scalar instructions per frame (what does a scalar instruction cost this kernel?)
-				unsigned junk = staged;
+				unsigned junk = in_chunk;
 				asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\t"
 				             "s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1" : "+s"(junk) : : "scc");
 			}
@@ -332,58 +339,44 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 		// the frame the first advance brings in
 		next_frame = *reinterpret_cast<const __attribute__((address_space(3))) int *>((uintptr_t)future_at);
 
-		bool done = false;
-		while (!done)
+		while (frames_left != 0)
 		{
 			static_for<TT>([&](auto r_tag) {
 				constexpr int R = decltype(r_tag)::value;
-				if (done)
-					return;
-				// the frames at this position: until the fraction wraps (or the tile ends)
-				for (;;)
+				if (frames_left != 0)
 				{
-					// the row of the frame PF frames on, requested before this frame's arithmetic
-					const bool wraps = g - (int)increment <= 0;
-					if constexpr (PF == 1)
+					// the frames at this position: until the fraction wraps (or the tile ends)
+					unsigned carry;
+					do
 					{
-						int g_next = g - (int)increment;
-						g_next += wraps ? 65536 : 0;
-						f32x16 w_next = w;
+						// the next frame's row, requested before this frame's arithmetic (F + INC and its carry as two scalar instructions:
+						// written in C++ hipcc does the add in the vector unit for its carry-out)
+						unsigned next;
+						asm("s_add_u32 %0, %2, %3\n\ts_cselect_b32 %1, 1, 0" : "=&s"(next), "=s"(carry) : "s"(F), "s"(INC) : "scc");
+						f32x16 w_next = w_a;
 						if constexpr (ABL != 1 && ABL != 3)
-							w_next = rows[(unsigned)g_next >> 6];
-						frame(r_tag);
-						w = w_next;
-						g = g_next;
-					}
-					else
+							w_next = load_row(next);
+						frame(r_tag, w_a);
+						w_a = w_next;
+						F = next;
+						stage_at += 8u;
+						if (--in_chunk == 0)
+						{
+							copy_out();
+							in_chunk = SEG_CHUNK;
+							frames_left -= SEG_CHUNK;
+							if (frames_left == 0)
+								carry = 2u;   // (the tile ends: leave the loop, no advance - asked once per chunk, not once per frame)
+						}
+					} while (carry == 0);
+					if (carry == 1u)
 					{
-						int g2 = g1 - (int)increment;
-						g2 += g2 <= 0 ? 65536 : 0;
-						f32x16 w2 = w1;
-						if constexpr (ABL != 1 && ABL != 3)
-							w2 = rows[(unsigned)g2 >> 6];
-						frame(r_tag);
-						w = w1;
-						w1 = w2;
-						g = g1;
-						g1 = g2;
+						// the position advances: the oldest slot's registers take the new frame, the names rotate by one
+						convert(next_frame, P[R % TT][0], P[R % TT][1]);
+						++advance;
+						next_frame = *reinterpret_cast<const __attribute__((address_space(3))) int *>((uintptr_t)(future_at + 256u * (advance < SEG_FUTURE ? advance : SEG_FUTURE - 1u)));
 					}
-					stage_at += 8u;
-					--frames_left;
-					if (++staged == SEG_CHUNK)
-						copy_out();
-					if (frames_left == 0)
-					{
-						done = true;
-						return;
-					}
-					if (wraps)
-						break;
 				}
-				// the position advances: the oldest slot's registers take the new frame, the names rotate by one
-				convert(next_frame, P[R % TT][0], P[R % TT][1]);
-				++advance;
-				next_frame = *reinterpret_cast<const __attribute__((address_space(3))) int *>((uintptr_t)(future_at + 256u * (advance < SEG_FUTURE ? advance : SEG_FUTURE - 1u)));
 			});
 		}
 

@@ -407,12 +407,18 @@ def test_segment_kernel_bit_exact(products, rates, frames, forced):
     R = int(ost.cfg.radius_frames)
     padded = ck.pad_frames(ck.noise_pcm(frames * ch, 77 + frames), ch, R)
     total = int(ck.count_output_frames(ost, frames))
+    # behind the output: a guard as long as a whole block of 64 segments - k_seg's stores reach their segment through a scalar offset
+    # added to ONE descriptor per chunk, and a segment that lies beyond the launch (the lanes of the last, partial block) must be
+    # dropped by the descriptor's range check, not land a segment further on
+    inc = int(ost.increment)
+    period = 65536 >> min(16, (inc & -inc).bit_length() - 1)
+    guard_samples = (64 * max(period, 1024) + 512) * ch
     d_in = api.DeviceAlloc(padded.nbytes + 64)
-    d_out = api.DeviceAlloc((total + 1) * ch * 4 + 4096)
+    d_out = api.DeviceAlloc((total + 1) * ch * 4 + guard_samples * 4 + 4096)
     api.DebugSegKernel(1 if forced else 0)
     try:
         api.CopyToDevice(d_in, padded)
-        guard = np.full(1024, 0x5A5A5A5A, dtype=np.int32)
+        guard = np.full(guard_samples, 0x5A5A5A5A, dtype=np.int32)
         # two calls: the first stopped by its capacity somewhere in the stream (an odd count: the second starts at any fraction)
         first = total // 3 + 1
         got = np.empty(total * ch, dtype=np.int32)

@@ -39,6 +39,23 @@ __global__ __launch_bounds__(768) void k(int *out, int loops, unsigned long long
 #define I_CVT(i) asm volatile("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f[i]) : "v"(b));
 #define I_MOVMAD(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b)); asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(p[i]) : "v"(b), "v"(c) : "vcc");
 #define I_FMA2(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f[i]) : "v"(g), "v"(g)); asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(q[i].x) : "v"(g), "v"(g));
+// round 5 (k_seg): the weight as a SCALAR pair, the neg / swap modifiers of the negative slots, and the frame's real dependency shape -
+// TWO accumulators taking turns (a chain per channel), with vector and with scalar weights
+#define I_PKFMA_S(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(q[i]) : "v"(h), "s"(hs));
+#define I_PKFMA_N(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(q[i]) : "v"(h), "v"(h));
+#define I_PKFMA_NS(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(q[i]) : "v"(h), "s"(hs));
+#define I_PKFMA_2(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(q[i & 1]) : "v"(h), "v"(h));
+#define I_PKFMA_2S(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(q[i & 1]) : "v"(h), "s"(hs));
+#define I_PKFMA_1(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(q[0]) : "v"(h), "v"(h));
+		f32x2 hs;
+		hs.x = __builtin_amdgcn_readfirstlane(__float_as_int(1.0f + loops * 1e-6f)) * 1e-9f;
+		hs.y = hs.x + 1.0f;
+		if constexpr (KIND == 17) { REP64(I_PKFMA_S) }
+		if constexpr (KIND == 18) { REP64(I_PKFMA_N) }
+		if constexpr (KIND == 19) { REP64(I_PKFMA_NS) }
+		if constexpr (KIND == 20) { REP64(I_PKFMA_2) }
+		if constexpr (KIND == 21) { REP64(I_PKFMA_2S) }
+		if constexpr (KIND == 22) { REP64(I_PKFMA_1) }
 		if constexpr (KIND == 0) { REP64(I_MOV) }
 		if constexpr (KIND == 1) { REP64(I_ADD) }
 		if constexpr (KIND == 2) { REP64(I_XAD) }
@@ -110,5 +127,11 @@ int main()
 	run<14>("v_cvt_f32_i32_sdwa", d_out, d_cyc);
 	run<15>("v_mov_b32 + v_mad_i64_i32 (per PAIR)", d_out, d_cyc);
 	run<16>("v_fma_f32 + v_fma_f32 (per PAIR)", d_out, d_cyc);
+	run<17>("v_pk_fma_f32, scalar weight pair", d_out, d_cyc);
+	run<18>("v_pk_fma_f32, swapped + negated sample pair", d_out, d_cyc);
+	run<19>("v_pk_fma_f32, swapped + negated, scalar weight", d_out, d_cyc);
+	run<20>("v_pk_fma_f32, TWO accumulators taking turns", d_out, d_cyc);
+	run<21>("v_pk_fma_f32, two accumulators, scalar weight", d_out, d_cyc);
+	run<22>("v_pk_fma_f32, ONE accumulator (dependent chain)", d_out, d_cyc);
 	return 0;
 }

@@ -2,11 +2,7 @@
 set -u
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05run8; rm -rf $O; mkdir -p $O
 cd $R
-for rep in 1 2; do for f in 0 5; do CLOWNRESAMPLER_AMD_SEG_FORM=$f python3 bench.py --workload cfg3 --no-check --no-cpu-baseline --no-host-paths --no-n1-reference 2>&1 | python3 -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        j=json.loads(l); print('cfg3 form $f: %7.1f us (median %7.1f)' % (j['ms_per_step']*1e3, j['launch_us']['median']))
-    elif 'rror' in l: print(l.strip()[:300])
-"; done; done > $O/seg_salu.log 2>&1
-cat $O/seg_salu.log
+( timeout 900 python3 -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "segment_kernel or (one_launch and cfg3)" 2>&1 | tail -8 ) > $O/seg_tests.log 2>&1
+cat $O/seg_tests.log
+bash tools/ab_env.sh "-;CLOWNRESAMPLER_AMD_NO_SEG=1;CLOWNRESAMPLER_AMD_SEG_TILE=128;CLOWNRESAMPLER_AMD_SEG_FORM=5;-;CLOWNRESAMPLER_AMD_NO_SEG=1" cfg3 > $O/seg_ab.log 2>&1
+cat $O/seg_ab.log

@@ -629,7 +629,7 @@ def main():
         kernel_name = "%s<2,%d> as dual mono (mono plan: %s)" % ({1: "k_poly", 4: "k_wave2"}[dual], info.slots, kernel_name)
         ran = dual
     # long launches of k_up2's shape run on k_seg (the lanes of a wave on frames of equal fraction, the row in scalar registers): the launch counters say
-    if ran == 3 and launches_by_kernel[8] >= args.steps:
+    if ran in (3, 4) and launches_by_kernel[8] >= args.steps:
         kernel_name = "k_seg<%d,%d>" % (ch, info.slots)
         ran = 8
     if launches_by_kernel[ran] < args.steps:

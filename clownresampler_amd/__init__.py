@@ -246,6 +246,7 @@ class Api:
         self._Advance = fn("ClownResamplerAMD_AdvanceState", None, [P(LowLevel_State), C.c_size_t], False)
         self._PlanShard = fn("ClownResamplerAMD_PlanShard", C.c_int, [P(LowLevel_State), C.c_size_t, C.c_uint, C.c_uint, P(Shard)], False)
         self._DeviceCount = fn("ClownResamplerAMD_DeviceCount", C.c_int, [], False)
+        self._IsUsable = fn("ClownResamplerAMD_IsUsable", C.c_int, [], False)
         self._SetDevice = fn("ClownResamplerAMD_SetDevice", C.c_int, [C.c_int], False)
         self._Shutdown = fn("ClownResamplerAMD_Shutdown", None, [], False)
         self._DeviceAlloc = fn("ClownResamplerAMD_DeviceAlloc", C.c_void_p, [C.c_size_t], False)
@@ -525,6 +526,10 @@ class Api:
 
     def DebugForceGenericKernel(self, on):
         self._ForceGeneric(1 if on else 0)
+
+    def IsUsable(self):
+        """1 when a gfx950 device is there for this library; never raises, never aborts (ClownResamplerAMD_IsUsable)"""
+        return int(self._IsUsable())
 
     def DeviceCount(self):
         return self._DeviceCount()

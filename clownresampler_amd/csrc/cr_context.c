@@ -230,11 +230,11 @@ static unsigned long long g_launch_count[CR_KERNEL_IDS];
 /* k_up2 as an instance's default kernel: see plan_geometry */
 #define CR_UP_DEFAULT_MAX_INCREMENT (65536u / 8u)
 #define CR_UP_DEFAULT_MIN_INCREMENT (65536u / 13u)
-/* k_seg (cr_kseg.hpp): the ratios it is built for (a tile of CR_SEG_MIN_TILE frames advances over at most 12 input frames), the tile
+/* k_seg (cr_kseg.hpp): the ratios it is built for (any pure upsampling its instance has a ring for: crhip_seg_instance), the tile
    sizes, and how much of a launch its last, partial super-block may waste in idle lanes before the launch stays with k_up2 */
 #define CR_SEG_MIN_INCREMENT 4096u
 #define CR_SEG_MIN_TILE 64u
-#define CR_SEG_MAX_TILE 256u
+#define CR_SEG_MAX_TILE 128u
 #define CR_SEG_MAX_WASTE 0.06
 /* a launch of a periodic ratio that starts mid-period is split (a few frames on the ordinary kernel, the rest on k_int) from this
    many output frames on: below, the second launch costs more than k_int saves */
@@ -319,6 +319,21 @@ int ClownResamplerAMD_DeviceCount(void)
 		return 0;
 
 	return count;
+}
+
+/* Never reports through the error handler: this is the question a client asks BEFORE it commits to this library. */
+int ClownResamplerAMD_IsUsable(void)
+{
+	crhip_device_info info;
+	int count = 0;
+	const int device = current_device();
+
+	if (crhip_device_count(&count) != 0 || count <= 0 || device < 0 || device >= count)
+		return 0;
+	if (crhip_get_device_info(device, &info) != 0)
+		return 0;
+	/* the kernels are gfx950 code objects, nothing else */
+	return strncmp(info.arch, "gfx950", 6) == 0;
 }
 
 static int ring_alloc(cr_ring *ring)
@@ -1483,21 +1498,20 @@ static void plan_brief_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *p
    window fits its registers and LDS entries; the float image of the rows is made once per store.  0 on success (available or not). */
 static int plan_seg_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan)
 {
-	uint32_t negmask = 0, pos_bits = 0, neg_bits = 0, threads = 0, lds = 0;
+	uint32_t negmask = 0, pos_bits = 0, neg_bits = 0, threads = 0, lds = 0, chunk = 0;
 	cr_plan_store *store = plan->store;
 	int per_cu = 0;
 	uint64_t g;
 
 	(void)ctx;
 	plan->seg.available = 0;
-	if (g_env.no_seg || !plan->use_poly || plan->poly.row_mode != CRHIP_ROWMODE_UPSAMPLE || plan->poly.window_extra != 0
-	 || !crhip_seg_instance(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, &negmask, &threads, &lds))
+	if (g_env.no_seg || !plan->use_poly || plan->poly.row_mode != CRHIP_ROWMODE_UPSAMPLE || plan->poly.window_extra != 0 || plan->increment >= 65536u
+	 || !crhip_seg_instance(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, (uint32_t)plan->increment, &negmask, &threads, &lds, &chunk))
 		return 0;
 	cr_poly_slot_signs(&plan->poly, &pos_bits, &neg_bits);
 	if ((neg_bits & ~negmask) != 0 || (pos_bits & negmask) != 0 || cr_poly_slots_reaching(&plan->poly, 65537) != 0 || plan->poly.rows > 1025u)
 		return 0;
-	/* a tile of at least CR_SEG_MIN_TILE frames must not advance over more input frames than the kernel keeps for it (SEG_FUTURE = 12) */
-	if (plan->increment < CR_SEG_MIN_INCREMENT || ((65535u + (uint64_t)(CR_SEG_MIN_TILE - 1u) * plan->increment) >> 16) > 12u)
+	if (plan->increment < CR_SEG_MIN_INCREMENT)
 		return 0;
 
 	if (store->d_rows_seg == NULL)
@@ -1529,7 +1543,7 @@ static int plan_seg_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan
 			return -1;
 	}
 
-	if (cr_check_hip(crhip_seg_prepare(plan->channels, plan->poly.slots, &per_cu), "k_seg setup") != 0)
+	if (cr_check_hip(crhip_seg_prepare(plan->channels, plan->poly.slots, (uint32_t)plan->increment, &per_cu), "k_seg setup") != 0)
 		return -1;
 	if (per_cu < 1)
 		return 0;
@@ -1538,6 +1552,7 @@ static int plan_seg_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan
 		;
 	plan->seg.period = g;
 	plan->seg.threads = threads;
+	plan->seg.chunk = chunk;
 	plan->seg.lds_bytes = lds;
 	plan->seg.max_blocks = (uint32_t)per_cu * (uint32_t)(g_ctx[plan->device]->info.compute_units > 0 ? g_ctx[plan->device]->info.compute_units : 256);
 	plan->seg.d_rows = store->d_rows_seg;
@@ -1961,17 +1976,16 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		const uint64_t seg = period >= 1024u ? period : 1024u;   /* (both powers of two) */
 		const uint64_t blocks64 = (n_out + 64u * seg - 1u) / (64u * seg);
 		const double waste = 1.0 - (double)n_out / ((double)blocks64 * 64.0 * (double)seg);
-		/* frames per lane and tile: a power of two from 64 to 256 (it divides S), as large as the tile's advances (at most 12) and the
-		   balance (two tiles per wave or more) allow - cfg 3: 128 frames, 2.3 tiles per wave, 115 us where 64-frame tiles take 121
-		   (profiles/r05_kseg_ab.log: a tile's first window is 7 scattered loads and 90 conversions per lane) */
+		/* frames per lane and tile: a power of two (it divides S) - 128 while that leaves every wave two tiles or more (cfg 3: 2.3 tiles
+		   per wave, 115 us where 64-frame tiles take 121: a tile's first window is scattered loads and 90 conversions per lane), else 64 */
 		uint64_t tile = CR_SEG_MAX_TILE;
 		const uint64_t waves = (uint64_t)plan->seg.max_blocks * (plan->seg.threads / 64u);
 
-		while (tile > CR_SEG_MIN_TILE && (((65535u + (tile - 1u) * plan->increment) >> 16) > 12u || blocks64 * (seg / tile) < 2u * waves))
+		while (tile > CR_SEG_MIN_TILE && blocks64 * (seg / tile) < 2u * waves)
 			tile /= 2u;
 		if (g_env.seg_tile >= 16 && (g_env.seg_tile & (g_env.seg_tile - 1)) == 0 && (uint64_t)g_env.seg_tile <= seg)
 			tile = (uint64_t)g_env.seg_tile;
-		if (((65535u + (tile - 1u) * plan->increment) >> 16) <= 12u && seg * 512u < (1ull << 32) && ((seg * plan->increment) >> 16) * 256u < (1ull << 32)
+		if (tile % plan->seg.chunk == 0 && seg % tile == 0 && seg * 512u < (1ull << 32) && ((seg * plan->increment) >> 16) * 256u < (1ull << 32)
 		 && (g_seg_mode == 1 || (waste <= CR_SEG_MAX_WASTE && blocks64 * (seg / tile) >= 2u * waves)))
 		{
 			crhip_seg_launch sl;
@@ -1994,13 +2008,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			sl.tiles_per_seg = (uint32_t)(seg / tile);
 			sl.n_tiles = blocks64 * sl.tiles_per_seg;
 			sl.debug_form = (uint32_t)g_env.seg_form;
-			if (sl.debug_form == 6u)
-			{
-				/* (diagnostic: four waves per SIMD, four future entries: tiles of 32 frames) */
-				sl.tile_frames = 32u;
-				sl.tiles_per_seg = (uint32_t)(seg / 32u);
-				sl.n_tiles = blocks64 * sl.tiles_per_seg;
-			}
+			sl.debug_stamps = g_debug_stamps;
 			grid = (sl.n_tiles + plan->seg.threads / 64u - 1u) / (plan->seg.threads / 64u);
 			sl.blocks = (uint32_t)(grid > plan->seg.max_blocks ? plan->seg.max_blocks : grid);
 			sl.d_tickets = ticket_block_for(g_ctx[plan->device], stream, &ring);

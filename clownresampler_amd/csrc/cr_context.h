@@ -107,7 +107,7 @@ typedef struct ClownResamplerAMD_Plan
 	{
 		int available;
 		uint64_t period;
-		uint32_t threads, lds_bytes, max_blocks;
+		uint32_t threads, lds_bytes, max_blocks, chunk;
 		const void *d_rows;
 	} seg;
 	uint32_t padded;   /* 1: k_poly's run-time-slot instance computes from padded tiles (crhip_poly_launch.padded) */

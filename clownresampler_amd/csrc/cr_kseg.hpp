@@ -32,35 +32,54 @@ namespace
 // (NEGMASK, as k_up2), a stream below 4 GiB either side of a super-block (32-bit buffer offsets).
 // A tile = K consecutive frames (a multiple of 16) of each of the 64 segments of one super-block; tiles are drawn as tickets.
 // ---------------------------------------------------------------------------------------------------------
-constexpr unsigned SEG_CHUNK = 16u;          // frames a lane stages before the wave copies them out: 128 bytes, one line, per lane
-constexpr unsigned SEG_LANE_STRIDE = 136u;   // bytes between the lanes' staging rows (34 dwords: 16 neighbouring lanes on 32 different banks)
-constexpr unsigned SEG_FUTURE = 12u;         // input frames beyond its first window that a tile may advance onto (kept in LDS, [entry][lane])
-constexpr unsigned seg_wave_bytes(unsigned future) { return 64u * SEG_LANE_STRIDE + future * 256u; }
-constexpr unsigned SEG_WAVE_BYTES = seg_wave_bytes(SEG_FUTURE);
+// A lane's frames are staged CHUNK at a time (CHUNK * 8 bytes per lane: a 128-byte line, or half of one) in rows CHUNK * 8 + 8 bytes apart
+// (16 neighbouring lanes on 32 different banks either way), and leave as CHUNK buffer stores of 64 / CHUNK whole pieces each.
+constexpr unsigned seg_lane_stride(unsigned chunk) { return chunk * 8u + 8u; }
+// The input frames a lane will advance onto wait in a RING in LDS, filled by LDS-DMA four frames per lane at a time (a "group":
+// buffer_load_dwordx4 ... lds, every lane from its own place in the stream, 1 KiB per group: [group][lane][4 frames]).
+constexpr unsigned seg_wave_bytes(unsigned chunk, unsigned groups) { return 64u * seg_lane_stride(chunk) + groups * 1024u; }
 
 // ABL (timing-only diagnostic instances, results WRONG): 1 = one row per tile (no scalar loads in the frame loop), 2 = no global stores,
-// 3 = both, 4 = ten more scalar instructions per frame.
-template <int TT, unsigned NEGMASK, int WAVES, int NT, int ABL = 0, unsigned FUT = SEG_FUTURE>
+// 3 = both.
+template <int TT, unsigned NEGMASK, int WAVES, int NT, unsigned CHUNK, unsigned NG, int ABL = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 {
-	constexpr unsigned SEG_FUTURE = FUT;                        // (a diagnostic instance trades entries for a fourth wave per SIMD)
-	constexpr unsigned SEG_WAVE_BYTES = seg_wave_bytes(FUT);
 	static_assert(TT == 15 && NEGMASK == 0x2A55u, "the frame body is written out for 15 slots, slots 0, 2, 4, 6, 9, 11, 13 negative");
+	static_assert((CHUNK == 16u || CHUNK == 8u) && (NG & (NG - 1u)) == 0 && NG >= 4u, "a line or half a line per lane and chunk; a power of two of ring groups, the first window's four at least");
 	typedef float f32x2 __attribute__((ext_vector_type(2)));
-	typedef float f32x4 __attribute__((ext_vector_type(4)));
 	typedef float f32x16 __attribute__((ext_vector_type(16)));
+	constexpr unsigned LANE_STRIDE = seg_lane_stride(CHUNK);
+	constexpr unsigned WAVE_BYTES = seg_wave_bytes(CHUNK, NG);
+	constexpr unsigned PER_STORE = 64u / CHUNK;   // segments one store instruction covers (CHUNK lanes, 8 bytes each, per segment)
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 	const unsigned lane = threadIdx.x & 63u;
 	const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	unsigned char *my_stage = smem + wave * SEG_WAVE_BYTES;
-	unsigned char *my_future = my_stage + 64u * SEG_LANE_STRIDE;
-	unsigned *waves_done = reinterpret_cast<unsigned *>(smem + WAVES * SEG_WAVE_BYTES);
+	unsigned char *my_stage = smem + wave * WAVE_BYTES;
+	unsigned char *my_ring = my_stage + 64u * LANE_STRIDE;
+	unsigned *waves_done = reinterpret_cast<unsigned *>(smem + WAVES * WAVE_BYTES);
 
 	if (threadIdx.x == 0)
 		*waves_done = 0;
 	__syncthreads();
+
+	// diagnostic instance only (ABL == 6): where wave 0 of every workgroup spends its shader cycles - [0] a tile's first window (requests,
+	// wait, conversions), [1] the wait for the scalar row (and the LDS) at the head of every frame, [2] the frames' arithmetic, [3] copy-outs,
+	// [4] the counted wait + ring requests before a chunk, [5] position advances, [6] frames, [7] tiles
+	unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = 0;
+	auto mark = [&](int which) {
+		if constexpr (ABL == 6)
+		{
+			__builtin_amdgcn_sched_barrier(0);
+			const unsigned long long now = __builtin_amdgcn_s_memtime();
+			__builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): s_memtime returns through the scalar data path
+			if (which >= 0)
+				phase[which] += now - t_mark;
+			t_mark = now;
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	};
 
 	// ---- tiles as tickets (k_up2's scheme: the first by global wave number, the rest from 32 counter lanes) ----
 	const uint64_t n_tiles = a.n_tiles;
@@ -94,6 +113,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 	const uint64_t S = a.seg_frames;
 	const unsigned tiles_per_seg = __builtin_amdgcn_readfirstlane(a.tiles_per_seg);
 	const unsigned tiles_shift = (unsigned)__builtin_ctz(tiles_per_seg);
+	// input frames a chunk can advance over, at most: what the ring must hold ahead of the wave (see top_up)
+	const unsigned chunk_advances = (65535u + CHUNK * increment) >> 16;
 	// (constant address space: a uniform load from it is an s_load whatever the kernel stores elsewhere)
 	const __attribute__((address_space(4))) f32x16 *rows = (const __attribute__((address_space(4))) f32x16 *)(uintptr_t)a.d_rows;
 	const uint64_t in_base = reinterpret_cast<uint64_t>(a.d_in);
@@ -124,9 +145,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 	asm volatile("" : "+{v117}"(zero_c), "+{v119}"(zero_d));   // the high halves of the normalisation's pinned addend pairs (see k_up2)
 
 	// staging: this lane's row, and where it reads for the copy-out (store i of a chunk: segments 4 i ... 4 i + 3, 16 lanes each)
-	const unsigned stage_row = (unsigned)(uintptr_t)my_stage + lane * SEG_LANE_STRIDE;
-	const unsigned copy_from = (unsigned)(uintptr_t)my_stage + (lane >> 4) * SEG_LANE_STRIDE + (lane & 15u) * 8u;
-	const unsigned future_at = (unsigned)(uintptr_t)my_future + lane * 4u;
+	const unsigned stage_row = (unsigned)(uintptr_t)my_stage + lane * LANE_STRIDE;
+	// (store i of a chunk: segments PER_STORE * i ... + PER_STORE - 1, CHUNK lanes each)
+	const unsigned copy_from = (unsigned)(uintptr_t)my_stage + (lane / CHUNK) * LANE_STRIDE + (lane % CHUNK) * 8u;
+	const unsigned ring_at = (unsigned)(uintptr_t)my_ring + lane * 16u;   // this lane's four frames of group 0
 
 	uint64_t tile = global_wave;
 	if (tile >= n_tiles)
@@ -144,6 +166,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 		unsigned *const counter = reinterpret_cast<unsigned *>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(counter_bits >> 32)) << 32)
 		                                                       | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)counter_bits));
 		const unsigned ticket = draw_ticket_begin(counter);
+		mark(-1);
 
 		// ---- where the tile is ----
 		// (tiles_per_seg is a power of two - S and K are - and everything below is wave-uniform by construction: say so, or hipcc
@@ -160,12 +183,28 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 		unsigned F = (unsigned)(pos & 0xFFFFu) << 16;
 		const unsigned INC = increment << 16;                                // (increment < 65536: upsampling)
 
-		// ---- the first window (TT frames) and the frames the tile will advance onto, per lane: TT + SEG_FUTURE dwords from the
-		//      lane's own place in the stream (beyond the caller's buffer: zeros) ----
+		// ---- the input side: entry n of the tile is input frame position + n of every lane's own stretch of the stream (beyond the caller's
+		//      buffer: zeros); group q = entries 4 q ... 4 q + 3 sits in ring slot q mod NG.  The first window is entries 0 ... TT - 1. ----
 		const unsigned in_at = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(position * 4u)) + lane_in_bytes;
-		int raw[28];
+		unsigned loaded = 0;   // groups requested so far (wave-uniform)
+		auto request_group = [&]() {
+			__builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (__attribute__((address_space(3))) void *)(my_ring + (loaded & (NG - 1u)) * 1024u), 16,
+			                                         (int)(in_at + loaded * 16u), 0, 0, 0);
+			++loaded;
+		};
+		// Before a chunk: everything the wave can advance onto until the end of the NEXT chunk has been requested (what it needs in THIS
+		// chunk was requested a chunk ago, ahead of that chunk's stores: the counted wait in front of the chunk covers it).
+		auto top_up = [&](unsigned advanced) {
+			const unsigned need = (unsigned)TT + advanced + 2u * chunk_advances + 1u;   // entries
+			while (loaded * 4u < need)
+				request_group();
+		};
+		// The first window comes straight into registers (four 16-byte loads per lane: entries 0 ... 15, the last one unused); the ring
+		// starts with group 3 - entry TT = 15, the frame the first advance brings in, is its last - and everything lands under ONE wait.
+		static_assert(TT == 15, "the ring starts at group 3: entry 15 is the first advance's");
+		int raw[16];
 #pragma unroll
-		for (int q = 0; q < 7; ++q)
+		for (int q = 0; q < 4; ++q)
 		{
 			const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)(in_at + 16u * q), 0, 0);
 			raw[4 * q] = v.x;
@@ -173,20 +212,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 			raw[4 * q + 2] = v.z;
 			raw[4 * q + 3] = v.w;
 		}
-		static_assert(TT + SEG_FUTURE <= 28, "seven 16-byte loads per lane");
+		loaded = 3u;
+		top_up(0);
+		// (the previous tile's last stores are older than these requests: all of it has to land - once per tile)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		f32x2 P[TT][2];   // slot s of rotation R is P[(s + R) % TT]
 #pragma unroll
 		for (int s = 0; s < TT; ++s)
 			convert(raw[s], P[s][0], P[s][1]);
-		// (the previous tile's reads of these entries are long done: same wave, LDS operations in order)
-#pragma unroll
-		for (int e = 0; e < (int)SEG_FUTURE; ++e)
-			*reinterpret_cast<__attribute__((address_space(3))) int *>((uintptr_t)(future_at + 256u * e)) = raw[TT + e];
+		mark(0);
+		if constexpr (ABL == 6)
+			phase[7] += 1;
 
 		// ---- the output side of the tile: 16 descriptors, one per store of a chunk (segments 4 i ... 4 i + 3), re-based per chunk ----
 		const uint64_t out_first = reinterpret_cast<uint64_t>(a.d_out) + first * 8u;
 		const uint64_t out_end = reinterpret_cast<uint64_t>(a.d_out) + a.n_out * 8u;
-		const unsigned store_at = (unsigned)((lane >> 4) * S * 8u) + (lane & 15u) * 8u;   // (< 2^32: the host)
+		const unsigned store_at = (unsigned)((lane / CHUNK) * S * 8u) + (lane % CHUNK) * 8u;   // (< 2^32: the host)
 
 		unsigned frames_left = K;
 		{
@@ -195,7 +236,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 				frames_left = (unsigned)seg_left;
 		}
 		frames_left = __builtin_amdgcn_readfirstlane(frames_left);
-		unsigned in_chunk = SEG_CHUNK;   // frames until the chunk is copied out (wave-uniform)
+		unsigned in_chunk = CHUNK;   // frames until the chunk is copied out (wave-uniform)
 		unsigned chunk = 0;         // chunks copied out
 		unsigned stage_at = stage_row;
 		unsigned advance = 0;       // input frames advanced onto so far
@@ -212,7 +253,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 		// super-block - 64 S frames of 8 bytes - below 2^32, so whatever is clamped away here lies beyond every store of the tile)
 		const uint64_t room64 = out_end > out_first ? out_end - out_first : 0;
 		const unsigned room = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(room64 > 0xFFFFFFFCull ? 0xFFFFFFFCull : room64));
-		const unsigned seg4_bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(S * 32u));   // four segments further on
+		const unsigned store_step = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(S * 8u * PER_STORE));   // the next store's segments
 
 		// A frame's result is written to its staging slot DURING THE NEXT frame (between that frame's two blocks of taps): the wait for the
 		// scalar row load at the head of every frame is lgkmcnt(0) - scalar loads return out of order, nothing less will do - and it would
@@ -221,43 +262,44 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 		i32x2 pending;
 		pending.x = 0;
 		pending.y = 0;
-		unsigned pending_at = stage_row + SEG_CHUNK * 8u;
+		unsigned pending_at = stage_row + CHUNK * 8u;
 		auto write_pending = [&]() {
 			asm volatile("ds_write_b64 %0, %1" ::"v"(pending_at), "v"(pending) : "memory");
 		};
 
 		auto copy_out = [&]() {
 			write_pending();   // the chunk's last frame
-			pending_at = stage_row + SEG_CHUNK * 8u;
+			pending_at = stage_row + CHUNK * 8u;
 			// the staged frames of the other lanes: same wave, LDS operations complete in order
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-			// every read first, then the stores (one wait for the LDS instead of sixteen)
-			i32x2 v[16];
+			// every read first, then the stores (one wait for the LDS instead of one per store)
+			i32x2 v[CHUNK];
 #pragma unroll
-			for (int i = 0; i < 16; ++i)
-				v[i] = *reinterpret_cast<const __attribute__((address_space(3))) i32x2 *>((uintptr_t)(copy_from + (unsigned)i * 4u * SEG_LANE_STRIDE));
-			// ONE descriptor per chunk: from segment 0's line of this chunk to the end of the stream; store i goes four segments further
-			// on each time through its SCALAR offset, which the range check of a raw buffer on gfx9 / gfx950 takes into account (a line,
+			for (int i = 0; i < (int)CHUNK; ++i)
+				v[i] = *reinterpret_cast<const __attribute__((address_space(3))) i32x2 *>((uintptr_t)(copy_from + (unsigned)i * PER_STORE * LANE_STRIDE));
+			// ONE descriptor per chunk: from segment 0's piece of this chunk to the end of the stream; store i goes PER_STORE segments further
+			// on each time through its SCALAR offset, which the range check of a raw buffer on gfx9 / gfx950 takes into account (a piece,
 			// or a segment, beyond the stream's end is dropped: tests/test_gpu_parity.py::test_segment_kernel_bit_exact holds a guard
 			// over a whole block of segments behind the output)
-			const unsigned chunk_off = chunk * (SEG_CHUNK * 8u);
+			const unsigned chunk_off = chunk * (CHUNK * 8u);
 			const uint64_t at = out_first + chunk_off;
 			unsigned left;
 			asm("s_sub_u32 %0, %1, %2\n\ts_cselect_b32 %0, 0, %0" : "=&s"(left) : "s"(room), "s"(chunk_off) : "scc");
 			const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
 			    reinterpret_cast<void *>(((uint64_t)__builtin_amdgcn_readfirstlane((int)(unsigned)(at >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)at)), 0,
 			    (int)left, 0x00020000);
-			unsigned soff = 0;
+			unsigned soff = 0, step = store_step;
+			asm volatile("" : "+s"(step));   // (one running sum, an add per store: hipcc otherwise keeps all sixteen multiples in scalar registers across the tile)
 #pragma unroll
-			for (int i = 0; i < 16; ++i)
+			for (int i = 0; i < (int)CHUNK; ++i)
 			{
 				if constexpr (ABL == 2 || ABL == 3)
 					asm volatile("" ::"v"(v[i]), "s"(soff));
 				else
 					__builtin_amdgcn_raw_buffer_store_b64(v[i], rsrc, (int)store_at, (int)soff, NT ? 2 : 0);
-				soff += seg4_bytes;
+				soff += step;
 			}
 			__builtin_amdgcn_wave_barrier();
 			++chunk;
@@ -290,13 +332,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 			             : "v"(CR_P(0, 0)), "v"(CR_P(1, 0)), "v"(CR_P(2, 0)), "v"(CR_P(3, 0)), "v"(CR_P(4, 0)), "v"(CR_P(5, 0)), "v"(CR_P(6, 0)), "v"(CR_P(7, 0)),
 			               "v"(CR_P(0, 1)), "v"(CR_P(1, 1)), "v"(CR_P(2, 1)), "v"(CR_P(3, 1)), "v"(CR_P(4, 1)), "v"(CR_P(5, 1)), "v"(CR_P(6, 1)), "v"(CR_P(7, 1)),
 			               "s"(wpair(0)), "s"(wpair(1)), "s"(wpair(2)), "s"(wpair(3)), "v"(chain_base));
-			if constexpr (ABL == 4)
-			{
-				// diagnostic: ten more scalar instructions per frame (what does a scalar instruction cost this kernel?)
-				unsigned junk = in_chunk;
-				asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\t"
-				             "s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1" : "+s"(junk) : : "scc");
-			}
 			write_pending();   // the previous frame's result: its LDS write has the rest of this frame to complete
 			// slots 8 (+), 9 (-), 10 (+), 11 (-), 12 (+), 13 (-), 14 (+)
 			asm volatile(CR_T(0, 2, 16, CR_SEL_EP) CR_T(1, 9, 16, CR_SEL_EP) CR_T(0, 3, 16, CR_SEL_ON) CR_T(1, 10, 16, CR_SEL_ON)
@@ -337,7 +372,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 		asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3");   // FP32 rounding: toward zero, for the chains (restored below)
 
 		// the frame the first advance brings in
-		next_frame = *reinterpret_cast<const __attribute__((address_space(3))) int *>((uintptr_t)future_at);
+		// entry TT + k is the frame advance k + 1 brings in: [group mod NG][lane][entry mod 4]
+		auto entry_at = [&](unsigned e) { return ring_at + ((e >> 2) & (NG - 1u)) * 1024u + (e & 3u) * 4u; };
+		next_frame = *reinterpret_cast<const __attribute__((address_space(3))) int *>((uintptr_t)entry_at((unsigned)TT));
 
 		while (frames_left != 0)
 		{
@@ -353,28 +390,55 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 						// written in C++ hipcc does the add in the vector unit for its carry-out)
 						unsigned next;
 						asm("s_add_u32 %0, %2, %3\n\ts_cselect_b32 %1, 1, 0" : "=&s"(next), "=s"(carry) : "s"(F), "s"(INC) : "scc");
+						if constexpr (ABL == 6)
+						{
+							mark(-1);
+							asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+							asm volatile("" : "+s"(w_a));
+							mark(1);
+						}
 						f32x16 w_next = w_a;
 						if constexpr (ABL != 1 && ABL != 3)
 							w_next = load_row(next);
 						frame(r_tag, w_a);
 						w_a = w_next;
+						if constexpr (ABL == 6)
+						{
+							mark(2);
+							phase[6] += 1;
+						}
 						F = next;
 						stage_at += 8u;
 						if (--in_chunk == 0)
 						{
+							mark(-1);
 							copy_out();
-							in_chunk = SEG_CHUNK;
-							frames_left -= SEG_CHUNK;
+							mark(3);
+							in_chunk = CHUNK;
+							frames_left -= CHUNK;
 							if (frames_left == 0)
 								carry = 2u;   // (the tile ends: leave the loop, no advance - asked once per chunk, not once per frame)
+							else
+							{
+								// the groups requested before this chunk have landed once only its own stores are outstanding (vmcnt counts
+								// loads and stores alike, in order); then the requests the chunk after the next will need
+								if constexpr (ABL == 2 || ABL == 3)
+									asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+								else
+									asm volatile("s_waitcnt vmcnt(%0)" ::"n"((int)CHUNK) : "memory");
+								top_up(advance + carry);
+								mark(4);
+							}
 						}
 					} while (carry == 0);
 					if (carry == 1u)
 					{
+						mark(-1);
 						// the position advances: the oldest slot's registers take the new frame, the names rotate by one
 						convert(next_frame, P[R % TT][0], P[R % TT][1]);
 						++advance;
-						next_frame = *reinterpret_cast<const __attribute__((address_space(3))) int *>((uintptr_t)(future_at + 256u * (advance < SEG_FUTURE ? advance : SEG_FUTURE - 1u)));
+						next_frame = *reinterpret_cast<const __attribute__((address_space(3))) int *>((uintptr_t)entry_at((unsigned)TT + advance));
+						mark(5);
 					}
 				}
 			});
@@ -388,6 +452,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 		tile = next;
 	}
 
+	if constexpr (ABL == 6)
+	{
+		if (lane == 0 && wave == 0 && a.debug_stamps != nullptr && blockIdx.x < 256u)
+			for (int q = 0; q < 8; ++q)
+				a.debug_stamps[8u * blockIdx.x + q] = phase[q];
+	}
 	retire();
 }
 

@@ -150,19 +150,21 @@ typedef struct crhip_seg_launch
 	uint64_t seg_frames;        /* S: a multiple of 65536 / gcd(increment, 65536) and of tile_frames; 512 S < 2^32 */
 	uint64_t seg_in_frames;     /* D = S * increment / 65536; 256 D < 2^32 */
 	uint64_t n_tiles;           /* ceil(n_out / (64 S)) * tiles_per_seg */
-	uint32_t increment;         /* 16.16; (65535 + (tile_frames - 1) * increment) >> 16 <= 12 */
+	uint32_t increment;         /* 16.16, below 65536 */
 	uint32_t first_slot;
 	uint32_t slots;             /* 15 */
-	uint32_t tile_frames;       /* K: a multiple of 16 */
+	uint32_t tile_frames;       /* K: a power of two, a multiple of the instance's chunk */
 	uint32_t tiles_per_seg;     /* S / K */
 	uint32_t blocks;
 	uint32_t *d_tickets;        /* CRHIP_TICKET_WORDS zeroed counters (as crhip_poly_launch.d_tickets) */
-	uint32_t debug_form;        /* 0; diagnostic instances: 1-3 timing-only ablations (results wrong), 4 = row loads two frames ahead */
+	uint32_t debug_form;        /* 0; diagnostic instances: 1-3 timing-only ablations (results wrong), 4 = cycle stamps per phase */
+	unsigned long long *debug_stamps;   /* form 4: receives 8 counters per workgroup (cr_kseg.hpp, ABL == 6) */
 } crhip_seg_launch;
 
-/* 1 and the slot signs the instance is built for (as crhip_poly_up_negmask) when there is a k_seg instance for the shape */
-int crhip_seg_instance(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t *negmask, uint32_t *threads, uint32_t *lds_bytes);
-int crhip_seg_prepare(uint32_t channels, uint32_t slots, int *per_cu);   /* one-time setup (dynamic LDS limit); not legal inside a capture */
+/* 1 and the slot signs the instance is built for (as crhip_poly_up_negmask) when there is a k_seg instance for the shape and the ratio;
+   *chunk: the frames a lane stages per copy-out (tile_frames must be a multiple) */
+int crhip_seg_instance(uint32_t channels, uint32_t slots, uint32_t row_mode, uint32_t norm_mode, uint32_t increment, uint32_t *negmask, uint32_t *threads, uint32_t *lds_bytes, uint32_t *chunk);
+int crhip_seg_prepare(uint32_t channels, uint32_t slots, uint32_t increment, int *per_cu);   /* one-time setup (dynamic LDS limit); not legal inside a capture */
 int crhip_launch_seg(const crhip_seg_launch *launch, void *stream);
 
 /* Many short constant-rate segments of ONE timeline in ONE launch (variable rate: ClownResamplerAMD_ResampleSegmentsDevice): the

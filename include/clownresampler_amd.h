@@ -59,6 +59,12 @@ const char *ClownResamplerAMD_BuildId(void);
 /* the values of CLOWNRESAMPLER_KERNEL_RADIUS this library was built for, space-separated ("3 5 8"; csrc/Makefile RADII) */
 const char *ClownResamplerAMD_BuiltRadii(void);
 int ClownResamplerAMD_DeviceCount(void);                /* 0 when there is none; never calls the error handler */
+/* 1 when the resampling entry points of this library can run in this process - a gfx950 (MI355X) device is visible to the calling thread's
+   selection - else 0.  Never calls the error handler, never aborts: the question to ask ONCE, at start-up, by a client that wants to fall
+   back on the reference's own header (clownresampler.h with CLOWNRESAMPLER_IMPLEMENTATION: same API, same results, one core) where
+   there is no such device, instead of meeting the default error handler's abort() in its first ClownResampler_*_Resample call.  This
+   library itself has no CPU path by design. */
+int ClownResamplerAMD_IsUsable(void);
 int ClownResamplerAMD_SetDevice(int ordinal);           /* process default: device used by calls of threads that have not chosen one; 0 on success */
 int ClownResamplerAMD_SetThreadDevice(int ordinal);     /* device used by subsequent calls of the CALLING THREAD (-1: follow the process default again) */
 int ClownResamplerAMD_GetDevice(void);                  /* what the calling thread's next call would use */

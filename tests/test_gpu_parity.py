@@ -49,6 +49,10 @@ def test_generic_kernel_bit_exact(golden, products, name):
     assert res == golden["cases"][name]
 
 
+def test_is_usable_on_the_gpu_box(products):
+    assert products[3].api.IsUsable() == 1
+
+
 def test_fast_kernel_is_what_runs(products):
     """The BASELINE configurations take the polyphase/LDS kernel, with the specialised instances."""
     for radius, ch, rates, slots in [(3, 2, (44100, 48000, 44100), 5), (8, 2, (8000, 96000, 8000), 15), (3, 8, (48000, 44100, 44100), 6)]:
@@ -329,6 +333,7 @@ def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch,
     ("cfg4", 3, 8, (48000, 44100, 44100), 28800000, 1, True),      # configs[3]: 8 channels, ticketed tiles
     ("cfg5", 3, 2, (44100, 48000, 44100), 158760000, 1, True),     # configs[4]: the hour as ONE launch (42,188 tiles)
     ("hq48", 8, 2, (44100, 48000, 44100), 26460000, 4, None),      # k_wave2: chunks of 4 wave-tiles (the 4 Mi batches of the host path get shorter ones)
+    ("up6", 8, 2, (8000, 48000, 8000), 6000000, 8, None),          # 6x with 8 lobes: k_seg by the rule (8.6 blocks of 64 segments)
     ("hq44", 8, 2, (48000, 44100, 44100), 28800000, 4, None),
     ("dn8", 3, 2, (44100, 8000, 8000), 26460000, 4, None),
     ("dn6x", 3, 2, (48000, 8000, 8000), 57600000, 5, True),        # k_int, ticket groups of several tiles
@@ -392,6 +397,9 @@ def test_one_launch_full_size_bit_exact(products, name, radius, ch, rates, frame
     ((9000, 96000, 9000), 60000, True),      # 10.67x: increment 6144 = 3 * 2048, the fraction repeats every 32 frames
     ((8000, 104000, 8000), 50000, True),     # 13x
     ((12000, 96000, 12000), 1500, True),     # a launch shorter than one tile per segment (96 frames of segment 0 ... 11)
+    ((8000, 36000, 8000), 60000, True),      # 4.5x: increment 14563, the most the ring of four groups takes (an advance in four and a half frames)
+    ((8000, 127999, 8000), 30000, True),     # 16x less a hair (increment 4096: the fraction repeats every 16 frames)
+    ((8000, 40000, 8000), 60000, True),      # 5x (increment 13107)
 ])
 def test_segment_kernel_bit_exact(products, rates, frames, forced):
     """k_seg (cr_kseg.hpp): the lanes of a wave S output frames apart, S * increment a multiple of 65536 - equal fractions, one polyphase

@@ -373,6 +373,22 @@ def test_resample_fails_loudly_without_a_device():
         p.high_run_i32(hs, ck.noise_pcm(200))
 
 
+def test_is_usable_answers_without_a_device(tmp_path):
+    """ClownResamplerAMD_IsUsable: the question a drop-in client asks once at start-up - 0 here, where there is no GPU,
+    without an error report and, in a plain C client with the DEFAULT (aborting) error handler installed, without an abort - so that the
+    client can choose the reference's own header instead of meeting abort() in its first resample call."""
+    p = _product.Product(3)
+    assert p.api.IsUsable() == 0 and p.api.lib.ClownResamplerAMD_LastErrorCode() == 0
+    src = tmp_path / "u.c"
+    src.write_text('#include <stdio.h>\n#include "clownresampler_amd.h"\n'
+                   'int main(void) { printf("%d %d\\n", ClownResamplerAMD_IsUsable(), ClownResamplerAMD_DeviceCount()); return 0; }\n')
+    exe = tmp_path / "u"
+    subprocess.run(["gcc", "-std=c89", "-pedantic", "-Wall", "-Wno-long-long", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", os.path.dirname(cr.LIB_PATH),
+                    "-lclownresampler_amd", "-Wl,-rpath," + os.path.dirname(cr.LIB_PATH)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split() == ["0", "0"], (r.returncode, r.stdout, r.stderr)
+
+
 def test_default_error_handler_aborts(tmp_path):
     """The C default (no handler installed): message on stderr and abort()."""
     src = tmp_path / "a.c"

@@ -1,0 +1,57 @@
+"""The product's HOST logic without a GPU, under sanitizers.
+
+tests/hostshim/ builds the host C sources of the product (clownresampler_amd/csrc: cr_api.c, cr_context.c, cr_plan.c, cr_device_api.c,
+cr_multi.c - batching, ticket-block rings, plan cache, helper threads, streaming windows, callback replay, segments, the sharded call)
+against tests/hostshim/crhip_fake.c, a plain-C implementation of the HIP seam csrc/crhip.h whose "kernels" are scalar models over the
+launch arguments (test infrastructure: it calls oracle/, it is never linked into libclownresampler_amd.so), and a C driver that holds every
+result to the oracle.  Run here: plain, -fsanitize=address,undefined (leak detection on) and -fsanitize=thread."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "tests", "hostshim")
+BUILD = os.path.join(SHIM, "build")
+
+
+@pytest.fixture(scope="module")
+def drivers():
+    targets = [os.path.join(BUILD, n) for n in ("driver", "driver_asan", "driver_tsan")]
+    r = subprocess.run(["make", "-s", "-j4", "-C", SHIM] + targets, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return targets
+
+
+def _run(exe, env_extra, timeout):
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=timeout, env=env)
+    tail = (r.stdout + r.stderr)[-6000:]
+    assert r.returncode == 0 and "driver: all passed" in r.stdout, tail
+    for name in ("bulk", "bulk_batches", "callback", "stream", "concurrent", "segments", "sharded", "device_threads", "shutdown"):
+        assert "ok " + name in r.stdout, tail
+    return r
+
+
+def test_host_logic_against_the_oracle(drivers):
+    _run(drivers[0], {}, 300)
+
+
+def test_host_logic_under_address_and_ub_sanitizers(drivers):
+    r = _run(drivers[1], {"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1:halt_on_error=1"}, 600)
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_host_logic_under_thread_sanitizer(drivers):
+    r = _run(drivers[2], {"TSAN_OPTIONS": "halt_on_error=0:exitcode=66"}, 900)
+    assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
+
+
+def test_fake_seam_is_not_in_the_product():
+    """the stand-in is test infrastructure: the shipped library exports nothing of it and does not contain the oracle"""
+    import clownresampler_amd as cr
+    out = subprocess.run(["nm", "-D", "--defined-only", cr.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "crhip_fake" not in out and "oracle_" not in out
+    out = subprocess.run(["nm", cr.LIB_PATH], capture_output=True, text=True).stdout
+    assert "crhip_fake_launches" not in out and "oracle_frame" not in out

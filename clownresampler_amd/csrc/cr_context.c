@@ -1976,17 +1976,21 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		const uint64_t seg = period >= 1024u ? period : 1024u;   /* (both powers of two) */
 		const uint64_t blocks64 = (n_out + 64u * seg - 1u) / (64u * seg);
 		const double waste = 1.0 - (double)n_out / ((double)blocks64 * 64.0 * (double)seg);
-		/* frames per lane and tile: a power of two (it divides S) - 128 while that leaves every wave two tiles or more (cfg 3: 2.3 tiles
-		   per wave, 115 us where 64-frame tiles take 121: a tile's first window is scattered loads and 90 conversions per lane), else 64 */
+		/* Frames per lane and tile (a multiple of the chunk; a segment's last tile may be shorter): 128 while that leaves the waves two
+		   tiles each or more, else 64.  Measured on cfg 3 (profiles/r05_kseg_tiles2.log): 64: 118.5 us, 128: 116.9, 144: 121.0, 160: 121.3
+		   (5,740 tiles on 3,072 waves: two each at most - and slower: a wave that has finished leaves its SIMD to the others, so many
+		   short tiles balance better than few long ones), 176: 130.4, 192: 136.2; a tile's first window (scattered loads, 90 conversions
+		   per lane, a drained store queue) is what speaks against 64. */
 		uint64_t tile = CR_SEG_MAX_TILE;
 		const uint64_t waves = (uint64_t)plan->seg.max_blocks * (plan->seg.threads / 64u);
 
-		while (tile > CR_SEG_MIN_TILE && blocks64 * (seg / tile) < 2u * waves)
+		while (tile > CR_SEG_MIN_TILE && blocks64 * ((seg + tile - 1u) / tile) < 2u * waves)
 			tile /= 2u;
-		if (g_env.seg_tile >= 16 && (g_env.seg_tile & (g_env.seg_tile - 1)) == 0 && (uint64_t)g_env.seg_tile <= seg)
+		if (g_env.seg_tile >= 16 && (uint64_t)g_env.seg_tile <= seg)
 			tile = (uint64_t)g_env.seg_tile;
-		if (tile % plan->seg.chunk == 0 && seg % tile == 0 && seg * 512u < (1ull << 32) && ((seg * plan->increment) >> 16) * 256u < (1ull << 32)
-		 && (g_seg_mode == 1 || (waste <= CR_SEG_MAX_WASTE && blocks64 * (seg / tile) >= 2u * waves)))
+		if (tile % plan->seg.chunk == 0 && seg * 512u < (1ull << 32) && ((seg * plan->increment) >> 16) * 256u < (1ull << 32)
+		 && blocks64 * ((seg + tile - 1u) / tile) < (1ull << 32)
+		 && (g_seg_mode == 1 || (waste <= CR_SEG_MAX_WASTE && blocks64 * ((seg + tile - 1u) / tile) >= waves + waves / 2u)))
 		{
 			crhip_seg_launch sl;
 			int ring, e;
@@ -2005,7 +2009,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			sl.first_slot = plan->poly.first_slot;
 			sl.slots = plan->poly.slots;
 			sl.tile_frames = (uint32_t)tile;
-			sl.tiles_per_seg = (uint32_t)(seg / tile);
+			sl.tiles_per_seg = (uint32_t)((seg + tile - 1u) / tile);
 			sl.n_tiles = blocks64 * sl.tiles_per_seg;
 			sl.debug_form = (uint32_t)g_env.seg_form;
 			sl.debug_stamps = g_debug_stamps;

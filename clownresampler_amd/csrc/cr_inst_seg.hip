@@ -64,7 +64,7 @@ int crhip_launch_seg(const crhip_seg_launch *launch, void *stream)
 {
 	const seg_shape *sh = shape_of(launch->increment);
 	if (launch->slots != 15u || launch->blocks == 0 || sh == nullptr || launch->tile_frames % sh->chunk != 0 || launch->tiles_per_seg == 0
-	 || (launch->tiles_per_seg & (launch->tiles_per_seg - 1u)) != 0)
+	 || (uint64_t)launch->tiles_per_seg * launch->tile_frames < launch->seg_frames || launch->n_tiles >= (1ull << 32))
 		return (int)hipErrorInvalidValue;
 	if (launch->n_out == 0)
 		return 0;

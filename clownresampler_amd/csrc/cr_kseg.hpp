@@ -112,7 +112,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 	const unsigned K = __builtin_amdgcn_readfirstlane(a.tile_frames);
 	const uint64_t S = a.seg_frames;
 	const unsigned tiles_per_seg = __builtin_amdgcn_readfirstlane(a.tiles_per_seg);
-	const unsigned tiles_shift = (unsigned)__builtin_ctz(tiles_per_seg);
 	// input frames a chunk can advance over, at most: what the ring must hold ahead of the wave (see top_up)
 	const unsigned chunk_advances = (65535u + CHUNK * increment) >> 16;
 	// (constant address space: a uniform load from it is an s_load whatever the kernel stores elsewhere)
@@ -124,20 +123,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 	// lane l's window lies l * D input frames behind lane 0's (4 bytes per stereo frame; the host keeps everything below 2^32)
 	const unsigned lane_in_bytes = lane * (unsigned)a.seg_in_frames * 4u;
 
-	// {max(v, 0), min(v, 0)} of both channels of a packed input frame, as floats (k_up2's `convert`)
+	// {max(v, 0), max(-v, 0)} of both channels of a packed input frame, as floats: the sample's positive and negative part, both as magnitudes
 	auto convert = [&](int packed, f32x2 &left, f32x2 &right) {
 		float v0, v1;
 		asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(v0) : "v"(packed));
 		asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(v1) : "v"(packed));
 		asm("v_max_f32_e64 %0, %1, 0" : "=v"(left.x) : "v"(v0));
-		asm("v_min_f32_e64 %0, %1, 0" : "=v"(left.y) : "v"(v0));
+		asm("v_max_f32_e64 %0, -%1, 0" : "=v"(left.y) : "v"(v0));
 		asm("v_max_f32_e64 %0, %1, 0" : "=v"(right.x) : "v"(v1));
-		asm("v_min_f32_e64 %0, %1, 0" : "=v"(right.y) : "v"(v1));
+		asm("v_max_f32_e64 %0, -%1, 0" : "=v"(right.y) : "v"(v1));
 	};
 
-	f32x2 chain_base;   // where a frame's two chains start: +-2^23, ulp 1 (cr_kup.hpp, FCHAIN)
+	// Where a frame's two chains start: 2^23, ulp 1 (cr_kup.hpp, FCHAIN).  Unlike k_up2, BOTH chains count upwards: one sums the products that
+	// are positive, the other the MAGNITUDES of the negative ones (a sample's negative part is kept as a magnitude, a slot with negative weights
+	// - staged as magnitudes too - takes the pair swapped: negative part x |weight| to the first chain, positive part x |weight| to the second).
+	// Round-toward-zero truncates either sum as C truncates the products (clownresampler.h:1020 via :625), and the frame's sum is the difference
+	// of the two accumulators' BITS (same exponent): one subtraction per channel, no sign to patch.
+	f32x2 chain_base;
 	chain_base.x = 8388608.0f;
-	chain_base.y = -8388608.0f;
+	chain_base.y = 8388608.0f;
 	asm volatile("" : "+v"(chain_base));
 	int thirty_one = 31;
 	asm volatile("" : "+v"(thirty_one));
@@ -145,9 +149,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 	asm volatile("" : "+{v117}"(zero_c), "+{v119}"(zero_d));   // the high halves of the normalisation's pinned addend pairs (see k_up2)
 
 	// staging: this lane's row, and where it reads for the copy-out (store i of a chunk: segments 4 i ... 4 i + 3, 16 lanes each)
+	// a lane's staging row: 8 bytes that take the write of "no frame yet", then its CHUNK frames
 	const unsigned stage_row = (unsigned)(uintptr_t)my_stage + lane * LANE_STRIDE;
 	// (store i of a chunk: segments PER_STORE * i ... + PER_STORE - 1, CHUNK lanes each)
-	const unsigned copy_from = (unsigned)(uintptr_t)my_stage + (lane / CHUNK) * LANE_STRIDE + (lane % CHUNK) * 8u;
+	const unsigned copy_from = (unsigned)(uintptr_t)my_stage + (lane / CHUNK) * LANE_STRIDE + 8u + (lane % CHUNK) * 8u;
 	const unsigned ring_at = (unsigned)(uintptr_t)my_ring + lane * 16u;   // this lane's four frames of group 0
 
 	uint64_t tile = global_wave;
@@ -169,13 +174,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 		mark(-1);
 
 		// ---- where the tile is ----
-		// (tiles_per_seg is a power of two - S and K are - and everything below is wave-uniform by construction: say so, or hipcc
-		// carries the tile's 64-bit bookkeeping through the vector unit and wraps every store in a waterfall loop)
-		const unsigned tile_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tile), tile_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(tile >> 32));
-		const uint64_t tile_u = ((uint64_t)tile_hi << 32) | tile_lo;
-		const uint64_t block = tile_u >> tiles_shift;
-		const unsigned t = tile_lo & (tiles_per_seg - 1u);
-		const uint64_t first = block * 64u * S + (uint64_t)t * K;           // lane 0's first frame; lane l's: first + l * S
+		// (everything below is wave-uniform by construction: say so, or hipcc carries the tile's 64-bit bookkeeping through the vector unit
+		// and wraps every store in a waterfall loop; the host keeps the tile count below 2^32)
+		const unsigned tile_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tile);
+		const unsigned block = (unsigned)__builtin_amdgcn_readfirstlane((int)(tile_lo / tiles_per_seg));
+		const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)(tile_lo - block * tiles_per_seg));
+		const uint64_t first = (uint64_t)block * 64u * S + (uint64_t)t * K;           // lane 0's first frame; lane l's: first + l * S
 		const uint64_t pos = a.pos0 + first * (uint64_t)increment;           // 16.16
 		const uint64_t position = (pos >> 16) + a.first_slot;                // input frame that slot 0 of lane 0's first frame multiplies
 		// the fraction of the wave's current frame in the TOP half of a register: adding the increment (shifted likewise) carries exactly
@@ -257,19 +261,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 
 		// A frame's result is written to its staging slot DURING THE NEXT frame (between that frame's two blocks of taps): the wait for the
 		// scalar row load at the head of every frame is lgkmcnt(0) - scalar loads return out of order, nothing less will do - and it would
-		// otherwise sit out the LDS write issued just in front of it, every frame.  `pending` is the frame waiting to be written; before
-		// the first frame of a tile (and after a copy-out) it is a dummy aimed at the 8 bytes of padding behind the lane's 128.
+		// otherwise sit out the LDS write issued just in front of it, every frame.  `pending` is the frame waiting to be written and
+		// stage_at where it goes: the slot of the wave's LAST frame - before the first frame of a chunk the 8 bytes in front of the row.
 		i32x2 pending;
 		pending.x = 0;
 		pending.y = 0;
-		unsigned pending_at = stage_row + CHUNK * 8u;
 		auto write_pending = [&]() {
-			asm volatile("ds_write_b64 %0, %1" ::"v"(pending_at), "v"(pending) : "memory");
+			asm volatile("ds_write_b64 %0, %1" ::"v"(stage_at), "v"(pending) : "memory");
 		};
 
 		auto copy_out = [&]() {
 			write_pending();   // the chunk's last frame
-			pending_at = stage_row + CHUNK * 8u;
 			// the staged frames of the other lanes: same wave, LDS operations complete in order
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
@@ -317,8 +319,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 			};
 #define CR_SEL_EP " op_sel_hi:[1,0,1]\n\t"
 #define CR_SEL_OP " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-#define CR_SEL_EN " op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-#define CR_SEL_ON " op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+#define CR_SEL_EN " op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+#define CR_SEL_ON " op_sel:[1,1,0] op_sel_hi:[0,1,1]\n\t"
 #define CR_T(acc, p, wq, SEL) "v_pk_fma_f32 %" #acc ", %" #p ", %" #wq ", %" #acc SEL
 #define CR_F(acc, p, wq, base, SEL) "v_pk_fma_f32 %" #acc ", %" #p ", %" #wq ", %" #base SEL
 #define CR_P(s, c) P[((s) + R) % TT][c]
@@ -349,9 +351,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 #undef CR_SEL_EN
 #undef CR_SEL_OP
 #undef CR_SEL_EP
-			// positive chain = 2^23 + p, negative chain = -(2^23 + q): the frame's sum is p - q
-			const int hi0 = (int)(__float_as_uint(a0.x) - __float_as_uint(a0.y) + 0x80000000u);
-			const int hi1 = (int)(__float_as_uint(a1.x) - __float_as_uint(a1.y) + 0x80000000u);
+			// first chain = 2^23 + p, second = 2^23 + q: the frame's sum is p - q
+			const int hi0 = (int)(__float_as_uint(a0.x) - __float_as_uint(a0.y));
+			const int hi1 = (int)(__float_as_uint(a1.x) - __float_as_uint(a1.y));
 			// (acc * reciprocal) / 32768 toward zero (clownresampler.h:1033), the row's last entry being 2 * reciprocal: k_up2's form
 			int out0, out1;
 			const int reciprocal2 = (int)__float_as_uint(w[TT]);
@@ -366,7 +368,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 			    : "vcc", "v116", "v118", "v122", "v123", "v126", "v127");
 			pending.x = out0;
 			pending.y = out1;
-			pending_at = stage_at;
 		};
 
 		asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3");   // FP32 rounding: toward zero, for the chains (restored below)
@@ -401,6 +402,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 						if constexpr (ABL != 1 && ABL != 3)
 							w_next = load_row(next);
 						frame(r_tag, w_a);
+						// (the rows TWO frames ahead - a third set of scalar registers - measured slower: 125 against 122 us, spills;
+						// profiles/r05_kseg_ab2.log)
 						w_a = w_next;
 						if constexpr (ABL == 6)
 						{

@@ -149,12 +149,12 @@ typedef struct crhip_seg_launch
 	uint64_t n_out;
 	uint64_t seg_frames;        /* S: a multiple of 65536 / gcd(increment, 65536) and of tile_frames; 512 S < 2^32 */
 	uint64_t seg_in_frames;     /* D = S * increment / 65536; 256 D < 2^32 */
-	uint64_t n_tiles;           /* ceil(n_out / (64 S)) * tiles_per_seg */
+	uint64_t n_tiles;           /* ceil(n_out / (64 S)) * tiles_per_seg, below 2^32 */
 	uint32_t increment;         /* 16.16, below 65536 */
 	uint32_t first_slot;
 	uint32_t slots;             /* 15 */
-	uint32_t tile_frames;       /* K: a power of two, a multiple of the instance's chunk */
-	uint32_t tiles_per_seg;     /* S / K */
+	uint32_t tile_frames;       /* K: a multiple of the instance's chunk (the last tile of a segment may be shorter) */
+	uint32_t tiles_per_seg;     /* ceil(S / K) */
 	uint32_t blocks;
 	uint32_t *d_tickets;        /* CRHIP_TICKET_WORDS zeroed counters (as crhip_poly_launch.d_tickets) */
 	uint32_t debug_form;        /* 0; diagnostic instances: 1-3 timing-only ablations (results wrong), 4 = cycle stamps per phase */

@@ -798,6 +798,9 @@ def main():
             "value_at_median": out_samples_all / (median_all * 1e-3) / 1e6,
             "roofline": roofline,
             "launch_mode": "hipGraph replay of the K steps" if graph is not None else "eager",
+            # which of this process's launches of the kernel the timed region was (in launch order, 0-based): tools/trace_timed_mean.py averages
+            # exactly those rows of a rocprofv3 --kernel-trace of the same command, so that profiles/ reproduces ms_per_step
+            "timed_dispatches": {"first": i_pre + args.warmup + lead_in_launches[0], "count": args.steps},
             "wall_ms_per_launch": wall_ms / (args.steps + lead_in_launches[0]),
             "parity_full_stream": check,
             "parity_full_stream_is": "every rank: EVERY sample its last timed launch wrote == the all-core oracle over the input that launch read (copied back from the device); all ranks agree",

@@ -344,13 +344,14 @@ class Api:
         _raise_if_failed(self.lib)
         return output[: n * ch], left.value, int(ran_out.value)
 
-    def LowLevel_ResampleBulkS16(self, resampler, precomputed, input_buffer, total_input_frames, output_capacity_frames=None):
+    def LowLevel_ResampleBulkS16(self, resampler, precomputed, input_buffer, total_input_frames, output_capacity_frames=None, output=None):
         """Clamped int16 output (examples/low-level.c:69-80 fused in).  Returns (int16 array, frames_not_processed, ran_out_of_input)."""
         keep, ptr = _as_i16(input_buffer)
         ch = resampler.channels
         if output_capacity_frames is None:
             output_capacity_frames = self.CountOutputFrames(resampler, total_input_frames) + 1
-        output = np.empty(max(output_capacity_frames, 1) * ch, dtype=np.int16)
+        if output is None:
+            output = np.empty(max(output_capacity_frames, 1) * ch, dtype=np.int16)
         left = C.c_size_t(total_input_frames)
         ran_out = cc_bool(0)
         n = self._BulkS16(C.byref(resampler), C.byref(precomputed), ptr, C.byref(left), output.ctypes.data_as(C.POINTER(C.c_int16)),

@@ -295,7 +295,7 @@ static void load_env(void)
 	e = getenv("CLOWNRESAMPLER_AMD_RT_WAVE2_MIN_SLOTS");
 	g_env.rt_wave2_min_slots = (e != NULL && atoi(e) > 0) ? atoi(e) : CR_RT_WAVE2_MIN_SLOTS;
 	e = getenv("CLOWNRESAMPLER_AMD_ROTATE_MIN_GAIN");
-	g_env.rotate_min_gain = (e != NULL && *e != '\0') ? atof(e) : CR_ROTATE_MIN_GAIN;
+	g_env.rotate_min_gain = (e != NULL && *e != '\0') ? atof(e) : -1.0;   /* (negative: unset - the rule's own thresholds, which differ for mono) */
 	e = getenv("CLOWNRESAMPLER_AMD_BRIEF_HALF_TILES");
 	g_env.brief_half_tiles = (e != NULL && *e != '\0' && atoi(e) >= 0) ? atoi(e) : -1;
 	g_env.loaded = 1;
@@ -1327,7 +1327,7 @@ static uint32_t plan_pick_rotation(const ClownResamplerAMD_Plan *plan, double *p
 	rotation = cr_poly_pick_swizzle_mapped(&plan->poly, plan->increment, plan->lane_map, plain, best);
 	/* (mono is the one shape whose LDS is busy enough for a smaller modelled gain to show: 44.1 -> 48 kHz models 12 -> 4 and measures
 	   77.6 -> 75.9 us rotated, profiles/r04_mono_rotated_rows_ab.log, where stereo and wider frames measure 0.5-1 % slower) */
-	if (form == 2 && *plain - *best < (plan->channels == 1u && g_env.rotate_min_gain == CR_ROTATE_MIN_GAIN ? 6.0 : g_env.rotate_min_gain))
+	if (form == 2 && *plain - *best < (g_env.rotate_min_gain >= 0.0 ? g_env.rotate_min_gain : (plan->channels == 1u ? 6.0 : CR_ROTATE_MIN_GAIN)))
 		rotation = 0u;
 	if (g_env.debug)
 		fprintf(stderr, "clownresampler_amd: plan variant %u, increment %llu: rows rotated by %u (modelled conflict cycles per row read %.2f -> %.2f)\n",
@@ -2426,7 +2426,7 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 	   so nothing needs staging.  host_direct 2: ONE launch over the whole call, the LDS-DMA reading the caller's input across the bus
 	   and the stores writing the caller's output, both directions of the link busy at once, no copy calls, no helper thread.
 	   host_direct 1: only the input is read in place (no uploads); the output still goes through device staging and the download
-	   thread.  Which of the three a call takes is a measured rule (profiles/r04_host_paths.log); pageable memory always stages. */
+	   thread.  Which of the three a call takes is a measured rule (profiles/r04_host_paths_pinned.log); pageable memory always stages. */
 	if (g_env.host_direct != 0)
 	{
 		/* (everything from the call's first frame to the end of the caller's padded buffer: what the staged path may read as well) */

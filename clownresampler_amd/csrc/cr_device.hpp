@@ -1209,6 +1209,17 @@ __device__ __forceinline__ unsigned draw_ticket_end(unsigned got)
 // ---------------------------------------------------------------------------------------------------------
 #define CRHIP_SGPR_BUDGET 80
 
+// ---------------------------------------------------------------------------------------------------------
+// One architecture.  Several kernels drop stores that would land behind the caller's buffer by the RANGE CHECK of a raw buffer descriptor
+// with the per-store offset in the instruction's SCALAR offset operand (k_poly's and k_wave2's dual-mono stores, k_up2's copy-out,
+// k_seg's segments): on gfx9 / gfx950 the check is "offset >= num_records - soffset", the scalar offset included.  Other targets
+// leave it out of the check (LLVM's AMDGPU usage notes) and would write out of bounds - so this code is refused anywhere else
+// (ADVICE r4), and the guard-region tests (tests/test_gpu_parity.py: dual mono, test_segment_kernel_bit_exact) stay a mandatory gate.
+// ---------------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libclownresampler_amd's kernels are written for gfx950 (MI355X) only: see the note on buffer range checks above"
+#endif
+
 } // namespace
 
 #endif // CR_DEVICE_HPP

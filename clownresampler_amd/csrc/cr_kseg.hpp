@@ -370,7 +370,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 			pending.y = out1;
 		};
 
-		asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3");   // FP32 rounding: toward zero, for the chains (restored below)
+		// FP32 rounding: toward zero, for the chains - and the mode the wave came with put back behind the tile (not a
+		// hard-coded 0).  Nothing between the two but the kernel's own asm arithmetic and integer / scalar code.
+		unsigned fp_mode;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_MODE, 0, 2)\n\ts_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" : "=s"(fp_mode));
 
 		// the frame the first advance brings in
 		// entry TT + k is the frame advance k + 1 brings in: [group mod NG][lane][entry mod 4]
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 			});
 		}
 
-		asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0");   // back to round-to-nearest-even
+		asm volatile("s_setreg_b32 hwreg(HW_REG_MODE, 0, 2), %0" ::"s"(fp_mode));
 
 		const uint64_t next = draw_resolve(draw_ticket_end(ticket));
 		if (next == ~0ull)

@@ -943,8 +943,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 		};
 
 		mark(0);
+		unsigned fp_mode = 0;   // (the wave's FP32 rounding mode is put back as it was found: ADVICE r4)
 		if constexpr (FCHAIN)
-			asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3");   // FP32 rounding: toward zero, for the chains of the frames
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_MODE, 0, 2)\n\ts_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" : "=s"(fp_mode));   // FP32 rounding: toward zero, for the chains of the frames
 		// the row of frame j + 1 is read before the arithmetic of frame j (two register sets, loop unrolled by two)
 		int wa[RS], wb[RS];
 		read_row(g, wa);
@@ -981,7 +982,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_up2(const crhip_poly_launch a)
 		if (any_extra)
 			one(wa, std::true_type());   // (its row was read as the prefetch of the last trip)
 		if constexpr (FCHAIN)
-			asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0");   // back to round-to-nearest-even
+			asm volatile("s_setreg_b32 hwreg(HW_REG_MODE, 0, 2), %0" ::"s"(fp_mode));   // back to the mode the wave came with
 
 		mark(1);
 		// the staged frames of the other lanes: same wave, LDS operations of a wave complete in order

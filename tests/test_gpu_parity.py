@@ -458,6 +458,38 @@ def test_segment_kernel_bit_exact(products, rates, frames, forced):
         api.DeviceFree(d_out)
 
 
+def test_segment_kernel_pointers_of_minimal_alignment(products):
+    """k_seg with an input pointer that is only int16-aligned and an output pointer that is only int32-aligned: every lane's 16-byte loads and
+    LDS-DMA requests start on 2 mod 4, the stores of whole lines on 4 mod 8 (all the reference's types ask for)."""
+    p, o = products[8], ck.oracle(8)
+    api = p.api
+    ch, rates, frames = 2, (8000, 96000, 8000), 40000
+    ok, ost = o.low_init(ch, *rates)
+    R = int(ost.cfg.radius_frames)
+    padded = ck.pad_frames(ck.noise_pcm(frames * ch, 4321), ch, R)
+    want, _, _ = o.low_resample_i32(ost, padded, frames)
+    total = want.size // ch
+    d_in = api.DeviceAlloc(padded.nbytes + 256)
+    d_out = api.DeviceAlloc(want.nbytes + 256)
+    api.DebugSegKernel(1)
+    try:
+        for in_off, out_off in ((2, 4), (6, 12), (14, 8)):
+            ok, st = p.low_init(ch, *rates)
+            api.CopyToDevice(d_in + in_off, padded)
+            plan = api.PlanCreate(st.raw, p.pre)
+            before = api.LaunchCount(8)
+            n, left, ran_out = api.ResampleDevice(plan, st.raw, d_in + in_off, frames, d_out + out_off, total + 8)
+            api.StreamSynchronize()
+            assert (n, left, ran_out) == (total, 0, 1) and api.LaunchCount(8) == before + 1
+            got = np.empty_like(want)
+            api.CopyFromDevice(got, d_out + out_off)
+            assert np.array_equal(got, want), (in_off, out_off)
+    finally:
+        api.DebugSegKernel(0)
+        api.DeviceFree(d_in)
+        api.DeviceFree(d_out)
+
+
 @pytest.mark.parametrize("radius,rates,frames,start", [
     (3, (44100, 48000, 44100), 3_000_000, (0, 0)),          # odd increment: the fraction repeats after 65,536 frames; ~3.3 M output frames -> H = 1,638,400
     (3, (44100, 48000, 44100), 1_234_567, (0, 0)),          # H rounded up past half: the second half is the shorter one
@@ -951,6 +983,63 @@ def test_clamped_int16_output(products, name):
     assert st.astuple() == ost.astuple()
     if name in ("amp_square_up", "cfg2_1min"):
         assert np.abs(want32).max() > 0x7FFF      # the clamp is actually exercised
+
+
+@pytest.mark.parametrize("kind", ["hipHostMalloc", "hipHostRegister"])
+def test_page_locked_host_buffers_take_the_direct_path_bit_exact(products, kind):
+    """when both of the caller's buffers are page-locked the host-pointer entry points run ONE launch that reads the input and
+    writes the output across PCIe (cr_run_host, CLOWNRESAMPLER_AMD_HOST_DIRECT) - no staging, so every kernel then works on host pointers
+    at whatever offset the caller's frames start.  Stereo (k_poly), a long mono call (dual mono), a whole-number ratio (k_int), 8x with 8
+    lobes (k_up2 / k_wave2), clamped int16 output; buffers that begin in the middle of an allocation, on odd frame / dword offsets;
+    hipHostMalloc'ed memory (torch's pinned tensors) and hipHostRegister'ed malloc memory: every sample against the oracle."""
+    import torch
+    rt = torch.cuda.cudart()
+
+    def locked(nbytes):
+        if kind == "hipHostMalloc":
+            t = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+            return t, t.numpy()
+        a = np.zeros(nbytes + 4096, dtype=np.uint8)
+        base = (a.ctypes.data + 4095) & ~4095
+        assert int(rt.cudaHostRegister(base, nbytes, 0)) == 0
+        return (a, base), np.frombuffer((C.c_uint8 * nbytes).from_address(base), dtype=np.uint8)
+
+    import ctypes as C
+    held = []
+    try:
+        for radius, ch, rates, frames, s16 in [(3, 2, (44100, 48000, 44100), 600000, False), (3, 1, (44100, 48000, 44100), 1300000, False), (3, 2, (96000, 48000, 48000), 400000, False),
+                                               (8, 2, (8000, 64000, 8000), 90000, False), (3, 2, (48000, 44100, 44100), 500000, True), (3, 5, (44100, 48000, 44100), 100000, False)]:
+            p, o = products[radius], ck.oracle(radius)
+            ok, st = p.low_init(ch, *rates)
+            ok, ost = o.low_init(ch, *rates)
+            R = int(ost.cfg.radius_frames)
+            padded = ck.pad_frames(ck.noise_pcm(frames * ch, 900 + frames), ch, R)
+            want, _, _ = o.low_resample_i32(ost, padded, frames)
+            total = want.size // ch
+            if s16:
+                want = np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16)
+            in_skip, out_skip = 3 * ch * 2 + 2, 5 * 4 if not s16 else 5 * 2      # the buffers begin mid-allocation, on 2 mod 4 / an odd dword (or short)
+            hold_in, raw_in = locked(padded.nbytes + 4096)
+            hold_out, raw_out = locked(want.nbytes + 4096 + 64)
+            held += [hold_in, hold_out]
+            src = raw_in[in_skip:in_skip + padded.nbytes].view(np.int16)
+            src[:] = padded
+            dst = raw_out[out_skip:out_skip + want.nbytes + 32].view(np.int16 if s16 else np.int32)
+            dst[:] = 0x5A5A if s16 else 0x5A5A5A5A
+            before = [p.api.LaunchCount(k) for k in range(9)]
+            if s16:
+                got, left, ran_out = p.api.LowLevel_ResampleBulkS16(st.raw, p.pre, src, frames, total + 1, output=dst)
+            else:
+                got, left, ran_out = p.api.LowLevel_ResampleBulk(st.raw, p.pre, src, frames, total + 1, output=dst)
+            launched = [a - b for a, b in zip([p.api.LaunchCount(k) for k in range(9)], before)]
+            assert (got.size // ch, left, ran_out) == (total, 0, 1) and st.astuple() == tuple(int(v) for v in ost.astuple())
+            assert sum(launched[:7]) + launched[8] == 1, ("page-locked buffers: one launch, nothing staged in batches", kind, rates, launched)
+            assert np.array_equal(got, want), (kind, radius, ch, rates)
+            assert np.all(dst[want.size:] == (0x5A5A if s16 else 0x5A5A5A5A)), "samples behind the last frame were written"
+    finally:
+        if kind == "hipHostRegister":
+            for h in held:
+                rt.cudaHostUnregister(h[1])
 
 
 def test_adjust_between_calls(products):

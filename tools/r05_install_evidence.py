@@ -17,6 +17,13 @@ for f in ("all_workloads", "channel_table", "host_paths_pinned", "gpu_tests", "k
     open(os.path.join(P, "r05_%s.log" % f), "w").writelines(text)
 
 
+if os.path.isdir(os.path.join(O, "preflight")):
+    dst = os.path.join(P, "r05_preflight_dry")
+    os.makedirs(dst, exist_ok=True)
+    for f in os.listdir(os.path.join(O, "preflight")):
+        shutil.copy(os.path.join(O, "preflight", f), os.path.join(dst, f))
+
+
 def line(w):
     return json.loads([x for x in open(os.path.join(P, "r05_bench_%s.json" % w)) if x.startswith("{")][0])
 

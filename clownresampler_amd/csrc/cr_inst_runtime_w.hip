@@ -2,7 +2,13 @@
 // output forms): what plans WITHOUT a specialised instance run when their windows are long enough for the 2-instruction tap
 // to pay and fit a wave's slice of the LDS (cr_context.c plan_geometry)  (see cr_instances.hpp)
 #include "cr_instances.hpp"
+// k_wave2s (a lane per channel PAIR: cr_kwave2s.hpp) never became a default - it measured slower than the run-time-slot k_poly for the wide
+// frames it was written for (profiles/r03_wave2s.log) - so it is NOT in the default build any more (a kernel nothing selects,
+// compiled into both libraries): `make CRA_CFLAGS=-DCRA_WITH_WAVE2S` brings it back behind variant 32 for comparison
+// (tests/test_gpu_parity.py::test_channel_pair_per_lane_kernel then runs instead of skipping).
+#ifdef CRA_WITH_WAVE2S
 #include "cr_kwave2s.hpp"
+#endif
 
 namespace
 {
@@ -23,11 +29,17 @@ namespace crk
 {
 void *runtime_wave2s_instance(uint32_t channels, int out16)
 {
+#ifdef CRA_WITH_WAVE2S
 	if (channels < 3 || channels > CRHIP_MAX_CHANNELS)
 		return nullptr;
 	if (channels % 2 == 0)
 		return out16 ? (void *)k_wave2s<1, 1, 1> : (void *)k_wave2s<1, 0, 1>;
 	return out16 ? (void *)k_wave2s<0, 1, 1> : (void *)k_wave2s<0, 0, 1>;
+#else
+	(void)channels;
+	(void)out16;
+	return nullptr;
+#endif
 }
 
 void *runtime_wave2_instance(uint32_t channels, uint32_t mode, int out16)

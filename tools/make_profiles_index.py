@@ -27,6 +27,28 @@ for doc in ("DESIGN.md", "README.md", "INTEGRATION.md"):
 cited.pop("INDEX.md", None)   # (this file)
 missing = [n for n in cited if not os.path.exists(os.path.join(P, n))]
 WHAT = [
+    (r"r05_bench_cfg2\.json", "the headline `bench.py` line (BASELINE configs[1], N = 1) of round 5's final build, with `roofline`, `cpu_baseline`, `parity_full_stream`, `strong_curve_n1`, `end_to_end`, `timed_dispatches`"),
+    (r"r05_bench_cfg2_steps20\.json", "the same command as the driver runs it (`--steps 20 --warmup 3`)"),
+    (r"r05_bench_(cfg3|cfg4|cfg5|hq48|hq44|dn8|cfg2_s16)\.json", "`bench.py` lines of the other workloads, same box and build"),
+    (r"r05_bench_n\d_sharedgpu_gloo\.json", "`bench.py --gpus N` with the ranks SHARING one GPU over gloo (validation of the N > 1 path; not a scaling measurement)"),
+    (r"r05_trace_timed_means\.log", "rocprofv3 `--kernel-trace` of the bench command: mean over ALL dispatches and over the TIMED ones bench.py names (`tools/trace_timed_mean.py`)"),
+    (r"r05_kernel_stats_.*\.csv", "`rocprofv3 --kernel-trace --stats` summary of the same `bench.py` command (average over every dispatch, clock ramp included)"),
+    (r"r05_kernel_trace_head_.*\.csv", "first dispatches of that trace: grid, LDS, register counts"),
+    (r"r05_(cfg2|cfg3|cfg4)_pmc_summary\.txt", "per-dispatch PMC means (separate `--pmc` passes), stamped with the library's source id; `bench.py` quotes `traffic` / `roofline_valu` from them"),
+    (r"r05_(hq48|hq44|dn8)_pmc_summary\.txt", "the same for the LDS-bound long-window shapes (VERDICT r4 item 3 asked for stamped summaries of the final build)"),
+    (r"r05_(cfg3|hq44|dn8)_lds_counters_before\.txt", "LDS-side counters (`SQ_LDS_*`, waits) of round 4's kernels, taken before round 5 touched anything"),
+    (r"r05_kup2_lds_ablations\.log", "timing-only builds of `k_up2`: no row reads per frame / conflict-free staging writes (what each costs)"),
+    (r"r05_kseg_.*\.log", "`k_seg`: same-box A/B against `k_up2`, tile sizes, timing-only ablations, where a wave's cycles go, forms tried and not kept"),
+    (r"r05_seg_ratio_sweep\.log", "`k_seg` against `k_up2` / `k_wave2` by upsampling ratio, 40 M output frames (`tools/seg_ratio_sweep.py`)"),
+    (r"r05_valurate\.log", "ns per wave-instruction of the tap's building blocks, incl. `v_pk_fma_f32` with a scalar weight pair"),
+    (r"r05_scatterwrite\.log", "what `k_seg`'s store pattern (whole lines, 64 segments 512 KB apart) costs against a contiguous one"),
+    (r"r05_pkfma_sgpr\.log", "`v_pk_fma_f32` with an SGPR-pair operand: the four `op_sel` forms give the expected lanes"),
+    (r"r05_parity_holes_gpu_tests\.log", "the C99-library and `HighLevel_Adjust` mid-stream tests, first green run"),
+    (r"r05_all_workloads\.log", "one line per workload of `bench.py`'s table: kernel, µs, Msamples/s, fraction of the roofline, full-stream parity"),
+    (r"r05_channel_table\.log", "every channel count 1-16 × ratio, 3 and 8 lobes (`tools/channel_table.py`)"),
+    (r"r05_gpu_tests.*\.log", "`pytest -m gpu` on the evidence box"),
+    (r"r05_host_paths_pinned\.log", "host-pointer entry point from pageable / page-locked memory"),
+    (r"r05_preflight_dry.*", "shared-GPU dry run of `tools/multi_gpu_preflight.sh` (VALIDATION ONLY)"),
     (r"r04_bench_cfg2\.json", "the headline `bench.py` line (BASELINE configs[1], N = 1) of the final build, with `roofline`, `cpu_baseline`, `parity_full_stream`, `strong_curve_n1`, `end_to_end`"),
     (r"r04_bench_(cfg3|cfg4|cfg5|hq48|cfg2_s16)\.json", "`bench.py` lines of the other workloads, same box and build"),
     (r"r04_bench_n\d_sharedgpu_gloo\.json", "`bench.py --gpus N` with the ranks SHARING one GPU over gloo (validation of the N > 1 path; not a scaling measurement)"),

@@ -23,7 +23,7 @@ build_id = cr.load(3).BuildId()
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if any(k in r["Kernel_Name"] for k in ("k_poly", "k_wave", "k_up", "k_generic", "k_int")):
+        if any(k in r["Kernel_Name"] for k in ("k_poly", "k_wave", "k_up", "k_seg", "k_generic", "k_int")):
             a = agg[r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += 1
 with open(out + "/pmc_summary.txt", "w") as w:

@@ -216,6 +216,60 @@ def test_launches_captured_into_a_graph(products):
             assert np.array_equal(side_out[k].cpu().numpy(), want), (rep, "side", k)
 
 
+def test_segment_kernel_on_streams_and_in_a_graph(products):
+    """k_seg (round 5) through the paths its launches share with the other kernels: two streams launching at once (each launch its own ticket
+    block), and launches captured into a hipGraph and replayed (never-recycled blocks from the capture pool) - forced, on a stream short
+    enough for the test (the rule takes it for ten-minute launches)."""
+    import torch
+    p, o = products[8], ck.oracle(8)
+    api = p.api
+    dev = torch.device("cuda", 0)
+    ch, rates, frames = 2, (8000, 64000, 8000), 60000
+    ok, ost = o.low_init(ch, *rates)
+    padded = ck.pad_frames(ck.noise_pcm(frames * ch, 77), ch, int(ost.cfg.radius_frames))
+    want = o.low_resample_i32(ost, padded, frames)[0]
+    n_out = want.size // ch
+    d_in = torch.from_numpy(padded).to(dev)
+    ok, st0 = p.low_init(ch, *rates)
+    plan = api.PlanCreate(st0.raw, p.pre)
+    api.DebugSegKernel(1)
+    try:
+        streams = [torch.cuda.Stream(dev) for _ in range(3)]
+        outs = [torch.zeros(want.size + 64, dtype=torch.int32, device=dev) for _ in range(12)]
+        before = api.LaunchCount(8)
+        torch.cuda.synchronize()
+        for k, t in enumerate(outs):
+            st = cr.LowLevel_State.from_buffer_copy(st0.raw)
+            api.ResampleDevice(plan, st, d_in.data_ptr(), frames, t.data_ptr(), n_out + 8, streams[k % 3].cuda_stream)
+        torch.cuda.synchronize()
+        assert api.LaunchCount(8) == before + len(outs)
+        for k, t in enumerate(outs):
+            assert np.array_equal(t.cpu().numpy()[:want.size], want), ("streams", k)
+        launches = 10
+        api.ReserveCaptureLaunches(launches)
+        gouts = [torch.zeros(want.size + 64, dtype=torch.int32, device=dev) for _ in range(launches)]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(streams[0]):
+            with torch.cuda.graph(graph, stream=streams[0]):
+                s = torch.cuda.current_stream(dev)
+                for k in range(launches):
+                    st = cr.LowLevel_State.from_buffer_copy(st0.raw)
+                    api.ResampleDevice(plan, st, d_in.data_ptr(), frames, gouts[k].data_ptr(), n_out + 8, s.cuda_stream)
+        for rep in range(2):
+            for t in gouts:
+                t.zero_()
+            torch.cuda.synchronize()
+            graph.replay()
+            st = cr.LowLevel_State.from_buffer_copy(st0.raw)
+            api.ResampleDevice(plan, st, d_in.data_ptr(), frames, outs[0].data_ptr(), n_out + 8, streams[1].cuda_stream)
+            torch.cuda.synchronize()
+            for k in range(launches):
+                assert np.array_equal(gouts[k].cpu().numpy()[:want.size], want), ("graph", rep, k)
+            assert np.array_equal(outs[0].cpu().numpy()[:want.size], want)
+    finally:
+        api.DebugSegKernel(0)
+
+
 @pytest.mark.parametrize("scale,expect_kernel", [(1, "fast"), (2, "generic"), (-1, "generic")])
 def test_caller_supplied_tables(products, scale, expect_kernel):
     """Plans are keyed by table CONTENTS, so a caller's own table is legitimate input.  The 32-bit kernels multiply with the

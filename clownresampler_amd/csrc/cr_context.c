@@ -247,6 +247,7 @@ static struct
 {
 	int loaded;
 	int dynamic_tiles;          /* CLOWNRESAMPLER_AMD_DYNAMIC_TILES: -1 unset, else 0 / 1 */
+	int w2_form;   /* diagnostic builds (-DCRA_WITH_W2_FORMS): k_wave2's timing-only forms */
 	int no_special, debug, no_occupancy_clamp, tile_groups, no_host_pipeline, no_small_call_path;
 	int no_replay_thread;       /* CLOWNRESAMPLER_AMD_NO_REPLAY_THREAD: the callback API never starts its compute-ahead helper thread */
 	int no_dual_mono;           /* CLOWNRESAMPLER_AMD_NO_DUAL_MONO: long mono launches stay on the mono kernels (the A/B leg) */
@@ -272,6 +273,8 @@ static void load_env(void)
 	g_env.dynamic_tiles = (e != NULL && *e != '\0') ? (atoi(e) != 0) : -1;
 	g_env.no_special = getenv("CLOWNRESAMPLER_AMD_NO_SPECIAL") != NULL;
 	g_env.no_seg = getenv("CLOWNRESAMPLER_AMD_NO_SEG") != NULL;
+	e = getenv("CLOWNRESAMPLER_AMD_W2_FORM");
+	g_env.w2_form = (e != NULL && *e != '\0') ? atoi(e) : 0;
 	e = getenv("CLOWNRESAMPLER_AMD_SEG_FORM");
 	g_env.seg_form = (e != NULL && *e != '\0') ? atoi(e) : 0;
 	e = getenv("CLOWNRESAMPLER_AMD_SEG_TILE");
@@ -1857,6 +1860,7 @@ static void fill_poly_launch(const ClownResamplerAMD_Plan *plan, crhip_poly_laun
 	l->lds_bytes = plan->lds_bytes;
 	l->specialised = plan->specialised;
 	l->variant = plan->variant;
+	l->debug_form = (uint32_t)g_env.w2_form;
 	l->plane_rows = plan->plane_rows;
 	l->swizzle = plan->lds_swizzle;
 	l->padded = plan->padded;

@@ -82,6 +82,7 @@ struct special
 	uint32_t mad_any_sign;                   // 1: the chain in mad[] is the any-sign form (ASM mode 3): no slot-sign precondition for the host to check
 	poly_fn mad_dual, mad_dual_rotated;      // stereo instances: mad[0] built with DUAL (a mono stream as two phase-aligned "channels", crhip_poly_launch.dual); nullptr if none
 	poly_fn wave2_dual;                      // ... and k_wave2 built with DUAL
+	poly_fn wave2_forms[3];                  // -DCRA_WITH_W2_FORMS only: k_wave2's timing-only forms 1 ... 3 (ABL; results wrong); nullptr otherwise
 };
 
 constexpr uint32_t MAD_VARIANT = 28;    // variant ids 28, 29
@@ -100,6 +101,14 @@ void add_wave2(special &s)
 	s.wave2_16 = (poly_fn)k_wave2<CH, TT, MODE, NORM, WAVES, NVW, ITER, 1, 1, NEGMASK, SIGNED, SAFEMASK>;
 	if constexpr (CH == 2)
 		s.wave2_dual = (poly_fn)k_wave2<CH, TT, MODE, NORM, WAVES, NVW, ITER, 0, 1, NEGMASK, SIGNED, SAFEMASK, 1>;   // a mono stream as two phase-aligned channels
+#ifdef CRA_WITH_W2_FORMS
+	if constexpr (CH == 2 && (TT == 15 || TT == 17 || TT == 33))
+	{
+		s.wave2_forms[0] = (poly_fn)k_wave2<CH, TT, MODE, NORM, WAVES, NVW, ITER, 0, 1, NEGMASK, SIGNED, SAFEMASK, 0, 1>;
+		s.wave2_forms[1] = (poly_fn)k_wave2<CH, TT, MODE, NORM, WAVES, NVW, ITER, 0, 1, NEGMASK, SIGNED, SAFEMASK, 0, 2>;
+		s.wave2_forms[2] = (poly_fn)k_wave2<CH, TT, MODE, NORM, WAVES, NVW, ITER, 0, 1, NEGMASK, SIGNED, SAFEMASK, 0, 3>;
+	}
+#endif
 	s.wave2_safemask = SAFEMASK;
 	s.wave2_waves = WAVES;
 	s.wave2_nvw = NVW;

@@ -668,6 +668,8 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 	if (sp != nullptr && v == WAVE2_VARIANT)
 	{
 		*geo = 150u;
+		if (launch->debug_form >= 1u && launch->debug_form <= 3u && !launch->out_s16 && sp->wave2_forms[launch->debug_form - 1u] != nullptr)
+			return sp->wave2_forms[launch->debug_form - 1u];   // (diagnostic build only)
 		return launch->out_s16 ? sp->wave2_16 : sp->wave2;
 	}
 

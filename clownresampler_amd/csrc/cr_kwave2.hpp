@@ -46,11 +46,18 @@ constexpr int wave2_reads_ahead(bool with_rows, int reads_per_slot, int tt, int 
 }
 
 // DUAL = 1: DUAL MONO (see k_poly): a stereo instance run on a MONO stream - output frames j and j + H, whose fractions are equal,
-// as its two channels.  The wave-tile's two mono windows are fetched into the two halves of the packed buffer by ONE descriptor
+// as its two channels.
+// ABL: 0 in every shipped instance.  Timing-only forms (WRONG results; built with -DCRA_WITH_W2_FORMS, reached through
+// CLOWNRESAMPLER_AMD_W2_FORM): 1 = every lane reads the window of the wave-tile's first frame (window reads without bank conflicts),
+// 2 = every lane reads row 0 (row reads without), 3 = both.
+// (Tried in round 5 and NOT kept: the frames of a full wave-tile as ONE pipeline of LDS reads - the first planes of frame i + 1 requested
+// while the last planes of frame i are multiplied, into the registers those planes were consumed from; bit-exact, no extra registers -
+// within +-1.5 % of frame by frame on every shape, profiles/r05_kwave2_frame_pipeline_ab.log: the waves of a SIMD already cover each
+// other's round trips; what binds is the SUM of LDS and VALU cycles, profiles/r05_kwave2_lds_forms.log.)  The wave-tile's two mono windows are fetched into the two halves of the packed buffer by ONE descriptor
 // (the second window's lanes add its distance to their offsets), the expansion pass writes them interleaved - X of the first
 // window's sample p into dword 0 of entry p + 1, of the second window's into dword 1 - and the frames leave as two 4-byte stores
 // through one descriptor that ends where the second half of the stream does.
-template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, int OUT16, int NT, unsigned NEGMASK, int SIGNED, unsigned SAFEMASK = 0, int DUAL = 0>
+template <int CH, int TT, int MODE, int NORM, int WAVES, int NVW, int ITER, int OUT16, int NT, unsigned NEGMASK, int SIGNED, unsigned SAFEMASK = 0, int DUAL = 0, int ABL = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 {
 	static_assert(CH >= 1 && CH <= 8, "one lane per frame");
@@ -374,6 +381,136 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 		return odd;
 	};
 
+		// accumulator pairs pinned to physical registers (see k_up2): A+ v[120:121], B+ v[122:123], A- v[124:125], B- v[126:127]
+		// (an accumulator's FIRST tap adds to {arm, 0} - a scratch register paired with a register that holds 0 for the whole
+		// kernel, v[118:119] - instead of to itself: no v_mov to clear it)
+#define CRHIP_W2_TAP_FIRST(LO, HI, VLO, VHI, X, W)                                                                                 \
+	asm("v_ashrrev_i32_e32 v118, 31, %2\n\t"                                                                                     \
+	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[118:119]"                                                               \
+	    : "=&{v" #LO "}"(VLO), "=&{v" #HI "}"(VHI) : "v"(X), "v"(W), "{v119}"(zero119) : "vcc", "v118")
+// (the arming move is the COMPILER's instruction: between two asm statements that touch a common pinned register hipcc pads with an
+// s_nop unless an instruction of its own stands in between - 28 s_nop per 15-slot stereo frame with the move inside the statement, 7 so)
+#define CRHIP_W2_TAP_MOV(LO, HI, VLO, VHI, X, W)                                                                                   \
+	VLO = (X);                                                                                                                     \
+	asm("v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
+	    : "+{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc")
+#define CRHIP_W2_TAP_MOV_SAFE(LO, HI, VLO, VHI, X, W)                                                                              \
+	asm("v_lshlrev_b32_e32 v118, 15, %2\n\t"                                                                                     \
+	    "v_mov_b32_e32 v" #LO ", %2\n\t"                                                                                         \
+	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, v118, %3, v[" #LO ":" #HI "]"                                                    \
+	    : "=&{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc", "v118")
+#define CRHIP_W2_TAP_MOV_FIRST(LO, HI, VLO, VHI, X, W)                                                                             \
+	asm("v_mov_b32_e32 v118, %2\n\t"                                                                                             \
+	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[118:119]"                                                               \
+	    : "=&{v" #LO "}"(VLO), "=&{v" #HI "}"(VHI) : "v"(X), "v"(W), "{v119}"(zero119) : "vcc", "v118")
+#define CRHIP_W2_TAP_SIGNED_FIRST(LO, HI, VLO, VHI, X, W)                                                                          \
+	asm("v_xor_b32_sdwa v118, sext(%2), sext(%3) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"      \
+	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[118:119]"                                                               \
+	    : "=&{v" #LO "}"(VLO), "=&{v" #HI "}"(VHI) : "v"(X), "v"(W), "{v119}"(zero119) : "vcc", "v118")
+#define CRHIP_W2_TAP(LO, HI, VLO, VHI, X, W)                                                                                       \
+	asm("v_ashrrev_i32_e32 v" #LO ", 31, %2\n\t"                                                                                  \
+	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
+	    : "=&{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc")
+#define CRHIP_W2_TAP_SIGNED(LO, HI, VLO, VHI, X, W)                                                                                \
+	asm("v_xor_b32_sdwa v" #LO ", sext(%2), sext(%3) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"   \
+	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
+	    : "=&{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc")
+	constexpr int FIRST_POS = SIGNED ? 0 : __builtin_ctz(~NEGMASK), FIRST_NEG = SIGNED ? -1 : (NEGMASK ? __builtin_ctz(NEGMASK) : -1);
+	// the taps of slot s on the pinned accumulators: channel(s) xa_s (and xb_s when `pair`) times w_s.  Inlined into fully unrolled
+	// loops: s and pair are constants wherever this is called.
+	auto slot_taps = [&](int s, bool pair, int xa_s, int xb_s, int w_s, int &lo0, int &hi0, int &lo1, int &hi1, int &lo2, int &hi2, int &lo3, int &hi3) __attribute__((always_inline)) {
+		if constexpr (SIGNED)
+		{
+			if (s == FIRST_POS)
+			{
+				CRHIP_W2_TAP_SIGNED_FIRST(120, 121, lo0, hi0, xa_s, w_s);
+				if (pair)
+					CRHIP_W2_TAP_SIGNED_FIRST(122, 123, lo1, hi1, xb_s, w_s);
+			}
+			else
+			{
+				CRHIP_W2_TAP_SIGNED(120, 121, lo0, hi0, xa_s, w_s);
+				if (pair)
+					CRHIP_W2_TAP_SIGNED(122, 123, lo1, hi1, xb_s, w_s);
+			}
+		}
+		else if constexpr (MOVARM)
+		{
+			static_assert(!MOVARM || (!((SAFEMASK >> (FIRST_POS < 0 ? 0 : FIRST_POS)) & 1u) && !((SAFEMASK >> (FIRST_NEG < 0 ? 0 : FIRST_NEG)) & 1u) && !(SAFEMASK & NEGMASK)),
+			              "an accumulator's first tap is an ordinary slot, and the unrestricted slots are positive ones");
+			if ((NEGMASK >> s) & 1u)
+			{
+				if (s == FIRST_NEG)
+				{
+					CRHIP_W2_TAP_MOV_FIRST(124, 125, lo2, hi2, xa_s, w_s);
+					if (pair)
+						CRHIP_W2_TAP_MOV_FIRST(126, 127, lo3, hi3, xb_s, w_s);
+				}
+				else
+				{
+					CRHIP_W2_TAP_MOV(124, 125, lo2, hi2, xa_s, w_s);
+					if (pair)
+						CRHIP_W2_TAP_MOV(126, 127, lo3, hi3, xb_s, w_s);
+				}
+			}
+			else if (s == FIRST_POS)
+			{
+				CRHIP_W2_TAP_MOV_FIRST(120, 121, lo0, hi0, xa_s, w_s);
+				if (pair)
+					CRHIP_W2_TAP_MOV_FIRST(122, 123, lo1, hi1, xb_s, w_s);
+			}
+			else if ((SAFEMASK >> s) & 1u)
+			{
+				CRHIP_W2_TAP_MOV_SAFE(120, 121, lo0, hi0, xa_s, w_s);
+				if (pair)
+					CRHIP_W2_TAP_MOV_SAFE(122, 123, lo1, hi1, xb_s, w_s);
+			}
+			else
+			{
+				CRHIP_W2_TAP_MOV(120, 121, lo0, hi0, xa_s, w_s);
+				if (pair)
+					CRHIP_W2_TAP_MOV(122, 123, lo1, hi1, xb_s, w_s);
+			}
+		}
+		else if ((NEGMASK >> s) & 1u)
+		{
+			if (s == FIRST_NEG)
+			{
+				CRHIP_W2_TAP_FIRST(124, 125, lo2, hi2, xa_s, w_s);
+				if (pair)
+					CRHIP_W2_TAP_FIRST(126, 127, lo3, hi3, xb_s, w_s);
+			}
+			else
+			{
+				CRHIP_W2_TAP(124, 125, lo2, hi2, xa_s, w_s);
+				if (pair)
+					CRHIP_W2_TAP(126, 127, lo3, hi3, xb_s, w_s);
+			}
+		}
+		else
+		{
+			if (s == FIRST_POS)
+			{
+				CRHIP_W2_TAP_FIRST(120, 121, lo0, hi0, xa_s, w_s);
+				if (pair)
+					CRHIP_W2_TAP_FIRST(122, 123, lo1, hi1, xb_s, w_s);
+			}
+			else
+			{
+				CRHIP_W2_TAP(120, 121, lo0, hi0, xa_s, w_s);
+				if (pair)
+					CRHIP_W2_TAP(122, 123, lo1, hi1, xb_s, w_s);
+			}
+		}
+	};
+#undef CRHIP_W2_TAP
+#undef CRHIP_W2_TAP_SIGNED
+#undef CRHIP_W2_TAP_FIRST
+#undef CRHIP_W2_TAP_MOV
+#undef CRHIP_W2_TAP_MOV_SAFE
+#undef CRHIP_W2_TAP_MOV_FIRST
+#undef CRHIP_W2_TAP_SIGNED_FIRST
+
 	// one output frame from the expanded window: CH normalised results into out[]
 	auto one_frame2 = [&](unsigned rel, unsigned x_odd, int *out) {
 		unsigned shift;
@@ -382,9 +519,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 		// 44.1 -> 48 kHz) and the 16 lanes a ds_read_b128 services together fall on 5-8 of the 16 bank slots: the row reads were
 		// half of this kernel's LDS cycles as conflicts (profiles/r02_kwave2_trials.log).  Within each block of 16 rows the rows
 		// are rotated by a host-chosen multiple of the block number, which spreads them over all 16 slots.
-		const unsigned phys = (row & ~15u) | ((__umul24(row >> 4, a.swizzle) + row) & 15u);
+		const unsigned phys = (ABL & 2) ? 0u : ((row & ~15u) | ((__umul24(row >> 4, a.swizzle) + row) & 15u));
 		// LDS byte address of sample 0 of slot 0 (the low 32 bits of a __shared__ pointer are the LDS address)
-		const unsigned win_at = (unsigned)(uintptr_t)my_x + (x_odd + ((rel >> 16) + shift) * CH) * 4u;
+		const unsigned win_at = (unsigned)(uintptr_t)my_x + (x_odd + ((ABL & 1) ? 0u : ((rel >> 16) + shift)) * CH) * 4u;
 		// LDS byte address of this frame's row in plane 0
 		const unsigned row_at = (unsigned)(uintptr_t)smem + phys * 16u;
 		const unsigned plane_bytes = a.plane_rows * 16u;
@@ -565,38 +702,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 			// (an accumulator's FIRST tap adds to {arm, 0} - a scratch register paired with a register that holds 0 for the whole
 			// kernel, v[118:119] - instead of to itself: no v_mov to clear it)
 			int lo0, hi0 = 0, lo1, hi1 = 0, lo2, hi2 = 0, lo3, hi3 = 0;
-			constexpr int FIRST_POS = SIGNED ? 0 : __builtin_ctz(~NEGMASK), FIRST_NEG = SIGNED ? -1 : (NEGMASK ? __builtin_ctz(NEGMASK) : -1);
-#define CRHIP_W2_TAP_FIRST(LO, HI, VLO, VHI, X, W)                                                                                 \
-	asm("v_ashrrev_i32_e32 v118, 31, %2\n\t"                                                                                     \
-	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[118:119]"                                                               \
-	    : "=&{v" #LO "}"(VLO), "=&{v" #HI "}"(VHI) : "v"(X), "v"(W), "{v119}"(zero119) : "vcc", "v118")
-// (the arming move is the COMPILER's instruction: between two asm statements that touch a common pinned register hipcc pads with an
-// s_nop unless an instruction of its own stands in between - 28 s_nop per 15-slot stereo frame with the move inside the statement, 7 so)
-#define CRHIP_W2_TAP_MOV(LO, HI, VLO, VHI, X, W)                                                                                   \
-	VLO = (X);                                                                                                                     \
-	asm("v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
-	    : "+{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc")
-#define CRHIP_W2_TAP_MOV_SAFE(LO, HI, VLO, VHI, X, W)                                                                              \
-	asm("v_lshlrev_b32_e32 v118, 15, %2\n\t"                                                                                     \
-	    "v_mov_b32_e32 v" #LO ", %2\n\t"                                                                                         \
-	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, v118, %3, v[" #LO ":" #HI "]"                                                    \
-	    : "=&{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc", "v118")
-#define CRHIP_W2_TAP_MOV_FIRST(LO, HI, VLO, VHI, X, W)                                                                             \
-	asm("v_mov_b32_e32 v118, %2\n\t"                                                                                             \
-	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[118:119]"                                                               \
-	    : "=&{v" #LO "}"(VLO), "=&{v" #HI "}"(VHI) : "v"(X), "v"(W), "{v119}"(zero119) : "vcc", "v118")
-#define CRHIP_W2_TAP_SIGNED_FIRST(LO, HI, VLO, VHI, X, W)                                                                          \
-	asm("v_xor_b32_sdwa v118, sext(%2), sext(%3) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"      \
-	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[118:119]"                                                               \
-	    : "=&{v" #LO "}"(VLO), "=&{v" #HI "}"(VHI) : "v"(X), "v"(W), "{v119}"(zero119) : "vcc", "v118")
-#define CRHIP_W2_TAP(LO, HI, VLO, VHI, X, W)                                                                                       \
-	asm("v_ashrrev_i32_e32 v" #LO ", 31, %2\n\t"                                                                                  \
-	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
-	    : "=&{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc")
-#define CRHIP_W2_TAP_SIGNED(LO, HI, VLO, VHI, X, W)                                                                                \
-	asm("v_xor_b32_sdwa v" #LO ", sext(%2), sext(%3) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"   \
-	    "v_mad_i64_i32 v[" #LO ":" #HI "], vcc, %2, %3, v[" #LO ":" #HI "]"                                                      \
-	    : "=&{v" #LO "}"(VLO), "+{v" #HI "}"(VHI) : "v"(X), "v"(W) : "vcc")
 			static_for<NQ>([&](auto q_tag) {
 				constexpr int q = decltype(q_tag)::value;
 				// reads issued after the last one of plane q - the planes ahead of it - may stay in flight
@@ -630,98 +735,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 						asm volatile("" : "+v"(xa[s]));
 						xb[s] = 0;
 					}
-					if constexpr (SIGNED)
-					{
-						if (s == FIRST_POS)
-						{
-							CRHIP_W2_TAP_SIGNED_FIRST(120, 121, lo0, hi0, xa[s], w[s]);
-							if (pair)
-								CRHIP_W2_TAP_SIGNED_FIRST(122, 123, lo1, hi1, xb[s], w[s]);
-						}
-						else
-						{
-							CRHIP_W2_TAP_SIGNED(120, 121, lo0, hi0, xa[s], w[s]);
-							if (pair)
-								CRHIP_W2_TAP_SIGNED(122, 123, lo1, hi1, xb[s], w[s]);
-						}
-					}
-					else if constexpr (MOVARM)
-					{
-						static_assert(!MOVARM || (!((SAFEMASK >> (FIRST_POS < 0 ? 0 : FIRST_POS)) & 1u) && !((SAFEMASK >> (FIRST_NEG < 0 ? 0 : FIRST_NEG)) & 1u) && !(SAFEMASK & NEGMASK)),
-						              "an accumulator's first tap is an ordinary slot, and the unrestricted slots are positive ones");
-						if ((NEGMASK >> s) & 1u)
-						{
-							if (s == FIRST_NEG)
-							{
-								CRHIP_W2_TAP_MOV_FIRST(124, 125, lo2, hi2, xa[s], w[s]);
-								if (pair)
-									CRHIP_W2_TAP_MOV_FIRST(126, 127, lo3, hi3, xb[s], w[s]);
-							}
-							else
-							{
-								CRHIP_W2_TAP_MOV(124, 125, lo2, hi2, xa[s], w[s]);
-								if (pair)
-									CRHIP_W2_TAP_MOV(126, 127, lo3, hi3, xb[s], w[s]);
-							}
-						}
-						else if (s == FIRST_POS)
-						{
-							CRHIP_W2_TAP_MOV_FIRST(120, 121, lo0, hi0, xa[s], w[s]);
-							if (pair)
-								CRHIP_W2_TAP_MOV_FIRST(122, 123, lo1, hi1, xb[s], w[s]);
-						}
-						else if ((SAFEMASK >> s) & 1u)
-						{
-							CRHIP_W2_TAP_MOV_SAFE(120, 121, lo0, hi0, xa[s], w[s]);
-							if (pair)
-								CRHIP_W2_TAP_MOV_SAFE(122, 123, lo1, hi1, xb[s], w[s]);
-						}
-						else
-						{
-							CRHIP_W2_TAP_MOV(120, 121, lo0, hi0, xa[s], w[s]);
-							if (pair)
-								CRHIP_W2_TAP_MOV(122, 123, lo1, hi1, xb[s], w[s]);
-						}
-					}
-					else if ((NEGMASK >> s) & 1u)
-					{
-						if (s == FIRST_NEG)
-						{
-							CRHIP_W2_TAP_FIRST(124, 125, lo2, hi2, xa[s], w[s]);
-							if (pair)
-								CRHIP_W2_TAP_FIRST(126, 127, lo3, hi3, xb[s], w[s]);
-						}
-						else
-						{
-							CRHIP_W2_TAP(124, 125, lo2, hi2, xa[s], w[s]);
-							if (pair)
-								CRHIP_W2_TAP(126, 127, lo3, hi3, xb[s], w[s]);
-						}
-					}
-					else
-					{
-						if (s == FIRST_POS)
-						{
-							CRHIP_W2_TAP_FIRST(120, 121, lo0, hi0, xa[s], w[s]);
-							if (pair)
-								CRHIP_W2_TAP_FIRST(122, 123, lo1, hi1, xb[s], w[s]);
-						}
-						else
-						{
-							CRHIP_W2_TAP(120, 121, lo0, hi0, xa[s], w[s]);
-							if (pair)
-								CRHIP_W2_TAP(122, 123, lo1, hi1, xb[s], w[s]);
-						}
-					}
+					slot_taps(s, pair, xa[s], xb[s], w[s], lo0, hi0, lo1, hi1, lo2, hi2, lo3, hi3);
 				}
 			});
-#undef CRHIP_W2_TAP
-#undef CRHIP_W2_TAP_SIGNED
-#undef CRHIP_W2_TAP_FIRST
-#undef CRHIP_W2_TAP_MOV
-#undef CRHIP_W2_TAP_MOV_SAFE
-#undef CRHIP_W2_TAP_MOV_FIRST
-#undef CRHIP_W2_TAP_SIGNED_FIRST
 			(void)lo0;
 			(void)lo1;
 			(void)lo2;
@@ -768,6 +784,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wave2(const crhip_poly_launch a)
 		else
 			store_ints<CH, NT>(reinterpret_cast<int *>(a.d_out) + frame * CH, out);
 	};
+
 
 	if (global_wave >= n_chunks)
 	{

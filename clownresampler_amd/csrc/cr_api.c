@@ -940,6 +940,13 @@ cc_bool ClownResampler_HighLevel_Init(ClownResampler_HighLevel_State *resampler,
 	if (!ClownResampler_LowLevel_Init(&resampler->low_level, channels, input_sample_rate, output_sample_rate, low_pass_filter_sample_rate))
 		return cc_false;
 
+	/* A window wider than the reference's staging buffer: ClownResampler_HighLevel_Adjust refuses it (:1202), the reference's Init
+	   does not look - and its first refill then asks the input callback for (0x1000 - 2 * radius * channels) / channels frames, a
+	   negative count as a size_t, into a buffer with no room at all: undefined behaviour (found by tests/soak_gpu.py: 6 channels
+	   43 -> 3 Hz with a 1 Hz filter, 13 channels 192 -> 8 kHz at radius 8).  Here Init applies Adjust's rule and refuses. */
+	if (channels != 0 && resampler->low_level.lowest_level.integer_stretched_kernel_radius * 2 >= STAGING_SAMPLES / channels)
+		return cc_false;
+
 	/* the radius at Init is the largest this state will ever accept (:1109, :1195) */
 	resampler->maximum_integer_stretched_kernel_radius = resampler->low_level.lowest_level.integer_stretched_kernel_radius;
 	resampler->leading_padding_frames_needed = resampler->maximum_integer_stretched_kernel_radius;

@@ -618,14 +618,15 @@ constexpr bool padded_frames()
 // SPLIT > 1: a frame of CH * SPLIT channels is shared by SPLIT neighbouring lanes, each taking CH of them (`base` then
 // already points at the lane's share of the first frame); FS is the distance between consecutive frames.
 // PH: the frame has CH * SPLIT - 1 channels (k_poly's phantom channel): a lane's share then starts on any 2-byte boundary.
-template <int CH, int TT, int MODE, int SWZ, int SPLIT = 1, int PH = 0>
+// FORM: 0 in every shipped instance; timing-only forms of k_poly (its ABL >> 4): bit 0 = every lane the same window, bit 1 = every lane row 0
+template <int CH, int TT, int MODE, int SWZ, int SPLIT = 1, int PH = 0, int FORM = 0>
 __device__ __forceinline__ void fetch_frame(const crhip_poly_launch &a, const int *rows, const unsigned char *base, unsigned rel, FrameData<CH, TT> &d)
 {
 	constexpr unsigned FB = (CH * SPLIT - PH) * 2;
 	unsigned shift;
 	const unsigned row = row_of<MODE>(a, rel & 0xFFFFu, shift);
-	const unsigned phys = SWZ ? ((row & ~15u) | ((__umul24(row >> 4, a.swizzle) + row) & 15u)) : row;
-	const unsigned char *src = base + ((rel >> 16) + shift) * FB;
+	const unsigned phys = (FORM & 2) ? 0u : (SWZ ? ((row & ~15u) | ((__umul24(row >> 4, a.swizzle) + row) & 15u)) : row);
+	const unsigned char *src = (FORM & 1) ? base : base + ((rel >> 16) + shift) * FB;
 	const i32x4 *plane0 = reinterpret_cast<const i32x4 *>(rows) + phys;
 
 #pragma unroll

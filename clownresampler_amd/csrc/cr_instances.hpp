@@ -82,6 +82,7 @@ struct special
 	uint32_t mad_any_sign;                   // 1: the chain in mad[] is the any-sign form (ASM mode 3): no slot-sign precondition for the host to check
 	poly_fn mad_dual, mad_dual_rotated;      // stereo instances: mad[0] built with DUAL (a mono stream as two phase-aligned "channels", crhip_poly_launch.dual); nullptr if none
 	poly_fn wave2_dual;                      // ... and k_wave2 built with DUAL
+	poly_fn mad_forms[6];                    // -DCRA_WITH_W2_FORMS only: timing-only forms of the rotated-rows chain kernel of the headline instance (see add_mad_forms)
 	poly_fn wave2_forms[3];                  // -DCRA_WITH_W2_FORMS only: k_wave2's timing-only forms 1 ... 3 (ABL; results wrong); nullptr otherwise
 };
 
@@ -198,6 +199,18 @@ special make_special()
 	{
 		s.mad[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 1>;
 		s.mad_rotated[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 1, 0, 0, 1>;
+#ifdef CRA_WITH_W2_FORMS
+		if constexpr (CH == 2 && TT == 5)
+		{
+			// k_poly's ABL: + 16 window reads without conflicts, + 32 row reads without; low codes 1 = no stores, 3 = no stores and no DMA
+			s.mad_forms[0] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 1, 16, 0, 1>;
+			s.mad_forms[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 1, 32, 0, 1>;
+			s.mad_forms[2] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 1, 48, 0, 1>;
+			s.mad_forms[3] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 1, 64 + 3, 0, 1>;
+			s.mad_forms[4] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 1, 48 + 3, 0, 1>;
+			s.mad_forms[5] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 1, 64 + 1, 0, 1>;
+		}
+#endif
 		s.mad[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 0, 0>;
 		s.mad_rotated[1] = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 1, 0, 0, 0>;
 		s.mad16 = (poly_fn)k_poly<CH, TT, MODE, NORM, GEOMETRY[3].threads, GEOMETRY[3].vecs, (int)(2u | (UPMASK << 8)), 1, 0, 0, 1, 1>;

@@ -689,7 +689,11 @@ static poly_fn select_poly(const crhip_poly_launch *launch, uint32_t *geo)
 	{
 		*geo = sp->mad_any_sign ? sp->mad_geo : (sp->lite ? sp->lite_variant % 5u : 3u);
 		if (launch->swizzle != 0 && sp->mad_rotated[0] != nullptr)
+		{
+			if (launch->debug_form >= 1u && launch->debug_form <= 6u && !launch->out_s16 && v == MAD_VARIANT && sp->mad_forms[launch->debug_form - 1u] != nullptr)
+				return sp->mad_forms[launch->debug_form - 1u];   // (diagnostic build only)
 			return launch->out_s16 ? sp->mad16_rotated : sp->mad_rotated[v - MAD_VARIANT];
+		}
 		return launch->out_s16 ? sp->mad16 : sp->mad[v - MAD_VARIANT];
 	}
 

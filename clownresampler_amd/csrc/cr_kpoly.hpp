@@ -20,7 +20,9 @@ namespace
 // U         output frames a lane works on at once (independent instruction streams to cover LDS latency)
 // SWZ       1 = the LDS image of the rows is swizzled (a.swizzle), 0 = plain (a.swizzle must be 0)
 // ABL       0 in every shipped instance.  Timing-only ablations (WRONG results, reachable only through the debug
-//           launch flag of tools/): 1 = no output stores, 2 = no input DMA, 3 = neither, 4 = DMA + stores but no arithmetic
+//           launch flag of tools/): 1 = no output stores, 2 = no input DMA, 3 = neither, 4 = DMA + stores but no arithmetic;
+//           + 16 = every lane reads the window of the tile's first frame (window reads without bank conflicts), + 32 = every lane
+//           reads row 0 (row reads without) - the pipelined frames of the specialised instances only
 // OUT16     1 = clamp to +-0x7FFF and store int16 (opt-in extension), 0 = the reference's unclamped int32
 // NT        1 = non-temporal output stores
 // SPLIT     lanes per frame: CH is then the channels of ONE lane and a frame has CH * SPLIT channels (8-channel
@@ -48,6 +50,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 	constexpr bool PADL = PADT != 0;
 	static_assert(!PADL || (padded_frames<CH, TT, SPLIT, PH>() && !DUAL && ABL == 0), "padded tiles: the run-time-slot instances of 9-11 and 13-15 channels");
 
+	constexpr int ABL_LDS = ABL >> 4;   // (bits 4, 5: the LDS forms)
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 	const unsigned tid = threadIdx.x;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 		    __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)rec, 0x00020000);
 #pragma unroll
 		for (int v = 0; v < NV; ++v)
-			if (!(ABL == 2 || ABL == 3) || a.n_out == 1)
+			if (!((ABL & 15) == 2 || (ABL & 15) == 3) || a.n_out == 1)
 			__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(tile + (v * NTHREADS + wave_first) * 16u), 16,
 			                                         (int)((v * NTHREADS + tid) * 16u), 0, 0, 0);
 		return shift;
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 				else
 					one_frame<CH, TT, MODE, NORM, ASM, SWZ, SPLIT, PH, PADT>(a, rows, base, lane_rel + (first / SPLIT) * a.increment, outv + u * CH);
 			}
-			if constexpr (ABL == 1 || ABL == 3)
+			if constexpr ((ABL & 15) == 1 || (ABL & 15) == 3)
 			{
 				// keep the arithmetic alive without the stores (cdna_hip_programming.md rule 17)
 #pragma unroll
@@ -516,10 +519,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 			constexpr int G = decltype(groups_tag)::value;
 			constexpr int N = G * U;   // frames per lane in this tile
 
-			if constexpr (TT > 0 && (ABL == 0 || ABL == 6))
+			if constexpr (TT > 0 && (ABL == 0 || ABL == 6 || ABL >= 16))
 			{
 				FrameData<CH, TT> d[2];
-				fetch_frame<CH, TT, MODE, SWZ, SPLIT, PH>(a, rows, base, lane_rel, d[0]);
+				fetch_frame<CH, TT, MODE, SWZ, SPLIT, PH, ABL_LDS>(a, rows, base, lane_rel, d[0]);
 #pragma unroll
 				for (int i = 0; i < N; ++i)
 				{
@@ -529,12 +532,18 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_sgpr(CRHIP_SGPR
 					if (i + 1 < N)
 					{
 						const unsigned next_first = (unsigned)((i + 1) / U) * GROUP + (unsigned)((i + 1) % U) * NTHREADS;
-						fetch_frame<CH, TT, MODE, SWZ, SPLIT, PH>(a, rows, base, lane_rel + (next_first / SPLIT) * a.increment, d[(i + 1) & 1]);
+						fetch_frame<CH, TT, MODE, SWZ, SPLIT, PH, ABL_LDS>(a, rows, base, lane_rel + (next_first / SPLIT) * a.increment, d[(i + 1) & 1]);
 					}
 					__builtin_amdgcn_sched_barrier(0);   // keep the reads above the arithmetic below
 					compute_frame<CH, TT, NORM, ASM>(d[i & 1], outv);
 
-					if constexpr (DUAL)
+					if constexpr ((ABL & 15) == 1 || (ABL & 15) == 3)
+					{
+#pragma unroll
+						for (int c = 0; c < CH; ++c)
+							asm volatile("" ::"v"(outv[c]));
+					}
+					else if constexpr (DUAL)
 						store_dual(first, outv);
 					else if constexpr (PH)
 						store_phantom(first + tid, outv);

@@ -73,7 +73,7 @@ typedef struct crhip_poly_launch
 	uint32_t padded;
 	uint32_t dual;
 	uint32_t dual_out_frames, dual_valid_frames, dual_in_bytes;   /* (all below 2^32: the host launches at most 2^30 pairs) */
-	uint32_t debug_form;        /* 0; k_wave2 in a -DCRA_WITH_W2_FORMS build: 1 ... 3 = its timing-only forms (results wrong) */
+	uint32_t debug_form;        /* 0; in a -DCRA_WITH_W2_FORMS build: timing-only forms (results wrong) of k_wave2 (1 ... 3) and of the headline k_poly (1 ... 6) */
 } crhip_poly_launch;
 
 /* One launch of the generic kernel: the reference arithmetic restated with 64-bit integers, one thread per

@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Randomised soak of the product against the oracle on a GPU box (test infrastructure; `tests/test_gpu_parity.py::test_soak_short`
+runs a fixed-seed minute of it, `python tests/soak_gpu.py --seconds 600` as long as one likes).
+
+Every trial draws a configuration the fixed case list of tests/_cases.py cannot cover by enumeration - any radius built, 1 ... 16
+channels, common and arbitrary rate triples (refused ones included: both sides must refuse), lengths from 0 frames to a few million
+(the host's kernel choice depends on the LENGTH of a launch: k_seg, dual mono, the brief-launch kernels and the small-call path all
+have thresholds), every input kind - and plays it through one of the entry points: one bulk call, chunks with a carried state, a
+consumer that stops, the high-level streaming API with an arbitrary pull size, the clamped int16 output.  Bit-exact or it is a
+failure, printed as a JSON case that `run_case` replays."""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+for p in (HERE, os.path.dirname(HERE)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+import _checkers  # noqa: E402
+from _cases import run_case  # noqa: E402
+from _product import Product  # noqa: E402
+
+COMMON = [8000, 11025, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000, 176400, 192000]
+KERNELS = ["k_generic", "k_poly", "k_wave", "k_up2", "k_wave2", "k_int", "k_wave2s", "(of which ticketed)", "k_seg"]
+
+
+FOCUS = [(8000, 96000), (8000, 64000), (8000, 48000), (11025, 96000), (8000, 44100), (44100, 48000), (48000, 44100), (8000, 88200),
+         (16000, 96000), (8000, 36000), (6000, 96000), (8000, 128000), (44100, 8000), (48000, 8000), (48000, 24000), (48000, 32000)]
+
+
+def draw_focus_case(rng):
+    """Long mono / stereo launches at the ratios whose kernels only LONG launches reach: k_seg (its last block of 64 segments may waste
+    6 % at most: lengths just under a whole number of blocks), k_up2, dual mono, the periodic k_int shapes."""
+    radius = rng.choice([8, 8, 8, 3])
+    ch = rng.choice([1, 2, 2])
+    i, o = rng.choice(FOCUS)
+    increment = (i << 16) // o
+    out_frames = int(10 ** rng.uniform(5.8, 7.1))
+    if rng.random() < 0.6 and 4096 <= increment < 65536:
+        import math
+        seg = max(65536 // math.gcd(increment, 65536), 1024)
+        blocks = rng.choice([1, 1, 2, 3]) if seg >= 16384 else rng.randint(2, 200)
+        out_frames = int(blocks * 64 * seg * rng.uniform(0.945, 1.0))
+    frames = min(max(1000, out_frames * increment >> 16), 6000000)
+    est = frames * max(o / i, 1e-3) * ch * (2 * radius * max(i / o, 1.0) + 1)
+    while est > 2.5e9:
+        frames //= 2
+        est /= 2
+    mode = rng.choice(["device", "device", "device", "device2", "low", "chunked", "s16"])
+    case = {"channels": ch, "rates": [i, o, min(i, o)], "radius": radius, "frames": frames, "input": rng.choice(["noise", "noise", "square", "min"]),
+            "seed": rng.randint(1, 1 << 30), "mode": "low", "focus": True}
+    if mode in ("device", "device2"):
+        # ONE ClownResamplerAMD_ResampleDevice call over the whole device-resident stream (the host-pointer entry points cut a call into
+        # 4 Mi-frame batches, which never reach k_seg / k_up2 / dual mono); "device2": stopped by the output capacity, then continued
+        case["device"] = 2 if mode == "device2" else 1
+        case["split"] = rng.uniform(0.05, 0.95)
+    elif mode == "chunked":
+        case["mode"] = "chunked"
+        case["chunks"] = [max(frames // rng.randint(2, 6), 1), max(frames // rng.randint(3, 40), 1)]
+    elif mode == "s16":
+        case["s16"] = True
+    return case
+
+
+def draw_case(rng, big_budget):
+    if big_budget and rng.random() < 0.05:
+        return draw_focus_case(rng)
+    radius = rng.choice([3, 3, 5, 8, 8])
+    ch = rng.choice([1, 1, 2, 2, 2, 2, 3, 4, 5, 6, 7, 8, rng.randint(9, 16)])
+    kind = rng.random()
+    if kind < 0.55:
+        i, o = rng.choice(COMMON), rng.choice(COMMON)
+    elif kind < 0.8:
+        i, o = rng.randint(4000, 200000), rng.randint(4000, 200000)
+    else:   # small integers: exact periodic ratios (k_int), extreme ones, refused ones
+        i, o = rng.randint(1, 64), rng.randint(1, 64)
+    lp = min(i, o) if rng.random() < 0.7 else max(1, int(min(i, o) * rng.uniform(0.3, 1.0)))
+    if rng.random() < 0.03:
+        lp = rng.choice([0, 1, max(i, o) * 2])
+    size = rng.random()
+    if size < 0.15:
+        frames = rng.randint(0, 300)
+    elif size < 0.75:
+        frames = int(10 ** rng.uniform(2.5, 5.3))
+    elif size < 0.93 or not big_budget:
+        frames = int(10 ** rng.uniform(5.3, 6.2))
+    else:
+        frames = int(10 ** rng.uniform(6.2, 6.9))
+    # keep the oracle's share of a trial bounded: output samples x taps
+    est = frames * max(o / max(i, 1), 1e-3) * ch * (2 * radius * max(i / max(o, 1), 1.0) + 1)
+    while est > 6e8 and frames > 1000:
+        frames //= 2
+        est /= 2
+    mode = rng.choice(["low", "low", "low", "chunked", "earlystop", "high", "s16"])
+    case = {"channels": ch, "rates": [i, o, lp], "radius": radius, "frames": frames,
+            "input": rng.choice(["noise", "noise", "noise", "noise", "square", "min", "max", "ramp", "impulse"]), "seed": rng.randint(1, 1 << 30)}
+    if mode == "chunked":
+        case["mode"] = "chunked"
+        case["chunks"] = [max(1, int(10 ** rng.uniform(0, 5))) for _ in range(rng.randint(1, 5))]
+        if frames / min(case["chunks"]) > 3000:
+            case["chunks"] = [max(c, frames // 2000 + 1) for c in case["chunks"]]
+    elif mode == "earlystop":
+        case["mode"] = "earlystop"
+        case["stop_every"] = max(1, int(10 ** rng.uniform(0, 5)))
+        out_frames = frames * o / max(i, 1)
+        if out_frames / case["stop_every"] > 2000:
+            case["stop_every"] = int(out_frames // 1500 + 1)
+    elif mode == "high":
+        case["mode"] = "high"
+        case["pull_chunk"] = rng.choice([0, 0, 1, 7, 256, 4096, 100000])
+        if frames > 400000:
+            case["frames"] = frames = rng.randint(1000, 400000)   # (the high-level API delivers frame by frame through a callback)
+    elif mode == "s16":
+        case["mode"] = "low"
+        case["s16"] = True
+    else:
+        case["mode"] = "low"
+    return case
+
+
+def run_trial(products, oracles, case):
+    """None when product and oracle agree (or both refuse), else a description of the difference."""
+    radius, ch, rates = case["radius"], case["channels"], case["rates"]
+    prod, orc = products[radius], oracles[radius]
+    ok_o, _ = orc.low_init(ch, *rates)
+    ok_p, _ = prod.low_init(ch, *rates)
+    if bool(ok_o) != bool(ok_p):
+        return "Init: oracle %s, product %s" % (ok_o, ok_p)
+    if not ok_o:
+        return None
+    if case["mode"] == "high":
+        # a window wider than the reference's 0x1000-sample staging buffer: the reference's Init accepts it and then overruns the buffer
+        # (undefined: clownresampler.h:1154 with the subtraction negative); the product's Init refuses, by the rule of :1202
+        _, so = orc.low_init(ch, *rates)
+        if int(so.cfg.radius_frames) * 2 >= 0x1000 // ch:
+            ok_h, _ = prod.high_init(ch, *rates)
+            return None if not ok_h else "HighLevel_Init accepted a window wider than the staging buffer"
+    if case.get("device"):
+        from _cases import make_input
+        from _checkers import count_output_frames, pad_frames
+        api = prod.api
+        pcm = make_input(case)
+        frames = len(pcm) // ch
+        _, so = orc.low_init(ch, *rates)
+        _, sp = prod.low_init(ch, *rates)
+        padded = pad_frames(pcm, ch, int(so.cfg.radius_frames))
+        want = orc.low_resample_i32_mt(so, padded, frames, threads=min(32, os.cpu_count() or 1))
+        total = want.size // ch
+        d_in = api.DeviceAlloc(padded.nbytes + 64)
+        d_out = api.DeviceAlloc(want.nbytes + 64)
+        try:
+            api.CopyToDevice(d_in, padded)
+            plan = api.PlanCreate(sp.raw, prod.pre)
+            if case["device"] == 1 or total < 2:
+                n, left, ran_out = api.ResampleDevice(plan, sp.raw, d_in, frames, d_out, total + 1)
+                api.StreamSynchronize()
+                if (n, left, ran_out) != (total, 0, 1):
+                    return "ResampleDevice returned %s, expected (%d, 0, 1)" % ((n, left, ran_out), total)
+            else:
+                # stopped by the capacity after `first` frames (clownresampler.h:1085-1088: the frames not yet consumed come back), then the rest
+                first = max(1, min(total - 1, int(total * case["split"])))
+                n1, left1, ran1 = api.ResampleDevice(plan, sp.raw, d_in, frames, d_out, first)
+                api.StreamSynchronize()
+                if n1 != first or ran1 != 0:
+                    return "first ResampleDevice call returned %s" % ((n1, left1, ran1),)
+                consumed = frames - left1
+                n2, left2, ran2 = api.ResampleDevice(plan, sp.raw, d_in + consumed * ch * 2, left1, d_out + first * ch * 4, total - first + 1)
+                api.StreamSynchronize()
+                if (n1 + n2, left2, ran2) != (total, 0, 1):
+                    return "two ResampleDevice calls returned %s + %s, expected %d frames" % ((n1, left1, ran1), (n2, left2, ran2), total)
+            got = np.empty_like(want)
+            api.CopyFromDevice(got, d_out)
+        finally:
+            api.DeviceFree(d_in)
+            api.DeviceFree(d_out)
+        if not np.array_equal(got, want):
+            d = np.flatnonzero(got != want)
+            return "%d samples differ, first at %d (frame %d): oracle %d, product %d" % (d.size, d[0], d[0] // ch, want[d[0]], got[d[0]])
+        end = total * int(so.increment)
+        if (int(sp.pos_int), int(sp.pos_frac)) != ((end >> 16) - frames, end & 0xFFFF):
+            return "final state %s" % ((int(sp.pos_int), int(sp.pos_frac)),)
+        return None
+    if case.get("s16"):
+        # the clamped int16 output (examples/low-level.c:69-80 fused in): the oracle's int32 stream clamped the same way
+        from _cases import make_input
+        from _checkers import pad_frames
+        pcm = make_input(case)
+        frames = len(pcm) // ch
+        _, so = orc.low_init(ch, *rates)
+        _, sp = prod.low_init(ch, *rates)
+        padded = pad_frames(pcm, ch, int(so.cfg.radius_frames))
+        want, left_o, ran_o = orc.low_resample_i32(so, padded, frames)
+        got, left_p, ran_p = prod.api.LowLevel_ResampleBulkS16(sp.raw, prod.pre, padded, frames)
+        want16 = np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16)
+        if got.size != want16.size or not np.array_equal(got, want16):
+            return "int16 output differs (%d against %d samples)" % (got.size, want16.size)
+        if (left_o, ran_o) != (left_p, ran_p) or so.astuple() != sp.astuple():
+            return "int16 call: state or return values differ"
+        return None
+    a = run_case(orc, case, keep_output=True)
+    b = run_case(prod, case, keep_output=True)
+    if a["frames"] != b["frames"]:
+        return "frames: oracle %d, product %d" % (a["frames"], b["frames"])
+    if not np.array_equal(a["_out"], b["_out"]):
+        d = np.flatnonzero(a["_out"] != b["_out"])
+        return "%d samples differ, first at %d (frame %d): oracle %d, product %d" % (d.size, d[0], d[0] // ch, a["_out"][d[0]], b["_out"][d[0]])
+    if a["state"] != b["state"]:
+        return "final state: oracle %s, product %s" % (a["state"], b["state"])
+    return None
+
+
+def soak(seconds, seed, big_budget=True, log=print, max_trials=None, trace=None):
+    rng = random.Random(seed)
+    products = {r: Product(r) for r in (3, 5, 8)}
+    oracles = {r: _checkers.oracle(r) for r in (3, 5, 8)}
+    api = products[3].api
+    start_counts = [api.LaunchCount(k) for k in range(len(KERNELS))]
+    t0 = time.time()
+    trials = failures = 0
+    by_mode = {}
+    while time.time() - t0 < seconds and (max_trials is None or trials < max_trials):
+        case = draw_case(rng, big_budget)
+        trials += 1
+        if trace is not None:   # (written BEFORE the trial: a crash of the process leaves its case as the last line)
+            trace.write("%d %s\n" % (trials, json.dumps(case)))
+            trace.flush()
+        key = "device" if case.get("device") else "s16" if case.get("s16") else case["mode"]
+        by_mode[key] = by_mode.get(key, 0) + 1
+        try:
+            diff = run_trial(products, oracles, case)
+        except Exception as e:   # an error report from the library is a finding too
+            diff = "exception: %r" % (e,)
+        if diff is not None:
+            failures += 1
+            log("FAIL trial %d: %s\n  case %s" % (trials, diff, json.dumps(case)))
+    counts = [api.LaunchCount(k) - s for k, s in enumerate(start_counts)]
+    log("soak: seed %d, %d trials in %.0f s, %d failure(s); by entry point %s; launches by kernel %s" % (
+        seed, trials, time.time() - t0, failures, by_mode, {KERNELS[k]: c for k, c in enumerate(counts) if c}))
+    return trials, failures
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-big", action="store_true", help="no multi-million-frame trials")
+    ap.add_argument("--trace", default="", help="file that receives every case before it runs")
+    ap.add_argument("--replay", default="", help="a JSON case (as printed) to run once instead of the soak")
+    args = ap.parse_args()
+    _checkers.build_checkers()
+    if args.replay:
+        case = json.loads(args.replay)
+        diff = run_trial({case["radius"]: Product(case["radius"])}, {case["radius"]: _checkers.oracle(case["radius"])}, case)
+        print("replay:", diff or "agrees")
+        sys.exit(1 if diff else 0)
+    trials, failures = soak(args.seconds, args.seed, not args.no_big, trace=open(args.trace, "w") if args.trace else None)
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -1960,3 +1960,14 @@ def test_chain_taps_at_the_sample_range_limits(products):
         xa, la, ra = p.low_resample_i32(a, padded[cut * ch:], frames - cut)
         xb, lb, rb = o.low_resample_i32(b, padded[cut * ch:], frames - cut)
         assert np.array_equal(xa, xb) and (la, ra) == (lb, rb) and a.astuple() == b.astuple(), (ch, i, out, frames)
+
+
+@pytest.mark.gpu
+def test_soak_short():
+    """A fixed-seed minute of tests/soak_gpu.py: random radius / channels / rate triples / lengths / entry points against the oracle,
+    bit-exact (the thresholds of the host's kernel choice depend on a launch's length: enumeration cannot cover them)."""
+    import soak_gpu
+    lines = []
+    trials, failures = soak_gpu.soak(45.0, 20261003, big_budget=True, log=lines.append)
+    assert failures == 0, "\n".join(lines)
+    assert trials >= 20, lines

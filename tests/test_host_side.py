@@ -373,6 +373,29 @@ def test_resample_fails_loudly_without_a_device():
         p.high_run_i32(hs, ck.noise_pcm(200))
 
 
+def test_highlevel_init_refuses_a_window_wider_than_the_staging_buffer():
+    """The reference's HighLevel_Init accepts any radius; with 2 * radius * channels beyond its 0x1000-sample staging buffer its first
+    refill asks the callback for a negative count of frames (clownresampler.h:1154) - undefined behaviour, found by tests/soak_gpu.py as
+    heap corruption in THIS library, which sized its window by the same subtraction.  The product applies HighLevel_Adjust's rule
+    (clownresampler.h:1202) at Init: refused, no error report, nothing allocated; the widest window that fits is still accepted."""
+    p = _product.Product(8)
+    for ch, rates in ((6, (43, 3, 1)), (13, (192000, 8000, 8000)), (16, (48000, 3000, 3000)), (1, (64000, 1, 1))):
+        ok, _ = p.low_init(ch, *rates)
+        if not ok:
+            continue   # (refused by the low level already)
+        st = p.api.LowLevel_State()
+        p.api.LowLevel_Init(st, ch, *rates)
+        radius = st.lowest_level.integer_stretched_kernel_radius
+        assert radius * 2 >= 0x1000 // ch, (ch, rates, radius)
+        ok, _ = p.high_init(ch, *rates)
+        assert not ok and p.api.lib.ClownResamplerAMD_LastErrorCode() == 0, (ch, rates)
+    # 2 channels 48 kHz -> 375 Hz at radius 8: 1024 frames of radius, 2 * 1024 * 2 = 0x1000 exactly: refused; one step milder: accepted
+    assert not p.high_init(2, 48000, 375, 375)[0]
+    ok, st = p.high_init(2, 48000, 376, 376)
+    assert ok and st.max_radius_frames * 2 < 0x1000 // 2
+    p.api.HighLevel_Release(st.raw)
+
+
 def test_is_usable_answers_without_a_device(tmp_path):
     """ClownResamplerAMD_IsUsable: the question a drop-in client asks once at start-up - 0 here, where there is no GPU,
     without an error report and, in a plain C client with the DEFAULT (aborting) error handler installed, without an abort - so that the

@@ -974,7 +974,12 @@ cc_bool ClownResampler_HighLevel_Init(ClownResampler_HighLevel_State *resampler,
 	return cc_true;
 }
 
-cc_bool ClownResampler_HighLevel_Resample(ClownResampler_HighLevel_State *resampler, const ClownResampler_Precomputed *precomputed, ClownResampler_InputCallback input_callback, ClownResampler_OutputCallback output_callback, const void *user_data)
+/* reference_schedule: refill with ONE pull of the reference's size, as the reference does (:1154) - for ClownResampler_HighLevel_ResampleEnd,
+   whose input callback is the library's own and counts trailing_padding_frames_remaining down in the caller's state: with a read-ahead
+   window a flush stopped by the consumer would otherwise have taken more of the padding than the reference's (radius 145, 11 channels:
+   82 frames per pull - the reference's state says 63 left where one big refill said 0; found by tests/soak_gpu.py).  A flush is at
+   most `radius` frames: nothing to read ahead for. */
+static cc_bool high_level_resample(ClownResampler_HighLevel_State *resampler, const ClownResampler_Precomputed *precomputed, ClownResampler_InputCallback input_callback, ClownResampler_OutputCallback output_callback, const void *user_data, int reference_schedule)
 {
 	const size_t channels = resampler->low_level.channels;
 	const size_t halo_samples = resampler->maximum_integer_stretched_kernel_radius * channels;
@@ -1015,7 +1020,7 @@ cc_bool ClownResampler_HighLevel_Resample(ClownResampler_HighLevel_State *resamp
 
 			if (limit > cr_stream_max_frames())
 				limit = cr_stream_max_frames();
-			if (limit < one_pull)
+			if (limit < one_pull || reference_schedule)
 				limit = one_pull;
 
 			memmove(stream->window, stream->window + stream->end - halo_samples, 2 * halo_samples * sizeof(stream->window[0]));
@@ -1102,6 +1107,11 @@ cc_bool ClownResampler_HighLevel_Resample(ClownResampler_HighLevel_State *resamp
 	return cc_false;
 }
 
+cc_bool ClownResampler_HighLevel_Resample(ClownResampler_HighLevel_State *resampler, const ClownResampler_Precomputed *precomputed, ClownResampler_InputCallback input_callback, ClownResampler_OutputCallback output_callback, const void *user_data)
+{
+	return high_level_resample(resampler, precomputed, input_callback, output_callback, user_data, 0);
+}
+
 #ifndef CLOWNRESAMPLER_NO_HIGH_LEVEL_ADJUST
 cc_bool ClownResampler_HighLevel_Adjust(ClownResampler_HighLevel_State *resampler, cc_u32f input_sample_rate, cc_u32f output_sample_rate, cc_u32f low_pass_filter_sample_rate)
 {
@@ -1156,7 +1166,7 @@ cc_bool ClownResampler_HighLevel_ResampleEnd(ClownResampler_HighLevel_State *res
 	context.output_callback = output_callback;
 	context.user_data = (void *)user_data;
 
-	return ClownResampler_HighLevel_Resample(resampler, precomputed, drain_input, drain_output, &context);
+	return high_level_resample(resampler, precomputed, drain_input, drain_output, &context, 1);
 }
 #endif
 

@@ -70,10 +70,12 @@ def make_script(seed, radius, max_out_frames=30000):
 def usable(script, oracle):
     """the configurations the reference itself handles: Init accepted, a table step, and halos that fit its 0x1000-sample staging
     buffer (beyond that the REFERENCE overruns its own buffer, :1112, :1154)"""
-    ok, st = oracle.high_init(script["channels"], *script["first"])
-    if not ok or st.low.cfg.table_step == 0:
+    # (the LOW-level Init answers both questions: the reference's high-level Init of a window wider than its staging buffer already
+    # writes beyond it - :1112 zeroes radius * channels samples - and the oracle restates it faithfully)
+    ok, low = oracle.low_init(script["channels"], *script["first"])
+    if not ok or low.cfg.table_step == 0:
         return False
-    if 2 * int(st.low.cfg.radius_frames) * script["channels"] >= 0x1000 - script["channels"]:
+    if 2 * int(low.cfg.radius_frames) * script["channels"] >= 0x1000 - script["channels"]:
         return False
     # bound the work: the per-frame Python callback is the slow part
     worst_ratio = max(RATES) / min(RATES)

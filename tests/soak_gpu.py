@@ -34,10 +34,10 @@ FOCUS = [(8000, 96000), (8000, 64000), (8000, 48000), (11025, 96000), (8000, 441
          (16000, 96000), (8000, 36000), (6000, 96000), (8000, 128000), (44100, 8000), (48000, 8000), (48000, 24000), (48000, 32000)]
 
 
-def draw_focus_case(rng):
+def draw_focus_case(rng, radii=(3, 5, 8)):
     """Long mono / stereo launches at the ratios whose kernels only LONG launches reach: k_seg (its last block of 64 segments may waste
     6 % at most: lengths just under a whole number of blocks), k_up2, dual mono, the periodic k_int shapes."""
-    radius = rng.choice([8, 8, 8, 3])
+    radius = rng.choice([r for r in (8, 8, 8, 3) if r in radii] or list(radii))
     ch = rng.choice([1, 2, 2])
     i, o = rng.choice(FOCUS)
     increment = (i << 16) // o
@@ -68,10 +68,14 @@ def draw_focus_case(rng):
     return case
 
 
-def draw_case(rng, big_budget):
+def draw_case(rng, big_budget, radii=(3, 5, 8)):
     if big_budget and rng.random() < 0.05:
-        return draw_focus_case(rng)
-    radius = rng.choice([3, 3, 5, 8, 8])
+        return draw_focus_case(rng, radii)
+    if rng.random() < 0.04:
+        # a scripted high-level session with Adjusts between the calls (tests/_scripts.py), at one of the streaming windows
+        return {"mode": "script", "radius": rng.choice(list(radii)), "seed": rng.randint(1, 1 << 30), "window": rng.choice([0, 0, 5000, 1 << 18]),
+                "channels": 0, "rates": [0, 0, 0], "frames": 0, "input": "noise"}
+    radius = rng.choice([r for r in (3, 3, 5, 8, 8) if r in radii])
     ch = rng.choice([1, 1, 2, 2, 2, 2, 3, 4, 5, 6, 7, 8, rng.randint(9, 16)])
     kind = rng.random()
     if kind < 0.55:
@@ -128,6 +132,20 @@ def run_trial(products, oracles, case):
     """None when product and oracle agree (or both refuse), else a description of the difference."""
     radius, ch, rates = case["radius"], case["channels"], case["rates"]
     prod, orc = products[radius], oracles[radius]
+    if case["mode"] == "script":
+        import _scripts
+        script = _scripts.make_script(case["seed"], radius)
+        if not _scripts.usable(script, orc):
+            return None
+        prod.api.SetStreamingWindow(case["window"])
+        try:
+            # (a flush while the source still has frames only with the reference's own window: _scripts.play)
+            a = _scripts.play(prod, script, early_end=case["window"] == 0)
+        finally:
+            prod.api.SetStreamingWindow(1 << 18)
+        b = _scripts.play(orc, script, early_end=case["window"] == 0)
+        d = _scripts.first_difference(a, b)
+        return None if d is None else "scripted session differs: %s" % (d,)
     ok_o, _ = orc.low_init(ch, *rates)
     ok_p, _ = prod.low_init(ch, *rates)
     if bool(ok_o) != bool(ok_p):
@@ -215,17 +233,17 @@ def run_trial(products, oracles, case):
     return None
 
 
-def soak(seconds, seed, big_budget=True, log=print, max_trials=None, trace=None):
+def soak(seconds, seed, big_budget=True, log=print, max_trials=None, trace=None, radii=(3, 5, 8)):
     rng = random.Random(seed)
-    products = {r: Product(r) for r in (3, 5, 8)}
-    oracles = {r: _checkers.oracle(r) for r in (3, 5, 8)}
-    api = products[3].api
+    products = {r: Product(r) for r in radii}
+    oracles = {r: _checkers.oracle(r) for r in radii}
+    api = products[radii[0]].api
     start_counts = [api.LaunchCount(k) for k in range(len(KERNELS))]
     t0 = time.time()
     trials = failures = 0
     by_mode = {}
     while time.time() - t0 < seconds and (max_trials is None or trials < max_trials):
-        case = draw_case(rng, big_budget)
+        case = draw_case(rng, big_budget, radii)
         trials += 1
         if trace is not None:   # (written BEFORE the trial: a crash of the process leaves its case as the last line)
             trace.write("%d %s\n" % (trials, json.dumps(case)))
@@ -250,6 +268,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-big", action="store_true", help="no multi-million-frame trials")
+    ap.add_argument("--radii", default="3,5,8", help="the radii the library under test was built for")
     ap.add_argument("--trace", default="", help="file that receives every case before it runs")
     ap.add_argument("--replay", default="", help="a JSON case (as printed) to run once instead of the soak")
     args = ap.parse_args()
@@ -259,7 +278,8 @@ def main():
         diff = run_trial({case["radius"]: Product(case["radius"])}, {case["radius"]: _checkers.oracle(case["radius"])}, case)
         print("replay:", diff or "agrees")
         sys.exit(1 if diff else 0)
-    trials, failures = soak(args.seconds, args.seed, not args.no_big, trace=open(args.trace, "w") if args.trace else None)
+    trials, failures = soak(args.seconds, args.seed, not args.no_big, trace=open(args.trace, "w") if args.trace else None,
+                            radii=tuple(int(r) for r in args.radii.split(",")))
     sys.exit(1 if failures else 0)
 
 

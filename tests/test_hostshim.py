@@ -55,3 +55,19 @@ def test_fake_seam_is_not_in_the_product():
     assert "crhip_fake" not in out and "oracle_" not in out
     out = subprocess.run(["nm", cr.LIB_PATH], capture_output=True, text=True).stdout
     assert "crhip_fake_launches" not in out and "oracle_frame" not in out
+
+
+def test_soak_through_the_python_mirror_under_address_sanitizer(drivers):
+    """tests/soak_gpu.py (the randomised soak the GPU box runs against the real kernels) pointed at the sanitizer build of the fake-seam
+    library through the ctypes mirror: every entry point's HOST logic - timeline walk, 4 Mi batching, states, callbacks, streaming
+    windows, scripted high-level sessions with Adjusts - on random configurations, under AddressSanitizer, a minute of it.  (Round 5:
+    this is how the high-level flush's pull schedule and the too-wide staging window were debugged without a GPU.)"""
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
+    env = dict(os.environ)
+    env.update({"CLOWNRESAMPLER_AMD_LIBRARY": os.path.join(BUILD, "libcr_hostshim_asan.so"), "LD_PRELOAD": asan, "ASAN_OPTIONS": "detect_leaks=0",
+                "CRA_FAKE_DEVICES": "1", "PYTHONPATH": ROOT + os.pathsep + os.path.join(ROOT, "tests")})
+    r = subprocess.run(["python3", os.path.join(ROOT, "tests", "soak_gpu.py"), "--seconds", "50", "--seed", "5", "--radii", "3,8", "--no-big"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    tail = (r.stdout + r.stderr)[-4000:]
+    assert r.returncode == 0 and " 0 failure(s)" in r.stdout, tail
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, tail

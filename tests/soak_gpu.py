@@ -101,7 +101,7 @@ def draw_case(rng, big_budget, radii=(3, 5, 8)):
     while est > 6e8 and frames > 1000:
         frames //= 2
         est /= 2
-    mode = rng.choice(["low", "low", "low", "chunked", "earlystop", "high", "s16"])
+    mode = rng.choice(["low", "low", "low", "chunked", "earlystop", "high", "s16", "callback"])
     case = {"channels": ch, "rates": [i, o, lp], "radius": radius, "frames": frames,
             "input": rng.choice(["noise", "noise", "noise", "noise", "square", "min", "max", "ramp", "impulse"]), "seed": rng.randint(1, 1 << 30)}
     if mode == "chunked":
@@ -123,6 +123,14 @@ def draw_case(rng, big_budget, radii=(3, 5, 8)):
     elif mode == "s16":
         case["mode"] = "low"
         case["s16"] = True
+    elif mode == "callback":
+        # ClownResampler_LowLevel_Resample, the reference's callback signature, the consumer stopping after `budgets` frames in turn and
+        # the caller resuming behind the frames that were consumed (clownresampler.h:1058-1092; examples/low-level.c:87-102)
+        case["mode"] = "callback"
+        out_frames = frames * o / max(i, 1)
+        if out_frames > 60000:
+            case["frames"] = frames = max(1, int(frames * 60000 / out_frames))
+        case["budgets"] = [max(1, int(10 ** rng.uniform(0, 4.5))) for _ in range(rng.randint(1, 6))]
     else:
         case["mode"] = "low"
     return case
@@ -203,6 +211,38 @@ def run_trial(products, oracles, case):
         end = total * int(so.increment)
         if (int(sp.pos_int), int(sp.pos_frac)) != ((end >> 16) - frames, end & 0xFFFF):
             return "final state %s" % ((int(sp.pos_int), int(sp.pos_frac)),)
+        return None
+    if case["mode"] == "callback":
+        from _cases import make_input
+        from _checkers import pad_frames
+        pcm = make_input(case)
+        frames = len(pcm) // ch
+        results = []
+        for engine in (orc, prod):
+            _, st = engine.low_init(ch, *rates)
+            padded = pad_frames(pcm, ch, int(st.cfg.radius_frames))
+            out, calls = [], []
+            pos, left, k = 0, frames, 0
+            while True:
+                budget = [case["budgets"][k % len(case["budgets"])]]
+                k += 1
+
+                def emit(frame):
+                    out.extend(frame)
+                    budget[0] -= 1
+                    return budget[0] > 0
+
+                before = left
+                r, left = engine.low_resample_cb(st, padded[pos * ch:], left, emit)
+                pos += before - left
+                calls.append((int(bool(r)), int(left)))
+                if r or k > 200000:
+                    break
+            results.append((out, calls, tuple(int(v) for v in st.astuple())))
+        if results[0][0] != results[1][0]:
+            return "callback API: frames differ (%d against %d samples)" % (len(results[0][0]), len(results[1][0]))
+        if results[0][1:] != results[1][1:]:
+            return "callback API: return values or state differ: oracle %s, product %s" % (results[0][1:][-1], results[1][1:][-1])
         return None
     if case.get("s16"):
         # the clamped int16 output (examples/low-level.c:69-80 fused in): the oracle's int32 stream clamped the same way

@@ -71,6 +71,20 @@ def draw_focus_case(rng, radii=(3, 5, 8)):
 def draw_case(rng, big_budget, radii=(3, 5, 8)):
     if big_budget and rng.random() < 0.05:
         return draw_focus_case(rng, radii)
+    if rng.random() < 0.03:
+        # variable rate on the device: a list of constant-rate segments over ONE device-resident timeline
+        # (ClownResamplerAMD_ResampleSegmentsDevice = Adjust + a low-level call per chunk in the reference, clownresampler.h:1052-1056)
+        radius = rng.choice(list(radii))
+        segs = []
+        for _ in range(rng.randint(1, 40)):
+            n = rng.choice([0, 1, 2, rng.randint(1, 200), int(10 ** rng.uniform(2, 4.6))])
+            if rng.random() < 0.6:
+                i, o = rng.choice(COMMON), rng.choice(COMMON)
+            else:
+                i, o = rng.randint(4000, 200000), rng.randint(4000, 200000)
+            segs.append([n, i, o, min(i, o) if rng.random() < 0.7 else max(1, int(min(i, o) * rng.uniform(0.4, 1.0)))])
+        return {"mode": "segments", "radius": radius, "channels": rng.choice([1, 2, 2, 3, 5, 8, 12]), "segments": segs, "s16": rng.random() < 0.25,
+                "segments_mode": rng.choice([0, 0, 1, 2]), "rates": segs[0][1:], "frames": sum(x[0] for x in segs), "input": "noise", "seed": rng.randint(1, 1 << 30)}
     if rng.random() < 0.04:
         # a scripted high-level session with Adjusts between the calls (tests/_scripts.py), at one of the streaming windows
         return {"mode": "script", "radius": rng.choice(list(radii)), "seed": rng.randint(1, 1 << 30), "window": rng.choice([0, 0, 5000, 1 << 18]),
@@ -140,6 +154,57 @@ def run_trial(products, oracles, case):
     """None when product and oracle agree (or both refuse), else a description of the difference."""
     radius, ch, rates = case["radius"], case["channels"], case["rates"]
     prod, orc = products[radius], oracles[radius]
+    if case["mode"] == "segments":
+        from _checkers import noise_pcm, pad_frames
+        api = prod.api
+        segments = [tuple(x) for x in case["segments"]]
+        # every segment's triple must be one the reference accepts; the halo is the widest radius among them
+        halo = 0
+        for n, *r3 in segments:
+            ok, st = orc.low_init(ch, *r3)
+            if not ok or int(st.cfg.table_step) == 0:
+                return None
+            halo = max(halo, int(st.cfg.radius_frames))
+        frames = case["frames"]
+        pcm = noise_pcm(max(frames, 1) * ch, case["seed"])[: frames * ch]
+        padded = pad_frames(pcm, ch, halo)
+        _, so = orc.low_init(ch, *segments[0][1:])
+        pos, outs, want_counts = 0, [], []
+        for n, *r3 in segments:
+            if not orc.low_adjust(so, *r3):
+                return None
+            R = int(so.cfg.radius_frames)
+            x, left, ran_out = orc.low_resample_i32(so, padded[(pos + halo - R) * ch:], n)
+            outs.append(np.array(x, dtype=np.int32))
+            want_counts.append(len(x) // ch)
+            pos += n
+        want = np.concatenate(outs) if outs else np.zeros(0, dtype=np.int32)
+        if case.get("s16"):
+            want = np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16)
+        sp = api.LowLevel_State()
+        api.LowLevel_Init(sp, ch, *segments[0][1:])
+        d_in = api.DeviceAlloc(padded.nbytes + 64)
+        d_out = api.DeviceAlloc(want.nbytes + 64)
+        api.DebugSegmentsMode(case.get("segments_mode", 0))
+        try:
+            api.CopyToDevice(d_in, padded)
+            n, counts = api.ResampleSegmentsDevice(sp, prod.pre, d_in + halo * ch * 2, halo, segments, d_out, max(want.size // ch, 1), s16=bool(case.get("s16")))
+            api.StreamSynchronize()
+            got = np.empty_like(want)
+            if want.size:
+                api.CopyFromDevice(got, d_out)
+        finally:
+            api.DebugSegmentsMode(0)
+            api.DeviceFree(d_in)
+            api.DeviceFree(d_out)
+        if n != want.size // ch or list(counts) != want_counts:
+            return "segments: %d frames %s, expected %d %s" % (n, list(counts)[:8], want.size // ch, want_counts[:8])
+        if not np.array_equal(got, want):
+            d = np.flatnonzero(got != want)
+            return "segments: %d samples differ, first at %d" % (d.size, d[0])
+        if (sp.lowest_level.stretched_kernel_radius, sp.position_integer, sp.position_fractional, sp.increment) != (so.cfg.stretched_radius, so.pos_int, so.pos_frac, so.increment):
+            return "segments: final state differs"
+        return None
     if case["mode"] == "script":
         import _scripts
         script = _scripts.make_script(case["seed"], radius)
@@ -273,9 +338,9 @@ def run_trial(products, oracles, case):
     return None
 
 
-def soak(seconds, seed, big_budget=True, log=print, max_trials=None, trace=None, radii=(3, 5, 8)):
+def soak(seconds, seed, big_budget=True, log=print, max_trials=None, trace=None, radii=(3, 5, 8), abi="c89"):
     rng = random.Random(seed)
-    products = {r: Product(r) for r in radii}
+    products = {r: Product(r, abi) for r in radii}
     oracles = {r: _checkers.oracle(r) for r in radii}
     api = products[radii[0]].api
     start_counts = [api.LaunchCount(k) for k in range(len(KERNELS))]
@@ -288,7 +353,7 @@ def soak(seconds, seed, big_budget=True, log=print, max_trials=None, trace=None,
         if trace is not None:   # (written BEFORE the trial: a crash of the process leaves its case as the last line)
             trace.write("%d %s\n" % (trials, json.dumps(case)))
             trace.flush()
-        key = "device" if case.get("device") else "s16" if case.get("s16") else case["mode"]
+        key = "device" if case.get("device") else case["mode"] if case["mode"] in ("segments", "script") else "s16" if case.get("s16") else case["mode"]
         by_mode[key] = by_mode.get(key, 0) + 1
         try:
             diff = run_trial(products, oracles, case)
@@ -308,6 +373,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-big", action="store_true", help="no multi-million-frame trials")
+    ap.add_argument("--abi", default="c89", help="c99: libclownresampler_amd_c99.so, the CC_USE_C99_INTEGERS build")
     ap.add_argument("--radii", default="3,5,8", help="the radii the library under test was built for")
     ap.add_argument("--trace", default="", help="file that receives every case before it runs")
     ap.add_argument("--replay", default="", help="a JSON case (as printed) to run once instead of the soak")
@@ -319,7 +385,7 @@ def main():
         print("replay:", diff or "agrees")
         sys.exit(1 if diff else 0)
     trials, failures = soak(args.seconds, args.seed, not args.no_big, trace=open(args.trace, "w") if args.trace else None,
-                            radii=tuple(int(r) for r in args.radii.split(",")))
+                            radii=tuple(int(r) for r in args.radii.split(",")), abi=args.abi)
     sys.exit(1 if failures else 0)
 
 

@@ -85,6 +85,12 @@ def draw_case(rng, big_budget, radii=(3, 5, 8)):
             segs.append([n, i, o, min(i, o) if rng.random() < 0.7 else max(1, int(min(i, o) * rng.uniform(0.4, 1.0)))])
         return {"mode": "segments", "radius": radius, "channels": rng.choice([1, 2, 2, 3, 5, 8, 12]), "segments": segs, "s16": rng.random() < 0.25,
                 "segments_mode": rng.choice([0, 0, 1, 2]), "rates": segs[0][1:], "frames": sum(x[0] for x in segs), "input": "noise", "seed": rng.randint(1, 1 << 30)}
+    if rng.random() < 0.03:
+        # ONE stream over several shards (devices) in one C call: ClownResamplerAMD_ResampleShardedDevice
+        i, o = (rng.choice(COMMON), rng.choice(COMMON)) if rng.random() < 0.7 else (rng.randint(4000, 200000), rng.randint(4000, 200000))
+        return {"mode": "sharded", "radius": rng.choice(list(radii)), "channels": rng.choice([1, 2, 2, 3, 6, 8, 11]), "rates": [i, o, min(i, o)],
+                "frames": rng.choice([0, 1, rng.randint(2, 300), int(10 ** rng.uniform(2.5, 5.5))]), "shards": rng.randint(1, 12), "gather": rng.choice([0, 1, 1]),
+                "s16": rng.random() < 0.25, "input": "noise", "seed": rng.randint(1, 1 << 30)}
     if rng.random() < 0.04:
         # a scripted high-level session with Adjusts between the calls (tests/_scripts.py), at one of the streaming windows
         return {"mode": "script", "radius": rng.choice(list(radii)), "seed": rng.randint(1, 1 << 30), "window": rng.choice([0, 0, 5000, 1 << 18]),
@@ -154,6 +160,68 @@ def run_trial(products, oracles, case):
     """None when product and oracle agree (or both refuse), else a description of the difference."""
     radius, ch, rates = case["radius"], case["channels"], case["rates"]
     prod, orc = products[radius], oracles[radius]
+    if case["mode"] == "sharded":
+        from _cases import make_input
+        from _checkers import pad_frames
+        api = prod.api
+        ok_o, so = orc.low_init(ch, *rates)
+        ok_p, sp = prod.low_init(ch, *rates)
+        if bool(ok_o) != bool(ok_p):
+            return "Init: oracle %s, product %s" % (ok_o, ok_p)
+        if not ok_o:
+            return None
+        pcm = make_input(case)
+        frames = len(pcm) // ch
+        R = int(so.cfg.radius_frames)
+        padded = pad_frames(pcm, ch, R)
+        want, _, _ = orc.low_resample_i32(so, padded, frames)
+        total = want.size // ch
+        s16 = bool(case.get("s16"))
+        unit = 2 if s16 else 4
+        if s16:
+            want = np.clip(want, -0x7FFF, 0x7FFF).astype(np.int16)
+        ndev = max(1, api.DeviceCount())
+        nshards = case["shards"]
+        allocated, shards, places = [], [], []
+        try:
+            for r in range(nshards):
+                sh = api.PlanShard(sp.raw, frames, r, nshards)
+                dev = (r * 7 + case["seed"]) % ndev
+                lo, hi = sh.first_input_frame, sh.first_input_frame + sh.input_frames + 2 * R
+                piece = np.ascontiguousarray(padded[lo * ch: hi * ch]) if sh.output_frames else np.zeros(8, dtype=np.int16)
+                d_in = api.DeviceAllocOn(dev, piece.nbytes + 64)
+                d_out = api.DeviceAllocOn(dev, max(1, sh.output_frames) * ch * unit + 64)
+                allocated += [d_in, d_out]
+                api.CopyToDevice(d_in, piece)
+                shards.append((dev, d_in, d_out, None))
+                places.append((sh.first_output_frame, sh.output_frames, d_out))
+            root_shard = case["seed"] % nshards
+            root = api.DeviceAllocOn(shards[root_shard][0], max(1, total) * ch * unit + 64)
+            allocated.append(root)
+            n = api.ResampleShardedDevice(sp.raw, prod.pre, frames, shards, s16=s16, gather_mode=case["gather"], root_shard=root_shard, root_output=root if case["gather"] else None)
+            if api.ShardedSynchronize(shards) != 0:
+                return "sharded: ShardedSynchronize failed"
+            if n != total:
+                return "sharded: %d frames, expected %d" % (n, total)
+            got = np.empty_like(want)
+            if case["gather"]:
+                if want.size:
+                    api.CopyFromDevice(got, root)
+            else:
+                for first, count, d_out in places:
+                    if count:
+                        part = np.empty(count * ch, dtype=want.dtype)
+                        api.CopyFromDevice(part, d_out)
+                        got[first * ch:(first + count) * ch] = part
+        finally:
+            for a in allocated:
+                api.DeviceFree(a)
+        if not np.array_equal(got, want):
+            d = np.flatnonzero(got != want)
+            return "sharded (%d shards): %d samples differ, first at %d" % (nshards, d.size, d[0])
+        if tuple(int(v) for v in sp.astuple()) != tuple(int(v) for v in so.astuple()):
+            return "sharded: final state differs"
+        return None
     if case["mode"] == "segments":
         from _checkers import noise_pcm, pad_frames
         api = prod.api
@@ -353,7 +421,7 @@ def soak(seconds, seed, big_budget=True, log=print, max_trials=None, trace=None,
         if trace is not None:   # (written BEFORE the trial: a crash of the process leaves its case as the last line)
             trace.write("%d %s\n" % (trials, json.dumps(case)))
             trace.flush()
-        key = "device" if case.get("device") else case["mode"] if case["mode"] in ("segments", "script") else "s16" if case.get("s16") else case["mode"]
+        key = "device" if case.get("device") else case["mode"] if case["mode"] in ("segments", "script", "sharded") else "s16" if case.get("s16") else case["mode"]
         by_mode[key] = by_mode.get(key, 0) + 1
         try:
             diff = run_trial(products, oracles, case)

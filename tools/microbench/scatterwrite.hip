@@ -50,6 +50,26 @@ __global__ __launch_bounds__(768) void segments(i32x2 *out, unsigned long long n
 	}
 }
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// a lane writes ITS OWN segment's line itself: eight 16-byte stores per 16 frames, every instruction 64 different lines
+__global__ __launch_bounds__(768) void own_lines(i32x2 *out, unsigned long long n_frames, unsigned K, unsigned long long S)
+{
+	const unsigned lane = threadIdx.x & 63u;
+	const unsigned long long wave = (unsigned long long)(threadIdx.x >> 6) * gridDim.x + blockIdx.x, waves = (unsigned long long)gridDim.x * 12u;
+	const unsigned long long blocks = (n_frames + 64 * S - 1) / (64 * S), per_seg = S / K, tiles = blocks * per_seg;
+	i32x4 v;
+	v.x = (int)lane;
+	v.y = (int)wave;
+	v.z = v.w = 7;
+	for (unsigned long long t = wave; t < tiles; t += waves)
+	{
+		const unsigned long long first = (t / per_seg) * 64 * S + (t % per_seg) * K + (unsigned long long)lane * S;
+		for (unsigned c = 0; c < K; c += 2u)
+			if (first + c + 1 < n_frames)
+				__builtin_nontemporal_store(v, reinterpret_cast<i32x4 *>(out + first + c));
+	}
+}
+
 int main()
 {
 	const unsigned long long n = 57600096ull;
@@ -81,6 +101,13 @@ int main()
 		snprintf(name, sizeof name, "segments 65536 apart, K %u", K);
 		time(name, [&] { hipLaunchKernelGGL(segments, 256, 768, 0, 0, out, n, K, 65536ull); });
 	}
+	for (unsigned K : {64u, 128u})
+	{
+		char name[64];
+		snprintf(name, sizeof name, "own lines 16 B/lane, K %u", K);
+		time(name, [&] { hipLaunchKernelGGL(own_lines, 256, 768, 0, 0, out, n, K, 65536ull); });
+	}
+	time("own lines, 1024 apart, K 64", [&] { hipLaunchKernelGGL(own_lines, 256, 768, 0, 0, out, n, 64u, 1024ull); });
 	time("segments 1024 apart, K 64", [&] { hipLaunchKernelGGL(segments, 256, 768, 0, 0, out, n, 64u, 1024ull); });
 	time("segments 4096 apart, K 64", [&] { hipLaunchKernelGGL(segments, 256, 768, 0, 0, out, n, 64u, 4096ull); });
 	return 0;

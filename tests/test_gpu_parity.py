@@ -329,6 +329,10 @@ def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch,
 @pytest.mark.parametrize("name,radius,ch,rates,frames,kernel,ticketed", [
     ("cfg2", 3, 2, (44100, 48000, 44100), 26460000, 1, True),     # BASELINE configs[1]: THE launch bench.py times (7,032 tiles on 512 workgroups, tickets)
     ("cfg3", 8, 2, (8000, 96000, 8000), 4800000, 8, None),         # configs[2]: k_seg (13.7 blocks of 64 segments: the lanes of a wave 65,536 frames apart)
+    ("cfg3h", 8, 2, (8000, 96000, 8000), 28800000, 8, None),       # an hour of it: 2.76 GB of output through ONE k_seg launch (82.4 blocks of 64 segments; offsets beyond 32 bits)
+    ("cfg3l", 8, 2, (8000, 96000, 8000), 57600000, 8, None),       # two hours: 5.5 GB of output, byte offsets beyond 2^32 in one k_seg launch
+    ("cfg2l", 3, 2, (44100, 48000, 44100), 476280000, 1, True),    # three hours of cfg 2: 4.15 GB of output, 1.9 GB of input through one k_poly launch
+    ("hq48l", 8, 2, (44100, 48000, 44100), 476280000, 4, None),    # the same through k_wave2
     ("cfg3m", 8, 2, (8000, 96000, 8000), 1200000, 3, None),        # 2.5 minutes of it: 3.4 such blocks, 14 % of the lane-steps of four idle - k_up2, wave-tiles drawn from global counters throughout
     ("cfg4", 3, 8, (48000, 44100, 44100), 28800000, 1, True),      # configs[3]: 8 channels, ticketed tiles
     ("cfg5", 3, 2, (44100, 48000, 44100), 158760000, 1, True),     # configs[4]: the hour as ONE launch (42,188 tiles)

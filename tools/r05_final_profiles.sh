@@ -27,7 +27,7 @@ for w in cfg2 cfg3 cfg4 hq48 hq44 dn8; do
 done
 cd $R
 # the bench lines, now that the stamped summaries exist (`traffic` and `roofline_valu` filled in for the BASELINE configurations)
-for w in cfg2 cfg3 cfg4; do cp $O/pmc_summary_$w.txt profiles/r05_${w}_pmc_summary.txt; done
+for w in cfg2 cfg3 cfg4 hq48 hq44 dn8; do cp $O/pmc_summary_$w.txt profiles/r05_${w}_pmc_summary.txt; done
 python3 bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 python3 bench.py --steps 20 --warmup 3 > $O/bench_cfg2_steps20.json 2>/dev/null     # as the driver runs it
 for w in cfg3 cfg4; do python3 bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; done

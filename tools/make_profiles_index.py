@@ -54,6 +54,8 @@ WHAT = [
     (r"r05_kwave2_frame_pipeline_ab\.log", "`k_wave2` with the frames of a wave-tile as one pipeline of LDS reads against frame by frame (bit-exact, ±1.5 %: not kept)"),
     (r"r05_kpoly_forms\.log", "timing-only forms of the headline `k_poly<2,5>`: compute floor, floor without bank conflicts, without stores; the int16 output by variant and tile size"),
     (r"r05_ldswin\.log", "`tools/microbench/ldswin.hip`: LDS cycles per window slot by lane spacing for `ds_read_b64`, 8-byte-aligned and 16-byte-aligned `ds_read_b128`"),
+    (r"r05_mono_env_sweep\.log", "the host's rules against their environment overrides on the mono and mild-downsampling shapes (rotation, tile size, tickets, dual mono, lane order): no override beats the rule"),
+    (r"r05_gpu_tests_last\.log", "`pytest -m gpu` with the long-stream tests added after the evidence run (same library build)"),
     (r"r05_ldsvalu\.log", "`tools/microbench/ldsvalu.hip`: LDS reads and VALU work of a wave add up rather than overlap"),
     (r"r04_bench_cfg2\.json", "the headline `bench.py` line (BASELINE configs[1], N = 1) of the final build, with `roofline`, `cpu_baseline`, `parity_full_stream`, `strong_curve_n1`, `end_to_end`"),
     (r"r04_bench_(cfg3|cfg4|cfg5|hq48|cfg2_s16)\.json", "`bench.py` lines of the other workloads, same box and build"),

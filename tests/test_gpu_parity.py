@@ -1451,6 +1451,12 @@ def test_highlevel_random_streams(products):
             out_rate = rng.choice([8000, 16000, 22050, 44100, 48000, 96000, rng.randrange(4000, 200000)])
             lp = rng.choice([min(i, out_rate), i, out_rate, max(1, min(i, out_rate) // 2)])
             frames = rng.choice([rng.randrange(1, 200), rng.randrange(200, 5000), rng.randrange(5000, 40000)])
+            # (the LOW-level Init first: with a window wider than its staging buffer the reference's high-level Init and Resample write
+            # beyond it - and so does the oracle's restatement; the product refuses such a window)
+            ok_l, low = o.low_init(ch, i, out_rate, lp)
+            if ok_l and 2 * int(low.cfg.radius_frames) >= 0x1000 // ch:
+                assert not p.high_init(ch, i, out_rate, lp)[0]
+                continue
             ok_a, a = p.high_init(ch, i, out_rate, lp)
             ok_b, b = o.high_init(ch, i, out_rate, lp)
             assert ok_a == ok_b

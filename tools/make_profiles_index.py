@@ -35,6 +35,7 @@ WHAT = [
     (r"r05_kernel_stats_.*\.csv", "`rocprofv3 --kernel-trace --stats` summary of the same `bench.py` command (average over every dispatch, clock ramp included)"),
     (r"r05_kernel_trace_head_.*\.csv", "first dispatches of that trace: grid, LDS, register counts"),
     (r"r05_(cfg2|cfg3|cfg4)_pmc_summary\.txt", "per-dispatch PMC means (separate `--pmc` passes), stamped with the library's source id; `bench.py` quotes `traffic` / `roofline_valu` from them"),
+    (r"r05_(cfg2_s16|dn1|mono|dn2)_pmc_summary\.txt", "the same for the int16 output form and the mono / mild-downsampling shapes (taken after the evidence run, same library build)"),
     (r"r05_(hq48|hq44|dn8)_pmc_summary\.txt", "the same for the LDS-bound long-window shapes (VERDICT r4 item 3 asked for stamped summaries of the final build)"),
     (r"r05_(cfg3|hq44|dn8)_lds_counters_before\.txt", "LDS-side counters (`SQ_LDS_*`, waits) of round 4's kernels, taken before round 5 touched anything"),
     (r"r05_kup2_lds_ablations\.log", "timing-only builds of `k_up2`: no row reads per frame / conflict-free staging writes (what each costs)"),

@@ -338,6 +338,8 @@ def test_long_streams_of_the_other_kernels_bit_exact(products, name, radius, ch,
     ("dn8l", 3, 2, (44100, 8000, 8000), 1200000000, 4, None),      # ... and through k_wave2
     ("monol", 3, 1, (44100, 48000, 44100), 1000000000, None, None),  # six hours of mono: 4.35 GB of output; dual mono where its 32-bit descriptors allow (cr_dual_mono_fits), the mono kernel beyond
     ("hq48ml", 8, 1, (44100, 48000, 44100), 1000000000, None, None),
+    ("monob", 3, 1, (44100, 48000, 44100), 985800000, None, None),    # 1.073 G output frames: 4.29 GB, a few megabytes below the 32-bit descriptor of the dual-mono stores (the guard's edge)
+    ("hq48mb", 8, 1, (44100, 48000, 44100), 985800000, None, None),
     ("cfg3m", 8, 2, (8000, 96000, 8000), 1200000, 3, None),        # 2.5 minutes of it: 3.4 such blocks, 14 % of the lane-steps of four idle - k_up2, wave-tiles drawn from global counters throughout
     ("cfg4", 3, 8, (48000, 44100, 44100), 28800000, 1, True),      # configs[3]: 8 channels, ticketed tiles
     ("cfg5", 3, 2, (44100, 48000, 44100), 158760000, 1, True),     # configs[4]: the hour as ONE launch (42,188 tiles)

@@ -148,8 +148,30 @@ def _load_library(abi="c89"):
     lib.ClownResamplerAMD_SetErrorHandler(_handler_keepalive[abi], None)
     lib.ClownResamplerAMD_LastErrorCode.restype = C.c_int
     lib.ClownResamplerAMD_LastErrorMessage.restype = C.c_char_p
+    lib.ClownResamplerAMD_DebugDumpFlightRecorder.argtypes = [C.c_int]
+    lib.ClownResamplerAMD_DebugDumpFlightRecorder.restype = None
+    lib.ClownResamplerAMD_DebugInstallAbortDump.restype = C.c_int
     _libs[abi] = lib
+    if _abort_dump["on"]:
+        lib.ClownResamplerAMD_DebugInstallAbortDump()
     return lib
+
+
+_abort_dump = {"on": os.environ.get("CLOWNRESAMPLER_AMD_ABORT_DUMP", "") not in ("", "0")}
+
+
+def install_abort_dump():
+    """From now on a SIGABRT of this process (the HIP runtime's answer to a GPU memory fault) first writes the library's flight
+    recorder - the last 64 launches / allocations with their address ranges - to stderr, then goes on to the handler that was
+    installed before (ClownResamplerAMD_DebugInstallAbortDump); for the libraries loaded so far and any loaded later."""
+    _abort_dump["on"] = True
+    for lib in _libs.values():
+        lib.ClownResamplerAMD_DebugInstallAbortDump()
+
+
+def dump_flight_recorder(fd=2):
+    for lib in _libs.values():
+        lib.ClownResamplerAMD_DebugDumpFlightRecorder(fd)
 
 
 def _raise_if_failed(lib):

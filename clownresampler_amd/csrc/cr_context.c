@@ -7,10 +7,12 @@
 #include "cr_context.h"
 
 #include <pthread.h>
+#include <signal.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "../../include/clownresampler_amd.h"
 
@@ -27,6 +29,7 @@ static __thread int t_last_code = 0;
 static __thread unsigned long t_error_serial = 0;
 static __thread char t_last_message[512];
 static __thread int t_deferred = 0;
+static volatile sig_atomic_t g_abort_dumped = 0;   /* the flight recorder (below) has been written out once */
 
 void cr_error_defer(int on)
 {
@@ -71,6 +74,11 @@ int cr_fail(int code, const char *format, ...)
 	{
 		fprintf(stderr, "clownresampler_amd: %s\n", t_last_message);
 		fflush(stderr);
+		if (!g_abort_dumped)
+		{
+			g_abort_dumped = 1;
+			ClownResamplerAMD_DebugDumpFlightRecorder(2);
+		}
 		abort();
 	}
 
@@ -109,6 +117,117 @@ void ClownResamplerAMD_ClearError(void)
 {
 	t_last_code = 0;
 	t_last_message[0] = '\0';
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* flight recorder                                                                                         */
+/* ------------------------------------------------------------------------------------------------------- */
+
+/* The last CR_FLIGHT_EVENTS things this process asked the device for through this library - kernel launches with every address
+   range they may touch, device allocations and releases - in a ring that costs a launch ~100 bytes of stores.  What a process that
+   dies of a GPU memory fault (reported by the runtime's own thread, a while after the launch returned) is otherwise unable to say:
+   ClownResamplerAMD_DebugDumpFlightRecorder writes it out, cr_fail's default (abort) does so too, and a client - the GPU tests -
+   may have it written when SIGABRT arrives (ClownResamplerAMD_DebugInstallAbortDump).  Nothing here allocates or locks. */
+#define CR_FLIGHT_EVENTS 64u
+enum { CR_FLIGHT_GENERIC = 0, CR_FLIGHT_POLY = 1, CR_FLIGHT_INT = 2, CR_FLIGHT_SEG = 3, CR_FLIGHT_TABLE = 4, CR_FLIGHT_MALLOC = 10, CR_FLIGHT_FREE = 11, CR_FLIGHT_HOST_ALLOC = 12, CR_FLIGHT_HOST_FREE = 13 };
+typedef struct cr_flight_event
+{
+	unsigned long long serial;      /* 0: never written */
+	uint32_t kind;
+	int32_t result;                 /* what the HIP call returned */
+	const void *d_in, *d_out, *aux, *tickets, *stream;   /* aux: rows image / table / segment table; for allocations d_out is the pointer */
+	uint64_t in_bytes, out_bytes, aux_bytes, n_out, pos0;
+	uint32_t increment, channels, slots, threads, blocks, lds_bytes, tile_frames, vecs, variant, flags;
+} cr_flight_event;
+static cr_flight_event g_flight[CR_FLIGHT_EVENTS];
+static unsigned long long g_flight_serial = 0;
+
+static cr_flight_event *flight_next(uint32_t kind)
+{
+	const unsigned long long serial = __atomic_add_fetch(&g_flight_serial, 1ull, __ATOMIC_RELAXED);
+	cr_flight_event *e = &g_flight[serial % CR_FLIGHT_EVENTS];
+
+	memset(e, 0, sizeof(*e));
+	e->kind = kind;
+	e->serial = serial;
+	return e;
+}
+
+static void flight_memory(uint32_t kind, const void *pointer, size_t bytes, int result)
+{
+	cr_flight_event *e = flight_next(kind);
+
+	e->d_out = pointer;
+	e->out_bytes = bytes;
+	e->result = result;
+}
+
+void ClownResamplerAMD_DebugDumpFlightRecorder(int fd)
+{
+	static const char *const names[] = {"k_generic", "k_poly-family", "k_int", "k_seg", "k_generic_segments"};
+	const unsigned long long last = __atomic_load_n(&g_flight_serial, __ATOMIC_RELAXED);
+	char line[640];
+	unsigned k;
+	int n;
+
+	n = snprintf(line, sizeof(line), "clownresampler_amd: flight recorder, %llu events so far, the last %u oldest first (library %s)\n", last, CR_FLIGHT_EVENTS,
+	             ClownResamplerAMD_BuildId());
+	if (n > 0 && write(fd, line, (size_t)n) < 0)
+		return;
+	for (k = 0; k < CR_FLIGHT_EVENTS; ++k)
+	{
+		const cr_flight_event *e = &g_flight[(last + 1u + k) % CR_FLIGHT_EVENTS];
+
+		if (e->serial == 0)
+			continue;
+		if (e->kind >= CR_FLIGHT_MALLOC)
+			n = snprintf(line, sizeof(line), "  #%llu %s %p + %llu -> %d\n", e->serial,
+			             e->kind == CR_FLIGHT_MALLOC ? "hipMalloc" : e->kind == CR_FLIGHT_FREE ? "hipFree" : e->kind == CR_FLIGHT_HOST_ALLOC ? "hipHostMalloc" : "hipHostFree",
+			             e->d_out, (unsigned long long)e->out_bytes, (int)e->result);
+		else
+			n = snprintf(line, sizeof(line), "  #%llu %s -> %d: in %p + %llu, out %p + %llu, aux %p + %llu, tickets %p, stream %p, n_out %llu, pos0 0x%llx, increment 0x%x, "
+			             "%u ch, %u slots, grid %u x %u, lds %u, tile %u, vecs %u, variant %u, flags 0x%x\n",
+			             e->serial, names[e->kind <= CR_FLIGHT_TABLE ? e->kind : 0], (int)e->result, e->d_in, (unsigned long long)e->in_bytes, e->d_out, (unsigned long long)e->out_bytes,
+			             e->aux, (unsigned long long)e->aux_bytes, e->tickets, e->stream, (unsigned long long)e->n_out, (unsigned long long)e->pos0, e->increment,
+			             e->channels, e->slots, e->blocks, e->threads, e->lds_bytes, e->tile_frames, e->vecs, e->variant, e->flags);
+		if (n > 0 && write(fd, line, (size_t)(n < (int)sizeof(line) ? n : (int)sizeof(line) - 1)) < 0)
+			return;
+	}
+}
+
+static struct sigaction g_abort_previous;
+static int g_abort_installed = 0;
+
+static void abort_dump(int sig, siginfo_t *info, void *context)
+{
+	if (!g_abort_dumped)
+	{
+		g_abort_dumped = 1;
+		ClownResamplerAMD_DebugDumpFlightRecorder(2);
+	}
+	/* then whoever was there before (Python's faulthandler in the tests), else the default action */
+	if ((g_abort_previous.sa_flags & SA_SIGINFO) && g_abort_previous.sa_sigaction != NULL)
+		g_abort_previous.sa_sigaction(sig, info, context);
+	else if (!(g_abort_previous.sa_flags & SA_SIGINFO) && g_abort_previous.sa_handler != SIG_DFL && g_abort_previous.sa_handler != SIG_IGN && g_abort_previous.sa_handler != NULL)
+		g_abort_previous.sa_handler(sig);
+	signal(SIGABRT, SIG_DFL);
+	raise(SIGABRT);
+}
+
+int ClownResamplerAMD_DebugInstallAbortDump(void)
+{
+	struct sigaction sa;
+
+	if (g_abort_installed)
+		return 0;
+	memset(&sa, 0, sizeof(sa));
+	sa.sa_sigaction = abort_dump;
+	sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+	sigemptyset(&sa.sa_mask);
+	if (sigaction(SIGABRT, &sa, &g_abort_previous) != 0)
+		return -1;
+	g_abort_installed = 1;
+	return 0;
 }
 
 /* ------------------------------------------------------------------------------------------------------- */
@@ -339,17 +458,172 @@ int ClownResamplerAMD_IsUsable(void)
 	return strncmp(info.arch, "gfx950", 6) == 0;
 }
 
+/* ---- the device operations, recorded (flight recorder above) ---- */
+static int dev_malloc(void **pointer, size_t bytes)
+{
+	const int code = crhip_malloc(pointer, bytes);
+
+	flight_memory(CR_FLIGHT_MALLOC, code == 0 ? *pointer : NULL, bytes, code);
+	return code;
+}
+
+static int dev_free(void *pointer)
+{
+	int code;
+
+	if (pointer == NULL)
+		return 0;
+	code = crhip_free(pointer);
+	flight_memory(CR_FLIGHT_FREE, pointer, 0, code);
+	return code;
+}
+
+static int host_alloc(void **pointer, size_t bytes)
+{
+	const int code = crhip_host_alloc(pointer, bytes);
+
+	flight_memory(CR_FLIGHT_HOST_ALLOC, code == 0 ? *pointer : NULL, bytes, code);
+	return code;
+}
+
+static int host_free(void *pointer)
+{
+	const int code = crhip_host_free(pointer);
+
+	flight_memory(CR_FLIGHT_HOST_FREE, pointer, 0, code);
+	return code;
+}
+
+static int launch_poly(const ClownResamplerAMD_Plan *plan, const crhip_poly_launch *l, void *stream)
+{
+	cr_flight_event *e = flight_next(CR_FLIGHT_POLY);
+
+	e->d_in = l->d_in;
+	e->in_bytes = l->in_valid_bytes;
+	e->d_out = l->d_out;
+	e->out_bytes = (l->dual ? (uint64_t)l->dual_out_frames + l->dual_valid_frames : l->n_out * l->channels) * (l->out_s16 ? 2u : 4u);
+	e->aux = l->d_rows;
+	e->aux_bytes = (uint64_t)l->plane_rows * l->row_stride * 4u;
+	e->tickets = l->d_tickets;
+	e->stream = stream;
+	e->n_out = l->n_out;
+	e->pos0 = l->pos0;
+	e->increment = l->increment;
+	e->channels = l->channels;
+	e->slots = l->slots;
+	e->threads = l->threads;
+	e->blocks = l->blocks;
+	e->lds_bytes = l->lds_bytes;
+	e->tile_frames = l->tile_frames;
+	e->vecs = l->vecs;
+	e->variant = l->variant;
+	e->flags = (l->specialised ? 1u : 0u) | (l->dual ? 2u : 0u) | (l->out_s16 ? 4u : 0u) | (l->dynamic_tiles ? 8u : 0u) | (l->padded ? 16u : 0u) | ((uint32_t)plan->device << 8);
+	e->result = -9999;   /* (still inside the launch call) */
+	return e->result = crhip_launch_poly(l, stream);
+}
+
+static int launch_int(const ClownResamplerAMD_Plan *plan, const crhip_int_launch *l, void *stream)
+{
+	cr_flight_event *e = flight_next(CR_FLIGHT_INT);
+
+	e->d_in = l->d_in;
+	e->in_bytes = l->in_valid_bytes;
+	e->d_out = l->d_out;
+	e->out_bytes = l->n_out * l->channels * (l->out_s16 ? 2u : 4u);
+	e->tickets = l->d_tickets;
+	e->stream = stream;
+	e->n_out = l->n_out;
+	e->pos0 = l->first_frame;
+	e->increment = l->ratio;
+	e->channels = l->channels;
+	e->slots = l->slots;
+	e->threads = plan->intk.shape.threads;
+	e->blocks = l->blocks;
+	e->variant = l->period;
+	e->flags = (l->out_s16 ? 4u : 0u) | ((uint32_t)plan->device << 8);
+	e->result = -9999;
+	return e->result = crhip_launch_int(l, stream);
+}
+
+static int launch_seg(const ClownResamplerAMD_Plan *plan, const crhip_seg_launch *l, void *stream)
+{
+	cr_flight_event *e = flight_next(CR_FLIGHT_SEG);
+
+	e->d_in = l->d_in;
+	e->in_bytes = l->in_valid_bytes;
+	e->d_out = l->d_out;
+	e->out_bytes = l->n_out * 8u;
+	e->aux = l->d_rows;
+	e->aux_bytes = (uint64_t)plan->poly.rows * 64u;
+	e->tickets = l->d_tickets;
+	e->stream = stream;
+	e->n_out = l->n_out;
+	e->pos0 = l->pos0;
+	e->increment = l->increment;
+	e->channels = 2u;
+	e->slots = l->slots;
+	e->threads = plan->seg.threads;
+	e->blocks = l->blocks;
+	e->lds_bytes = plan->seg.lds_bytes;
+	e->tile_frames = l->tile_frames;
+	e->flags = (uint32_t)plan->device << 8;
+	e->result = -9999;
+	return e->result = crhip_launch_seg(l, stream);
+}
+
+static int launch_generic(const ClownResamplerAMD_Plan *plan, const crhip_generic_launch *l, uint64_t in_bytes, void *stream)
+{
+	cr_flight_event *e = flight_next(CR_FLIGHT_GENERIC);
+
+	e->d_in = l->d_in;
+	e->in_bytes = in_bytes;
+	e->d_out = l->d_out;
+	e->out_bytes = l->n_out * l->channels * (l->out64 == 1u ? 8u : l->out64 == 2u ? 2u : 4u);
+	e->aux = l->d_table;
+	e->aux_bytes = (uint64_t)l->table_len * 4u;
+	e->stream = stream;
+	e->n_out = l->n_out;
+	e->pos0 = (l->pos_int << 16) + l->pos_frac;
+	e->increment = (uint32_t)l->increment;
+	e->channels = l->channels;
+	e->slots = (uint32_t)l->radius_frames * 2u;
+	e->threads = 256u;
+	e->flags = (l->out64 << 2) | ((uint32_t)plan->device << 8);
+	e->result = -9999;
+	return e->result = crhip_launch_generic(l, stream);
+}
+
+static int launch_segments(const ClownResamplerAMD_Plan *plan, const crhip_segments_launch *l, void *stream)
+{
+	cr_flight_event *e = flight_next(CR_FLIGHT_TABLE);
+
+	e->d_in = l->d_in;
+	e->d_out = l->d_out;
+	e->out_bytes = l->n_out * l->channels * (l->out_s16 ? 2u : 4u);
+	e->aux = l->d_segments;
+	e->aux_bytes = (uint64_t)l->n_segments * sizeof(crhip_segment);
+	e->tickets = l->d_table;
+	e->stream = stream;
+	e->n_out = l->n_out;
+	e->channels = l->channels;
+	e->slots = l->n_segments;
+	e->threads = 256u;
+	e->flags = (l->out_s16 ? 4u : 0u) | ((uint32_t)plan->device << 8);
+	e->result = -9999;
+	return e->result = crhip_launch_segments(l, stream);
+}
+
 static int ring_alloc(cr_ring *ring)
 {
 	const size_t bytes = (size_t)CR_RING_SLOTS * CRHIP_TICKET_WORDS * sizeof(uint32_t);
 
 	memset(ring, 0, sizeof(*ring));
-	if (cr_check_hip(crhip_malloc((void **)&ring->blocks, bytes), "hipMalloc(tickets)") != 0)
+	if (cr_check_hip(dev_malloc((void **)&ring->blocks, bytes), "hipMalloc(tickets)") != 0)
 		return -1;
 	if (cr_check_hip(crhip_memset(ring->blocks, 0, bytes, NULL), "hipMemset(tickets)") != 0
 	 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
 	{
-		crhip_free(ring->blocks);
+		dev_free(ring->blocks);
 		ring->blocks = NULL;
 		return -1;
 	}
@@ -383,12 +657,12 @@ static int capture_pool_grow(cr_device_ctx *ctx, size_t blocks)
 	if (list == NULL)
 		return cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
 	ctx->capture_chunks = list;
-	if (cr_check_hip(crhip_malloc((void **)&chunk, bytes), "hipMalloc(capture tickets)") != 0)
+	if (cr_check_hip(dev_malloc((void **)&chunk, bytes), "hipMalloc(capture tickets)") != 0)
 		return -1;
 	if (cr_check_hip(crhip_memset(chunk, 0, bytes, NULL), "hipMemset(capture tickets)") != 0
 	 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
 	{
-		crhip_free(chunk);
+		dev_free(chunk);
 		return -1;
 	}
 	if (ctx->capture_chunk_count == 0)
@@ -624,7 +898,7 @@ int ClownResamplerAMD_ReleaseCapturedLaunches(void)
 		const size_t bytes = ctx->capture_first_blocks * CRHIP_TICKET_WORDS * sizeof(uint32_t);
 
 		while (ctx->capture_chunk_count > 1u)
-			crhip_free(ctx->capture_chunks[--ctx->capture_chunk_count]);   /* (hipFree waits for work that still uses it) */
+			dev_free(ctx->capture_chunks[--ctx->capture_chunk_count]);   /* (hipFree waits for work that still uses it) */
 		if (cr_check_hip(crhip_memset(ctx->capture_chunks[0], 0, bytes, NULL), "hipMemset(capture tickets)") != 0
 		 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
 			r = -1;
@@ -655,9 +929,9 @@ static void store_release(cr_plan_store *store, int device_usable)
 	if (device_usable)
 	{
 		/* hipFree waits for the device: a launch that was enqueued with these rows has finished by the time they go */
-		crhip_free(store->d_table);
-		crhip_free(store->d_rows);
-		crhip_free(store->d_rows_seg);
+		dev_free(store->d_table);
+		dev_free(store->d_rows);
+		dev_free(store->d_rows_seg);
 	}
 	cr_poly_free(&store->poly);
 	free(store);
@@ -709,24 +983,24 @@ static int release_device_locked(cr_device_ctx *ctx)
 	if (ctx->ready)
 	{
 		for (k = 0; k < ctx->ring_count; ++k)
-			crhip_free(ctx->rings[k].blocks);
+			dev_free(ctx->rings[k].blocks);
 		for (k = 0; k < ctx->capture_chunk_count; ++k)
-			crhip_free(ctx->capture_chunks[k]);
-		crhip_free(ctx->workspace.d_in);
-		crhip_free(ctx->workspace.d_out);
+			dev_free(ctx->capture_chunks[k]);
+		dev_free(ctx->workspace.d_in);
+		dev_free(ctx->workspace.d_out);
 		if (ctx->workspace.stream != NULL)
 			crhip_stream_destroy(ctx->workspace.stream);
 		if (ctx->small != NULL)
-			crhip_host_free(ctx->small);
+			host_free(ctx->small);
 		if (ctx->seg_host != NULL)
-			crhip_host_free(ctx->seg_host);
-		crhip_free(ctx->seg_dev);
+			host_free(ctx->seg_host);
+		dev_free(ctx->seg_dev);
 		if (ctx->seg_event != NULL)
 			crhip_event_destroy(ctx->seg_event);
 		for (k = 0; k < CR_EXTRA_SETS; ++k)
 		{
-			crhip_free(ctx->workspace_more[k].d_in);
-			crhip_free(ctx->workspace_more[k].d_out);
+			dev_free(ctx->workspace_more[k].d_in);
+			dev_free(ctx->workspace_more[k].d_out);
 			if (ctx->workspace_more[k].stream != NULL)
 				crhip_stream_destroy(ctx->workspace_more[k].stream);
 		}
@@ -817,7 +1091,7 @@ void *ClownResamplerAMD_DeviceAlloc(size_t bytes)
 
 	if (cr_ensure_device() != 0)
 		return NULL;
-	if (cr_check_hip(crhip_malloc(&p, bytes != 0 ? bytes : 16), "hipMalloc") != 0)
+	if (cr_check_hip(dev_malloc(&p, bytes != 0 ? bytes : 16), "hipMalloc") != 0)
 		return NULL;
 	return p;
 }
@@ -825,7 +1099,7 @@ void *ClownResamplerAMD_DeviceAlloc(size_t bytes)
 void ClownResamplerAMD_DeviceFree(void *device_pointer)
 {
 	if (device_pointer != NULL && cr_ensure_device() == 0)
-		cr_check_hip(crhip_free(device_pointer), "hipFree");
+		cr_check_hip(dev_free(device_pointer), "hipFree");
 }
 
 int ClownResamplerAMD_CopyToDevice(void *device_destination, const void *host_source, size_t bytes)
@@ -1538,7 +1812,7 @@ static int plan_seg_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan
 			}
 			image[r * 16u + 15u] = 2u * (uint32_t)row[plan->poly.slots];   /* the reciprocal, doubled: k_up2's normalisation (cr_kup.hpp) */
 		}
-		failed = cr_check_hip(crhip_malloc(&store->d_rows_seg, bytes), "hipMalloc(rows, k_seg)") != 0
+		failed = cr_check_hip(dev_malloc(&store->d_rows_seg, bytes), "hipMalloc(rows, k_seg)") != 0
 		      || cr_check_hip(crhip_memcpy_h2d(store->d_rows_seg, image, bytes, NULL), "hipMemcpy(rows, k_seg)") != 0
 		      || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0;
 		free(image);
@@ -1726,7 +2000,7 @@ ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t t
 			goto fail;
 		}
 
-		if (cr_check_hip(crhip_malloc((void **)&store->d_table, table_len * sizeof(int32_t)), "hipMalloc(table)") != 0
+		if (cr_check_hip(dev_malloc((void **)&store->d_table, table_len * sizeof(int32_t)), "hipMalloc(table)") != 0
 		 || cr_check_hip(crhip_memcpy_h2d(store->d_table, table, table_len * sizeof(int32_t), NULL), "hipMemcpy(table)") != 0
 		 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
 			goto fail_plan;
@@ -1783,7 +2057,7 @@ ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t t
 				goto fail_plan;
 			}
 
-			if (cr_check_hip(crhip_malloc((void **)&store->d_rows, bytes), "hipMalloc(rows)") != 0
+			if (cr_check_hip(dev_malloc((void **)&store->d_rows, bytes), "hipMalloc(rows)") != 0
 			 || cr_check_hip(crhip_memcpy_h2d(store->d_rows, image, bytes, NULL), "hipMemcpy(rows)") != 0
 			 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
 			{
@@ -1960,12 +2234,12 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 					const uint64_t per_wave = waves / ((uint64_t)il.blocks * waves_per_block);
 					il.ticket_tiles = per_wave >= 32u ? 4u : (per_wave >= 16u ? 2u : 1u);
 				}
-				e = crhip_launch_int(&il, stream);
+				e = launch_int(plan, &il, stream);
 				ticket_block_enqueued(g_ctx[plan->device], ring);
 				__atomic_fetch_add(&g_launch_count[CR_COUNT_TICKETED], 1ull, __ATOMIC_RELAXED);
 				return cr_check_hip(e, "k_int launch");
 			}
-			return cr_check_hip(crhip_launch_int(&il, stream), "k_int launch");
+			return cr_check_hip(launch_int(plan, &il, stream), "k_int launch");
 		}
 	}
 
@@ -2022,7 +2296,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			sl.d_tickets = ticket_block_for(g_ctx[plan->device], stream, &ring);
 			if (sl.d_tickets == NULL)
 				return -1;
-			e = crhip_launch_seg(&sl, stream);
+			e = launch_seg(plan, &sl, stream);
 			ticket_block_enqueued(g_ctx[plan->device], ring);
 			__atomic_fetch_add(&g_launch_count[CR_COUNT_SEG], 1ull, __ATOMIC_RELAXED);
 			return cr_check_hip(e, "k_seg launch");
@@ -2080,7 +2354,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			l.d_tickets = ticket_block_for(g_ctx[plan->device], stream, &ring);
 			if (l.d_tickets == NULL)
 				return -1;
-			e = crhip_launch_poly(&l, stream);
+			e = launch_poly(plan, &l, stream);
 			ticket_block_enqueued(g_ctx[plan->device], ring);
 			__atomic_fetch_add(&g_launch_count[wave2 ? 4 : 1], 1ull, __ATOMIC_RELAXED);
 			if (!wave2 && l.dynamic_tiles != 0u)
@@ -2160,7 +2434,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			l.d_tickets = ticket_block_for(g_ctx[plan->device], stream, &ring);
 			if (l.d_tickets == NULL)
 				return -1;
-			e = crhip_launch_poly(&l, stream);
+			e = launch_poly(plan, &l, stream);
 			ticket_block_enqueued(g_ctx[plan->device], ring);
 			__atomic_fetch_add(&g_launch_count[l.variant == CRHIP_VARIANT_RT_WAVE2S ? 6 : vecs >= 200u ? 3 : vecs >= 150u ? 4 : vecs >= 100u ? 2 : 1], 1ull, __ATOMIC_RELAXED);
 			if (vecs < 100u && l.dynamic_tiles != 0u)
@@ -2190,7 +2464,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 		g.out64 = out_s16 ? 2u : 0u;
 
 		__atomic_fetch_add(&g_launch_count[0], 1ull, __ATOMIC_RELAXED);
-		return cr_check_hip(crhip_launch_generic(&g, stream), "k_generic launch");
+		return cr_check_hip(launch_generic(plan, &g, in_valid_bytes, stream), "k_generic launch");
 	}
 }
 
@@ -2217,13 +2491,13 @@ int cr_segments_run(const ClownResamplerAMD_Plan *plan, const void *d_in, void *
 		const size_t want = count + count / 4 + 64;
 
 		if (ctx->seg_host != NULL)
-			crhip_host_free(ctx->seg_host);
-		crhip_free(ctx->seg_dev);
+			host_free(ctx->seg_host);
+		dev_free(ctx->seg_dev);
 		ctx->seg_host = NULL;
 		ctx->seg_dev = NULL;
 		ctx->seg_capacity = 0;
-		if (cr_check_hip(crhip_host_alloc((void **)&ctx->seg_host, want * sizeof(crhip_segment)), "hipHostMalloc(segment table)") != 0
-		 || cr_check_hip(crhip_malloc((void **)&ctx->seg_dev, want * sizeof(crhip_segment)), "hipMalloc(segment table)") != 0)
+		if (cr_check_hip(host_alloc((void **)&ctx->seg_host, want * sizeof(crhip_segment)), "hipHostMalloc(segment table)") != 0
+		 || cr_check_hip(dev_malloc((void **)&ctx->seg_dev, want * sizeof(crhip_segment)), "hipMalloc(segment table)") != 0)
 			bad = 1;
 		else
 			ctx->seg_capacity = want;
@@ -2245,7 +2519,7 @@ int cr_segments_run(const ClownResamplerAMD_Plan *plan, const void *d_in, void *
 		l.channels = plan->channels;
 		l.out_s16 = out_s16 ? 1u : 0u;
 		bad = cr_check_hip(crhip_memcpy_h2d(ctx->seg_dev, ctx->seg_host, count * sizeof(crhip_segment), stream), "hipMemcpyAsync(segment table)") != 0
-		   || cr_check_hip(crhip_launch_segments(&l, stream), "k_generic_segments launch") != 0
+		   || cr_check_hip(launch_segments(plan, &l, stream), "k_generic_segments launch") != 0
 		   || cr_check_hip(crhip_event_record(ctx->seg_event, stream), "hipEventRecord") != 0;
 		ctx->seg_in_use = 1;   /* (also after a failure part-way: the copy may be queued) */
 		__atomic_fetch_add(&g_launch_count[0], 1ull, __ATOMIC_RELAXED);
@@ -2267,11 +2541,11 @@ static int grow(unsigned char **p, size_t *have, size_t want)
 	want += want / 4 + 4096;
 
 	if (*p != NULL)
-		crhip_free(*p);
+		dev_free(*p);
 	*p = NULL;
 	*have = 0;
 
-	if (cr_check_hip(crhip_malloc((void **)p, want), "hipMalloc(staging)") != 0)
+	if (cr_check_hip(dev_malloc((void **)p, want), "hipMalloc(staging)") != 0)
 		return -1;
 
 	*have = want;
@@ -2410,7 +2684,7 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 			ws = workspace_acquire(ctx, 0, 0); /* (the lock and the stream) */
 			if (ws == NULL)
 				return -1;
-			if (ctx->small == NULL && cr_check_hip(crhip_host_alloc((void **)&ctx->small, CR_SMALL_CALL_BYTES), "hipHostMalloc(small-call block)") != 0)
+			if (ctx->small == NULL && cr_check_hip(host_alloc((void **)&ctx->small, CR_SMALL_CALL_BYTES), "hipHostMalloc(small-call block)") != 0)
 			{
 				ctx->small = NULL;
 				workspace_release(ctx);
@@ -2635,7 +2909,7 @@ int cr_run_single_frame(const ClownResamplerAMD_Plan *plan, const int16_t *host_
 
 	bad = cr_check_hip(crhip_memcpy_h2d(ws->d_in, host_window, in_bytes, ws->stream), "hipMemcpyAsync(H2D)") != 0
 	   || cr_check_hip(crhip_memcpy_h2d(ws->d_out + acc_bytes, acc_in, acc_bytes, ws->stream), "hipMemcpyAsync(H2D)") != 0
-	   || cr_check_hip(crhip_launch_generic(&g, ws->stream), "k_generic launch") != 0
+	   || cr_check_hip(launch_generic(plan, &g, in_bytes, ws->stream), "k_generic launch") != 0
 	   || cr_check_hip(crhip_memcpy_d2h(acc_out, ws->d_out, acc_bytes, ws->stream), "hipMemcpyAsync(D2H)") != 0
 	   || cr_check_hip(crhip_stream_sync(ws->stream), "hipStreamSynchronize") != 0;
 

@@ -230,6 +230,15 @@ void ClownResamplerAMD_DebugDisableDualMono(int on);
    (the polyphase kernels), 2 = always ONE launch for all segments (the generic kernel with a segment table). */
 void ClownResamplerAMD_DebugSegmentsMode(int mode);
 
+/* Flight recorder: the last 64 device operations of this library in this process - every kernel launch with the address ranges it was
+   given (input + readable bytes, output + bytes, rows / table image, ticket block, stream, grid), every device allocation and release - written
+   as text to the file descriptor `fd`; uses nothing but snprintf into a stack buffer and write(2).  The default error handler writes it to
+   stderr before it aborts.  ClownResamplerAMD_DebugInstallAbortDump has it written to stderr when the PROCESS receives SIGABRT - which
+   is how the HIP runtime ends a process whose GPU reported a memory fault, from a thread of its own, some time after the faulting
+   launch returned - and then passes the signal on to the handler that was installed before (0 on success). */
+void ClownResamplerAMD_DebugDumpFlightRecorder(int fd);
+int ClownResamplerAMD_DebugInstallAbortDump(void);
+
 /* Debug/test access to the host copy of the polyphase rows (rows * row_stride int32). */
 const int32_t *ClownResamplerAMD_PlanRows(const ClownResamplerAMD_Plan *plan);
 /* Row index the kernels compute for a fractional position (host mirror of the device formula). */

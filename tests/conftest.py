@@ -23,6 +23,37 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _real_stderr(text):
+    """file descriptor 2 itself: not sys.stderr, which pytest replaces while a test runs"""
+    try:
+        os.write(2, text.encode())
+    except OSError:
+        pass
+
+
+_TRACE = os.environ.get("CRA_TEST_TRACE", "1") != "0"
+_gpu_session = {"on": False}
+
+
+def pytest_collection_modifyitems(config, items):
+    _gpu_session["on"] = any(item.get_closest_marker("gpu") is not None for item in items) and _gpu_present()
+
+
+def _gpu_present():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_runtest_logstart(nodeid, location):
+    """A run that dies (SIGABRT from the HIP runtime's fault handler thread, glibc's heap check) leaves no report: the node id of the
+    test it died in goes to the real stderr BEFORE the test starts (GPU runs only; CRA_TEST_TRACE=0 turns it off)."""
+    if _TRACE and _gpu_session["on"]:
+        _real_stderr("\n[test] %s\n" % nodeid)
+
+
 @pytest.fixture(scope="session")
 def golden():
     import json
@@ -35,3 +66,13 @@ def _built_checkers():
     """The oracle is C: make sure it is compiled (and the in-place reference build, where /root/reference exists)."""
     import _checkers
     _checkers.build_checkers()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _abort_speaks():
+    """GPU runs: a SIGABRT (how the HIP runtime ends a process whose GPU reported a memory fault) writes the library's flight
+    recorder - the last 64 launches and allocations with their address ranges - to stderr before Python's faulthandler has its say."""
+    if _gpu_session["on"]:
+        import clownresampler_amd as cr
+        cr.install_abort_dump()
+    yield

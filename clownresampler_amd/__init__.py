@@ -151,6 +151,8 @@ def _load_library(abi="c89"):
     lib.ClownResamplerAMD_DebugDumpFlightRecorder.argtypes = [C.c_int]
     lib.ClownResamplerAMD_DebugDumpFlightRecorder.restype = None
     lib.ClownResamplerAMD_DebugInstallAbortDump.restype = C.c_int
+    lib.ClownResamplerAMD_DebugSelfCheck.argtypes = [C.c_char_p, C.c_size_t]
+    lib.ClownResamplerAMD_DebugSelfCheck.restype = C.c_int
     _libs[abi] = lib
     if _abort_dump["on"]:
         lib.ClownResamplerAMD_DebugInstallAbortDump()
@@ -167,6 +169,17 @@ def install_abort_dump():
     _abort_dump["on"] = True
     for lib in _libs.values():
         lib.ClownResamplerAMD_DebugInstallAbortDump()
+
+
+def self_check():
+    """ClownResamplerAMD_DebugSelfCheck on every library this process has loaded: [] when all are at rest, else [(abi, findings, message)]."""
+    bad = []
+    for abi, lib in _libs.items():
+        buf = C.create_string_buffer(2048)
+        n = lib.ClownResamplerAMD_DebugSelfCheck(buf, len(buf))
+        if n != 0:
+            bad.append((abi, n, buf.value.decode("utf-8", "replace")))
+    return bad
 
 
 def dump_flight_recorder(fd=2):

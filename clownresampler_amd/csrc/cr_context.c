@@ -2964,6 +2964,146 @@ void ClownResamplerAMD_DebugSegmentsMode(int mode)
 	g_segments_mode = (mode >= 0 && mode <= 2) ? mode : 0;
 }
 
+/* The library at REST (no call in progress on any thread): what its process-wide state must look like then.  Waits for the devices it has
+   touched, so every launch it ever enqueued has finished.  0 and an empty message when everything holds; otherwise the number of
+   findings, the first few in `message`.  (the reference has no globals; this library has - plan cache, ticket rings,
+   capture pool, staging sets, test hooks - and the GPU tests check after every test that they have returned to rest.) */
+int ClownResamplerAMD_DebugSelfCheck(char *message, size_t capacity)
+{
+	int findings = 0, d;
+	size_t at = 0;
+	const ClownResamplerAMD_Plan *plan;
+	const int previous_device = current_device();
+
+#define FINDING(...) \
+	do \
+	{ \
+		++findings; \
+		if (message != NULL && at + 1 < capacity) \
+		{ \
+			const int n_ = snprintf(message + at, capacity - at, __VA_ARGS__); \
+			if (n_ > 0) \
+				at += (size_t)n_ < capacity - at ? (size_t)n_ : capacity - at - 1; \
+			if (at + 2 < capacity) \
+			{ \
+				message[at++] = ';'; \
+				message[at++] = ' '; \
+				message[at] = '\0'; \
+			} \
+		} \
+	} while (0)
+
+	if (message != NULL && capacity != 0)
+		message[0] = '\0';
+
+	/* test hooks back at their defaults */
+	if (g_force_generic) FINDING("DebugForceGenericKernel is still on");
+	if (g_no_int_kernel) FINDING("DebugDisableIntKernel is still on");
+	if (g_no_dual_mono) FINDING("DebugDisableDualMono is still on");
+	if (g_seg_mode != 0) FINDING("DebugSegKernel is still %d", g_seg_mode);
+	if (g_segments_mode != 0) FINDING("DebugSegmentsMode is still %d", g_segments_mode);
+	if (g_variant >= 0) FINDING("DebugSetVariant is still %d", g_variant);
+	if (g_debug_stamps != NULL) FINDING("DebugSetStampBuffer is still set");
+
+	pthread_mutex_lock(&g_lock);
+
+	/* plans: nobody holds one; a store's reference count = the plans (and dual-mono partners) that view it */
+	for (plan = g_plans; plan != NULL; plan = plan->next)
+	{
+		const ClownResamplerAMD_Plan *other;
+		int views = 0;
+
+		if (plan->users != 0)
+			FINDING("plan %p (%u ch, increment %llu) is held by %u calls", (const void *)plan, plan->channels, (unsigned long long)plan->increment, plan->users);
+		if (plan->store == NULL)
+		{
+			FINDING("plan %p has no store", (const void *)plan);
+			continue;
+		}
+		for (other = g_plans; other != NULL; other = other->next)
+		{
+			views += other->store == plan->store;
+			views += other->dual.partner != NULL && other->dual.partner->store == plan->store;
+		}
+		if (views != plan->store->refs)
+			FINDING("store %p: %d references counted, %d plans view it", (const void *)plan->store, plan->store->refs, views);
+		if (plan->d_table != plan->store->d_table || (plan->use_poly && plan->d_rows != plan->store->d_rows) || (plan->seg.available && plan->seg.d_rows != plan->store->d_rows_seg))
+			FINDING("plan %p: its views of table / rows are not its store's", (const void *)plan);
+		if (plan->dual.partner != NULL && (plan->dual.partner->store != plan->store || plan->dual.partner->d_rows != plan->store->d_rows))
+			FINDING("plan %p: the dual-mono partner views other rows", (const void *)plan);
+	}
+
+	for (d = 0; d < CR_MAX_DEVICES; ++d)
+	{
+		cr_device_ctx *ctx = g_ctx[d];
+		unsigned r;
+		uint32_t *host;
+		const size_t ring_words = (size_t)CR_RING_SLOTS * CRHIP_TICKET_WORDS;
+
+		if (ctx == NULL || !ctx->ready)
+			continue;
+		if (crhip_set_device(d) != 0 || crhip_device_sync() != 0)
+		{
+			FINDING("device %d: hipDeviceSynchronize failed", d);
+			continue;
+		}
+		if (pthread_mutex_trylock(&ctx->workspace_lock) != 0)
+			FINDING("device %d: the staging workspace is locked", d);
+		else
+		{
+			if (ctx->seg_in_use && ctx->seg_event != NULL && crhip_event_sync(ctx->seg_event) != 0)
+				FINDING("device %d: the segment table's event does not complete", d);
+			pthread_mutex_unlock(&ctx->workspace_lock);
+		}
+		if (pthread_mutex_trylock(&ctx->ring_lock) != 0)
+		{
+			FINDING("device %d: the ticket rings are locked", d);
+			continue;
+		}
+		/* every ticket block of every ring reads zero: each launch leaves its block as it found it */
+		host = (uint32_t *)malloc(ring_words * sizeof(uint32_t));
+		for (r = 0; host != NULL && r < ctx->ring_count; ++r)
+		{
+			size_t w;
+
+			if (ctx->rings[r].pending != 0)
+				FINDING("device %d ring %u: %u launches drawn and not enqueued", d, r, ctx->rings[r].pending);
+			if (crhip_memcpy_d2h(host, ctx->rings[r].blocks, ring_words * sizeof(uint32_t), NULL) != 0 || crhip_stream_sync(NULL) != 0)
+			{
+				FINDING("device %d ring %u: cannot be read back", d, r);
+				continue;
+			}
+			for (w = 0; w < ring_words; ++w)
+				if (host[w] != 0)
+				{
+					FINDING("device %d ring %u: block %lu word %lu reads %u, not 0", d, r, (unsigned long)(w / CRHIP_TICKET_WORDS), (unsigned long)(w % CRHIP_TICKET_WORDS), host[w]);
+					break;
+				}
+		}
+		/* the part of the capture pool that has not been handed out reads zero too */
+		if (host != NULL && ctx->capture_left != 0)
+		{
+			const size_t words = ctx->capture_left * CRHIP_TICKET_WORDS < ring_words ? ctx->capture_left * CRHIP_TICKET_WORDS : ring_words;
+			size_t w;
+
+			if (crhip_memcpy_d2h(host, ctx->capture_at, words * sizeof(uint32_t), NULL) == 0 && crhip_stream_sync(NULL) == 0)
+				for (w = 0; w < words; ++w)
+					if (host[w] != 0)
+					{
+						FINDING("device %d: unused capture block word %lu reads %u, not 0", d, (unsigned long)w, host[w]);
+						break;
+					}
+		}
+		free(host);
+		pthread_mutex_unlock(&ctx->ring_lock);
+	}
+	pthread_mutex_unlock(&g_lock);
+	if (previous_device >= 0 && g_ctx[previous_device] != NULL && g_ctx[previous_device]->ready)
+		crhip_set_device(previous_device);
+#undef FINDING
+	return findings;
+}
+
 uint32_t ClownResamplerAMD_PlanDualMonoKernel(const ClownResamplerAMD_Plan *plan)
 {
 	const ClownResamplerAMD_Plan *partner = plan != NULL ? plan->dual.partner : NULL;

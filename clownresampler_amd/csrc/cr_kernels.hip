@@ -34,6 +34,7 @@
 //
 // gfx950 only.  No CUDA/HIP dual paths.
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -222,13 +223,111 @@ int crhip_get_device_info(int ordinal, crhip_device_info *info)
 	return 0;
 }
 
+// DIAGNOSTIC (CLOWNRESAMPLER_AMD_GUARD_MALLOC=1 / 2 in the environment at first use): every device allocation of the library - rows images,
+// tables, ticket blocks, staging sets, the segment table - is placed with the virtual-memory API so that it ENDS on the last mapped byte
+// (1; 16-byte aligned, so up to 15 bytes of slack) or STARTS on the first (2) of its own mapping, the pages on either side reserved and
+// unmapped, and is unmapped when it is freed: a kernel that strays outside an internal buffer, or uses one that has been released, is
+// a GPU memory fault at once instead of a read of whatever hipMalloc put next door.  There is no GPU AddressSanitizer on this pool;
+// the GPU tests run the suite once this way (tests/test_gpu_guarded.py).
+namespace
+{
+struct guard_rec
+{
+	void *base;
+	size_t reserved, mapped;
+	hipMemGenericAllocationHandle_t handle;
+	void *first;
+};
+std::map<void *, guard_rec> g_guarded;
+std::mutex g_guard_lock;
+
+int guard_mode()
+{
+	static const int mode = [] {
+		const char *e = getenv("CLOWNRESAMPLER_AMD_GUARD_MALLOC");
+		return (e != nullptr && *e != '\0' && *e != '0') ? (*e == '2' ? 2 : 1) : 0;
+	}();
+	return mode;
+}
+
+int guard_malloc(void **device_pointer, size_t bytes, int mode)
+{
+	int device = 0;
+	hipError_t e = hipGetDevice(&device);
+	if (e != hipSuccess)
+		return (int)e;
+	hipMemAllocationProp prop = {};
+	prop.type = hipMemAllocationTypePinned;
+	prop.location.type = hipMemLocationTypeDevice;
+	prop.location.id = device;
+	size_t g = 0;
+	e = hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityMinimum);
+	if (e != hipSuccess)
+		return (int)e;
+	if (g < 4096)
+		g = 4096;
+	guard_rec r = {};
+	r.mapped = ((bytes != 0 ? bytes : 1) + g - 1) / g * g;
+	r.reserved = r.mapped + 2 * g;
+	e = hipMemAddressReserve(&r.base, r.reserved, g, nullptr, 0);
+	if (e != hipSuccess)
+		return (int)e;
+	e = hipMemCreate(&r.handle, r.mapped, &prop, 0);
+	if (e != hipSuccess)
+	{
+		(void)hipMemAddressFree(r.base, r.reserved);
+		return (int)e;
+	}
+	r.first = static_cast<char *>(r.base) + g;
+	hipMemAccessDesc desc = {};
+	desc.location = prop.location;
+	desc.flags = hipMemAccessFlagsProtReadWrite;
+	e = hipMemMap(r.first, r.mapped, 0, r.handle, 0);
+	if (e == hipSuccess)
+		e = hipMemSetAccess(r.first, r.mapped, &desc, 1);
+	if (e != hipSuccess)
+	{
+		(void)hipMemUnmap(r.first, r.mapped);
+		(void)hipMemRelease(r.handle);
+		(void)hipMemAddressFree(r.base, r.reserved);
+		return (int)e;
+	}
+	char *p = static_cast<char *>(r.first);
+	if (mode == 1)
+		p += (r.mapped - bytes) & ~(size_t)15;
+	*device_pointer = p;
+	std::lock_guard<std::mutex> hold(g_guard_lock);
+	g_guarded[p] = r;
+	return 0;
+}
+} // namespace
+
 int crhip_malloc(void **device_pointer, size_t bytes)
 {
+	if (guard_mode() != 0)
+		return guard_malloc(device_pointer, bytes, guard_mode());
 	return (int)hipMalloc(device_pointer, bytes);
 }
 
 int crhip_free(void *device_pointer)
 {
+	if (guard_mode() != 0 && device_pointer != nullptr)
+	{
+		guard_rec r;
+		{
+			std::lock_guard<std::mutex> hold(g_guard_lock);
+			const auto it = g_guarded.find(device_pointer);
+			if (it == g_guarded.end())
+				return (int)hipFree(device_pointer);
+			r = it->second;
+			g_guarded.erase(it);
+		}
+		hipError_t e = hipDeviceSynchronize();   // (what hipFree does before it lets memory go)
+		const hipError_t u = hipMemUnmap(r.first, r.mapped);
+		const hipError_t h = hipMemRelease(r.handle);
+		const hipError_t a = hipMemAddressFree(r.base, r.reserved);
+		return (int)(e != hipSuccess ? e : u != hipSuccess ? u : h != hipSuccess ? h : a);
+	}
 	return (int)hipFree(device_pointer);
 }
 

@@ -230,6 +230,11 @@ void ClownResamplerAMD_DebugDisableDualMono(int on);
    (the polyphase kernels), 2 = always ONE launch for all segments (the generic kernel with a segment table). */
 void ClownResamplerAMD_DebugSegmentsMode(int mode);
 
+/* The library at rest - to be called when no call is in progress on any thread: waits for every device it has used, then checks its
+   process-wide state: no plan held by a call, every rows store referenced by exactly the plans that view it, every ticket block of every
+   ring (and the unused part of the capture pool) reading zero, no lock held, every Debug* hook back at its default.  Returns the number
+   of findings (0: at rest) and describes the first few in `message`. */
+int ClownResamplerAMD_DebugSelfCheck(char *message, size_t capacity);
 /* Flight recorder: the last 64 device operations of this library in this process - every kernel launch with the address ranges it was
    given (input + readable bytes, output + bytes, rows / table image, ticket block, stream, grid), every device allocation and release - written
    as text to the file descriptor `fd`; uses nothing but snprintf into a stack buffer and write(2).  The default error handler writes it to

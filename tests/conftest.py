@@ -76,3 +76,18 @@ def _abort_speaks():
         import clownresampler_amd as cr
         cr.install_abort_dump()
     yield
+
+
+@pytest.fixture(autouse=True)
+def _library_back_at_rest(request):
+    """After every GPU test: the device idle without a sticky error, and the library's process-wide state where a fresh process has it
+    (ClownResamplerAMD_DebugSelfCheck: no plan held, stores referenced by exactly their plans, every ticket block zero, hooks at their
+    defaults) - a leak or a stale mode fails THE TEST THAT LEFT IT, not one two hundred tests later."""
+    yield
+    if request.node.get_closest_marker("gpu") is None or not _gpu_session["on"]:
+        return
+    import torch
+    import clownresampler_amd as cr
+    torch.cuda.synchronize()
+    bad = cr.self_check()
+    assert not bad, "the library is not at rest after this test: %s" % (bad,)

@@ -332,14 +332,23 @@ static size_t resample_bulk(ClownResampler_LowLevel_State *resampler, const Clow
 		const ClownResamplerAMD_Plan *plan = plan_for(&resampler->lowest_level, precomputed, resampler->channels, resampler->increment, 0);
 		int failed;
 
+		/* a failure (recorded: ClownResamplerAMD_LastErrorCode) = "the consumer took nothing and said stop": state and *total_input_frames untouched */
 		if (plan == NULL)
+		{
+			if (ran_out_of_input != NULL)
+				*ran_out_of_input = cc_false;
 			return 0;
+		}
 
 		failed = cr_run_host(plan, input_buffer, (uint64_t)*total_input_frames + 2 * resampler->lowest_level.integer_stretched_kernel_radius,
 		                     pos_int, pos_frac, emit, output, out_s16);
 		cr_plan_release(plan);
 		if (failed != 0)
+		{
+			if (ran_out_of_input != NULL)
+				*ran_out_of_input = cc_false;
 			return 0;
+		}
 	}
 	else if (stopped)
 	{
@@ -697,16 +706,20 @@ cc_bool ClownResampler_LowLevel_Resample(ClownResampler_LowLevel_State *resample
 		return cc_true;
 	}
 
+	/* A failure - no plan, no memory, a launch or a copy that the device refuses - is reported as the reference's OTHER outcome: "the
+	   callback said stop" (cc_false), the state and *total_input_frames as they are after the frames the consumer HAS been given (none:
+	   untouched).  The reference cannot fail here (clownresampler.h:746-748); of its two outcomes this is the one after which a client
+	   still owns its unprocessed input.  ClownResamplerAMD_LastErrorCode() tells the two apart. */
 	plan = plan_for(&resampler->lowest_level, precomputed, channels, resampler->increment, 0);
 	if (plan == NULL)
-		return cc_true;
+		return cc_false;
 
 	batch_out = (int32_t *)malloc((size_t)(available < batch_limit ? available : batch_limit) * channels * sizeof(int32_t));
 	if (batch_out == NULL)
 	{
 		cr_plan_release(plan);
 		cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
-		return cc_true;
+		return cc_false;
 	}
 
 	/* 1. the growing batches, one after the other on this thread */
@@ -850,9 +863,11 @@ cc_bool ClownResampler_LowLevel_Resample(ClownResampler_LowLevel_State *resample
 
 	if (failed || done < available)
 	{
-		/* a device failure was reported through the error handler and the handler returned: stop where we are */
-		settle_stopped(resampler, total_input_frames, start_int, start_frac, done);
-		return cc_true;
+		/* a device failure was recorded (and the handler, if any, returned): stop where we are - as if the consumer had said stop on the
+		   last frame it was given; if it was given none, nothing has happened */
+		if (done != 0)
+			settle_stopped(resampler, total_input_frames, start_int, start_frac, done);
+		return cc_false;
 	}
 
 	settle_exhausted(resampler, total_input_frames, start_int, start_frac, available);
@@ -1027,8 +1042,10 @@ static cc_bool high_level_resample(ClownResampler_HighLevel_State *resampler, co
 
 			if (cr_stream_reserve(stream, 2 * halo_samples + limit * channels) != 0)
 			{
+				/* (the window keeps its two halos, empty in between: the next call refills) */
+				stream->start = stream->end = halo_samples;
 				cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
-				return cc_true;
+				return cc_false;
 			}
 
 			stream->start = halo_samples;
@@ -1045,8 +1062,10 @@ static cc_bool high_level_resample(ClownResampler_HighLevel_State *resampler, co
 
 				if (cr_stream_note_pull(stream, stream->start + have * channels) != 0)
 				{
+					/* (the frames pulled so far stay in the window: the next call resamples them) */
+					stream->end = stream->start + have * channels;
 					cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "out of host memory");
-					return cc_true;
+					return cc_false;
 				}
 			}
 
@@ -1091,10 +1110,10 @@ static cc_bool high_level_resample(ClownResampler_HighLevel_State *resampler, co
 
 			stream->start = stream->end - frames * channels; /* :1171 */
 
-			/* a device failure was reported and the (non-default) error handler returned: the window was not
-			   consumed, so looping would never end - give control back to the caller */
+			/* a device failure was recorded: what the consumer has not been given stays in the window (the next call goes on there),
+			   and the caller gets the "output callback said stop" outcome - looping here would never end */
 			if (cr_error_serial() != errors_before)
-				return cc_true;
+				return cc_false;
 
 			/* read further ahead only for consumers that take everything they are given */
 			if (consumer_stopped)

@@ -72,14 +72,34 @@ int cr_fail(int code, const char *format, ...)
 	}
 	else
 	{
-		fprintf(stderr, "clownresampler_amd: %s\n", t_last_message);
-		fflush(stderr);
-		if (!g_abort_dumped)
+		/* No handler installed.  The reference has no failing path (clownresampler.h:746-748: its two outcomes are "ran out of input" and
+		   "the callback said stop"), and a drop-in must not end the host process over an error it can hand back: the failure is RECORDED
+		   (ClownResamplerAMD_LastErrorCode / LastErrorMessage on this thread), said once on stderr - the first few of a process, so that a
+		   stream that falls silent has an explanation - and the entry point returns the "callback said stop" outcome with nothing consumed
+		   beyond what the consumer was given.  CLOWNRESAMPLER_AMD_ABORT_ON_ERROR=1 in the environment restores the hard stop (with the
+		   flight recorder) for whoever prefers a core dump at the first failure. */
+		static int said = 0;
+		static int abort_on_error = -1;
+
+		if (abort_on_error < 0)
 		{
-			g_abort_dumped = 1;
-			ClownResamplerAMD_DebugDumpFlightRecorder(2);
+			const char *e = getenv("CLOWNRESAMPLER_AMD_ABORT_ON_ERROR");
+			abort_on_error = (e != NULL && *e != '\0' && *e != '0') ? 1 : 0;
 		}
-		abort();
+		if (abort_on_error || __atomic_fetch_add(&said, 1, __ATOMIC_RELAXED) < 8)
+		{
+			fprintf(stderr, "clownresampler_amd: %s\n", t_last_message);
+			fflush(stderr);
+		}
+		if (abort_on_error)
+		{
+			if (!g_abort_dumped)
+			{
+				g_abort_dumped = 1;
+				ClownResamplerAMD_DebugDumpFlightRecorder(2);
+			}
+			abort();
+		}
 	}
 
 	return code;
@@ -3002,7 +3022,7 @@ int ClownResamplerAMD_DebugSelfCheck(char *message, size_t capacity)
 	if (g_no_dual_mono) FINDING("DebugDisableDualMono is still on");
 	if (g_seg_mode != 0) FINDING("DebugSegKernel is still %d", g_seg_mode);
 	if (g_segments_mode != 0) FINDING("DebugSegmentsMode is still %d", g_segments_mode);
-	if (g_variant >= 0) FINDING("DebugSetVariant is still %d", g_variant);
+	if (g_variant >= 0 && g_variant != CR_DEFAULT_VARIANT) FINDING("DebugSetVariant is still %d", g_variant);
 	if (g_debug_stamps != NULL) FINDING("DebugSetStampBuffer is still set");
 
 	pthread_mutex_lock(&g_lock);

@@ -238,10 +238,10 @@ struct guard_rec
 	hipMemGenericAllocationHandle_t handle;
 	void *first;
 };
-std::map<void *, guard_rec> g_guarded;
-std::mutex g_guard_lock;
+static std::map<void *, guard_rec> g_guarded;
+static std::mutex g_guard_lock;
 
-int guard_mode()
+static int guard_mode()
 {
 	static const int mode = [] {
 		const char *e = getenv("CLOWNRESAMPLER_AMD_GUARD_MALLOC");
@@ -250,7 +250,7 @@ int guard_mode()
 	return mode;
 }
 
-int guard_malloc(void **device_pointer, size_t bytes, int mode)
+static int guard_malloc(void **device_pointer, size_t bytes, int mode)
 {
 	int device = 0;
 	hipError_t e = hipGetDevice(&device);
@@ -325,8 +325,10 @@ int crhip_free(void *device_pointer)
 		hipError_t e = hipDeviceSynchronize();   // (what hipFree does before it lets memory go)
 		const hipError_t u = hipMemUnmap(r.first, r.mapped);
 		const hipError_t h = hipMemRelease(r.handle);
-		const hipError_t a = hipMemAddressFree(r.base, r.reserved);
-		return (int)(e != hipSuccess ? e : u != hipSuccess ? u : h != hipSuccess ? h : a);
+		// The address range is NOT given back (hipMemAddressFree): it stays reserved and unmapped for the life of the process, so that a
+		// stale pointer faults for good - and because a range that was freed and handed out again showed kernels and the copy engines
+		// different contents on this runtime (tools/experiments/r06/vmm_probe.py): a diagnostic mode must not add a hazard of its own.
+		return (int)(e != hipSuccess ? e : u != hipSuccess ? u : h);
 	}
 	return (int)hipFree(device_pointer);
 }

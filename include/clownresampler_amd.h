@@ -30,8 +30,13 @@ extern "C" {
  * Errors.  The reference's resample calls have no error channel (their cc_bool means "ran out of
  * input" vs "callback stopped", clownresampler.h:746-748), and this library has no CPU fallback, so a
  * runtime failure (no GPU, HIP error, out of device memory, unsupported argument) goes to a handler.
- * The default handler prints "clownresampler_amd: <message>" to stderr and calls abort().
- * A replacement handler may return; the failed call then produces no frames and leaves the state untouched.
+ * With NO handler installed the failure is recorded for the calling thread (ClownResamplerAMD_LastErrorCode / LastErrorMessage), the
+ * message is written to stderr (the first eight of a process), and the failed call returns - it never ends the process: the entry
+ * point reports the reference's "callback stopped" outcome (cc_false; ClownResampler_LowLevel_ResampleBulk and the device entry
+ * points: 0 frames, *ran_out_of_input = cc_false) with the state and *total_input_frames as they are after the frames the consumer
+ * HAS been given (none: untouched), so the client still owns its input and may try again or fall back.  The same holds after a
+ * handler that returns.  CLOWNRESAMPLER_AMD_ABORT_ON_ERROR=1 in the environment (read at the first failure) makes the handler-less
+ * default print, dump the flight recorder and abort() instead.
  * ------------------------------------------------------------------------------------------- */
 enum
 {
@@ -62,7 +67,7 @@ int ClownResamplerAMD_DeviceCount(void);                /* 0 when there is none;
 /* 1 when the resampling entry points of this library can run in this process - a gfx950 (MI355X) device is visible to the calling thread's
    selection - else 0.  Never calls the error handler, never aborts: the question to ask ONCE, at start-up, by a client that wants to fall
    back on the reference's own header (clownresampler.h with CLOWNRESAMPLER_IMPLEMENTATION: same API, same results, one core) where
-   there is no such device, instead of meeting the default error handler's abort() in its first ClownResampler_*_Resample call.  This
+   there is no such device, instead of finding out from a failed first ClownResampler_*_Resample call.  This
    library itself has no CPU path by design. */
 int ClownResamplerAMD_IsUsable(void);
 int ClownResamplerAMD_SetDevice(int ordinal);           /* process default: device used by calls of threads that have not chosen one; 0 on success */
@@ -237,8 +242,8 @@ void ClownResamplerAMD_DebugSegmentsMode(int mode);
 int ClownResamplerAMD_DebugSelfCheck(char *message, size_t capacity);
 /* Flight recorder: the last 64 device operations of this library in this process - every kernel launch with the address ranges it was
    given (input + readable bytes, output + bytes, rows / table image, ticket block, stream, grid), every device allocation and release - written
-   as text to the file descriptor `fd`; uses nothing but snprintf into a stack buffer and write(2).  The default error handler writes it to
-   stderr before it aborts.  ClownResamplerAMD_DebugInstallAbortDump has it written to stderr when the PROCESS receives SIGABRT - which
+   as text to the file descriptor `fd`; uses nothing but snprintf into a stack buffer and write(2).  With CLOWNRESAMPLER_AMD_ABORT_ON_ERROR=1 a
+   failure writes it to stderr before it aborts.  ClownResamplerAMD_DebugInstallAbortDump has it written to stderr when the PROCESS receives SIGABRT - which
    is how the HIP runtime ends a process whose GPU reported a memory fault, from a thread of its own, some time after the faulting
    launch returned - and then passes the signal on to the handler that was installed before (0 on success). */
 void ClownResamplerAMD_DebugDumpFlightRecorder(int fd);

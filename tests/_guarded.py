@@ -14,6 +14,7 @@ import os
 import numpy as np
 
 _hip = None
+KEEP_ADDRESSES = os.environ.get("CRA_GUARDED_KEEP", "1") != "0"
 
 
 class _Location(C.Structure):
@@ -122,13 +123,18 @@ class Guarded:
         self.place = place
         self.live = True
         if fill is not None:
-            _check(h.hipMemset(C.c_void_p(self.first), fill, self.mapped), "hipMemset")
+            # (a host-side pattern copied in, and the device waited for: hipMemset on such a mapping was seen to land LATE - after a
+            # device-to-host copy issued behind it - on this runtime; tools/experiments/r06/vmm_probe.py)
+            pattern = np.full(self.mapped, fill, dtype=np.uint8)
+            _check(h.hipMemcpy(C.c_void_p(self.first), pattern.ctypes.data_as(C.c_void_p), self.mapped, 1), "hipMemcpy(H2D, fill)")
+            _check(h.hipDeviceSynchronize(), "hipDeviceSynchronize")
 
     def write(self, array, at=0):
         a = np.ascontiguousarray(array)
         assert at + a.nbytes <= self.nbytes, (at, a.nbytes, self.nbytes)
         if a.nbytes:
             _check(hip().hipMemcpy(C.c_void_p(self.ptr + at), a.ctypes.data_as(C.c_void_p), a.nbytes, 1), "hipMemcpy(H2D)")
+            _check(hip().hipDeviceSynchronize(), "hipDeviceSynchronize")
 
     def read(self, dtype, count=None, at=0):
         dtype = np.dtype(dtype)
@@ -136,22 +142,29 @@ class Guarded:
         out = np.empty(count, dtype=dtype)
         assert at + out.nbytes <= self.nbytes
         if out.nbytes:
+            _check(hip().hipDeviceSynchronize(), "hipDeviceSynchronize")
             _check(hip().hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr + at), out.nbytes, 2), "hipMemcpy(D2H)")
         return out
 
     def read_mapped(self):
         """every mapped byte (the buffer and the slack the placement left inside the mapping)"""
         out = np.empty(self.mapped, dtype=np.uint8)
+        _check(hip().hipDeviceSynchronize(), "hipDeviceSynchronize")
         _check(hip().hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.first), out.nbytes, 2), "hipMemcpy(D2H)")
         return out
 
     def close(self):
+        """Unmaps and gives the physical pages back; the ADDRESS RANGE stays reserved for the life of the process (KEEP_ADDRESSES).  On this
+        runtime a range that was unmapped, freed and handed out again by the next hipMemAddressReserve showed kernels, hipMemset and the
+        copy engines DIFFERENT contents - some of them still translating through the old mapping (tools/experiments/r06/vmm_probe.py,
+        profiles/r06_vmm_probe.log: 16 of 48 buffers bad with reuse, 0 of 48 without).  A test allocator must not add a hazard of its own."""
         if self.live:
             h = hip()
             h.hipDeviceSynchronize()
             h.hipMemUnmap(C.c_void_p(self.first), self.mapped)
             h.hipMemRelease(self.handle)
-            h.hipMemAddressFree(self.base, self.reserved)
+            if not KEEP_ADDRESSES:
+                h.hipMemAddressFree(self.base, self.reserved)
             self.live = False
 
     def __enter__(self):

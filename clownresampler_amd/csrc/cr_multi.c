@@ -150,6 +150,22 @@ size_t cr_resample_sharded(ClownResampler_LowLevel_State *resampler, uint64_t ta
 		   after the kernels are in their queues) */
 		unsigned q;
 
+		/* EXPERIMENTAL beyond one rank: this path has never issued an RCCL operation between two devices (the build pool has one GPU per
+		   box; with one rank ncclGather is a local copy).  Until tools/multi_gpu_preflight.sh has passed on a multi-GPU node a client has
+		   to ask for it by name; CLOWNRESAMPLER_AMD_GATHER_PEER_COPY - hipMemcpyPeerAsync per shard over its own xGMI link, exercised with
+		   eight shards - is the gather to use. */
+		if (shard_count > 1u)
+		{
+			const char *e = getenv("CLOWNRESAMPLER_AMD_EXPERIMENTAL_RCCL");
+
+			if (e == NULL || *e == '\0' || *e == '0')
+			{
+				cr_fail(CLOWNRESAMPLER_AMD_ERROR_ARGUMENT, "CLOWNRESAMPLER_AMD_GATHER_RCCL with %u shards is experimental (never run between two devices): set "
+				        "CLOWNRESAMPLER_AMD_EXPERIMENTAL_RCCL=1 to use it, or gather with CLOWNRESAMPLER_AMD_GATHER_PEER_COPY", shard_count);
+				return 0;
+			}
+		}
+
 		for (r = 0; r < shard_count; ++r)
 			for (q = 0; q < r; ++q)
 				if (shards[q].device == shards[r].device)

@@ -314,7 +314,9 @@ size_t ClownResamplerAMD_ResampleSegmentsDevice(ClownResampler_LowLevel_State *r
  *                                        once - checked before anything is launched).  It has only ever run with ONE rank (the
  *                                        test pool has single-GPU boxes), where no NCCL operation is issued at all: treat it as
  *                                        unvalidated between distinct GPUs and prefer PEER_COPY until
- *                                        tests/test_gpu_ranks.py::test_two_distinct_gpus_over_rccl has run on a multi-GPU node
+ *                                        tests/test_gpu_ranks.py::test_two_distinct_gpus_over_rccl has run on a multi-GPU node.
+ *                                        With MORE THAN ONE shard the call is refused (error ARGUMENT, nothing launched) unless
+ *                                        CLOWNRESAMPLER_AMD_EXPERIMENTAL_RCCL=1 is set in the environment
  * Nothing is synchronised: use ClownResamplerAMD_ShardedSynchronize (or the streams) before reading.  Returns the total
  * number of output frames and leaves *resampler as ONE ClownResampler_LowLevel_Resample over the whole input would
  * (clownresampler.h:1065-1067); 0 after an error (reported through the handler).

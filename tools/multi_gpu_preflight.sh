@@ -59,7 +59,7 @@ step 900 "cr_multi $SHARDS shards, peer copies" tools/bin/cr_multi "$SHARDS" "$F
 if [ "$DRY" = 1 ]; then
 	say "== cr_multi rccl: skipped in a dry run (with one device no RCCL operation is issued: nothing would be learnt)"
 else
-	step 900 "cr_multi $SHARDS shards, RCCL gather (EXPERIMENTAL until this passes)" tools/bin/cr_multi "$SHARDS" "$FRAMES" rccl
+	step 900 "cr_multi $SHARDS shards, RCCL gather (EXPERIMENTAL until this passes)" env CLOWNRESAMPLER_AMD_EXPERIMENTAL_RCCL=1 tools/bin/cr_multi "$SHARDS" "$FRAMES" rccl
 fi
 
 # ---- 3. the curve ----------------------------------------------------------------------------------------------------------

@@ -30,6 +30,44 @@
 static __thread int t_device = 0;
 static unsigned long long g_launches[4];   /* poly, generic, segments, other */
 
+/* ---- failure injection: crhip_fake_fail(kind, n) makes the n-th next operation of that kind fail ONCE with a HIP-like
+   error code; 0 disarms.  What the host logic does with a device that says no - at an allocation, a launch, a copy, a synchronise - is
+   under test: nothing may leak (LeakSanitizer), no state may move, the entry points hand the failure back (clownresampler.h:746-748). */
+enum { FAKE_FAIL_MALLOC = 0, FAKE_FAIL_HOST_ALLOC = 1, FAKE_FAIL_LAUNCH = 2, FAKE_FAIL_COPY = 3, FAKE_FAIL_SYNC = 4, FAKE_FAIL_KINDS = 5 };
+#define FAKE_ERROR_INJECTED 2   /* hipErrorOutOfMemory's number */
+static int g_fail_in[FAKE_FAIL_KINDS];
+static unsigned long long g_failed[FAKE_FAIL_KINDS];
+
+void crhip_fake_fail(int kind, int nth)
+{
+	if (kind >= 0 && kind < FAKE_FAIL_KINDS)
+		__atomic_store_n(&g_fail_in[kind], nth, __ATOMIC_RELAXED);
+}
+
+unsigned long long crhip_fake_failed(int kind)
+{
+	return kind >= 0 && kind < FAKE_FAIL_KINDS ? __atomic_load_n(&g_failed[kind], __ATOMIC_RELAXED) : 0;
+}
+
+static int injected(int kind)
+{
+	int n = __atomic_load_n(&g_fail_in[kind], __ATOMIC_RELAXED);
+
+	while (n > 0)
+	{
+		if (__atomic_compare_exchange_n(&g_fail_in[kind], &n, n - 1, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED))
+		{
+			if (n == 1)
+			{
+				__atomic_fetch_add(&g_failed[kind], 1ull, __ATOMIC_RELAXED);
+				return 1;
+			}
+			return 0;
+		}
+	}
+	return 0;
+}
+
 static int device_count_now(void)
 {
 	const char *e = getenv("CRA_FAKE_DEVICES");
@@ -39,7 +77,7 @@ static int device_count_now(void)
 
 const char *crhip_error_string(int code)
 {
-	return code == 0 ? "no error" : code == FAKE_ERROR_LAUNCH ? "fake device: a launch broke one of its invariants (see stderr)" : "fake device: invalid value";
+	return code == 0 ? "no error" : code == FAKE_ERROR_INJECTED ? "fake device: injected failure" : code == FAKE_ERROR_LAUNCH ? "fake device: a launch broke one of its invariants (see stderr)" : "fake device: invalid value";
 }
 
 int crhip_device_count(int *count)
@@ -80,6 +118,11 @@ int crhip_get_device_info(int ordinal, crhip_device_info *info)
 int crhip_malloc(void **device_pointer, size_t bytes)
 {
 	/* a little slack behind, as hipMalloc's granularity gives: NOT in front - an underrun is a bug worth seeing */
+	if (injected(FAKE_FAIL_MALLOC))
+	{
+		*device_pointer = NULL;
+		return FAKE_ERROR_INJECTED;
+	}
 	*device_pointer = malloc(bytes != 0 ? bytes : 1);
 	return *device_pointer != NULL ? 0 : 2;
 }
@@ -92,6 +135,11 @@ int crhip_free(void *device_pointer)
 
 int crhip_host_alloc(void **host_pointer, size_t bytes)
 {
+	if (injected(FAKE_FAIL_HOST_ALLOC))
+	{
+		*host_pointer = NULL;
+		return FAKE_ERROR_INJECTED;
+	}
 	*host_pointer = malloc(bytes != 0 ? bytes : 1);
 	return *host_pointer != NULL ? 0 : 2;
 }
@@ -113,6 +161,8 @@ int crhip_host_alias(const void *host, size_t bytes, void **device_alias)
 int crhip_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
 {
 	(void)stream;
+	if (injected(FAKE_FAIL_COPY))
+		return FAKE_ERROR_INJECTED;
 	memcpy(dst, src, bytes);
 	return 0;
 }
@@ -120,6 +170,8 @@ int crhip_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
 int crhip_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
 {
 	(void)stream;
+	if (injected(FAKE_FAIL_COPY))
+		return FAKE_ERROR_INJECTED;
 	memcpy(dst, src, bytes);
 	return 0;
 }
@@ -146,7 +198,7 @@ int crhip_stream_destroy(void *stream)
 int crhip_stream_sync(void *stream)
 {
 	(void)stream;
-	return 0;
+	return injected(FAKE_FAIL_SYNC) ? FAKE_ERROR_INJECTED : 0;
 }
 
 int crhip_device_sync(void)
@@ -321,6 +373,8 @@ int crhip_launch_poly(const crhip_poly_launch *l, void *stream)
 	uint32_t w;
 
 	(void)stream;
+	if (injected(FAKE_FAIL_LAUNCH))
+		return FAKE_ERROR_INJECTED;
 	__atomic_fetch_add(&g_launches[0], 1ull, __ATOMIC_RELAXED);
 
 	/* what every k_poly launch has to satisfy */
@@ -418,6 +472,8 @@ int crhip_launch_generic(const crhip_generic_launch *g, void *stream)
 	uint64_t j;
 
 	(void)stream;
+	if (injected(FAKE_FAIL_LAUNCH))
+		return FAKE_ERROR_INJECTED;
 	__atomic_fetch_add(&g_launches[1], 1ull, __ATOMIC_RELAXED);
 	if (g->n_out == 0 || g->d_table == NULL || g->d_out == NULL || g->channels == 0 || g->channels > CRHIP_MAX_CHANNELS || (g->d_acc_in != NULL && g->n_out != 1) || g->out64 > 2)
 	{
@@ -454,6 +510,8 @@ int crhip_launch_segments(const crhip_segments_launch *l, void *stream)
 	uint32_t k = 0;
 
 	(void)stream;
+	if (injected(FAKE_FAIL_LAUNCH))
+		return FAKE_ERROR_INJECTED;
 	__atomic_fetch_add(&g_launches[2], 1ull, __ATOMIC_RELAXED);
 	if (l->n_out == 0 || l->n_segments == 0 || l->d_segments == NULL || l->d_table == NULL || l->d_segments[0].first_out != 0)
 	{

@@ -566,6 +566,234 @@ static void test_shutdown(void)
 	printf("ok shutdown\n");
 }
 
+/* ---- 10. a device that says no: every entry point hands the failure back - the reference's "callback said stop" outcome
+   (clownresampler.h:746-748), the state and the input count as after what the consumer HAS been given - and the same call, repeated, is right ---- */
+void crhip_fake_fail(int kind, int nth);
+unsigned long long crhip_fake_failed(int kind);
+enum { FAIL_MALLOC = 0, FAIL_HOST_ALLOC = 1, FAIL_LAUNCH = 2, FAIL_COPY = 3, FAIL_SYNC = 4, FAIL_KINDS = 5 };
+static const char *const fail_names[FAIL_KINDS] = {"hipMalloc", "hipHostMalloc", "launch", "copy", "synchronise"};
+static int quiet_errors = 0;
+
+static void on_error_counted(int code, const char *message, void *user)
+{
+	(void)code;
+	(void)message;
+	++*(int *)user;
+}
+
+static void disarm(void)
+{
+	int k;
+
+	for (k = 0; k < FAIL_KINDS; ++k)
+		crhip_fake_fail(k, 0);
+}
+
+static void test_failures(void)
+{
+	const unsigned channels = 2;
+	const size_t frames = 30000, radius = 3;
+	int16_t *pcm = padded_noise(frames, channels, radius, 77);
+	const size_t room = frames * 2;
+	int32_t *out = (int32_t *)malloc(room * channels * sizeof(int32_t)), *want = (int32_t *)malloc(room * channels * sizeof(int32_t));
+	int reported = 0, kind, nth;
+	size_t want_frames;
+
+	(void)quiet_errors;
+	ClownResamplerAMD_SetErrorHandler(on_error_counted, &reported);
+	{
+		oracle_lowlevel ost;
+		size_t left = frames;
+		uint8_t ran = 0;
+
+		oracle_low_init(&ost, 3, channels, 44100, 48000, 44100);
+		want_frames = oracle_low_resample_i32(&ost, table, table_len, pcm, &left, want, room, ORACLE_NORM_CURRENT, 0, &ran);
+	}
+
+	for (kind = 0; kind < FAIL_KINDS; ++kind)
+		for (nth = 1; nth <= 4; ++nth)
+		{
+			ClownResampler_LowLevel_State st, before;
+			size_t left = frames, n;
+			cc_bool ran_out = 7;
+			unsigned long long failed_before = crhip_fake_failed(kind);
+			int injected_here;
+
+			/* every failure meets a COLD library: plans, staging sets and ticket rings all have to be made again */
+			ClownResamplerAMD_Shutdown();
+			ClownResamplerAMD_ClearError();
+			reported = 0;
+
+			/* (a) the bulk entry point */
+			ClownResampler_LowLevel_Init(&st, channels, 44100, 48000, 44100);
+			before = st;
+			crhip_fake_fail(kind, nth);
+			n = ClownResampler_LowLevel_ResampleBulk(&st, &pre, pcm, &left, out, room, &ran_out);
+			disarm();
+			injected_here = crhip_fake_failed(kind) != failed_before;
+			if (injected_here)
+			{
+				CHECK(n == 0 && ran_out == cc_false && left == frames && memcmp(&st, &before, sizeof(st)) == 0 && ClownResamplerAMD_LastErrorCode() != 0 && reported != 0,
+				      "bulk, %s #%d: %zu frames, ran_out %d, %zu left, error %d", fail_names[kind], nth, n, (int)ran_out, left, ClownResamplerAMD_LastErrorCode());
+				ClownResamplerAMD_ClearError();
+				n = ClownResampler_LowLevel_ResampleBulk(&st, &pre, pcm, &left, out, room, &ran_out);
+			}
+			CHECK(n == want_frames && left == 0 && ran_out == cc_true && memcmp(out, want, n * channels * sizeof(int32_t)) == 0 && ClownResamplerAMD_LastErrorCode() == 0,
+			      "bulk after %s #%d: %zu of %zu frames", fail_names[kind], nth, n, want_frames);
+		}
+
+	/* (b) the callback form: a failure part-way = a stop after the frames already handed out; the rest on the next call */
+	for (kind = 0; kind < FAIL_KINDS; ++kind)
+		for (nth = 1; nth <= 12; nth += (nth < 4 ? 1 : 4))
+		{
+			ClownResampler_LowLevel_State st;
+			oracle_lowlevel ost;
+			sink got;
+			size_t left = frames, calls = 0;
+			unsigned long long failed_before = crhip_fake_failed(kind);
+			cc_bool r = cc_false;
+
+			ClownResamplerAMD_Shutdown();
+			ClownResamplerAMD_ClearError();
+			memset(&got, 0, sizeof(got));
+			got.out = out;
+			got.at = 0;
+			got.stop_at = (size_t)-1;
+			ClownResampler_LowLevel_Init(&st, channels, 44100, 48000, 44100);
+			crhip_fake_fail(kind, nth);
+			while (calls < 8)
+			{
+				const size_t consumed_before = frames - left;
+
+				r = ClownResampler_LowLevel_Resample(&st, &pre, pcm + consumed_before * channels, &left, sink_frame, &got);
+				disarm();
+				++calls;
+				if (r)
+					break;
+				CHECK(ClownResamplerAMD_LastErrorCode() != 0, "callback, %s #%d: cc_false without a stop or an error", fail_names[kind], nth);
+				ClownResamplerAMD_ClearError();
+			}
+			oracle_low_init(&ost, 3, channels, 44100, 48000, 44100);
+			(void)ost;
+			CHECK(r == cc_true && left == 0 && got.at == want_frames * channels && memcmp(out, want, got.at * sizeof(int32_t)) == 0,
+			      "callback, %s #%d (%s): %zu of %zu samples after %zu calls", fail_names[kind], nth, crhip_fake_failed(kind) != failed_before ? "injected" : "not reached",
+			      got.at, want_frames * channels, calls);
+		}
+
+	/* (c) the high-level API: the window keeps what it has pulled; the stream comes out whole however often the device said no */
+	for (kind = 0; kind < FAIL_KINDS; ++kind)
+		for (nth = 1; nth <= 9; nth += 4)
+		{
+			static ClownResampler_HighLevel_State hs;
+			both io;
+			size_t calls = 0;
+			cc_bool r = cc_false;
+			size_t high_frames = 0;
+			int32_t *high_want = (int32_t *)malloc(room * channels * sizeof(int32_t));
+
+			ClownResamplerAMD_Shutdown();
+			ClownResamplerAMD_ClearError();
+			/* the oracle's own high-level run of the same source */
+			{
+				oracle_highlevel oh;
+				both ref;
+
+				memset(&ref, 0, sizeof(ref));
+				ref.src.pcm = pcm + radius * channels;
+				ref.src.frames = frames;
+				ref.src.channels = channels;
+				ref.src.chunk = 0;
+				ref.out.out = high_want;
+				ref.out.stop_at = (size_t)-1;
+				oracle_high_init(&oh, 3, channels, 44100, 48000, 44100);
+				if (oracle_high_resample(&oh, table, table_len, pull_both_oracle, sink_both_oracle, &ref))
+					oracle_high_end(&oh, table, table_len, sink_both_oracle, &ref);
+				high_frames = ref.out.at;
+			}
+			memset(&io, 0, sizeof(io));
+			io.src.pcm = pcm + radius * channels;
+			io.src.frames = frames;
+			io.src.channels = channels;
+			io.src.chunk = 0;
+			io.out.out = out;
+			io.out.stop_at = (size_t)-1;
+			CHECK(ClownResampler_HighLevel_Init(&hs, channels, 44100, 48000, 44100), "HighLevel_Init");
+			crhip_fake_fail(kind, nth);
+			while (calls < 16)
+			{
+				r = ClownResampler_HighLevel_Resample(&hs, &pre, pull_both, sink_both, &io);
+				disarm();
+				++calls;
+				if (r)
+					break;
+				CHECK(ClownResamplerAMD_LastErrorCode() != 0, "high level, %s #%d: cc_false without a stop or an error", fail_names[kind], nth);
+				ClownResamplerAMD_ClearError();
+			}
+			CHECK(r == cc_true, "high level, %s #%d: the source never ran dry", fail_names[kind], nth);
+			ClownResampler_HighLevel_ResampleEnd(&hs, &pre, sink_both, &io);
+			CHECK(io.out.at == high_frames && memcmp(out, high_want, high_frames * sizeof(int32_t)) == 0, "high level, %s #%d: %zu of %zu samples", fail_names[kind], nth, io.out.at, high_frames);
+			ClownResamplerAMD_HighLevel_Release(&hs);
+			free(high_want);
+		}
+
+	/* (d) variable-rate segments on the "device": 0 frames, the state untouched; the repeat is right */
+	{
+		const size_t halo = 24;
+		ClownResamplerAMD_Segment segments[3] = {{12000, 44100, 48000, 44100}, {8000, 48000, 44100, 44100}, {10000 - 2 * (24 - 3), 44100, 88200, 44100}};
+		int mode;
+
+		for (mode = 1; mode <= 2; ++mode)
+			for (kind = 0; kind < FAIL_KINDS; ++kind)
+				for (nth = 1; nth <= 5; nth += 2)
+				{
+					ClownResampler_LowLevel_State st, before;
+					size_t counts[3], n, total;
+					unsigned long long failed_before = crhip_fake_failed(kind);
+					int16_t *d_in;
+					int32_t *d_out;
+
+					ClownResamplerAMD_Shutdown();
+					ClownResamplerAMD_ClearError();
+					d_in = (int16_t *)ClownResamplerAMD_DeviceAlloc((frames + 2 * radius) * channels * sizeof(int16_t));
+					d_out = (int32_t *)ClownResamplerAMD_DeviceAlloc(room * channels * sizeof(int32_t));
+					CHECK(d_in != NULL && d_out != NULL, "DeviceAlloc");
+					ClownResamplerAMD_CopyToDevice(d_in, pcm, (frames + 2 * radius) * channels * sizeof(int16_t));
+					ClownResamplerAMD_DebugSegmentsMode(mode);
+					ClownResampler_LowLevel_Init(&st, channels, 44100, 48000, 44100);
+					before = st;
+					/* (the timeline's frame 0 lies `halo` frames into the buffer: the first 24 - 3 frames of noise serve as halo) */
+					crhip_fake_fail(kind, nth);
+					n = ClownResamplerAMD_ResampleSegmentsDevice(&st, &pre, d_in + halo * channels, halo, segments, 3, d_out, room, 0, counts, NULL);
+					disarm();
+					if (crhip_fake_failed(kind) != failed_before)
+					{
+						CHECK(n == 0 && memcmp(&st, &before, sizeof(st)) == 0 && ClownResamplerAMD_LastErrorCode() != 0, "segments mode %d, %s #%d: %zu frames, error %d", mode, fail_names[kind], nth, n, ClownResamplerAMD_LastErrorCode());
+						ClownResamplerAMD_ClearError();
+						n = ClownResamplerAMD_ResampleSegmentsDevice(&st, &pre, d_in + halo * channels, halo, segments, 3, d_out, room, 0, counts, NULL);
+					}
+					ClownResamplerAMD_StreamSynchronize(NULL);
+					total = counts[0] + counts[1] + counts[2];
+					CHECK(n != 0 && n == total && ClownResamplerAMD_LastErrorCode() == 0, "segments mode %d after %s #%d: %zu frames (%zu)", mode, fail_names[kind], nth, n, total);
+					ClownResamplerAMD_DebugSegmentsMode(0);
+					ClownResamplerAMD_DeviceFree(d_in);
+					ClownResamplerAMD_DeviceFree(d_out);
+				}
+	}
+
+	{
+		char message[512];
+		const int findings = ClownResamplerAMD_DebugSelfCheck(message, sizeof(message));
+		CHECK(findings == 0, "after the failures the library is not at rest: %s", message);
+	}
+	ClownResamplerAMD_SetErrorHandler(on_error, NULL);
+	free(pcm);
+	free(out);
+	free(want);
+	printf("ok failures (injected: %llu hipMalloc, %llu hipHostMalloc, %llu launches, %llu copies, %llu synchronises)\n", crhip_fake_failed(0), crhip_fake_failed(1),
+	       crhip_fake_failed(2), crhip_fake_failed(3), crhip_fake_failed(4));
+	CHECK(crhip_fake_failed(0) >= 8 && crhip_fake_failed(2) >= 8 && crhip_fake_failed(3) >= 4 && crhip_fake_failed(4) >= 8, "the injections did not reach the library");
+}
+
 int main(int argc, char **argv)
 {
 	static const struct
@@ -573,7 +801,7 @@ int main(int argc, char **argv)
 		const char *name;
 		void (*run)(void);
 	} tests[] = {{"bulk", test_bulk}, {"bulk_batches", test_bulk_batches}, {"callback", test_callback}, {"stream", test_stream}, {"concurrent", test_concurrent},
-	             {"segments", test_segments}, {"sharded", test_sharded}, {"device_threads", test_device_threads}, {"shutdown", test_shutdown}};
+	             {"segments", test_segments}, {"sharded", test_sharded}, {"device_threads", test_device_threads}, {"failures", test_failures}, {"shutdown", test_shutdown}};
 	size_t i, k;
 
 	setenv("CRA_FAKE_DEVICES", "4", 0);

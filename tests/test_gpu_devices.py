@@ -312,3 +312,38 @@ def test_c_client_drives_every_device(args):
     if "rccl" in args and r.returncode != 0 and "librccl" in r.stderr:
         pytest.skip("librccl unusable on this box: " + r.stderr[-300:])
     assert r.returncode == 0 and "cr_multi: OK" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+
+
+def test_rccl_gather_between_shards_is_opt_in(products):
+    """CLOWNRESAMPLER_AMD_GATHER_RCCL has never issued an RCCL operation between two devices (one GPU per box here).
+    With more than one shard the call is REFUSED before anything is launched - error ARGUMENT, 0 frames, the state untouched, the
+    message naming the way out - unless CLOWNRESAMPLER_AMD_EXPERIMENTAL_RCCL=1; the peer-copy gather, which has run with eight shards, is
+    what a client gets to use."""
+    import torch
+    assert not os.environ.get("CLOWNRESAMPLER_AMD_EXPERIMENTAL_RCCL")
+    p = products[3]
+    api = p.api
+    dev = torch.device("cuda", 0)
+    ch, frames = 2, 50000
+    ok, st = p.low_init(ch, 44100, 48000, 44100)
+    before = st.astuple()
+    d_in = torch.zeros((frames + 6) * ch, dtype=torch.int16, device=dev)
+    d_out = torch.zeros(60000 * ch, dtype=torch.int32, device=dev)
+    shards = [(0, d_in.data_ptr(), d_out.data_ptr(), None), (0, d_in.data_ptr(), d_out.data_ptr(), None)]
+    launches = [api.LaunchCount(k) for k in range(9)]
+    with pytest.raises(cr.ClownResamplerError) as e:
+        api.ResampleShardedDevice(st.raw, p.pre, frames, shards, gather_mode=cr.GATHER_RCCL, root_shard=0, root_output=d_out.data_ptr())
+    assert "CLOWNRESAMPLER_AMD_EXPERIMENTAL_RCCL" in str(e.value) and "PEER_COPY" in str(e.value)
+    assert st.astuple() == before and [api.LaunchCount(k) for k in range(9)] == launches
+
+
+def test_preflight_dry_run(tmp_path):
+    """tools/multi_gpu_preflight.sh - the one command for the day a multi-GPU node is at hand - in its quick dry mode on THIS box: the
+    one-call sharded entry point with 8 shards and peer copies through the C client, bench.py at 1 rank and at 2 ranks (sharing the GPU
+    over gloo), the table: the script itself stays runnable, step by step in fresh processes."""
+    env = dict(os.environ, CRA_PREFLIGHT_DRY="1", CRA_PREFLIGHT_QUICK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CRA_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "multi_gpu_preflight.sh"), str(tmp_path)], capture_output=True, text=True, timeout=1500, env=env)
+    log = open(os.path.join(str(tmp_path), "preflight.log")).read() if os.path.exists(os.path.join(str(tmp_path), "preflight.log")) else ""
+    assert r.returncode == 0 and "ALL STEPS PASSED" in r.stdout, (r.stdout[-3000:], log[-3000:])

@@ -29,7 +29,7 @@ def _run(exe, env_extra, timeout):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=timeout, env=env)
     tail = (r.stdout + r.stderr)[-6000:]
     assert r.returncode == 0 and "driver: all passed" in r.stdout, tail
-    for name in ("bulk", "bulk_batches", "callback", "stream", "concurrent", "segments", "sharded", "device_threads", "shutdown"):
+    for name in ("bulk", "bulk_batches", "callback", "stream", "concurrent", "segments", "sharded", "device_threads", "failures", "shutdown"):
         assert "ok " + name in r.stdout, tail
     return r
 

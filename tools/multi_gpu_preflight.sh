@@ -4,6 +4,9 @@
 #   bash tools/multi_gpu_preflight.sh [outdir]            on a node with >= 2 GPUs: the real thing (RCCL over xGMI, peer copies)
 #   CRA_PREFLIGHT_DRY=1 bash tools/multi_gpu_preflight.sh the steps a ONE-GPU box allows (ranks share the GPU over gloo; validation
 #                                                         only: the timings are those of ranks contending for one GPU)
+#   CRA_PREFLIGHT_DRY=1 CRA_PREFLIGHT_QUICK=1 ...         the dry run in two minutes, for the GPU test suite to run on every box
+#                                                         (tests/test_gpu_devices.py::test_preflight_dry_run): no pytest step (the suite
+#                                                         is the caller), a minute of audio over 8 shards, bench at 1 and 2 ranks, few steps
 #
 # What has never run on distinct GPUs and runs here, in this order, every step in a FRESH process under its
 # own timeout (never an exec from a process that has touched the GPU; a hung step is killed and reported, the rest still runs):
@@ -22,6 +25,9 @@ LOG=$OUT/preflight.log
 : > "$LOG"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 DRY=${CRA_PREFLIGHT_DRY:-0}
+QUICK=${CRA_PREFLIGHT_QUICK:-0}
+[ "$QUICK" = 1 ] && DRY=1
+BENCH_ARGS=$([ "$QUICK" = 1 ] && echo "--steps 6 --warmup 2 --prewarm-ms 10" || echo "")
 say() { echo "$@" | tee -a "$LOG"; }
 FAILED=0
 step() {   # step <seconds> <name> <command...>
@@ -44,7 +50,9 @@ if [ "$NGPU" -lt 2 ] && [ "$DRY" != 1 ]; then
 fi
 
 # ---- 1. the tests --------------------------------------------------------------------------------------------------------
-if [ "$DRY" = 1 ]; then
+if [ "$QUICK" = 1 ]; then
+	say "== tests: skipped in a quick dry run (the test suite is the caller)"
+elif [ "$DRY" = 1 ]; then
 	step 900 "tests (shared GPU: rank processes + device contexts)" python3 -m pytest tests/test_gpu_ranks.py tests/test_gpu_devices.py -m gpu -q -x
 else
 	step 600 "tests: two distinct GPUs over RCCL" python3 -m pytest "tests/test_gpu_ranks.py::test_two_distinct_gpus_over_rccl" -m gpu -q -x
@@ -55,6 +63,7 @@ fi
 HOUR=158760000    # BASELINE configs[4]: one hour of stereo 44.1 kHz
 SHARDS=$([ "$NGPU" -ge 8 ] && echo 8 || echo "$NGPU"); [ "$DRY" = 1 ] && SHARDS=8
 FRAMES=$([ "$DRY" = 1 ] && echo 26460000 || echo $HOUR)
+[ "$QUICK" = 1 ] && FRAMES=2646000
 step 900 "cr_multi $SHARDS shards, peer copies" tools/bin/cr_multi "$SHARDS" "$FRAMES" peer
 if [ "$DRY" = 1 ]; then
 	say "== cr_multi rccl: skipped in a dry run (with one device no RCCL operation is issued: nothing would be learnt)"
@@ -64,12 +73,13 @@ fi
 
 # ---- 3. the curve ----------------------------------------------------------------------------------------------------------
 for n in 1 2 4 8; do
+	if [ "$QUICK" = 1 ] && [ "$n" -gt 2 ]; then continue; fi
 	if [ "$DRY" != 1 ] && [ "$n" -gt "$NGPU" ]; then say "== bench --gpus $n: skipped ($NGPU GPUs)"; continue; fi
 	port=$((29500 + n))
 	if [ "$n" = 1 ]; then
-		step 900 "bench --gpus 1" bash -c "python3 bench.py --gpus 1 > '$OUT/bench_n1.json' 2> '$OUT/bench_n1.err'"
+		step 900 "bench --gpus 1" bash -c "python3 bench.py --gpus 1 $BENCH_ARGS > '$OUT/bench_n1.json' 2> '$OUT/bench_n1.err'"
 	elif [ "$DRY" = 1 ]; then
-		step 1200 "bench --gpus $n (ranks share one GPU, gloo: VALIDATION ONLY)" bash -c "CRA_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port bench.py --gpus $n --rank-timeout 900 > '$OUT/bench_n$n.json' 2> '$OUT/bench_n$n.err'"
+		step 1200 "bench --gpus $n (ranks share one GPU, gloo: VALIDATION ONLY)" bash -c "CRA_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port bench.py --gpus $n --rank-timeout 900 $BENCH_ARGS > '$OUT/bench_n$n.json' 2> '$OUT/bench_n$n.err'"
 	else
 		step 1200 "bench --gpus $n (RCCL)" bash -c "python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port bench.py --gpus $n --rank-timeout 900 > '$OUT/bench_n$n.json' 2> '$OUT/bench_n$n.err'"
 	fi

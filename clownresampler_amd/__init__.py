@@ -292,6 +292,7 @@ class Api:
         self._ForceGeneric = fn("ClownResamplerAMD_DebugForceGenericKernel", None, [C.c_int], False)
         self._SetVariant = fn("ClownResamplerAMD_DebugSetVariant", None, [C.c_int], False)
         self._SetStreamingWindow = fn("ClownResamplerAMD_SetStreamingWindow", None, [C.c_size_t], False)
+        self._HostVisible = fn("ClownResamplerAMD_DebugHostIsDeviceVisible", C.c_int, [C.c_void_p, C.c_size_t], False)
         self._libc_free = C.CDLL(None).free
         self._libc_free.argtypes = [C.c_void_p]
 
@@ -503,6 +504,10 @@ class Api:
     def PlanKernelAt(self, plan, position_fractional=0):
         """kernel id a launch from this fractional position takes (PlanInfo.kernel numbering, 5 = k_int)"""
         return int(self._PlanKernelAt(plan, position_fractional))
+
+    def HostIsDeviceVisible(self, address, nbytes):
+        """1 when the host-pointer entry points would use [address, address + nbytes) in place (page-locked, device-addressable), 0 when they stage it"""
+        return int(self._HostVisible(C.c_void_p(address), nbytes))
 
     def DebugSegmentsMode(self, mode):
         """0: the rule picks, 1: one launch per segment, 2: one launch for all segments (segment table)"""

@@ -2984,6 +2984,17 @@ void ClownResamplerAMD_DebugSegmentsMode(int mode)
 	g_segments_mode = (mode >= 0 && mode <= 2) ? mode : 0;
 }
 
+/* 1 when the host-pointer entry points would read / write [host, host + bytes) IN PLACE (page-locked memory the current device can address:
+   hipHostMalloc, hipHostRegister), 0 when they stage it (pageable memory) - the question cr_run_host asks of every larger call. */
+int ClownResamplerAMD_DebugHostIsDeviceVisible(const void *host, size_t bytes)
+{
+	void *alias = NULL;
+
+	if (cr_ensure_device() != 0)
+		return 0;
+	return crhip_host_alias(host, bytes, &alias) == 0 && alias != NULL;
+}
+
 /* The library at REST (no call in progress on any thread): what its process-wide state must look like then.  Waits for the devices it has
    touched, so every launch it ever enqueued has finished.  0 and an empty message when everything holds; otherwise the number of
    findings, the first few in `message`.  (the reference has no globals; this library has - plan cache, ticket rings,

@@ -235,6 +235,9 @@ void ClownResamplerAMD_DebugDisableDualMono(int on);
    (the polyphase kernels), 2 = always ONE launch for all segments (the generic kernel with a segment table). */
 void ClownResamplerAMD_DebugSegmentsMode(int mode);
 
+/* 1 when the host-pointer entry points would work on [host, host + bytes) in place - page-locked memory the current device can address
+   (hipHostMalloc, hipHostRegister) - instead of staging it (pageable memory: 0). */
+int ClownResamplerAMD_DebugHostIsDeviceVisible(const void *host, size_t bytes);
 /* The library at rest - to be called when no call is in progress on any thread: waits for every device it has used, then checks its
    process-wide state: no plan held by a call, every rows store referenced by exactly the plans that view it, every ticket block of every
    ring (and the unused part of the capture pool) reading zero, no lock held, every Debug* hook back at its default.  Returns the number

@@ -1058,8 +1058,12 @@ def test_page_locked_host_buffers_take_the_direct_path_bit_exact(products, kind)
             assert np.all(dst[want.size:] == (0x5A5A if s16 else 0x5A5A5A5A)), "samples behind the last frame were written"
     finally:
         if kind == "hipHostRegister":
+            # every registration is taken back BEFORE its memory is freed - and is seen to be gone: a range that stayed registered would
+            # be handed out again by malloc, and the runtime would treat whatever lands there as device-visible memory
+            codes = [int(rt.cudaHostUnregister(h[1])) for h in held]
+            assert codes == [0] * len(held), ("hipHostUnregister", codes)
             for h in held:
-                rt.cudaHostUnregister(h[1])
+                assert p.api.HostIsDeviceVisible(h[1], 4096) == 0, "a range is still registered after hipHostUnregister"
 
 
 def test_adjust_between_calls(products):

@@ -71,3 +71,52 @@ def test_soak_through_the_python_mirror_under_address_sanitizer(drivers):
     tail = (r.stdout + r.stderr)[-4000:]
     assert r.returncode == 0 and " 0 failure(s)" in r.stdout, tail
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, tail
+
+
+@pytest.fixture(scope="module")
+def instance_libraries():
+    """the fake seam + the product's real instance tables (tests/hostshim/Makefile, flavour_inst): needs the product's HIP objects, which
+    __graft_entry__.build() / `make -C clownresampler_amd/csrc` leave in clownresampler_amd/csrc/build"""
+    if not os.path.exists(os.path.join(ROOT, "clownresampler_amd", "csrc", "build", "cr_kernels.o")):
+        r = subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "clownresampler_amd", "csrc")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    targets = [os.path.join(BUILD, n) for n in ("libcr_hostshim_inst.so", "libcr_hostshim_inst_asan.so")]
+    r = subprocess.run(["make", "-s", "-j4", "-C", SHIM] + targets, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return targets
+
+
+def _instances(library, steps, sanitized, extra_env=None, timeout=1500):
+    env = dict(os.environ)
+    env.update({"CLOWNRESAMPLER_AMD_LIBRARY": library, "CRA_FAKE_DEVICES": "1", "PYTHONPATH": ROOT + os.pathsep + os.path.join(ROOT, "tests")})
+    env.pop("CLOWNRESAMPLER_AMD_BRIEF_HALF_TILES", None)
+    if sanitized:
+        asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
+        stdcxx = subprocess.run(["gcc", "-print-file-name=libstdc++.so.6"], capture_output=True, text=True, check=True).stdout.strip()
+        env.update({"LD_PRELOAD": asan + " " + stdcxx, "ASAN_OPTIONS": "detect_leaks=0:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1:halt_on_error=1"})
+    env.update(extra_env or {})
+    r = subprocess.run(["python3", os.path.join(SHIM, "instances_driver.py")] + steps, capture_output=True, text=True, timeout=timeout, env=env)
+    tail = (r.stdout + r.stderr)[-5000:]
+    assert r.returncode == 0 and "instances driver: all passed" in r.stdout, tail
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, tail
+    return r
+
+
+def test_specialised_launch_arithmetic_against_the_oracle(instance_libraries):
+    """every plan with the kernel, variant and geometry it has on the GPU (the product's own instance tables answer), every
+    launch checked by the product's own launch function, validated range by range and computed by a scalar model of its arguments: the
+    device-resident cases, the host-pointer cases (staged and "page-locked"), the segment lists GPUTEST_r05 died in, dual mono, k_seg, k_int,
+    brief shapes, padded tiles, the callback forms - all equal to the oracle, the plan cache at two plans."""
+    r = _instances(instance_libraries[0], [], False)
+    for step in ("cases", "bulk", "direct", "segments", "long", "callback"):
+        assert "ok " + step in r.stdout, r.stdout[-3000:]
+    assert "(3, 1, 65535)" in r.stdout and "(4, 1, 30)" in r.stdout     # k_up2 and k_wave2 plans were made
+    _instances(instance_libraries[0], ["long_up2"], False, {"CLOWNRESAMPLER_AMD_BRIEF_HALF_TILES": "0"})
+
+
+def test_specialised_launch_arithmetic_under_address_sanitizer(instance_libraries):
+    """... and the same under AddressSanitizer + UBSan: "device memory" is malloc of the exact size, so a launch whose input, output, rows image or
+    ticket block leaves its allocation by one byte - or names an image that an eviction has freed - is reported; so is every 32-bit
+    descriptor field that overflows on the way (UBSan)."""
+    _instances(instance_libraries[1], ["cases", "direct", "segments", "long", "callback"], True, timeout=2400)
+    _instances(instance_libraries[1], ["long_up2"], True, {"CLOWNRESAMPLER_AMD_BRIEF_HALF_TILES": "0"})

@@ -375,6 +375,8 @@ static unsigned long long g_launch_count[CR_KERNEL_IDS];
 #define CR_SEG_MIN_TILE 64u
 #define CR_SEG_MAX_TILE 128u
 #define CR_SEG_MAX_WASTE 0.06
+/* consecutive tiles an XCD takes per round (crhip_seg_launch.xcd_run; cr_kseg.hpp): neighbouring tiles read neighbouring bytes of the same input lines */
+#define CR_SEG_XCD_RUN 16
 /* a launch of a periodic ratio that starts mid-period is split (a few frames on the ordinary kernel, the rest on k_int) from this
    many output frames on: below, the second launch costs more than k_int saves */
 #define CR_INT_SPLIT_MIN_FRAMES 8192u
@@ -400,6 +402,7 @@ static struct
 	int no_seg;                 /* CLOWNRESAMPLER_AMD_NO_SEG: long k_up2-shaped launches stay with k_up2 (the A/B leg) */
 	int seg_form;               /* CLOWNRESAMPLER_AMD_SEG_FORM: diagnostic instance of k_seg (crhip_seg_launch.debug_form) */
 	int seg_tile;               /* CLOWNRESAMPLER_AMD_SEG_TILE: k_seg's frames per lane and tile (a multiple of 16; unset: the rule) */
+	int seg_xcd_run;            /* CLOWNRESAMPLER_AMD_SEG_XCD_RUN: k_seg's consecutive tiles per XCD and round (a multiple of 4; 0: one by one; unset: CR_SEG_XCD_RUN) */
 	int brief_half_tiles;       /* CLOWNRESAMPLER_AMD_BRIEF_HALF_TILES: k_up launches of fewer half wave-tiles per wave take the plan's other kernel (0: none do; unset: per instance) */
 } g_env;
 static pthread_once_t g_env_once = PTHREAD_ONCE_INIT;
@@ -418,6 +421,8 @@ static void load_env(void)
 	g_env.seg_form = (e != NULL && *e != '\0') ? atoi(e) : 0;
 	e = getenv("CLOWNRESAMPLER_AMD_SEG_TILE");
 	g_env.seg_tile = (e != NULL && *e != '\0') ? atoi(e) : 0;
+	e = getenv("CLOWNRESAMPLER_AMD_SEG_XCD_RUN");
+	g_env.seg_xcd_run = (e != NULL && *e != '\0' && atoi(e) >= 0 && atoi(e) % 4 == 0) ? atoi(e) : CR_SEG_XCD_RUN;
 	g_env.debug = getenv("CLOWNRESAMPLER_AMD_DEBUG") != NULL;
 	g_env.no_occupancy_clamp = getenv("CLOWNRESAMPLER_AMD_NO_OCCUPANCY_CLAMP") != NULL;
 	e = getenv("CLOWNRESAMPLER_AMD_TILE_GROUPS");
@@ -2311,6 +2316,7 @@ int cr_plan_launch(const ClownResamplerAMD_Plan *plan, const void *d_in, uint64_
 			sl.n_tiles = blocks64 * sl.tiles_per_seg;
 			sl.debug_form = (uint32_t)g_env.seg_form;
 			sl.debug_stamps = g_debug_stamps;
+			sl.xcd_run = (uint32_t)g_env.seg_xcd_run;
 			grid = (sl.n_tiles + plan->seg.threads / 64u - 1u) / (plan->seg.threads / 64u);
 			sl.blocks = (uint32_t)(grid > plan->seg.max_blocks ? plan->seg.max_blocks : grid);
 			sl.d_tickets = ticket_block_for(g_ctx[plan->device], stream, &ring);

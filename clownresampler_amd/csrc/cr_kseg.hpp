@@ -87,12 +87,33 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 	const uint64_t global_waves = (uint64_t)gridDim.x * WAVES;
 	const unsigned LANES = global_waves < 32u ? (unsigned)global_waves : 32u;
 	const unsigned lane_id = (unsigned)(global_wave % LANES);
-	const uint64_t lane_tiles = n_tiles > lane_id ? (n_tiles - lane_id + LANES - 1u) / LANES : 0;
+	// Which tiles a sequence takes.  Plain: lane_id, lane_id + 32, ... - neighbouring tiles, whose lanes read neighbouring BYTES of the same
+	// 64 input lines (a tile advances a lane ~43 bytes at 12x), then run on waves of eight different XCDs, and every XCD's L2 fetches the
+	// line for itself: 87.5 MiB fetched for 18.3 MiB of input on cfg 3 (profiles/r05_cfg3_pmc_summary.txt).  With a.xcd_run = G (a multiple
+	// of 4; the grid a multiple of 8, so that a workgroup's XCD - its number mod 8, as the dispatcher deals them - is its waves' lane_id
+	// mod 8): the tiles go out in rounds of 8 G, XCD x takes the G CONSECUTIVE tiles [G x, G x + G) of each round, its four sequences
+	// every fourth of them - the runs of one round are in flight together on one XCD, and a line is fetched once per run.
+	const unsigned G = (LANES == 32u && (gridDim.x & 7u) == 0u) ? a.xcd_run : 0u;
+	const unsigned xcd = lane_id & 7u, sub = lane_id >> 3, per = G / 4u;   // (sub: 0 ... 3)
+	auto tile_of = [&](uint64_t k) -> uint64_t {
+		if (G == 0u)
+			return lane_id + (uint64_t)LANES * k;
+		return (k / per) * (8ull * G) + (uint64_t)G * xcd + 4ull * (k % per) + sub;
+	};
+	uint64_t lane_tiles;   // tiles of this sequence: the k with tile_of(k) < n_tiles (tile_of ascends)
+	if (G == 0u)
+		lane_tiles = n_tiles > lane_id ? (n_tiles - lane_id + LANES - 1u) / LANES : 0;
+	else
+	{
+		const uint64_t rem = n_tiles % (8ull * G), first = (uint64_t)G * xcd + sub;
+		const uint64_t partial = rem > first ? (rem - first + 3u) / 4u : 0;
+		lane_tiles = (n_tiles / (8ull * G)) * per + (partial < per ? partial : per);
+	}
 	const unsigned lane_waves = (unsigned)((global_waves - lane_id + LANES - 1u) / LANES);
 	unsigned *lane_counter = a.d_tickets + lane_id * 32u;
 	auto draw_resolve = [&](unsigned got) -> uint64_t {
 		const uint64_t k = (uint64_t)lane_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)got);
-		return k < lane_tiles ? lane_id + (uint64_t)LANES * k : ~0ull;
+		return k < lane_tiles ? tile_of(k) : ~0ull;
 	};
 	auto retire = [&]() {
 		if (lane == 0 && __hip_atomic_fetch_add(waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == WAVES - 1u)
@@ -155,12 +176,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_seg(const crhip_seg_launch a)
 	const unsigned copy_from = (unsigned)(uintptr_t)my_stage + (lane / CHUNK) * LANE_STRIDE + 8u + (lane % CHUNK) * 8u;
 	const unsigned ring_at = (unsigned)(uintptr_t)my_ring + lane * 16u;   // this lane's four frames of group 0
 
-	uint64_t tile = global_wave;
-	if (tile >= n_tiles)
+	// a wave's first tile: its rank among the waves of its sequence
+	if (global_wave / LANES >= lane_tiles)
 	{
 		retire();
 		return;
 	}
+	uint64_t tile = tile_of(global_wave / LANES);
 
 	for (;;)
 	{

@@ -160,6 +160,7 @@ typedef struct crhip_seg_launch
 	uint32_t *d_tickets;        /* CRHIP_TICKET_WORDS zeroed counters (as crhip_poly_launch.d_tickets) */
 	uint32_t debug_form;        /* 0; diagnostic instances: 1-3 timing-only ablations (results wrong), 4 = cycle stamps per phase */
 	unsigned long long *debug_stamps;   /* form 4: receives 8 counters per workgroup (cr_kseg.hpp, ABL == 6) */
+	uint32_t xcd_run;           /* 0: tiles dealt to the 32 ticket sequences one by one; G (a multiple of 4): in runs of G consecutive tiles per XCD (cr_kseg.hpp) */
 } crhip_seg_launch;
 
 /* 1 and the slot signs the instance is built for (as crhip_poly_up_negmask) when there is a k_seg instance for the shape and the ratio;

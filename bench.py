@@ -535,10 +535,13 @@ def main():
                     step(i)
                 torch.cuda.synchronize(device)
                 graph = torch.cuda.CUDAGraph()
+                capture_counts_before = [api.LaunchCount(k) for k in range(9)]
                 with torch.cuda.graph(graph, stream=side):
                     stream = torch.cuda.current_stream(device)
                     for i in range(args.steps):
                         step(i)
+                # what the CAPTURE enqueued, by kernel: a replay runs exactly these (not a made-up count)
+                captured_by_kernel = [api.LaunchCount(k) - capture_counts_before[k] for k in range(9)]
             stream = side
         except Exception as e:  # capture not possible on this stack: fall back to eager launches
             if rank == 0:
@@ -591,7 +594,7 @@ def main():
     wall = time.perf_counter() - t0
     launches_by_kernel = [api.LaunchCount(k) - counts_before[k] for k in range(9)]   # what the bracketed region ran: lead-in + the K timed launches (graph replays launch nothing new)
     if graph is not None:
-        launches_by_kernel = [args.steps] * 9
+        launches_by_kernel = captured_by_kernel   # (one replay of the captured K steps: the launches the capture recorded)
     dev_ms = max(ev0.elapsed_time(ev1), 0.0)
     mean_ms = dev_ms / args.steps
     last_set = (args.steps - 1) % len(sets)
@@ -806,6 +809,7 @@ def main():
             # exactly those rows of a rocprofv3 --kernel-trace of the same command, so that profiles/ reproduces ms_per_step
             "timed_dispatches": {"first": i_pre + args.warmup + lead_in_launches[0], "count": args.steps},
             "wall_ms_per_launch": wall_ms / (args.steps + lead_in_launches[0]),
+            "wall_ms_per_step": wall_ms / (args.steps + lead_in_launches[0]),   # (the key's name until round 4; the same figure)
             "parity_full_stream": check,
             "parity_full_stream_is": "every rank: EVERY sample its last timed launch wrote == the all-core oracle over the input that launch read (copied back from the device); all ranks agree",
             "parity_full_stream_detail": check_detail,

@@ -273,6 +273,7 @@ class Api:
         self._SegKernel = fn("ClownResamplerAMD_DebugSegKernel", None, [C.c_int], False)
         self._PlanDualMono = fn("ClownResamplerAMD_PlanDualMonoKernel", C.c_uint32, [C.c_void_p], False)
         self._PlanPadded = fn("ClownResamplerAMD_PlanPaddedTiles", C.c_uint32, [C.c_void_p], False)
+        self._PlanSeg = fn("ClownResamplerAMD_PlanSegKernel", C.c_uint32, [C.c_void_p], False)
         self._SegmentsMode = fn("ClownResamplerAMD_DebugSegmentsMode", None, [C.c_int], False)
         self._HighRelease = fn("ClownResamplerAMD_HighLevel_Release", None, [P(HighLevel_State)], False)
         self._WindowCount = fn("ClownResamplerAMD_StreamingWindowCount", C.c_size_t, [], False)
@@ -512,6 +513,10 @@ class Api:
     def DebugSegmentsMode(self, mode):
         """0: the rule picks, 1: one launch per segment, 2: one launch for all segments (segment table)"""
         self._SegmentsMode(mode)
+
+    def PlanSegKernel(self, plan):
+        """8 when long launches of this plan may take k_seg, else 0"""
+        return int(self._PlanSeg(plan))
 
     def PlanDualMonoKernel(self, plan):
         """0, or the kernel id of the stereo instance long launches of this mono plan run on (dual mono)"""

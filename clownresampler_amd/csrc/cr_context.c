@@ -419,6 +419,10 @@ static void load_env(void)
 	g_env.w2_form = (e != NULL && *e != '\0') ? atoi(e) : 0;
 	e = getenv("CLOWNRESAMPLER_AMD_SEG_FORM");
 	g_env.seg_form = (e != NULL && *e != '\0') ? atoi(e) : 0;
+#ifndef CRA_WITH_W2_FORMS
+	if (g_env.seg_form != 4)   /* (1 ... 3: timing-only forms, results wrong - a diagnostic build's; 4 = cycle stamps, results right) */
+		g_env.seg_form = 0;
+#endif
 	e = getenv("CLOWNRESAMPLER_AMD_SEG_TILE");
 	g_env.seg_tile = (e != NULL && *e != '\0') ? atoi(e) : 0;
 	e = getenv("CLOWNRESAMPLER_AMD_SEG_XCD_RUN");
@@ -1158,13 +1162,25 @@ int ClownResamplerAMD_StreamSynchronize(void *hip_stream)
 
 static void fill_poly_launch(const ClownResamplerAMD_Plan *plan, crhip_poly_launch *l);
 
+/* Variants from 1000 up are DIAGNOSTIC instances.  1006 ... 1008 compute what the kernel they stand for computes (they add clock stamps); the
+   others are timing-only forms whose RESULTS ARE WRONG by design - those a shipped library never takes, whatever the environment says: only
+   a diagnostic build (make CRA_CFLAGS=-DCRA_WITH_W2_FORMS) accepts them. */
+static int diagnostic_variant(int variant)
+{
+#ifdef CRA_WITH_W2_FORMS
+	return variant >= 1000 && variant <= 1013;
+#else
+	return variant >= 1006 && variant <= 1008;
+#endif
+}
+
 static uint32_t current_variant(void)
 {
 	if (g_variant < 0)
 	{
 		const char *e = getenv("CLOWNRESAMPLER_AMD_VARIANT");
 		g_variant = (e != NULL && *e != '\0') ? atoi(e) : CR_DEFAULT_VARIANT;
-		if (g_variant < 0 || (g_variant >= crhip_poly_variants() && !(g_variant >= 1000 && g_variant <= 1013)))
+		if (g_variant < 0 || (g_variant >= crhip_poly_variants() && !diagnostic_variant(g_variant)))
 			g_variant = CR_DEFAULT_VARIANT;
 	}
 	return (uint32_t)g_variant;
@@ -1807,7 +1823,7 @@ static int plan_seg_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan
 
 	(void)ctx;
 	plan->seg.available = 0;
-	if (g_env.no_seg || !plan->use_poly || plan->poly.row_mode != CRHIP_ROWMODE_UPSAMPLE || plan->poly.window_extra != 0 || plan->increment >= 65536u
+	if (g_env.no_seg || g_env.no_special || !plan->use_poly || plan->poly.row_mode != CRHIP_ROWMODE_UPSAMPLE || plan->poly.window_extra != 0 || plan->increment >= 65536u
 	 || !crhip_seg_instance(plan->channels, plan->poly.slots, plan->poly.row_mode, plan->poly.norm_mode, (uint32_t)plan->increment, &negmask, &threads, &lds, &chunk))
 		return 0;
 	cr_poly_slot_signs(&plan->poly, &pos_bits, &neg_bits);
@@ -1837,17 +1853,24 @@ static int plan_seg_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan
 			}
 			image[r * 16u + 15u] = 2u * (uint32_t)row[plan->poly.slots];   /* the reciprocal, doubled: k_up2's normalisation (cr_kup.hpp) */
 		}
-		failed = cr_check_hip(dev_malloc(&store->d_rows_seg, bytes), "hipMalloc(rows, k_seg)") != 0
-		      || cr_check_hip(crhip_memcpy_h2d(store->d_rows_seg, image, bytes, NULL), "hipMemcpy(rows, k_seg)") != 0
-		      || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0;
+		/* k_seg is an OPTIONAL fast path: whatever fails here leaves the plan without it (k_up2 / k_wave2 serve the configuration), and the
+		   store only ever holds an image that has arrived whole - a sibling plan must not find a pointer to rows nobody filled */
+		void *rows = NULL;
+
+		failed = crhip_malloc(&rows, bytes) != 0;
+		flight_memory(CR_FLIGHT_MALLOC, failed ? NULL : rows, bytes, failed);
+		if (!failed && (crhip_memcpy_h2d(rows, image, bytes, NULL) != 0 || crhip_stream_sync(NULL) != 0))
+		{
+			dev_free(rows);
+			failed = 1;
+		}
 		free(image);
 		if (failed)
-			return -1;
+			return 0;
+		store->d_rows_seg = rows;
 	}
 
-	if (cr_check_hip(crhip_seg_prepare(plan->channels, plan->poly.slots, (uint32_t)plan->increment, &per_cu), "k_seg setup") != 0)
-		return -1;
-	if (per_cu < 1)
+	if (crhip_seg_prepare(plan->channels, plan->poly.slots, (uint32_t)plan->increment, &per_cu) != 0 || per_cu < 1)
 		return 0;
 	/* 65536 / gcd(increment, 65536) */
 	for (g = 65536u; g > 1u && (plan->increment & (65536u / g * 2u - 1u)) == 0; g >>= 1)
@@ -3150,6 +3173,11 @@ uint32_t ClownResamplerAMD_PlanDualMonoKernel(const ClownResamplerAMD_Plan *plan
 	return partner->vecs >= 150u ? 4u : 1u;
 }
 
+uint32_t ClownResamplerAMD_PlanSegKernel(const ClownResamplerAMD_Plan *plan)
+{
+	return (plan != NULL && plan->seg.available && g_seg_mode != 2) ? (uint32_t)CR_COUNT_SEG : 0u;
+}
+
 uint32_t ClownResamplerAMD_PlanPaddedTiles(const ClownResamplerAMD_Plan *plan)
 {
 	return plan != NULL && plan->use_poly ? plan->padded : 0u;
@@ -3199,7 +3227,7 @@ uint32_t ClownResamplerAMD_PlanRowOf(const ClownResamplerAMD_Plan *plan, uint32_
 
 void ClownResamplerAMD_DebugSetVariant(int variant)
 {
-	g_variant = ((variant >= 0 && variant < crhip_poly_variants()) || (variant >= 1000 && variant <= 1013)) ? variant : CR_DEFAULT_VARIANT;
+	g_variant = ((variant >= 0 && variant < crhip_poly_variants()) || diagnostic_variant(variant)) ? variant : CR_DEFAULT_VARIANT;
 }
 
 void ClownResamplerAMD_DebugForceGenericKernel(int on)

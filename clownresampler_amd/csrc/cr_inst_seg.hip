@@ -19,8 +19,15 @@ struct seg_shape
 	seg_fn fn[5];          // [0] the kernel, [1 ... 3] timing-only ablations (results wrong), [4] cycle stamps per phase
 	unsigned chunk, groups, lds;
 };
+// (the timing-only forms exist in a diagnostic build only - make CRA_CFLAGS=-DCRA_WITH_W2_FORMS - so that nothing in the environment can make
+// a shipped library compute wrong samples; the stamped form computes what the kernel computes)
+#ifdef CRA_WITH_W2_FORMS
+#define CR_SEG_FORM(abl) k_seg<15, 0x2A55u, SEG_WAVES, 1, 16u, 4u, abl>
+#else
+#define CR_SEG_FORM(abl) nullptr
+#endif
 const seg_shape seg_shapes[1] = {
-    {{k_seg<15, 0x2A55u, SEG_WAVES, 1, 16u, 4u>, k_seg<15, 0x2A55u, SEG_WAVES, 1, 16u, 4u, 1>, k_seg<15, 0x2A55u, SEG_WAVES, 1, 16u, 4u, 2>, k_seg<15, 0x2A55u, SEG_WAVES, 1, 16u, 4u, 3>, k_seg<15, 0x2A55u, SEG_WAVES, 1, 16u, 4u, 6>},
+    {{k_seg<15, 0x2A55u, SEG_WAVES, 1, 16u, 4u>, CR_SEG_FORM(1), CR_SEG_FORM(2), CR_SEG_FORM(3), k_seg<15, 0x2A55u, SEG_WAVES, 1, 16u, 4u, 6>},
      16u, 4u, SEG_WAVES * seg_wave_bytes(16u, 4u) + 16u},
 };
 // the shape a ratio takes: the ring must hold what two chunks can advance over (k_seg, top_up) plus the group in use
@@ -54,7 +61,8 @@ int crhip_seg_prepare(uint32_t channels, uint32_t slots, uint32_t increment, int
 		return (int)hipErrorInvalidValue;
 	hipError_t e = hipSuccess;
 	for (int f = 0; f < 5 && e == hipSuccess; ++f)
-		e = hipFuncSetAttribute((const void *)sh->fn[f], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh->lds);
+		if (sh->fn[f] != nullptr)
+			e = hipFuncSetAttribute((const void *)sh->fn[f], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh->lds);
 	if (e != hipSuccess)
 		return (int)e;
 	return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, (const void *)sh->fn[0], SEG_WAVES * 64, sh->lds);
@@ -68,7 +76,7 @@ int crhip_launch_seg(const crhip_seg_launch *launch, void *stream)
 		return (int)hipErrorInvalidValue;
 	if (launch->n_out == 0)
 		return 0;
-	hipLaunchKernelGGL(sh->fn[launch->debug_form < 5u ? launch->debug_form : 0u], dim3(launch->blocks), dim3(SEG_WAVES * 64), sh->lds, (hipStream_t)stream, *launch);
+	hipLaunchKernelGGL(sh->fn[(launch->debug_form < 5u && sh->fn[launch->debug_form] != nullptr) ? launch->debug_form : 0u], dim3(launch->blocks), dim3(SEG_WAVES * 64), sh->lds, (hipStream_t)stream, *launch);
 	return (int)hipGetLastError();
 }
 

@@ -216,12 +216,16 @@ void ClownResamplerAMD_DebugDisableIntKernel(int on);
 /* 0, or the kernel (numbered as ClownResamplerAMD_PlanInfo.kernel: 1 = k_poly, 4 = k_wave2) of the STEREO instance that long launches
    of this MONO plan run on as "dual mono": output frames j and j + H, whose fractional positions are equal, as its two channels. */
 uint32_t ClownResamplerAMD_PlanDualMonoKernel(const ClownResamplerAMD_Plan *plan);
+/* 8 (the number ClownResamplerAMD_DebugLaunchCount counts k_seg under) when LONG launches of this plan may take k_seg - stereo, 15 slots with
+   the instance's slot signs, 4x to 16x upsampling; which launch does is the launch-length rule's to say (ClownResamplerAMD_DebugSegKernel) -
+   else 0.  ClownResamplerAMD_PlanInfo.kernel names the kernel of the plan's ordinary launches. */
+uint32_t ClownResamplerAMD_PlanSegKernel(const ClownResamplerAMD_Plan *plan);
 /* 1 when the plan's k_poly instance computes from PADDED tiles: 9-11 and 13-15 channels without a specialised instance, up to 2:1
    downsampling - a frame of 18 to 30 bytes leaves a lane's share of it on any 2-byte boundary, so every tile is repacked once,
    LDS -> LDS, to frames of 32 bytes whose shares are one aligned 16-byte read per tap (CLOWNRESAMPLER_AMD_NO_PADDED_TILES in the
    environment at first use: never). */
 uint32_t ClownResamplerAMD_PlanPaddedTiles(const ClownResamplerAMD_Plan *plan);
-/* Test hook for k_seg (long stereo launches of 8x - 13x upsampling with 8 lobes: the lanes of a wave on output frames of equal fraction,
+/* Test hook for k_seg (long stereo launches of 4x - 16x upsampling with 8 lobes - increments 4096 ... 16384, CR_SEG_MIN_INCREMENT and the instance's ring: the lanes of a wave on output frames of equal fraction,
    the polyphase row in scalar registers): 0 = the rule (launches whose last, partial block of 64 segments wastes little), 1 = every
    launch the kernel can take, 2 = never (also CLOWNRESAMPLER_AMD_NO_SEG in the environment at first use).  Kernel 8 of
    ClownResamplerAMD_DebugLaunchCount counts its launches. */

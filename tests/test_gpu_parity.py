@@ -432,6 +432,7 @@ def test_segment_kernel_bit_exact(products, rates, frames, forced):
     ok, st = p.low_init(ch, *rates)
     ok, ost = o.low_init(ch, *rates)
     plan = api.PlanCreate(st.raw, p.pre)
+    assert api.PlanSegKernel(plan) == 8, "the plan says its long launches may take k_seg (ADVICE r5: clients see it, not only the launch counter)"
     R = int(ost.cfg.radius_frames)
     padded = ck.pad_frames(ck.noise_pcm(frames * ch, 77 + frames), ch, R)
     total = int(ck.count_output_frames(ost, frames))

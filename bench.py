@@ -38,6 +38,12 @@ import subprocess
 import sys
 import time
 
+# The runtime copies more than 1 MiB between the device and pageable host memory by page-locking the host range in place; the only aborts this
+# project has seen on the GPU box - GPU page faults at heap addresses during such copies by torch (tests/conftest.py, HISTORY.md round 6) - came
+# from there.  This process's torch copies (the parity check reads every sample of the last timed launch back) stay on the staging path;
+# nothing in the timed region is a host copy.  Read when libamdhip64 initialises: set before torch is imported; child rank processes inherit it.
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -523,6 +523,66 @@ static int host_free(void *pointer)
 	return code;
 }
 
+/* Copies between the device and PAGEABLE host memory (the caller's buffers of the host-pointer entry points, the library's own malloc'ed
+   images) go out in pieces of at most 1 MiB.  The runtime's answer to a larger one is to page-lock the host range IN PLACE (hsa_amd_memory_lock,
+   device address == host address) and let the copy engine work on the caller's heap (profiles/r06_copy_path.txt: "HSA Copy Using Pinned
+   resource" above 1 MiB, "... Using Staging resource" up to it).  Every abort of a GPU test run that could be placed - three, rounds 5 and 6 -
+   was a GPU page fault at an address inside the process's brk heap, reported while the main thread sat in such a copy (a 1.1-1.2 MB
+   tensor.cpu() of the test), none of this library's launches having been given a host address (the flight recorder above).  What inside the
+   runtime or the kernel driver goes wrong has not been established (HISTORY.md, round 6); what this library can do is keep ITS copies of a
+   client's pageable memory off that path: pieces the runtime stages through its own pinned buffers.  CLOWNRESAMPLER_AMD_PAGEABLE_PIECE in the
+   environment (bytes; 0: whole copies, the behaviour of rounds 1-5) is the A/B hook. */
+#define CR_PAGEABLE_PIECE ((size_t)1 << 20)
+static size_t pageable_piece(void)
+{
+	static size_t piece = (size_t)-1;
+
+	if (piece == (size_t)-1)
+	{
+		const char *e = getenv("CLOWNRESAMPLER_AMD_PAGEABLE_PIECE");
+		piece = (e != NULL && *e != '\0') ? (size_t)strtoull(e, NULL, 10) : CR_PAGEABLE_PIECE;
+	}
+	return piece;
+}
+
+static int copy_pageable_h2d(void *device_destination, const void *host_source, size_t bytes, void *stream)
+{
+	const size_t piece = pageable_piece();
+	size_t at = 0;
+
+	if (piece == 0 || bytes <= piece)
+		return crhip_memcpy_h2d(device_destination, host_source, bytes, stream);
+	while (at < bytes)
+	{
+		const size_t n = bytes - at < piece ? bytes - at : piece;
+		const int code = crhip_memcpy_h2d((unsigned char *)device_destination + at, (const unsigned char *)host_source + at, n, stream);
+
+		if (code != 0)
+			return code;
+		at += n;
+	}
+	return 0;
+}
+
+static int copy_pageable_d2h(void *host_destination, const void *device_source, size_t bytes, void *stream)
+{
+	const size_t piece = pageable_piece();
+	size_t at = 0;
+
+	if (piece == 0 || bytes <= piece)
+		return crhip_memcpy_d2h(host_destination, device_source, bytes, stream);
+	while (at < bytes)
+	{
+		const size_t n = bytes - at < piece ? bytes - at : piece;
+		const int code = crhip_memcpy_d2h((unsigned char *)host_destination + at, (const unsigned char *)device_source + at, n, stream);
+
+		if (code != 0)
+			return code;
+		at += n;
+	}
+	return 0;
+}
+
 static int launch_poly(const ClownResamplerAMD_Plan *plan, const crhip_poly_launch *l, void *stream)
 {
 	cr_flight_event *e = flight_next(CR_FLIGHT_POLY);
@@ -1135,7 +1195,7 @@ int ClownResamplerAMD_CopyToDevice(void *device_destination, const void *host_so
 {
 	if (cr_ensure_device() != 0)
 		return -1;
-	if (cr_check_hip(crhip_memcpy_h2d(device_destination, host_source, bytes, NULL), "hipMemcpyAsync(H2D)") != 0)
+	if (cr_check_hip(copy_pageable_h2d(device_destination, host_source, bytes, NULL), "hipMemcpyAsync(H2D)") != 0)
 		return -1;
 	return cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0 ? -1 : 0;
 }
@@ -1144,7 +1204,7 @@ int ClownResamplerAMD_CopyFromDevice(void *host_destination, const void *device_
 {
 	if (cr_ensure_device() != 0)
 		return -1;
-	if (cr_check_hip(crhip_memcpy_d2h(host_destination, device_source, bytes, NULL), "hipMemcpyAsync(D2H)") != 0)
+	if (cr_check_hip(copy_pageable_d2h(host_destination, device_source, bytes, NULL), "hipMemcpyAsync(D2H)") != 0)
 		return -1;
 	return cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0 ? -1 : 0;
 }
@@ -1859,7 +1919,7 @@ static int plan_seg_shape(const cr_device_ctx *ctx, ClownResamplerAMD_Plan *plan
 
 		failed = crhip_malloc(&rows, bytes) != 0;
 		flight_memory(CR_FLIGHT_MALLOC, failed ? NULL : rows, bytes, failed);
-		if (!failed && (crhip_memcpy_h2d(rows, image, bytes, NULL) != 0 || crhip_stream_sync(NULL) != 0))
+		if (!failed && (copy_pageable_h2d(rows, image, bytes, NULL) != 0 || crhip_stream_sync(NULL) != 0))
 		{
 			dev_free(rows);
 			failed = 1;
@@ -2049,7 +2109,7 @@ ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t t
 		}
 
 		if (cr_check_hip(dev_malloc((void **)&store->d_table, table_len * sizeof(int32_t)), "hipMalloc(table)") != 0
-		 || cr_check_hip(crhip_memcpy_h2d(store->d_table, table, table_len * sizeof(int32_t), NULL), "hipMemcpy(table)") != 0
+		 || cr_check_hip(copy_pageable_h2d(store->d_table, table, table_len * sizeof(int32_t), NULL), "hipMemcpy(table)") != 0
 		 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
 			goto fail_plan;
 	}
@@ -2106,7 +2166,7 @@ ClownResamplerAMD_Plan *cr_plan_get_on(int device, uint64_t table_hash, size_t t
 			}
 
 			if (cr_check_hip(dev_malloc((void **)&store->d_rows, bytes), "hipMalloc(rows)") != 0
-			 || cr_check_hip(crhip_memcpy_h2d(store->d_rows, image, bytes, NULL), "hipMemcpy(rows)") != 0
+			 || cr_check_hip(copy_pageable_h2d(store->d_rows, image, bytes, NULL), "hipMemcpy(rows)") != 0
 			 || cr_check_hip(crhip_stream_sync(NULL), "hipStreamSynchronize") != 0)
 			{
 				free(image);
@@ -2672,7 +2732,7 @@ static void *download_thread(void *arg)
 		/* stream order: after the batch's kernel */
 		code = crhip_stream_wait_event(d->stream, d->slot[s].ready);
 		if (code == 0)
-			code = crhip_memcpy_d2h(d->slot[s].host_dst, d->slot[s].dev_src, d->slot[s].bytes, d->stream);
+			code = copy_pageable_d2h(d->slot[s].host_dst, d->slot[s].dev_src, d->slot[s].bytes, d->stream);
 		if (code == 0)
 			code = crhip_stream_sync(d->stream);
 		pthread_mutex_lock(&d->lock);
@@ -2863,7 +2923,7 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 		if (alias_in != NULL)   /* the input is read where it lies (alias_in is the device's address of host_in + pos_int frames) */
 			bad = cr_plan_launch(plan, (const unsigned char *)alias_in + (size_t)(pi - pos_int) * frame_in, extent * frame_in, w->d_out, 0, pf, n, ws->stream, out_s16) != 0;
 		else
-			bad = cr_check_hip(crhip_memcpy_h2d(w->d_in, host_in + pi * plan->channels, (size_t)extent * frame_in, ws->stream), "hipMemcpyAsync(H2D)") != 0
+			bad = cr_check_hip(copy_pageable_h2d(w->d_in, host_in + pi * plan->channels, (size_t)extent * frame_in, ws->stream), "hipMemcpyAsync(H2D)") != 0
 			   || cr_plan_launch(plan, w->d_in, extent * frame_in, w->d_out, 0, pf, n, ws->stream, out_s16) != 0;
 		if (have_thread && !bad)
 			bad = cr_check_hip(crhip_event_record(dl.slot[set].ready, ws->stream), "hipEventRecord") != 0;
@@ -2883,7 +2943,7 @@ int cr_run_host(const ClownResamplerAMD_Plan *plan, const int16_t *host_in, uint
 		}
 		else
 		{
-			bad = cr_check_hip(crhip_memcpy_d2h((unsigned char *)host_out + done * frame_out, w->d_out, (size_t)n * frame_out, ws->stream), "hipMemcpyAsync(D2H)") != 0
+			bad = cr_check_hip(copy_pageable_d2h((unsigned char *)host_out + done * frame_out, w->d_out, (size_t)n * frame_out, ws->stream), "hipMemcpyAsync(D2H)") != 0
 			   || cr_check_hip(crhip_stream_sync(ws->stream), "hipStreamSynchronize") != 0;
 		}
 
@@ -2956,7 +3016,7 @@ int cr_run_single_frame(const ClownResamplerAMD_Plan *plan, const int16_t *host_
 	g.channels = plan->channels;
 	g.out64 = 1;
 
-	bad = cr_check_hip(crhip_memcpy_h2d(ws->d_in, host_window, in_bytes, ws->stream), "hipMemcpyAsync(H2D)") != 0
+	bad = cr_check_hip(copy_pageable_h2d(ws->d_in, host_window, in_bytes, ws->stream), "hipMemcpyAsync(H2D)") != 0
 	   || cr_check_hip(crhip_memcpy_h2d(ws->d_out + acc_bytes, acc_in, acc_bytes, ws->stream), "hipMemcpyAsync(H2D)") != 0
 	   || cr_check_hip(launch_generic(plan, &g, in_bytes, ws->stream), "k_generic launch") != 0
 	   || cr_check_hip(crhip_memcpy_d2h(acc_out, ws->d_out, acc_bytes, ws->stream), "hipMemcpyAsync(D2H)") != 0
@@ -3128,7 +3188,7 @@ int ClownResamplerAMD_DebugSelfCheck(char *message, size_t capacity)
 
 			if (ctx->rings[r].pending != 0)
 				FINDING("device %d ring %u: %u launches drawn and not enqueued", d, r, ctx->rings[r].pending);
-			if (crhip_memcpy_d2h(host, ctx->rings[r].blocks, ring_words * sizeof(uint32_t), NULL) != 0 || crhip_stream_sync(NULL) != 0)
+			if (copy_pageable_d2h(host, ctx->rings[r].blocks, ring_words * sizeof(uint32_t), NULL) != 0 || crhip_stream_sync(NULL) != 0)
 			{
 				FINDING("device %d ring %u: cannot be read back", d, r);
 				continue;
@@ -3146,7 +3206,7 @@ int ClownResamplerAMD_DebugSelfCheck(char *message, size_t capacity)
 			const size_t words = ctx->capture_left * CRHIP_TICKET_WORDS < ring_words ? ctx->capture_left * CRHIP_TICKET_WORDS : ring_words;
 			size_t w;
 
-			if (crhip_memcpy_d2h(host, ctx->capture_at, words * sizeof(uint32_t), NULL) == 0 && crhip_stream_sync(NULL) == 0)
+			if (copy_pageable_d2h(host, ctx->capture_at, words * sizeof(uint32_t), NULL) == 0 && crhip_stream_sync(NULL) == 0)
 				for (w = 0; w < words; ++w)
 					if (host[w] != 0)
 					{

@@ -2001,6 +2001,24 @@ def test_chain_taps_at_the_sample_range_limits(products):
 
 
 @pytest.mark.gpu
+def test_self_check_fires(products):
+    """the check that runs after every GPU test (tests/conftest.py, ClownResamplerAMD_DebugSelfCheck) is not a formality -
+    a test hook left on is a finding, named; back at its default the library is at rest again."""
+    api = products[3].api
+    assert cr.self_check() == []
+    for leave, restore, word in ((lambda: api.DebugSegmentsMode(2), lambda: api.DebugSegmentsMode(0), "DebugSegmentsMode"),
+                                 (lambda: api.DebugForceGenericKernel(True), lambda: api.DebugForceGenericKernel(False), "DebugForceGenericKernel"),
+                                 (lambda: api.DebugSegKernel(1), lambda: api.DebugSegKernel(0), "DebugSegKernel"),
+                                 (lambda: api.DebugSetVariant(7), lambda: api.DebugSetVariant(-1), "DebugSetVariant")):
+        leave()
+        try:
+            bad = cr.self_check()
+            assert bad and bad[0][1] >= 1 and word in bad[0][2], (word, bad)
+        finally:
+            restore()
+        assert cr.self_check() == []
+
+
 def test_soak_short():
     """A fixed-seed minute of tests/soak_gpu.py: random radius / channels / rate triples / lengths / entry points against the oracle,
     bit-exact (the thresholds of the host's kernel choice depend on a launch's length: enumeration cannot cover them)."""

@@ -100,3 +100,21 @@ def _library_back_at_rest(request):
     torch.cuda.synchronize()
     bad = cr.self_check()
     assert not bad, "the library is not at rest after this test: %s" % (bad,)
+
+
+@pytest.fixture(autouse=True)
+def _pinned_copy_probe(request):
+    """DIAGNOSTIC (CRA_PINNED_COPY_PROBE=1, with GPU_PINNED_MIN_XFER_SIZE=1 so that the runtime's default applies): after every GPU test, the copy
+    the suite's deaths happened in - torch's tensor.cpu() of 1,204,416 bytes into fresh pageable memory, which the runtime serves by page-locking
+    the destination in place.  If some test ARMS the process, the first copy after it dies and names it (HISTORY.md, round 6)."""
+    yield
+    if os.environ.get("CRA_PINNED_COPY_PROBE") != "1" or request.node.get_closest_marker("gpu") is None or not _gpu_session["on"]:
+        return
+    import torch
+    n = int(os.environ.get("CRA_PINNED_COPY_ELEMENTS", "301104"))
+    z = torch.arange(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(int(os.environ.get("CRA_PINNED_COPY_REPEATS", "2"))):
+        y = z.cpu().numpy()
+        assert y[0] == 0 and y[-1] == n - 1
+        del y

@@ -347,3 +347,48 @@ def test_preflight_dry_run(tmp_path):
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "multi_gpu_preflight.sh"), str(tmp_path)], capture_output=True, text=True, timeout=1500, env=env)
     log = open(os.path.join(str(tmp_path), "preflight.log")).read() if os.path.exists(os.path.join(str(tmp_path), "preflight.log")) else ""
     assert r.returncode == 0 and "ALL STEPS PASSED" in r.stdout, (r.stdout[-3000:], log[-3000:])
+
+
+_COPY_PATH_SNIPPET = r"""
+import os, sys
+sys.path[:0] = [%(root)r, %(tests)r]
+import numpy as np
+import torch
+torch.cuda.init()
+import _checkers as ck, _product
+p, o = _product.Product(3), ck.oracle(3)
+ch, rates, frames = 2, (44100, 48000, 44100), 1500000          # 6 MB in, 13 MB out: far beyond the runtime's 1 MiB threshold
+ok, st = p.low_init(ch, *rates); ok, ost = o.low_init(ch, *rates)
+padded = ck.pad_frames(ck.noise_pcm(frames * ch, 11), ch, 3)
+want = o.low_resample_i32(ost, padded, frames)[0]
+print("=====BEGIN", file=sys.stderr, flush=True)
+got, left, ran_out = p.api.LowLevel_ResampleBulk(st.raw, p.pre, padded, frames)
+d = p.api.DeviceAlloc(padded.nbytes)
+p.api.CopyToDevice(d, padded)
+back = np.empty_like(padded)
+p.api.CopyFromDevice(back, d)
+p.api.DeviceFree(d)
+print("=====END", file=sys.stderr, flush=True)
+assert left == 0 and np.array_equal(got, want) and np.array_equal(back, padded)
+print("COPIES-OK")
+"""
+
+
+def test_pageable_copies_stay_off_the_runtimes_pinned_path():
+    """Round 6's regression test: every abort of a GPU test run that could be placed was a GPU page fault at a HEAP address
+    during a copy of more than 1 MiB between the device and pageable memory, which the runtime serves by page-locking the host range in place
+    ("HSA Copy Using Pinned resource" in its own log).  The library's copies of a client's pageable memory - the staged host-pointer entry
+    point, CopyToDevice / CopyFromDevice - now leave in 1 MiB pieces, which the runtime stages ("... Using Staging resource"): with the
+    runtime's defaults in force, not ONE pinned copy between the markers; with CLOWNRESAMPLER_AMD_PAGEABLE_PIECE=0 (whole copies, the library of
+    rounds 1-5) the same calls make them - so the check can see what it checks."""
+    code = _COPY_PATH_SNIPPET % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+    counts = {}
+    for piece in ("1048576", "0"):
+        env = dict(os.environ, AMD_LOG_LEVEL="4", CLOWNRESAMPLER_AMD_PAGEABLE_PIECE=piece, GPU_PINNED_MIN_XFER_SIZE="1")   # (1 MiB: the runtime's default)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "COPIES-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+        log = r.stderr.split("=====BEGIN", 1)[1].split("=====END", 1)[0]
+        counts[piece] = (log.count("Using Pinned resource"), log.count("Using Staging resource"))
+    if counts["0"][0] == 0:
+        pytest.skip("this runtime's log does not name its pinned copies (%r): nothing to hold the library against" % (counts,))
+    assert counts["1048576"][0] == 0 and counts["1048576"][1] > 0, counts

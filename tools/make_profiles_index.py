@@ -27,6 +27,34 @@ for doc in ("DESIGN.md", "README.md", "INTEGRATION.md"):
 cited.pop("INDEX.md", None)   # (this file)
 missing = [n for n in cited if not os.path.exists(os.path.join(P, n))]
 WHAT = [
+    (r"r06_bench_cfg2\.json", "the headline `bench.py` line (BASELINE configs[1], N = 1) of round 6's final build, with `roofline`, `cpu_baseline`, `parity_full_stream`, `strong_curve_n1`, `end_to_end`"),
+    (r"r06_bench_cfg2_steps20\.json", "the same command as the driver runs it (`--steps 20 --warmup 3`)"),
+    (r"r06_bench_(cfg3|cfg4|cfg5|hq48|hq44|dn8|cfg2_s16)\.json", "`bench.py` lines of the other workloads, same box and build"),
+    (r"r06_bench_n2_sharedgpu_gloo\.json", "`bench.py --gpus 2` with the ranks SHARING one GPU over gloo (validation of the N > 1 path; not a scaling measurement)"),
+    (r"r06_trace_timed_means\.log", "rocprofv3 `--kernel-trace` of the bench command: mean over ALL dispatches and over the TIMED ones bench.py names (`tools/trace_timed_mean.py`)"),
+    (r"r06_kernel_stats_.*\.csv", "`rocprofv3 --kernel-trace --stats` summary of the same `bench.py` command (average over every dispatch, clock ramp included)"),
+    (r"r06_kernel_trace_head_.*\.csv", "first dispatches of that trace: grid, LDS, register counts"),
+    (r"r06_(cfg2|cfg3|cfg4)_pmc_summary\.txt", "per-dispatch PMC means (separate `--pmc` passes), stamped with the library's source id; `bench.py` quotes `traffic` / `roofline_valu` from them"),
+    (r"r06_lines\.log", "one line per workload of the final lease: kernel, µs, fraction, parity, traffic"),
+    (r"r06_kseg_xcd_ab\.log", "`k_seg`: tiles dealt one by one against runs of 4 ... 128 consecutive tiles per XCD, same box, three rounds"),
+    (r"r06_kseg_xcd_pmc\.log", "... and the counters of the two legs: `FETCH_SIZE` 87,343 -> 12,557 KiB per launch"),
+    (r"r06_kseg_ab\.log", "`k_seg` on the final build: default against `xcd_run` 0 and against `k_up2`"),
+    (r"r06_host_path_ab\.log", "the host-pointer entry points from pageable memory: copies in 1 MiB pieces against whole copies (the runtime's pinned-in-place path)"),
+    (r"r06_host_paths\.log", "the host-pointer entry points on the final build"),
+    (r"r06_loop_a_summary\.log", "the GPU suite ten times in fresh processes BEFORE the containment: one death"),
+    (r"r06_loop_[bcd]_summary\.log", "the GPU suite in loops of fresh processes AFTER it, three leases: 10 + 10 + 12 green"),
+    (r"r06_death_loop_a\.txt", "the death of lease a: the runtime's fault line (a heap address), the flight recorder, the Python stack (`tensor.cpu()`)"),
+    (r"r06_repro3_death_flight_recorder\.log", "the death under guarded library allocations: same test, same copy, a heap address"),
+    (r"r06_repro3_summary\.log", "the guarded-buffer tests and the suite under `CLOWNRESAMPLER_AMD_GUARD_MALLOC=1 / 2`"),
+    (r"r06_copy_path\.txt", "the runtime's own log of a 0.9 MB, a 1.2 MB and a 5 MB copy into pageable memory: staging up to 1 MiB, page-locked in place above"),
+    (r"r06_minxfer_probe\.txt", "`GPU_PINNED_MIN_XFER_SIZE` moves that threshold (what the test and bench processes set)"),
+    (r"r06_hipfree_probe\.log", "`hipFree` / `hipHostFree` wait for work in flight"),
+    (r"r06_va_reuse_probe\.log", "device addresses handed out again by `hipMalloc`: kernels and copy engines agree on their contents (82,393 rounds)"),
+    (r"r06_vmm_probe.*\.log", "address ranges of the virtual-memory API handed out again: they do NOT (why the guarded allocators keep their ranges)"),
+    (r"r06_asan_gpu_suite\.log", "the GPU suite with the library's host code under AddressSanitizer"),
+    (r"r06_arming_probe\.log", "a pinned-path copy after every GPU test: three full runs survive"),
+    (r"r06_(pin_cache_probe_heap|pin_cache_probe_mmap|pin_overlap_probe|register_reuse_probe|window_heap_trim)\.log", "the stories about the runtime's pinned copies that were tried in isolation and survive"),
+    (r"r06_repro1_summary\.log", "the first loop of the round: 25 windows + 6 full suites, green"),
     (r"r05_bench_cfg2\.json", "the headline `bench.py` line (BASELINE configs[1], N = 1) of round 5's final build, with `roofline`, `cpu_baseline`, `parity_full_stream`, `strong_curve_n1`, `end_to_end`, `timed_dispatches`"),
     (r"r05_bench_cfg2_steps20\.json", "the same command as the driver runs it (`--steps 20 --warmup 3`)"),
     (r"r05_bench_(cfg3|cfg4|cfg5|hq48|hq44|dn8|cfg2_s16)\.json", "`bench.py` lines of the other workloads, same box and build"),

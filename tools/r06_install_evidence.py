@@ -30,7 +30,7 @@ def line(w):
 
 TIMED = {}
 for l in open(os.path.join(P, "r06_trace_timed_means.log")):
-    m = re.match(r"(\w+): (\d+) dispatches.*all: mean ([\d.]+) us; timed region \[\d+, \d+\): mean ([\d.]+) us", l)
+    m = re.match(r"(\w+)[^:]*: (\d+) dispatches.*all: mean ([\d.]+) us; timed region \[\d+, \d+\): mean ([\d.]+) us", l)
     if m:
         TIMED[m.group(1)] = (int(m.group(2)), float(m.group(3)), float(m.group(4)))
 
@@ -71,7 +71,8 @@ cb = c2["cpu_baseline"]
 rows.append("| reference C path on this box's host (`cpu_baseline`, kind \"%s\") | | %.0f on 1 core; %.0f on %d cores (oracle driver) | | | | | |" % (cb["kind"], cb["value"], cb["all_cores"]["value"], cb["all_cores"]["cores"]))
 e2e, cbk, s1 = c2["end_to_end"], c2["callback_api"], c2["strong_curve_n1"]
 n2 = line("n2_sharedgpu_gloo")
-tests = "; ".join(l.split(" rc ")[1].split(" in ")[0] for l in open(os.path.join(ROOT, "gpurun_out", "r06", "loop_d", "summary.log")) if l.startswith("full"))
+runs = [l for l in open(os.path.join(P, "r06_loop_d_summary.log")) if l.startswith("full")]
+tests = "%d of %d runs green (%s each)" % (sum(" rc 0 " in l for l in runs), len(runs), runs[0].split(" rc 0 ")[1].split(" in ")[0])
 notes = ("\n(One box, the final build of round 6 - source id `%s`, which stamps the PMC summaries `profiles/r06_{cfg2,cfg3,cfg4}_pmc_summary.txt`; bench lines `profiles/r06_bench_*.json`, "
          "rocprofv3 kernel stats `profiles/r06_kernel_stats_*.csv`. The rows WITHOUT a GB/s figure are round 5's box and build (`profiles/r05_all_workloads.log`): their kernels did not change in round 6 "
          "- only `cr_kseg.hpp` (cfg 3) did. `parity_full_stream` true in every line. The same lease: `pytest -m gpu` in a loop of fresh processes: %s "

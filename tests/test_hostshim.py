@@ -120,3 +120,17 @@ def test_specialised_launch_arithmetic_under_address_sanitizer(instance_librarie
     descriptor field that overflows on the way (UBSan)."""
     _instances(instance_libraries[1], ["cases", "direct", "segments", "long", "callback"], True, timeout=2400)
     _instances(instance_libraries[1], ["long_up2"], True, {"CLOWNRESAMPLER_AMD_BRIEF_HALF_TILES": "0"})
+
+
+def test_c_driver_with_the_real_instance_tables_under_sanitizers(instance_libraries):
+    """The C driver of the plain fake seam (threads: concurrent callers over a small plan cache, device-resident launches from many threads, the
+    compute-ahead and download helper threads, failure injection at malloc / launch / copy / sync) against the library with the product's REAL
+    instance tables: plain, under ASan + UBSan with leak detection, under ThreadSanitizer."""
+    targets = [os.path.join(BUILD, n) for n in ("driver_inst", "driver_inst_asan", "driver_inst_tsan")]
+    r = subprocess.run(["make", "-s", "-j4", "-C", SHIM] + targets, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    _run(targets[0], {}, 300)
+    r = _run(targets[1], {"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1:halt_on_error=1"}, 900)
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-4000:]
+    r = _run(targets[2], {"TSAN_OPTIONS": "halt_on_error=0:exitcode=66"}, 1200)
+    assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
